@@ -1,0 +1,248 @@
+"""
+Pins the oracle (oracle/ref_port.py, a CPU restatement) to golden vectors that
+were produced by the reference's own code (tests/golden/gen_golden.py).
+CPU-only; runs everywhere.
+"""
+import ast
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle import ref_port as P
+
+
+def _crc_rows(a):
+    a = np.ascontiguousarray(a)
+    return np.array([zlib.crc32(a[i].tobytes()) for i in range(len(a))], np.uint32)
+
+
+# -- G1 / G2 ------------------------------------------------------------------
+
+def _scan_cases():
+    g = load_golden("g1_g2_scans")
+    params = g["params"]
+    for i in range(int(g["n_inputs"])):
+        ik = "i%02d" % i
+        for pi, (gam, lam) in enumerate(params):
+            yield g, ik, pi, float(gam), float(lam)
+
+
+def test_gae_bit_exact_vs_reference():
+    n = 0
+    for g, ik, pi, gam, lam in _scan_cases():
+        adv, ret = P.gae_scan(g[ik + "_r"], g[ik + "_v"], g[ik + "_d"], g[ik + "_lv"], gam, lam)
+        key = "%s_p%d" % (ik, pi)
+        np.testing.assert_array_equal(adv, g[key + "_adv"], err_msg=key)
+        np.testing.assert_array_equal(ret, g[key + "_ret"], err_msg=key)
+        n += 1
+    assert n == 72
+
+
+def test_gae_legacy_promotion_bit_exact_and_close():
+    for g, ik, pi, gam, lam in _scan_cases():
+        key = "%s_p%d" % (ik, pi)
+        adv, _ = P.gae_scan(g[ik + "_r"], g[ik + "_v"], g[ik + "_d"], g[ik + "_lv"], gam, lam,
+                            promo="legacy")
+        np.testing.assert_array_equal(adv, g[key + "_adv_legacy"], err_msg=key)
+        # the two promotions agree within the north_star tolerance
+        tol = 1e-5 * np.maximum(1, np.abs(g[key + "_adv"]))
+        assert np.all(np.abs(adv - g[key + "_adv"]) <= tol), key
+
+
+def test_nstep_bit_exact_vs_reference():
+    n = 0
+    for g, ik, pi, gam, lam in _scan_cases():
+        key = "%s_p%d" % (ik, pi)
+        if key + "_nret" not in g:
+            continue
+        ret, adv = P.nstep_returns(g[ik + "_r"], g[ik + "_d"], g[ik + "_v"], g[ik + "_lv"], gam)
+        np.testing.assert_array_equal(ret, g[key + "_nret"], err_msg=key)
+        np.testing.assert_array_equal(adv, g[key + "_nadv"], err_msg=key)
+        ret64, _ = P.nstep_returns(g[ik + "_r"], g[ik + "_d"], g[ik + "_v"], g[ik + "_lv"], gam,
+                                   promo="legacy")
+        np.testing.assert_array_equal(ret64, g[key + "_nret_legacy"], err_msg=key)
+        tol = 1e-5 * np.maximum(1, np.abs(ret))
+        assert np.all(np.abs(ret64 - ret) <= tol), key
+        n += 1
+    assert n == 54
+
+
+# -- G3 -----------------------------------------------------------------------
+
+def test_valids_and_zeroing():
+    g = load_golden("g3_valids")
+    for c in range(int(g["n_cases"])):
+        k = "c%02d" % c
+        valids = P.valid_mask(g[k + "_flags"])
+        np.testing.assert_array_equal(valids, g[k + "_valids"], err_msg=k)
+        a, r, v = P.zero_invalid(valids, g[k + "_adv"], g[k + "_ret"], g[k + "_val"])
+        np.testing.assert_array_equal(a, g[k + "_adv_z"])
+        np.testing.assert_array_equal(r, g[k + "_ret_z"])
+        np.testing.assert_array_equal(v, g[k + "_val_z"])
+
+
+# -- G4 -----------------------------------------------------------------------
+
+def test_process_samples():
+    g = load_golden("g4_process_samples")
+    for c in range(int(g["n_cases"])):
+        k = "c%02d" % c
+        gam, lam, use_valids, std_adv = g[k + "_cfg"]
+        out = P.process_samples(g[k + "_r"], g[k + "_d"], g[k + "_v"], g[k + "_lv"],
+                                g[k + "_need"], float(gam), float(lam) if lam != 1 else 1,
+                                use_valids=bool(use_valids), standardize_adv=bool(std_adv))
+        np.testing.assert_array_equal(out["returns"], g[k + "_ret"], err_msg=k)
+        np.testing.assert_array_equal(out["advantages"], g[k + "_adv"], err_msg=k)
+        if use_valids:
+            np.testing.assert_array_equal(out["valids"], g[k + "_valids"])
+            np.testing.assert_array_equal(out["value"], g[k + "_value_after"])
+
+
+# -- G5 -----------------------------------------------------------------------
+
+def test_action_sampling_bit_exact():
+    g = load_golden("g5_sampling")
+    for c in range(int(g["n_cases"])):
+        k = "c%02d" % c
+        acts = P.sample_actions(g[k + "_prob"], g[k + "_u"])
+        assert acts.dtype == g[k + "_act"].dtype
+        np.testing.assert_array_equal(acts, g[k + "_act"], err_msg=k)
+        # and the uniforms are what numpy's legacy global stream yields
+        rs = np.random.RandomState(int(g[k + "_seed"]))
+        np.testing.assert_array_equal(rs.rand(len(acts)), g[k + "_u"])
+
+
+# -- G6 -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("gi", range(4))
+def test_env_port_matches_reference_env(gi):
+    g = load_golden("g6_env")
+    k = "g%d" % gi
+    kwargs = dict(ast.literal_eval(str(g[k + "_kwargs"])))
+    rng = np.random.RandomState(int(g[k + "_seed"]))
+    env = P.PortedAtariEnv(game=str(g[k + "_game"]), rng=rng, **kwargs)
+    obs = env.reset()
+    keep = {int(i): j for j, i in enumerate(g[k + "_keep_idx"])}
+    np.testing.assert_array_equal(obs[-1], g[k + "_keep_last"][keep[-1]])
+    for i, a in enumerate(g[k + "_acts"]):
+        o, r, d, info = env.step(a)
+        assert r == g[k + "_rew"][i] and type(r) is np.float32, (i, r)
+        assert d == g[k + "_done"][i], i
+        assert info.get("raw_reward", r) == g[k + "_raw"][i], i
+        assert info.get("need_reset", d) == g[k + "_need"][i], i
+        if d and info.get("need_reset", True):
+            assert g[k + "_reset"][i]
+            o = env.reset()
+        assert env.tick == g[k + "_tick"][i], i
+        assert zlib.crc32(o.tobytes()) == g[k + "_crc"][i], i
+        if i in keep:
+            np.testing.assert_array_equal(o[-1], g[k + "_keep_last"][keep[i]])
+            np.testing.assert_array_equal([bool(f.any()) for f in o],
+                                          g[k + "_keep_nonzero"][keep[i]])
+    assert g[k + "_done"].sum() > 0
+
+
+# -- G7 -----------------------------------------------------------------------
+
+class TablePolicyPort(object):
+    """The fixtures' table policy (tests/golden/gen_golden.py:TablePolicy), with
+    sampling through the oracle's sample_actions + the global numpy RNG."""
+
+    def __init__(self, prob_table, value_table):
+        self.prob_table, self.value_table = prob_table, value_table
+
+    @staticmethod
+    def keys(obs):
+        obs = np.asarray(obs)
+        return obs.reshape(obs.shape[0], -1).astype(np.int64).sum(axis=1) % 64
+
+    def get_actions(self, obs):
+        k = self.keys(obs)
+        prob, value = self.prob_table[k], self.value_table[k]
+        return P.sample_actions(prob, np.random.rand(len(k))), dict(prob=prob, value=value)
+
+
+def replay_rollout(g, sampler_factory=None):
+    n_parallel, envs_per, horizon, n_batches, seed, mbr, maxlen = [int(x) for x in g["cfg"]]
+    env_kwargs = dict(ast.literal_eval(str(g["env_args"])))
+    smp = P.CpuSamplerPort(str(g["game"]), horizon, n_parallel, envs_per,
+                           max_path_length=np.inf if maxlen < 0 else maxlen,
+                           mid_batch_reset=bool(mbr), env_kwargs=env_kwargs)
+    np.random.seed(seed)
+    n_act, sample_size = smp.initialize(seed + 1, discount=float(g["discount"]))
+    # master-side draws the reference makes between initialize and the first serve
+    # (build_step_buffer x2: act_server/buffers.py:24-30; build_policy_buffer: :33-38)
+    obs_shape = smp.step_obs.shape[1:]
+    for _ in range(2):
+        np.random.randint(low=0, high=255, size=obs_shape, dtype=np.uint8)
+        np.random.randint(n_act, dtype=np.uint8)
+    np.random.randint(low=0, high=255, size=obs_shape, dtype=np.uint8)
+    np.random.rand()                                    # policy.get_action -> weighted_sample
+    return smp, TablePolicyPort(g["prob_table"], g["value_table"]), n_batches
+
+
+@pytest.mark.parametrize("tag", ["breakout", "pong_maxlen", "seaquest_nomid", "breakout_noop0"])
+def test_sampler_port_matches_reference_sampler(tag):
+    g = load_golden("g7_rollout_" + tag)
+    smp, policy, n_batches = replay_rollout(g)
+    mbr = bool(g["cfg"][5])
+    traj = []
+    for b in range(n_batches):
+        buf, completed = smp.obtain_samples(policy)
+        np.testing.assert_array_equal(buf["actions"], g["actions"][b], err_msg="b%d" % b)
+        np.testing.assert_array_equal(buf["prob"], g["prob"][b])
+        np.testing.assert_array_equal(buf["value"], g["value"][b])
+        if mbr:
+            np.testing.assert_array_equal(buf["rewards"], g["rewards"][b], err_msg="b%d" % b)
+            np.testing.assert_array_equal(buf["dones"], g["dones"][b])
+            np.testing.assert_array_equal(buf["raw_reward"], g["raw_reward"][b])
+            np.testing.assert_array_equal(buf["need_reset"], g["need_reset"][b])
+            np.testing.assert_array_equal(_crc_rows(buf["observations"]), g["obs_crc"][b])
+        else:
+            # NonResetCollector leaves stale rows after the first reset condition
+            # (SURVEY.md appendix A.4): compare under the valids mask
+            t = smp.horizon
+            valid = P.valid_mask(g["need_reset"][b].reshape(-1, t)).reshape(-1).astype(bool)
+            valid_here = P.valid_mask(buf["need_reset"].reshape(-1, t)).reshape(-1).astype(bool)
+            np.testing.assert_array_equal(valid_here, valid)
+            for key in ("rewards", "dones", "raw_reward", "need_reset"):
+                np.testing.assert_array_equal(buf[key][valid], g[key][b][valid], err_msg=key)
+            np.testing.assert_array_equal(_crc_rows(buf["observations"])[valid],
+                                          g["obs_crc"][b][valid])
+        np.testing.assert_array_equal(_crc_rows(buf["extra_observations"]), g["extra_crc"][b])
+        if b == 0:
+            np.testing.assert_array_equal(buf["observations"][:, -1],
+                                          g["first_batch_newest_frames"])
+        for ti in completed:
+            traj.append((b,) + ti.as_tuple())
+    want = sorted((int(b),) + tuple(float(x) for x in row)
+                  for b, row in zip(g["traj_batch"], g["traj"]))
+    got = sorted((b,) + tuple(float(x) for x in row) for (b, *row) in traj)
+    assert len(want) > 0
+    assert got == want
+
+
+# -- G8 / G9 ------------------------------------------------------------------
+
+def test_minibatch_indices():
+    g = load_golden("g8_mbidx")
+    for c in range(int(g["n_cases"])):
+        bs, n, seed = [int(x) for x in g["c%d_cfg" % c]]
+        np.random.seed(seed)
+        for ep in range(3):
+            mbs = P.minibatch_indices(bs, n, True)
+            want = g["c%d_idx" % c][ep]
+            assert len(mbs) == len(want) == max((n - bs) // bs + 1, 0) if n >= bs else len(mbs) == 0
+            for a, b in zip(mbs, want):
+                np.testing.assert_array_equal(a, b)
+        ns = P.minibatch_indices(bs, n, False)
+        np.testing.assert_array_equal(
+            np.array([[m[0], m[-1] + 1] for m in ns], np.int64).reshape(-1, 2),
+            g["c%d_noshuffle" % c])
+
+
+def test_n_itr_table():
+    for n_steps, sample_size, log_steps, n_itr, log_itrs in load_golden("g9_nitr")["table"]:
+        assert P.n_itr_for(int(n_steps), int(sample_size), int(log_steps)) == (n_itr, log_itrs)
