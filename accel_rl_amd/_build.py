@@ -1,0 +1,60 @@
+"""Build libaccel_rl_hip.so (hand-written HIP, gfx950) in-tree with hipcc.
+
+The shared object lives next to this file so that it travels with a repo
+snapshot; it is git-ignored.  hipcc cross-compiles without a GPU present.
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libaccel_rl_hip.so")
+SOURCES = ["batch_ops.hip", "scan.hip", "env.hip", "optim.hip"]
+ARCH = "gfx950"
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    deps.append(os.path.join(ROOT, "include", "accel_rl_hip.h"))
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_extension(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into one shared library."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libaccel_rl_hip.so")
+    objs = []
+    build_dir = os.path.join(PKG_DIR, "csrc", "_obj")
+    os.makedirs(build_dir, exist_ok=True)
+    common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
+              "-ffp-contract=off",           # numpy-exact arithmetic (no implicit fma)
+              "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(build_dir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if out.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % out.stdout.decode(errors="replace"))
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_extension(force=True, verbose=True))

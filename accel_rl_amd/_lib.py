@@ -1,0 +1,232 @@
+"""ctypes binding of libaccel_rl_hip.so (include/accel_rl_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, the
+product raises.  PyTorch is used only as the owner of device memory and
+streams; the ABI itself sees raw pointers and sizes.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libaccel_rl_hip.so")
+
+ARL_ABI_VERSION = 1
+PROMO_NEP50, PROMO_LEGACY = 0, 1
+OPT_ADAM, OPT_RMSPROP = 0, 1
+MAX_ACTIONS = 18
+RAW_H, RAW_W, OBS_H, OBS_W = 210, 160, 104, 80
+OPT_PARTIALS = 1024
+
+_vp, _i32, _i64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double
+
+
+class ArlGame(C.Structure):
+    _fields_ = [("bank", _vp), ("n_frames", _i32), ("n_actions", _i32),
+                ("action_set", _i32 * MAX_ACTIONS), ("start_lives", _i32),
+                ("life_period", _i32), ("frame_skip", _i32), ("n_stack", _i32),
+                ("clip_reward", _i32), ("episodic_lives", _i32)]
+
+
+class ArlEnvState(C.Structure):
+    _fields_ = [("n_env", _i64), ("tick", _vp), ("emu_lives", _vp), ("env_lives", _vp),
+                ("phase", _vp), ("over", _vp), ("frozen", _vp),
+                ("traj_len", _vp), ("traj_nonzero", _vp), ("traj_ret", _vp),
+                ("traj_raw", _vp), ("traj_disc", _vp), ("traj_curdisc", _vp),
+                ("frame_a", _vp), ("frame_b", _vp), ("frame_mode", _vp), ("reset_flag", _vp),
+                ("noop_ring", _vp), ("noop_cursor", _vp), ("epoch", _vp),
+                ("noop_ring_len", _i32), ("envs_per_stream", _i32),
+                ("done_count", _vp), ("done_int", _vp), ("done_flt", _vp),
+                ("done_capacity", _i32)]
+
+
+class ArlRollout(C.Structure):
+    _fields_ = [("horizon", _i32), ("observations", _vp), ("rewards", _vp), ("dones", _vp),
+                ("raw_reward", _vp), ("need_reset", _vp), ("actions", _vp), ("prob", _vp),
+                ("value", _vp), ("step_obs", _vp)]
+
+
+class ArlOptState(C.Structure):
+    _fields_ = [("n_params", _i64), ("params", _vp), ("grads", _vp), ("slot0", _vp),
+                ("slot1", _vp), ("step_count", _vp), ("lr_mult", _vp), ("partials", _vp),
+                ("grad_norm_log", _vp), ("norm_log_len", _i32)]
+
+
+_SIGNATURES = {
+    "arl_abi_version": (_i32, []),
+    "arl_last_error": (C.c_char_p, []),
+    "arl_gae_scan": (_i32, [_vp, _vp, _vp, _vp, _f64, _f64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "arl_nstep_return": (_i32, [_vp, _vp, _vp, _vp, _f64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "arl_valids_mask": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "arl_standardize_workspace_bytes": (_i64, []),
+    "arl_standardize": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
+    "arl_sample_categorical": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "arl_env_act_step": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
+                                _vp, _vp, _vp, _vp, _i32, _i32, _f64, _f64, _vp]),
+    "arl_env_frame_step": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
+                                  _i32, _i32, _vp]),
+    "arl_env_reset": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
+                             _vp, _i32, _vp]),
+    "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "arl_gather_scale_obs": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the shared library.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libaccel_rl_hip.so is not built (%s).  Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `python accel_rl_amd/_build.py`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.arl_abi_version() != ARL_ABI_VERSION:
+        raise RuntimeError("libaccel_rl_hip.so ABI %d != binding %d" % (lib.arl_abi_version(), ARL_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().arl_last_error().decode(errors="replace")
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("accel_rl_amd kernels need device (HIP) tensors; got a %s tensor -- "
+                           "there is no CPU path" % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr(stream=None):
+    s = torch.cuda.current_stream() if stream is None else stream
+    return s.cuda_stream
+
+
+def _want(t, dtype, name):
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+
+
+# ---------------------------------------------------------------------------
+# thin typed wrappers (device tensors in, device tensors out)
+# ---------------------------------------------------------------------------
+
+def gae_scan(rewards, values, dones, last_values, discount, gae_lambda, n_env, horizon,
+             advantages, returns, promo=PROMO_NEP50, stream=None):
+    for t, n in ((rewards, "rewards"), (values, "values"), (last_values, "last_values"),
+                 (advantages, "advantages"), (returns, "returns")):
+        _want(t, torch.float32, n)
+    if dones.dtype not in (torch.uint8, torch.bool):
+        raise TypeError("dones must be uint8/bool")
+    assert rewards.numel() == values.numel() == dones.numel() == n_env * horizon
+    assert last_values.numel() == n_env and advantages.numel() == returns.numel() == n_env * horizon
+    _check(load().arl_gae_scan(ptr(rewards), ptr(values), ptr(dones), ptr(last_values),
+                               float(discount), float(gae_lambda), n_env, horizon, promo,
+                               ptr(advantages), ptr(returns), stream_ptr(stream)), "arl_gae_scan")
+
+
+def nstep_return(rewards, dones, values, last_values, discount, n_env, horizon,
+                 returns, advantages, promo=PROMO_NEP50, stream=None):
+    for t, n in ((rewards, "rewards"), (values, "values"), (last_values, "last_values"),
+                 (advantages, "advantages"), (returns, "returns")):
+        _want(t, torch.float32, n)
+    assert rewards.numel() == values.numel() == dones.numel() == n_env * horizon
+    assert last_values.numel() == n_env and advantages.numel() == returns.numel() == n_env * horizon
+    _check(load().arl_nstep_return(ptr(rewards), ptr(dones), ptr(values), ptr(last_values),
+                                   float(discount), n_env, horizon, promo, ptr(returns),
+                                   ptr(advantages), stream_ptr(stream)), "arl_nstep_return")
+
+
+def valids_mask(reset_flags, n_env, horizon, valids, advantages=None, returns=None, values=None,
+                stream=None):
+    _want(valids, torch.int8, "valids")
+    assert reset_flags.numel() == valids.numel() == n_env * horizon
+    _check(load().arl_valids_mask(ptr(reset_flags), n_env, horizon, ptr(valids), ptr(advantages),
+                                  ptr(returns), ptr(values), stream_ptr(stream)), "arl_valids_mask")
+
+
+def standardize_workspace(device):
+    return torch.empty(load().arl_standardize_workspace_bytes() // 8, dtype=torch.float64, device=device)
+
+
+def standardize(advantages, valids, workspace, eps=1e-6, stream=None):
+    _want(advantages, torch.float32, "advantages")
+    if valids is not None:
+        _want(valids, torch.int8, "valids")
+        assert valids.numel() == advantages.numel()
+    _check(load().arl_standardize(ptr(advantages), ptr(valids), advantages.numel(), float(eps),
+                                  ptr(workspace), stream_ptr(stream)), "arl_standardize")
+
+
+def sample_categorical(prob, uniforms, actions, stream=None):
+    _want(prob, torch.float32, "prob")
+    _want(uniforms, torch.float64, "uniforms")
+    _want(actions, torch.uint8, "actions")
+    batch, n_act = prob.shape
+    assert uniforms.numel() == batch and actions.numel() == batch
+    _check(load().arl_sample_categorical(ptr(prob), ptr(uniforms), batch, n_act, ptr(actions),
+                                         stream_ptr(stream)), "arl_sample_categorical")
+
+
+def preprocess_frames(raw_a, raw_b, out, stream=None):
+    _want(raw_b, torch.uint8, "raw_b")
+    n = raw_b.shape[0]
+    assert tuple(raw_b.shape[1:3]) == (RAW_H, RAW_W) and tuple(out.shape) == (n, OBS_H, OBS_W)
+    _check(load().arl_preprocess_frames(ptr(raw_a), ptr(raw_b), n, ptr(out), stream_ptr(stream)),
+           "arl_preprocess_frames")
+
+
+def gather_scale_obs(obs, idx, out, scale, stream=None):
+    _want(obs, torch.uint8, "obs")
+    _want(out, torch.float32, "out")
+    if idx is not None:
+        _want(idx, torch.int32, "idx")
+    batch = out.shape[0]
+    row_bytes = obs[0].numel()
+    assert out[0].numel() == row_bytes and (idx is None or idx.numel() == batch)
+    _check(load().arl_gather_scale_obs(ptr(obs), ptr(idx), batch, row_bytes, float(scale), ptr(out),
+                                       stream_ptr(stream)), "arl_gather_scale_obs")
+
+
+def env_act_step(game, state, rollout, prob, value, uniforms, step, mid_batch_reset,
+                 max_path_length, discount, active=None, stream=None):
+    _check(load().arl_env_act_step(C.byref(game), C.byref(state), C.byref(rollout), ptr(prob),
+                                   ptr(value), ptr(uniforms), ptr(active), step,
+                                   int(bool(mid_batch_reset)),
+                                   float(max_path_length), float(discount), stream_ptr(stream)),
+           "arl_env_act_step")
+
+
+def env_frame_step(game, state, rollout, step, max_start_noops, stream=None):
+    _check(load().arl_env_frame_step(C.byref(game), C.byref(state), C.byref(rollout), step,
+                                     int(max_start_noops), stream_ptr(stream)), "arl_env_frame_step")
+
+
+def env_reset(game, state, rollout, flags, max_start_noops, stream=None):
+    _check(load().arl_env_reset(C.byref(game), C.byref(state), C.byref(rollout), ptr(flags),
+                                int(max_start_noops), stream_ptr(stream)), "arl_env_reset")
+
+
+def opt_step(opt, method, learning_rate, avg_factor, clip, beta1_or_rho, beta2, epsilon, stream=None):
+    _check(load().arl_opt_step(C.byref(opt), method, learning_rate, avg_factor,
+                               0.0 if clip is None else clip, beta1_or_rho, beta2, epsilon,
+                               stream_ptr(stream)), "arl_opt_step")

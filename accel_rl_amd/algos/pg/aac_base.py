@@ -1,0 +1,124 @@
+"""Advantage actor-critic base: process_samples on the device + loss definitions.
+
+Reference: accel_rl/algos/pg/aac_base.py:15-177.  process_samples there is a
+Python double loop over envs and time calling numpy scalar code
+(algos/pg/util.py:6-63); here it is: one policy forward for the bootstrap values
+-> arl_gae_scan or arl_nstep_return -> (arl_valids_mask) -> (arl_standardize),
+all on the sampler's GPU, directly on the rollout buffer the sampler filled.
+The loss graph (aac_base.py:60-70) is torch autograd over the policy's forward.
+"""
+import torch
+
+from accel_rl_amd import _lib
+from accel_rl_amd.algos.base import RLAlgorithm
+from accel_rl_amd.buffers import buffer_with_segs_view
+from accel_rl_amd.util.quick_args import save_args
+import numpy as np
+
+LR_SCHEDULES = ["linear"]
+
+
+def valids_mean(expression, valids=None):
+    """reference: algos/pg/util.py:49-53"""
+    if valids is None:
+        return expression.mean()
+    v = valids.to(expression.dtype)
+    return torch.sum(v * expression) * (1. / torch.sum(v))
+
+
+class AdvActorCriticBase(RLAlgorithm):
+
+    def __init__(self, discount, gae_lambda, v_loss_coeff=1, ent_loss_coeff=0.01,
+                 standardize_adv=False, lr_schedule=None, promo="nep50"):
+        if lr_schedule is not None and lr_schedule not in LR_SCHEDULES:
+            raise ValueError("Unrecognized lr_schedule: {}, should be None (for constant) or "
+                             "in: {}".format(lr_schedule, LR_SCHEDULES))
+        save_args(vars(), underscore=False)
+        self.need_extra_obs = True          # (signal sent to the sampler)
+        self._promo = dict(nep50=_lib.PROMO_NEP50, legacy=_lib.PROMO_LEGACY)[promo]
+
+    def initialize(self, policy, env_spec, sample_size, horizon, mid_batch_reset):
+        if mid_batch_reset and policy.recurrent:
+            raise NotImplementedError
+        dev = policy.device
+        self.policy = policy
+        self._lr_mult = torch.ones(1, dtype=torch.float32, device=dev)
+        self._use_valids = not (mid_batch_reset and not policy.recurrent)   # aac_base.py:53-58
+        self._dist_info_keys = policy.distribution.dist_info_keys
+        input_names = ["observations", "actions", "advantages", "returns", "old_value"]
+        input_names += ["old_%s" % k for k in self._dist_info_keys]
+        opt_examples = dict(advantages=np.float32(1), returns=np.float32(1))
+        if self._use_valids:
+            input_names.append("valids")
+            opt_examples["valids"] = np.int8(1)
+        self.optimizer.initialize(inputs=input_names, losses=self._losses, constraints=None,
+                                  target=policy, lr_mult=self._lr_mult)
+        self._opt_buf = buffer_with_segs_view(opt_examples, sample_size, horizon, dev)
+        self._batch_size = sample_size
+        self._mid_batch_reset = mid_batch_reset
+        self._horizon = horizon
+        self._n_env = sample_size // horizon
+        self._std_ws = _lib.standardize_workspace(dev)
+
+    def set_n_itr(self, n_itr):
+        self.n_itr = n_itr
+
+    def optimize_policy(self, itr, samples_data):
+        opt_data = self.process_samples(itr, samples_data)
+        opt_input_values = self.prep_opt_inputs(itr, samples_data, opt_data)
+        _, grad_norm = self.optimizer.optimize(opt_input_values)
+        return opt_data, dict(GradNorm=grad_norm)
+
+    def process_samples(self, itr, samples_data):
+        """reference: aac_base.py:108-145"""
+        n, t = self._n_env, self._horizon
+        opt = self._opt_buf
+        last_values = self.policy.value(samples_data["extra_observations"]).contiguous()   # :112
+        r, d = samples_data["rewards"], samples_data["dones"]
+        v = samples_data["agent_infos"]["value"]
+        if self.gae_lambda == 1:                                    # :115-121
+            _lib.nstep_return(r, d, v, last_values, self.discount, n, t,
+                              opt["returns"], opt["advantages"], promo=self._promo)
+        else:                                                        # :122-127
+            _lib.gae_scan(r, v, d, last_values, self.discount, self.gae_lambda, n, t,
+                          opt["advantages"], opt["returns"], promo=self._promo)
+        valids = None
+        if self._use_valids:                                         # :129-134
+            flags = samples_data["env_infos"].get("need_reset", d)
+            _lib.valids_mask(flags, n, t, opt["valids"], opt["advantages"], opt["returns"], v)
+            valids = opt["valids"]
+        if self.standardize_adv:                                     # :136-143
+            _lib.standardize(opt["advantages"], valids, self._std_ws, 1e-6)
+        return opt
+
+    def prep_opt_inputs(self, itr, samples_data, opt_data):
+        """reference: aac_base.py:147-170"""
+        agent_infos = samples_data["agent_infos"]
+        values = (samples_data["observations"], samples_data["actions"], opt_data["advantages"],
+                  opt_data["returns"], agent_infos["value"])
+        values += tuple(agent_infos[k] for k in self._dist_info_keys)
+        if self._use_valids:
+            values += (opt_data["valids"],)
+        if self.lr_schedule == "linear":
+            self._lr_mult.fill_(max((self.n_itr - itr) / self.n_itr, 0.))
+        return values
+
+    # ---- loss graph (aac_base.py:60-70) ---------------------------------------
+    def _losses(self, mb):
+        policy = self.policy
+        new_dist_info, new_value = policy.dist_info_value_sym(mb["observations"], mb.get("idx"))
+        valids = mb.get("valids")
+        old_dist_info = {k: mb["old_%s" % k] for k in self._dist_info_keys}
+        v_loss = self.v_loss_coeff * valids_mean((new_value - mb["returns"]) ** 2, valids)
+        ent = policy.distribution.entropy_sym(new_dist_info)
+        ent_loss = - self.ent_loss_coeff * valids_mean(ent, valids)
+        pi_loss = self.pi_loss(policy, mb["actions"], mb["advantages"], old_dist_info,
+                               new_dist_info, valids)
+        return pi_loss, v_loss, ent_loss
+
+    def pi_loss(self, policy, act, adv, old_dist_info, new_dist_info, valids):
+        raise NotImplementedError
+
+    @property
+    def opt_info_keys(self):
+        return ["GradNorm"]

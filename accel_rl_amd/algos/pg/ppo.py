@@ -1,0 +1,43 @@
+"""PPO (reference: accel_rl/algos/pg/ppo.py:11-67): defaults lr 1e-3, adam(eps 1e-5),
+4 epochs, minibatch 512, no grad clip, shuffle, gamma 0.99, lambda 0.95,
+clip 0.2 * lr_mult, v_loss_coeff 1."""
+import torch
+
+from accel_rl_amd.algos.pg.aac_base import AdvActorCriticBase, valids_mean
+from accel_rl_amd.optimizers import update_methods
+from accel_rl_amd.optimizers.single import PpoOptimizer
+from accel_rl_amd.optimizers.sync import SyncPpoOptimizer
+
+
+class BasePPO(AdvActorCriticBase):
+
+    def __init__(self, OptimizerCls, optimizer_args=None, discount=0.99, gae_lambda=0.95,
+                 clip_param=0.2, **kwargs):
+        args = dict(num_slices=1, learning_rate=1e-3, epochs=4, minibatch_size=64 * 8,
+                    update_method=update_methods.adam, update_method_args=dict(epsilon=1e-5),
+                    grad_norm_clip=None, shuffle=True)
+        args.update(optimizer_args or dict())
+        self.optimizer = OptimizerCls(**args)
+        self.clip_param = clip_param
+        super().__init__(discount=discount, gae_lambda=gae_lambda, **kwargs)
+
+    def pi_loss(self, policy, act, adv, old_dist_info, new_dist_info, valids):
+        ratio = policy.distribution.likelihood_ratio_sym(act, old_dist_info, new_dist_info)
+        clip = self.clip_param * self._lr_mult                 # ppo.py:46 (anneals with lr)
+        surr_1 = ratio * adv
+        surr_2 = torch.minimum(torch.maximum(ratio, 1. - clip), 1. + clip) * adv
+        return - valids_mean(torch.minimum(surr_1, surr_2), valids)
+
+
+class PPO(BasePPO):
+    """Single GPU"""
+
+    def __init__(self, OptimizerCls=PpoOptimizer, **kwargs):
+        super().__init__(OptimizerCls=OptimizerCls, **kwargs)
+
+
+class mPPO(BasePPO):
+    """Multi-GPU synchronous"""
+
+    def __init__(self, OptimizerCls=SyncPpoOptimizer, **kwargs):
+        super().__init__(OptimizerCls=OptimizerCls, **kwargs)

@@ -1,0 +1,168 @@
+// Flat-bucket optimiser step for gfx950: one fp32 vector holds every trainable
+// parameter (the same flat vector the reference all-reduces,
+// accel_rl/optimizers/util.py:35-39), so averaging, global-norm clipping and the
+// adam / rmsprop update are two streaming launches over P floats instead of a
+// per-tensor kernel zoo.
+//
+//   launch 1  sumsq_kernel   : partial sums of g^2 in f64 (fixed order => deterministic)
+//   launch 2  update_kernel  : every block folds the partials, derives
+//                              norm / clip scale / a_t, then streams p, g, m, v.
+//
+// Replaces (reference root): optimizers/util.py:63-76 (avg_grads_from_flat,
+// apply_grad_norm_clip -> lasagne total_norm_constraint), the lasagne update
+// restated in optimizers/update_methods_stats.py:11-33 (rmsprop) / :55-87 (adam),
+// call order of optimizers/sync/sync_ppo_optimizer.py:27-34.
+// Bound: HBM (adam: read p,g,m,v + write p,m,v = 28 B/param; + 4 B/param for the norm).
+
+#include "arl_common.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+__device__ __forceinline__ double block_sum_d(double x, double* lds) {
+    x = wave_sum_d(x);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) lds[w] = x;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0;
+        for (int i = 0; i < nw; ++i) s += lds[i];
+        lds[0] = s;
+    }
+    __syncthreads();
+    const double r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n,
+                                                    double* __restrict__ partials,
+                                                    float* __restrict__ step_count) {
+    __shared__ double lds[8];
+    double s = 0;
+    const int64_t n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = g4[i];
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float v = g[(n4 << 2) + threadIdx.x];
+        s += (double)v * v;
+    }
+    s = block_sum_d(s, lds);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = s;
+        if (blockIdx.x == 0) step_count[0] += 1.0f;       // t = t_prev + 1 (update_methods_stats.py:66)
+    }
+}
+
+template <int METHOD>
+__device__ __forceinline__ void update_one(float& p, float g, float& s0, float& s1, float avg,
+                                           float cscale, float lr, float a_t, float b1, float b2,
+                                           float eps) {
+    const float gg = (g * avg) * cscale;                     // util.py:66, then total_norm_constraint
+    if (METHOD == ARL_OPT_ADAM) {
+        const float m = b1 * s0 + (1.f - b1) * gg;          // :76
+        const float v = b2 * s1 + (1.f - b2) * (gg * gg);    // :77
+        const float step = a_t * m / (sqrtf(v) + eps);       // :78
+        s0 = m; s1 = v;
+        p = p - step;
+    } else {
+        const float acc = b1 * s0 + (1.f - b1) * (gg * gg);  // :24 (rho = b1)
+        const float step = lr * gg / sqrtf(acc + eps);       // :28
+        s0 = acc;
+        p = p - step;
+    }
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(256) void update_kernel(arl_opt_state o, int n_partials, float lr_base,
+                                                     float avg, float clip, float b1, float b2,
+                                                     float eps) {
+    __shared__ double lds[8];
+    double s = 0;
+    for (int i = threadIdx.x; i < n_partials; i += blockDim.x) s += o.partials[i];
+    s = block_sum_d(s, lds);
+    // norm of the AVERAGED gradient (sync_ppo_optimizer.py:28-32: avg, then norm/clip)
+    const float norm = avg * (float)sqrt(s);
+    float cscale = 1.f;
+    if (clip > 0.f) {
+        const float target = fminf(fmaxf(norm, 0.f), clip);  // lasagne total_norm_constraint
+        cscale = target / (1e-7f + norm);
+    }
+    const float t = o.step_count[0];
+    const float lr = lr_base * o.lr_mult[0];
+    float a_t = 0.f;
+    if (METHOD == ARL_OPT_ADAM)
+        a_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));   // :67
+    if (blockIdx.x == 0 && threadIdx.x == 0 && o.grad_norm_log) {
+        const int k = ((int)t - 1) % o.norm_log_len;
+        o.grad_norm_log[k < 0 ? 0 : k] = norm;
+    }
+    const int64_t n = o.n_params, n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float4* p4 = reinterpret_cast<float4*>(o.params);
+    const float4* g4 = reinterpret_cast<const float4*>(o.grads);
+    float4* m4 = reinterpret_cast<float4*>(o.slot0);
+    float4* v4 = reinterpret_cast<float4*>(o.slot1);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 p = p4[i];
+        const float4 g = g4[i];
+        float4 m = m4[i];
+        float4 v = (METHOD == ARL_OPT_ADAM) ? v4[i] : make_float4(0, 0, 0, 0);
+        update_one<METHOD>(p.x, g.x, m.x, v.x, avg, cscale, lr, a_t, b1, b2, eps);
+        update_one<METHOD>(p.y, g.y, m.y, v.y, avg, cscale, lr, a_t, b1, b2, eps);
+        update_one<METHOD>(p.z, g.z, m.z, v.z, avg, cscale, lr, a_t, b1, b2, eps);
+        update_one<METHOD>(p.w, g.w, m.w, v.w, avg, cscale, lr, a_t, b1, b2, eps);
+        p4[i] = p;
+        m4[i] = m;
+        if (METHOD == ARL_OPT_ADAM) v4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        float p = o.params[i], m = o.slot0[i], v = (METHOD == ARL_OPT_ADAM) ? o.slot1[i] : 0.f;
+        update_one<METHOD>(p, o.grads[i], m, v, avg, cscale, lr, a_t, b1, b2, eps);
+        o.params[i] = p;
+        o.slot0[i] = m;
+        if (METHOD == ARL_OPT_ADAM) o.slot1[i] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int arl_opt_step(const arl_opt_state* opt, int32_t method, float learning_rate,
+                            float avg_factor, float clip, float beta1_or_rho, float beta2,
+                            float epsilon, void* stream) {
+    ARL_REQUIRE(opt, ARL_E_ARG, "null state");
+    ARL_REQUIRE(opt->params && opt->grads && opt->slot0 && opt->step_count && opt->lr_mult &&
+                    opt->partials, ARL_E_ARG, "null pointer in state");
+    ARL_REQUIRE(method == ARL_OPT_ADAM || method == ARL_OPT_RMSPROP, ARL_E_ARG, "unknown method");
+    ARL_REQUIRE(method != ARL_OPT_ADAM || opt->slot1, ARL_E_ARG, "adam needs slot1");
+    ARL_REQUIRE(opt->n_params > 0, ARL_E_ARG, "n_params <= 0");
+    ARL_REQUIRE(!opt->grad_norm_log || opt->norm_log_len > 0, ARL_E_ARG, "norm_log_len <= 0");
+    ARL_REQUIRE(arl::aligned16(opt->params) && arl::aligned16(opt->grads) && arl::aligned16(opt->slot0) &&
+                    (!opt->slot1 || arl::aligned16(opt->slot1)), ARL_E_ALIGN, "flat buffers must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t nb = ((opt->n_params >> 2) + 255) / 256;
+    if (nb < 1) nb = 1;
+    if (nb > ARL_OPT_PARTIALS) nb = ARL_OPT_PARTIALS;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)nb), dim3(256), 0, s, opt->grads, opt->n_params,
+                       opt->partials, opt->step_count);
+    int rc = arl::check_launch("sumsq_kernel");
+    if (rc) return rc;
+    const unsigned grid = arl::stream_grid(opt->n_params >> 2, 256);
+    if (method == ARL_OPT_ADAM)
+        hipLaunchKernelGGL((update_kernel<ARL_OPT_ADAM>), dim3(grid), dim3(256), 0, s, *opt, (int)nb,
+                           learning_rate, avg_factor, clip, beta1_or_rho, beta2, epsilon);
+    else
+        hipLaunchKernelGGL((update_kernel<ARL_OPT_RMSPROP>), dim3(grid), dim3(256), 0, s, *opt, (int)nb,
+                           learning_rate, avg_factor, clip, beta1_or_rho, beta2, epsilon);
+    return arl::check_launch("update_kernel");
+}

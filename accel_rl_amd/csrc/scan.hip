@@ -1,0 +1,293 @@
+// Return / advantage scans for gfx950 (MI355X).
+//
+//   arl_gae_scan      <- gen_adv_est      accel_rl/algos/pg/util.py:6-23
+//   arl_nstep_return  <- discount_returns accel_rl/algos/pg/util.py:26-37 (+ aac_base.py:121)
+//   arl_valids_mask   <- update_valids / zero_after_reset  util.py:40-63
+//
+// The batch is env-major ([n_env][horizon], horizon = 5 in every reference
+// config), so one env's segment is `horizon` consecutive floats.  The scan is a
+// reverse-time recurrence that is independent across envs and must follow the
+// reference's rounding order, so the short-horizon kernel keeps it sequential:
+// one lane per env.  What would otherwise be a 20-byte-stride access pattern is
+// staged through LDS: a workgroup copies its tile of EPB*horizon contiguous
+// elements with 16-byte coalesced global loads into LDS, lanes then walk their
+// own segment in LDS (stride `horizon` words; a +1-word skew per 32 words makes
+// even horizons bank-conflict free), results go back through the same LDS tile
+// and leave as 16-byte coalesced stores.  HBM traffic is exactly the algorithmic
+// 17 B per (env, t) + 4 B per env.  Bound: HBM bandwidth.
+//
+// This file is compiled with -ffp-contract=off: the dtype walk below reproduces
+// numpy's (unfused) arithmetic bit for bit.
+
+#include "arl_common.h"
+
+namespace {
+
+__device__ __forceinline__ int skewed(int idx, int skew_mask) {
+    return idx + ((idx >> 5) & skew_mask);
+}
+
+// One lane's reverse scan over its segment held in LDS.  out0/out1 overwrite
+// the r/v tiles in place: GAE -> (adv, ret); NSTEP -> (ret, adv).
+template <bool NSTEP, int PROMO>
+__device__ __forceinline__ void lane_scan_lds(float* sr, float* sv, const uint8_t* sd,
+                                              int lane_env, int T, int skew_mask,
+                                              float last_v, double gamma, double gl) {
+    const float g32 = (float)gamma;
+    if (NSTEP) {
+        if (PROMO == ARL_PROMO_NEP50) {
+            float run = last_v;                       // util.py:29, np.float32 scalar
+            for (int t = T - 1; t >= 0; --t) {
+                const int idx = lane_env * T + t;
+                const int p = skewed(idx, skew_mask);
+                const float rr = sr[p], vv = sv[p];
+                run = sd[idx] ? rr : (run * g32) + rr; // util.py:31-35 (f32 *=, +=)
+                sr[p] = run;
+                sv[p] = run - vv;                     // aac_base.py:121
+            }
+        } else {
+            double run = (double)last_v;
+            for (int t = T - 1; t >= 0; --t) {
+                const int idx = lane_env * T + t;
+                const int p = skewed(idx, skew_mask);
+                const float rr = sr[p], vv = sv[p];
+                run = sd[idx] ? (double)rr : (run * gamma) + (double)rr;
+                const float ret = (float)run;
+                sr[p] = ret;
+                sv[p] = ret - vv;
+            }
+        }
+    } else {
+        double carry = 0.0;                           // util.py:13
+        float v_next = last_v;                        // util.py:9
+        for (int t = T - 1; t >= 0; --t) {
+            const int idx = lane_env * T + t;
+            const int p = skewed(idx, skew_mask);
+            const float rr = sr[p], vv = sv[p];
+            const double nd = sd[idx] ? 0.0 : 1.0;    // util.py:8 (int64 -> f64)
+            const double gv = (PROMO == ARL_PROMO_NEP50) ? (double)(g32 * v_next)
+                                                         : gamma * (double)v_next;
+            const double delta = ((double)rr + gv * nd) - (double)vv;   // util.py:15
+            carry = delta + (gl * nd) * carry;                          // util.py:16-17
+            const float a = (float)carry;
+            sr[p] = a;
+            sv[p] = a + vv;                                             // util.py:21
+            v_next = vv;
+        }
+    }
+}
+
+// EPB envs per workgroup, EPB threads.  Requires 16-byte aligned r/v/out and
+// 4-byte aligned dones (checked by the host wrapper).
+template <bool NSTEP, int PROMO, int EPB>
+__global__ __launch_bounds__(EPB) void scan_lds_kernel(
+    const float* __restrict__ r, const float* __restrict__ v, const uint8_t* __restrict__ d,
+    const float* __restrict__ lv, double gamma, double gl, int64_t n_env, int T,
+    int skew_mask, int cap, float* __restrict__ out0, float* __restrict__ out1) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sr = reinterpret_cast<float*>(smem);
+    float* sv = sr + cap;
+    uint8_t* sd = reinterpret_cast<uint8_t*>(sv + cap);
+    const int tid = threadIdx.x;
+    const int64_t n_tiles = (n_env + EPB - 1) / EPB;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t e0 = tile * EPB;
+        const int n_here = (int)((n_env - e0) < EPB ? (n_env - e0) : EPB);
+        const int elems = n_here * T;
+        const int64_t base = e0 * T;
+        const float4* gr4 = reinterpret_cast<const float4*>(r + base);
+        const float4* gv4 = reinterpret_cast<const float4*>(v + base);
+        const uint32_t* gd4 = reinterpret_cast<const uint32_t*>(d + base);
+        const int nq = elems >> 2;
+        // prefetch this lane's bootstrap value while the tile streams in
+        const float last_v = (tid < n_here) ? lv[e0 + tid] : 0.f;
+
+        for (int q = tid; q < nq; q += EPB) {
+            const float4 a = gr4[q];
+            const float4 b = gv4[q];
+            const uint32_t dd = gd4[q];
+            const int p = skewed(q << 2, skew_mask);   // 4 elems never straddle a 32-group
+            sr[p] = a.x; sr[p + 1] = a.y; sr[p + 2] = a.z; sr[p + 3] = a.w;
+            sv[p] = b.x; sv[p + 1] = b.y; sv[p + 2] = b.z; sv[p + 3] = b.w;
+            *reinterpret_cast<uint32_t*>(sd + (q << 2)) = dd;
+        }
+        for (int i = (nq << 2) + tid; i < elems; i += EPB) {
+            const int p = skewed(i, skew_mask);
+            sr[p] = r[base + i];
+            sv[p] = v[base + i];
+            sd[i] = d[base + i];
+        }
+        __syncthreads();
+
+        if (tid < n_here)
+            lane_scan_lds<NSTEP, PROMO>(sr, sv, sd, tid, T, skew_mask, last_v, gamma, gl);
+        __syncthreads();
+
+        float4* go0 = reinterpret_cast<float4*>(out0 + base);
+        float4* go1 = reinterpret_cast<float4*>(out1 + base);
+        for (int q = tid; q < nq; q += EPB) {
+            const int p = skewed(q << 2, skew_mask);
+            go0[q] = make_float4(sr[p], sr[p + 1], sr[p + 2], sr[p + 3]);
+            go1[q] = make_float4(sv[p], sv[p + 1], sv[p + 2], sv[p + 3]);
+        }
+        for (int i = (nq << 2) + tid; i < elems; i += EPB) {
+            const int p = skewed(i, skew_mask);
+            out0[base + i] = sr[p];
+            out1[base + i] = sv[p];
+        }
+        __syncthreads();   // tile reuse
+    }
+}
+
+// Any horizon, any alignment: one lane per env straight on global memory.
+template <bool NSTEP, int PROMO>
+__global__ __launch_bounds__(256) void scan_direct_kernel(
+    const float* __restrict__ r, const float* __restrict__ v, const uint8_t* __restrict__ d,
+    const float* __restrict__ lv, double gamma, double gl, int64_t n_env, int T,
+    float* __restrict__ out0, float* __restrict__ out1) {
+    const float g32 = (float)gamma;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_env;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = e * T;
+        if (NSTEP) {
+            if (PROMO == ARL_PROMO_NEP50) {
+                float run = lv[e];
+                for (int t = T - 1; t >= 0; --t) {
+                    const float rr = r[base + t];
+                    run = d[base + t] ? rr : (run * g32) + rr;
+                    out0[base + t] = run;
+                    out1[base + t] = run - v[base + t];
+                }
+            } else {
+                double run = (double)lv[e];
+                for (int t = T - 1; t >= 0; --t) {
+                    const float rr = r[base + t];
+                    run = d[base + t] ? (double)rr : (run * gamma) + (double)rr;
+                    const float ret = (float)run;
+                    out0[base + t] = ret;
+                    out1[base + t] = ret - v[base + t];
+                }
+            }
+        } else {
+            double carry = 0.0;
+            float v_next = lv[e];
+            for (int t = T - 1; t >= 0; --t) {
+                const float rr = r[base + t], vv = v[base + t];
+                const double nd = d[base + t] ? 0.0 : 1.0;
+                const double gv = (PROMO == ARL_PROMO_NEP50) ? (double)(g32 * v_next)
+                                                             : gamma * (double)v_next;
+                const double delta = ((double)rr + gv * nd) - (double)vv;
+                carry = delta + (gl * nd) * carry;
+                const float a = (float)carry;
+                out0[base + t] = a;
+                out1[base + t] = a + vv;
+                v_next = vv;
+            }
+        }
+    }
+}
+
+// valids[e,t] = (t <= first set flag); zero adv/ret/value past it.
+__global__ __launch_bounds__(256) void valids_kernel(
+    const uint8_t* __restrict__ flags, int64_t n_env, int T, int8_t* __restrict__ valids,
+    float* __restrict__ adv, float* __restrict__ ret, float* __restrict__ val) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_env;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t base = e * T;
+        bool ok = true;                       // util.py:58-63
+        for (int t = 0; t < T; ++t) {
+            valids[base + t] = ok ? 1 : 0;
+            if (!ok) {                        // util.py:44-46
+                if (adv) adv[base + t] = 0.f;
+                if (ret) ret[base + t] = 0.f;
+                if (val) val[base + t] = 0.f;
+            }
+            if (flags[base + t]) ok = false;
+        }
+    }
+}
+
+template <bool NSTEP, int PROMO, int EPB>
+int launch_lds(const float* r, const float* v, const uint8_t* d, const float* lv, double gamma,
+               double gl, int64_t n_env, int T, float* o0, float* o1, hipStream_t s) {
+    const int skew_mask = (T & 1) ? 0 : ~0;
+    const int raw = EPB * T;
+    const int cap = ((raw + (raw >> 5) + 4) + 3) & ~3;       // floats, 16-B multiple
+    const size_t lds = (size_t)cap * 8 + (size_t)raw + 16;
+    const int64_t tiles = (n_env + EPB - 1) / EPB;
+    const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
+    hipLaunchKernelGGL((scan_lds_kernel<NSTEP, PROMO, EPB>), dim3(grid), dim3(EPB), lds, s, r, v,
+                       d, lv, gamma, gl, n_env, T, skew_mask, cap, o0, o1);
+    return arl::check_launch("scan_lds_kernel");
+}
+
+template <bool NSTEP, int PROMO>
+int dispatch(const float* r, const float* v, const uint8_t* d, const float* lv, double gamma,
+             double gl, int64_t n_env, int T, float* o0, float* o1, hipStream_t s) {
+    const bool vec_ok = arl::aligned16(r) && arl::aligned16(v) && arl::aligned16(o0) &&
+                        arl::aligned16(o1) && arl::aligned4(d);
+    // Tile = EPB envs.  LDS per tile ~ 9.3 * EPB * T bytes: cap it near 20 KB so 8
+    // workgroups stay resident per CU; for small batches prefer narrower tiles so the
+    // launch still spreads over many CUs (a 256-env batch = 4 x 64-env tiles).
+    if (vec_ok && T <= 34) {
+        int epb = (T <= 8) ? 256 : (T <= 17 ? 128 : 64);
+        while (epb > 64 && (n_env + epb - 1) / epb < 512) epb >>= 1;
+        if (epb == 256) return launch_lds<NSTEP, PROMO, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
+        if (epb == 128) return launch_lds<NSTEP, PROMO, 128>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
+        return launch_lds<NSTEP, PROMO, 64>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
+    }
+    hipLaunchKernelGGL((scan_direct_kernel<NSTEP, PROMO>), dim3(arl::stream_grid(n_env, 256)),
+                       dim3(256), 0, s, r, v, d, lv, gamma, gl, n_env, T, o0, o1);
+    return arl::check_launch("scan_direct_kernel");
+}
+
+int check_scan_args(const void* a, const void* b, const void* c, const void* d, const void* e,
+                    const void* f, int64_t n_env, int32_t T, int32_t promo) {
+    if (!a || !b || !c || !d || !e || !f) { arl::set_error("scan: null pointer"); return ARL_E_ARG; }
+    if (n_env < 0 || T <= 0) { arl::set_error("scan: bad n_env/horizon"); return ARL_E_ARG; }
+    if (n_env * (int64_t)T > ((int64_t)1 << 40)) { arl::set_error("scan: too large"); return ARL_E_RANGE; }
+    if (promo != ARL_PROMO_NEP50 && promo != ARL_PROMO_LEGACY) { arl::set_error("scan: bad promo"); return ARL_E_ARG; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int arl_gae_scan(const float* rewards, const float* values, const uint8_t* dones,
+                            const float* last_values, double discount, double gae_lambda,
+                            int64_t n_env, int32_t horizon, int32_t promo, float* advantages,
+                            float* returns, void* stream) {
+    int rc = check_scan_args(rewards, values, dones, last_values, advantages, returns, n_env, horizon, promo);
+    if (rc) return rc;
+    if (n_env == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const double gl = discount * gae_lambda;          // util.py:17, python floats
+    if (promo == ARL_PROMO_NEP50)
+        return dispatch<false, ARL_PROMO_NEP50>(rewards, values, dones, last_values, discount, gl, n_env, horizon, advantages, returns, s);
+    return dispatch<false, ARL_PROMO_LEGACY>(rewards, values, dones, last_values, discount, gl, n_env, horizon, advantages, returns, s);
+}
+
+extern "C" int arl_nstep_return(const float* rewards, const uint8_t* dones, const float* values,
+                                const float* last_values, double discount, int64_t n_env,
+                                int32_t horizon, int32_t promo, float* returns, float* advantages,
+                                void* stream) {
+    int rc = check_scan_args(rewards, values, dones, last_values, advantages, returns, n_env, horizon, promo);
+    if (rc) return rc;
+    if (n_env == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (promo == ARL_PROMO_NEP50)
+        return dispatch<true, ARL_PROMO_NEP50>(rewards, values, dones, last_values, discount, 0.0, n_env, horizon, returns, advantages, s);
+    return dispatch<true, ARL_PROMO_LEGACY>(rewards, values, dones, last_values, discount, 0.0, n_env, horizon, returns, advantages, s);
+}
+
+extern "C" int arl_valids_mask(const uint8_t* reset_flags, int64_t n_env, int32_t horizon,
+                               int8_t* valids, float* advantages, float* returns, float* values,
+                               void* stream) {
+    ARL_REQUIRE(reset_flags && valids, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(n_env >= 0 && horizon > 0, ARL_E_ARG, "bad n_env/horizon");
+    if (n_env == 0) return 0;
+    hipLaunchKernelGGL(valids_kernel, dim3(arl::stream_grid(n_env, 256)), dim3(256), 0,
+                       (hipStream_t)stream, reset_flags, n_env, (int)horizon, valids, advantages,
+                       returns, values);
+    return arl::check_launch("valids_kernel");
+}

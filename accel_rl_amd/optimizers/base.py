@@ -1,0 +1,91 @@
+"""Optimizer interface (reference: accel_rl/optimizers/base.py:3-13) and the
+shared flat-bucket machinery.
+
+`initialize(inputs, losses, constraints, target, givens=None, lr_mult=1)` keeps
+the reference's argument names.  With Theano gone, `inputs` is the list of input
+NAMES (tuple order of prep_opt_inputs, aac_base.py:147-170) and `losses` is a
+callable `losses(minibatch: dict) -> (pi_loss, v_loss, ent_loss)` built by the
+algorithm from the policy's autograd forward; `target` is the policy;
+`lr_mult` a 1-element device tensor (the linear schedule writes it)."""
+import numpy as np
+import torch
+
+from accel_rl_amd import _lib
+
+NORM_LOG_LEN = 64
+
+
+def iterate_mb_idxs(batch_size, data_length, shuffle=False):
+    """Minibatch index arrays; one fresh host permutation per call, tail dropped
+    (reference: accel_rl/optimizers/util.py:8-18)."""
+    if shuffle:
+        order = np.arange(data_length)
+        np.random.shuffle(order)
+    for lo in range(0, data_length - batch_size + 1, batch_size):
+        yield order[lo:lo + batch_size] if shuffle else np.arange(lo, lo + batch_size)
+
+
+class BaseOptimizer(object):
+
+    def initialize(self, inputs, losses, constraints, target, givens=None, lr_mult=1):
+        raise NotImplementedError
+
+    def optimize(self, inputs):
+        raise NotImplementedError
+
+    @property
+    def parallelism_tag(self):
+        raise NotImplementedError
+
+    # ---- shared: flat bucket + HIP update ------------------------------------
+    def _setup_bucket(self, target, lr_mult):
+        self._target = target
+        dev = target.device
+        n = target.flat_params.numel()
+        self._slot0 = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._slot1 = torch.zeros(n, dtype=torch.float32, device=dev) \
+            if self._update_method.name == "adam" else None
+        self._step_count = torch.zeros(1, dtype=torch.float32, device=dev)
+        if not isinstance(lr_mult, torch.Tensor):
+            lr_mult = torch.full((1,), float(lr_mult), dtype=torch.float32, device=dev)
+        self._lr_mult = lr_mult
+        self._partials = torch.zeros(_lib.OPT_PARTIALS, dtype=torch.float64, device=dev)
+        self._norm_log = torch.zeros(NORM_LOG_LEN, dtype=torch.float32, device=dev)
+        self._n_updates = 0
+        st = _lib.ArlOptState()
+        st.n_params = n
+        st.params, st.grads = target.flat_params.data_ptr(), target.flat_grads.data_ptr()
+        st.slot0 = self._slot0.data_ptr()
+        st.slot1 = self._slot1.data_ptr() if self._slot1 is not None else None
+        st.step_count, st.lr_mult = self._step_count.data_ptr(), self._lr_mult.data_ptr()
+        st.partials, st.grad_norm_log = self._partials.data_ptr(), self._norm_log.data_ptr()
+        st.norm_log_len = NORM_LOG_LEN
+        self._opt_state = st
+        a = self._update_args
+        if self._update_method.name == "adam":
+            self._kernel_args = (a["beta1"], a["beta2"], a["epsilon"])
+        else:
+            self._kernel_args = (a["rho"], 0.0, a["epsilon"])
+
+    def _backward(self, losses, minibatch):
+        """Gradient of the summed loss into the flat gradient bucket."""
+        self._target.flat_grads.zero_()
+        loss = sum(losses(minibatch))
+        loss.backward()
+        return loss.detach()
+
+    def _apply_update(self, avg_factor=1.0):
+        """(avg) -> global norm (-> clip) -> adam/rmsprop: two HIP launches."""
+        b1, b2, eps = self._kernel_args
+        _lib.opt_step(self._opt_state, self._update_method.kernel_id, self._learning_rate,
+                      avg_factor, self._grad_norm_clip, b1, b2, eps)
+        self._n_updates += 1
+
+    def _recent_grad_norms(self, count):
+        """Device tensor [count] with the global grad norms of the last `count` updates
+        (the update kernel logs them into a ring; no host sync here)."""
+        assert 0 < count <= NORM_LOG_LEN
+        first = (self._n_updates - count) % NORM_LOG_LEN
+        if first + count <= NORM_LOG_LEN:
+            return self._norm_log[first:first + count].clone()
+        return torch.cat([self._norm_log[first:], self._norm_log[:first + count - NORM_LOG_LEN]])

@@ -1,0 +1,98 @@
+"""Single-GPU optimizers (reference: accel_rl/optimizers/single/a2c_optimizer.py:11-50,
+single/ppo_optimizer.py:11-75)."""
+import numpy as np
+import torch
+
+from accel_rl_amd.optimizers.base import BaseOptimizer, iterate_mb_idxs
+
+
+class A2cOptimizer(BaseOptimizer):
+    """One gradient step on the whole batch."""
+
+    def __init__(self, learning_rate, update_method, update_method_args=None, grad_norm_clip=None):
+        self._learning_rate = learning_rate
+        self._update_method = update_method
+        self._update_args = update_method.resolve(**(update_method_args or dict()))
+        self._grad_norm_clip = grad_norm_clip
+
+    def initialize(self, inputs, losses, constraints, target, givens=None, lr_mult=1):
+        self._input_names = list(inputs)
+        self._losses = losses
+        self._setup_bucket(target, lr_mult)
+
+    def optimize(self, inputs):
+        minibatch = dict(zip(self._input_names, inputs))
+        minibatch["idx"] = None
+        loss = self._backward(self._losses, minibatch)
+        self._share_grad()
+        self._apply_update(self._avg_factor())
+        return loss, self._recent_grad_norms(1)
+
+    def _share_grad(self):
+        pass
+
+    def _avg_factor(self):
+        return 1.0
+
+    @property
+    def parallelism_tag(self):
+        return "single"
+
+
+class PpoOptimizer(BaseOptimizer):
+    """epochs x minibatches over a batch that stays resident in HBM; minibatch rows
+    are selected by host-shuffled index vectors (np.random.shuffle, one
+    permutation per epoch, tail dropped -- optimizers/util.py:8-18)."""
+
+    def __init__(self, learning_rate, update_method, update_method_args, epochs, minibatch_size,
+                 grad_norm_clip=None, shuffle=True, num_slices=1):
+        self._learning_rate = learning_rate
+        self._update_method = update_method
+        self._update_args = update_method.resolve(**(update_method_args or dict()))
+        self._epochs = epochs
+        self._minibatch_size = minibatch_size
+        self._shuffle = shuffle
+        self._grad_norm_clip = grad_norm_clip
+
+    def initialize(self, inputs, losses, constraints, target, givens=None, lr_mult=1):
+        self._input_names = list(inputs)
+        self._losses = losses
+        self._setup_bucket(target, lr_mult)
+        self._idx_host = None
+
+    def optimize(self, inputs):
+        data = dict(zip(self._input_names, inputs))      # "_f_load": already on the device
+        return self._do_updates(data, len(inputs[0]))
+
+    def _do_updates(self, data, data_length):
+        bs = self._minibatch_size
+        # all epochs' permutations up front: same RNG consumption order as the reference
+        # (nothing else draws from the global stream inside optimize), one H2D copy
+        per_epoch = [list(iterate_mb_idxs(bs, data_length, self._shuffle)) for _ in range(self._epochs)]
+        flat = [mb for ep in per_epoch for mb in ep]
+        if not flat:
+            return [], []
+        host = torch.from_numpy(np.stack(flat).astype(np.int32))
+        idx_dev = host.to(self._target.device, non_blocking=True)
+        losses = []
+        for k in range(len(flat)):
+            idx = idx_dev[k]
+            mb = dict(idx=idx, observations=data["observations"])
+            idx64 = idx.long()
+            for name, tensor in data.items():
+                if name != "observations":
+                    mb[name] = tensor.index_select(0, idx64)
+            losses.append(self._backward(self._losses, mb))
+            self._share_grad()
+            self._apply_update(self._avg_factor())
+        return losses, self._recent_grad_norms(len(flat))
+
+    def _share_grad(self):
+        pass
+
+    def _avg_factor(self):
+        return 1.0
+
+    @property
+    def parallelism_tag(self):
+        return "single"

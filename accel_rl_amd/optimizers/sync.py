@@ -1,0 +1,43 @@
+"""Synchronous multi-GPU optimizers: local gradient -> all-reduce(SUM) of the ONE
+flat fp32 gradient bucket over RCCL/xGMI -> x 1/n_gpu -> global-norm clip ->
+identical local update on every rank.
+
+Reference: accel_rl/optimizers/sync/base.py:10-24 (init_comm, _share_grad),
+sync/sync_a2c_optimizer.py:13-59, sync/sync_ppo_optimizer.py:13-78; order
+"avg, then norm/clip" from sync_ppo_optimizer.py:27-34 / optimizers/util.py:63-67.
+The collective is torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" for
+the CPU tests of the protocol)."""
+import torch.distributed as dist
+
+from accel_rl_amd.optimizers.single import A2cOptimizer, PpoOptimizer
+
+
+class _SyncMixin(object):
+    _comm = None
+    _n_gpu = 1
+    _rank = 0
+
+    def init_comm(self, gpu_comm, rank, n_gpu):
+        """`gpu_comm`: a torch.distributed process group (None = default group)."""
+        self._comm = gpu_comm
+        self._rank = rank
+        self._n_gpu = n_gpu
+
+    def _share_grad(self):
+        if self._n_gpu > 1:
+            dist.all_reduce(self._target.flat_grads, op=dist.ReduceOp.SUM, group=self._comm)
+
+    def _avg_factor(self):
+        return 1.0 / self._n_gpu
+
+    @property
+    def parallelism_tag(self):
+        return "synchronous"
+
+
+class SyncA2cOptimizer(_SyncMixin, A2cOptimizer):
+    pass
+
+
+class SyncPpoOptimizer(_SyncMixin, PpoOptimizer):
+    pass

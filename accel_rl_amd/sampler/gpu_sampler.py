@@ -1,0 +1,320 @@
+"""GpuVecSampler: the whole rollout on one MI355X.
+
+Drop-in for the reference's ActsrvAltOvrlpSampler
+(accel_rl/sampler/act_server/alternating/overlap/sampler.py:20-151 plus its
+worker processes, overlap/worker.py:116-153): same constructor, same
+initialize / policy_init / obtain_samples / shutdown contract, same
+`samples_buf` keys, dtypes and env-major layout -- but the 2*n_parallel CPU
+worker processes, their semaphores and the per-step host<->device copies are
+gone.  Per agent step the device runs: policy forward (torch) -> act_step kernel
+(sample action, emulate, bookkeeping) -> frame_step kernel (pixels, stores).
+The whole horizon can be captured once in a hipGraph and replayed per batch.
+
+What stays on the host, to keep results identical to the reference on the same
+seeds (DESIGN.md "RNG streams"): numpy's global MT19937 supplies the action
+uniforms (np.random.rand, rllab/misc/special.py:24) -- drawn for the whole batch
+in one call and uploaded once -- and one RandomState per *simulated* worker
+(seed + i, sampler.py:179) supplies emulator phases and start no-ops, pre-drawn
+into a device ring that env.hip consumes in the reference's order.
+
+`n_parallel` / `envs_per` keep their meaning for layout and RNG streams only:
+env index e = (group * n_parallel + rank) * envs_per + i (sampler.py:160-185).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from accel_rl_amd import _lib
+from accel_rl_amd.buffers import (buffer_with_segs_view, batch_buffer, combine_distinct_buffers,
+                                  buffer_length, count_buffer_size)
+from accel_rl_amd.envs import synthetic_atari as synth
+from accel_rl_amd.sampler.base import BaseMbSampler
+from accel_rl_amd.sampler.util import TrajInfo
+from accel_rl_amd.util import logger
+from accel_rl_amd.util.misc import nbytes_unit, struct
+
+NOOP_RING = 4096
+
+
+class GpuVecSampler(BaseMbSampler):
+
+    def __init__(self, n_parallel=1, envs_per=1, device=None, use_graph=True, **kwargs):
+        super().__init__(n_parallel=n_parallel, envs_per=envs_per, **kwargs)
+        self._total_n_envs = 2 * n_parallel * envs_per
+        self.device = device
+        self.use_graph = use_graph
+        self._graph = None
+
+    # ------------------------------------------------------------------ API
+    def initialize(self, seed, affinities=None, discount=1, need_extra_obs=False):
+        if not getattr(self.EnvCls, "batched_device_env", False):
+            raise TypeError("GpuVecSampler needs an EnvCls with the batched device protocol "
+                            "(e.g. SynthAtariEnv); got {}".format(self.EnvCls))
+        _lib.load()                                       # fail loudly, before anything else
+        affinities = affinities or dict()
+        if self.device is None:
+            self.device = torch.device("cuda", int(affinities.get("gpu", 0) or 0))
+        self.device = torch.device(self.device)
+        dev = self.device
+        n, t = self._total_n_envs, self.horizon
+        self.seed = seed
+        self.discount = 1. if discount is None else discount
+        self.need_extra_obs = need_extra_obs
+        self.sample_size = n * t
+
+        # -- master-side example env + example transition: same global-RNG draws
+        #    as sampler.py:42 and act_server/buffers.py:8-9
+        env = self.EnvCls(**self.env_args)
+        synth.draw_noops(np.random, env.max_start_noops)           # env.reset()
+        env.action_space.sample()                                  # env.step(sample())
+        self.env = env
+        self.env_spec = env.spec
+        n_act = env.action_space.n
+        f = env.num_img_obs
+        obs_example = torch.zeros((f, synth.OBS_H, synth.OBS_W), dtype=torch.uint8)
+        env_infos = dict()
+        if env.clip_reward:
+            env_infos["raw_reward"] = np.float32(0)
+        if env.episodic_lives:
+            env_infos["need_reset"] = False
+        examples = dict(observations=obs_example, rewards=np.float32(0), dones=False,
+                        env_infos=env_infos)
+        self.envs_buf = buffer_with_segs_view(examples, n * t, t, dev)
+        if need_extra_obs:
+            self.envs_buf.extra_observations = batch_buffer(obs_example, n, dev)
+        # step buffers: observation_space.sample() + action_space.sample() per group
+        # (act_server/buffers.py:24-30) -- drawn only to keep the RNG stream aligned
+        for _ in range(2):
+            env.observation_space.sample()
+            env.action_space.sample()
+        self.step_obs = torch.zeros((n, f, synth.OBS_H, synth.OBS_W), dtype=torch.uint8, device=dev)
+
+        # -- game description + frame bank in HBM
+        self.bank = torch.from_numpy(synth.frame_bank(env.game_id)).to(dev)
+        g = _lib.ArlGame()
+        g.bank = self.bank.data_ptr()
+        g.n_frames, g.n_actions = synth.K_FRAMES, n_act
+        for i, code in enumerate(env.action_set):
+            g.action_set[i] = code
+        g.start_lives, g.life_period = env.start_lives, synth.LIFE_PERIOD
+        g.frame_skip, g.n_stack = env.frame_skip, f
+        g.clip_reward, g.episodic_lives = int(env.clip_reward), int(env.episodic_lives)
+        self._game = g
+
+        # -- per-env state (SoA) and the simulated workers' RNG streams
+        n_streams = 2 * self.n_parallel
+        i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)      # noqa: E731
+        u8 = lambda *s: torch.zeros(s, dtype=torch.uint8, device=dev)       # noqa: E731
+        f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)    # noqa: E731
+        self._st = struct(
+            tick=i32(n), emu_lives=i32(n), env_lives=i32(n), phase=i32(n), over=u8(n),
+            frozen=u8(n), traj_len=i32(n), traj_nonzero=i32(n), traj_ret=f32(n), traj_raw=f32(n),
+            traj_disc=f32(n), traj_curdisc=torch.ones(n, dtype=torch.float64, device=dev),
+            frame_a=i32(n), frame_b=i32(n), frame_mode=u8(n), reset_flag=u8(n),
+            noop_ring=u8(n_streams, NOOP_RING),
+            noop_cursor=torch.zeros((2, n_streams), dtype=torch.int64, device=dev),
+            epoch=i32(1), done_count=i32(1), done_int=i32(n * t, 3), done_flt=f32(n * t, 3),
+        )
+        self._worker_rngs = []
+        phases = np.zeros(n, np.int32)
+        ring = np.zeros((n_streams, NOOP_RING), np.uint8)
+        for w in range(n_streams):                       # group-major worker order
+            rs = np.random.RandomState((seed + w) % 4294967294)   # initialize_worker -> set_seed
+            for i in range(self.envs_per):               # envs = [EnvCls(...) ...] (worker.py:122)
+                phases[w * self.envs_per + i] = synth.draw_phase(rs)
+                synth.draw_noops(rs, env.max_start_noops)
+            if env.max_start_noops > 0:
+                ring[w] = synth.draw_noops(rs, env.max_start_noops, size=NOOP_RING)
+            self._worker_rngs.append(rs)
+        self._ring_host = ring
+        self._ring_produced = np.full(n_streams, NOOP_RING, np.int64)
+        self._st.phase.copy_(torch.from_numpy(phases))
+        self._st.noop_ring.copy_(torch.from_numpy(ring))
+
+        s = _lib.ArlEnvState()
+        s.n_env = n
+        for k in ("tick", "emu_lives", "env_lives", "phase", "over", "frozen", "traj_len",
+                  "traj_nonzero", "traj_ret", "traj_raw", "traj_disc", "traj_curdisc", "frame_a",
+                  "frame_b", "frame_mode", "reset_flag", "noop_ring", "noop_cursor", "epoch",
+                  "done_count", "done_int", "done_flt"):
+            setattr(s, k, self._st[k].data_ptr())
+        s.noop_ring_len, s.envs_per_stream, s.done_capacity = NOOP_RING, self.envs_per, n * t
+        self._state = s
+
+        # -- start_envs (sampler/util.py:26-33): reset every env, in env order per stream
+        self._rollout = None
+        ro = self._make_rollout(None)
+        with torch.cuda.device(dev):
+            _lib.env_reset(self._game, self._state, ro, None, env.max_start_noops)
+            if self.max_decorrelation_steps:
+                self._decorrelate()
+        return self.env_spec, self.sample_size, self.horizon, self.mid_batch_reset
+
+    def policy_init(self, policy):
+        """reference: sampler.py:81-95"""
+        dev, n, t = self.device, self._total_n_envs, self.horizon
+        self.policy = policy
+        n_act = self.env_spec.action_space.n
+        # build_policy_buffer (act_server/buffers.py:33-38): example action + agent_info;
+        # the reference evaluates the policy once on a random observation
+        policy.reset(n_batch=1)
+        example_obs = self.env_spec.observation_space.sample()
+        policy.get_action(torch.from_numpy(example_obs).to(dev))
+        examples = dict(actions=np.zeros((), self.env_spec.action_space.dtype),
+                        agent_infos=dict(prob=np.zeros(n_act, np.float32), value=np.float32(0)))
+        policy_buf = buffer_with_segs_view(examples, n * t, t, dev)
+        self.samples_buf = combine_distinct_buffers(self.envs_buf, policy_buf)
+        assert buffer_length(self.samples_buf) == self.sample_size
+        policy.reset(n_batch=self.n_parallel * self.envs_per)
+        self._rollout = self._make_rollout(self.samples_buf)
+        self._uniforms_host = torch.empty(t * n, dtype=torch.float64).pin_memory()
+        self._uniforms = torch.empty((t, n), dtype=torch.float64, device=dev)
+        self._done_host = torch.zeros(1 + 2 * 2 * self.n_parallel, dtype=torch.int64).pin_memory()
+        logger.log("GpuVecSampler -- total_n_envs: {}".format(self.total_n_envs))
+        logger.log("GpuVecSampler -- batch buffer size: {:,.1f} {}".format(
+            *nbytes_unit(count_buffer_size(self.samples_buf))))
+
+    def obtain_samples(self, itr):
+        """reference: sampler.py:97-104 (+ serve_actions :120-151)"""
+        n, t = self._total_n_envs, self.horizon
+        # one np.random.rand(B) per (step, group) in the reference == one flat draw here
+        self._uniforms_host.copy_(torch.from_numpy(np.random.rand(t * n)))
+        with torch.cuda.device(self.device):
+            if self.use_graph:
+                if self._graph is None:
+                    self._capture()
+                self._graph.replay()
+            else:
+                self._enqueue_batch()
+        return self.samples_buf, self._drain_traj_infos()
+
+    def shutdown(self):
+        self._graph = None
+
+    @property
+    def alternating(self):
+        # every env is served in one forward per step; nothing alternates on the device
+        return False
+
+    # -------------------------------------------------------------- internals
+    def _make_rollout(self, buf):
+        ro = _lib.ArlRollout()
+        ro.horizon = self.horizon
+        ro.step_obs = self.step_obs.data_ptr()
+        if buf is not None:
+            ro.observations = buf.observations.data_ptr()
+            ro.rewards, ro.dones = buf.rewards.data_ptr(), buf.dones.data_ptr()
+            ro.raw_reward = buf.env_infos["raw_reward"].data_ptr() if "raw_reward" in buf.env_infos else None
+            ro.need_reset = buf.env_infos["need_reset"].data_ptr() if "need_reset" in buf.env_infos else None
+            ro.actions = buf.actions.data_ptr()
+            ro.prob, ro.value = buf.agent_infos["prob"].data_ptr(), buf.agent_infos["value"].data_ptr()
+        return ro
+
+    def _enqueue_batch(self):
+        """All device work of one batch, on the current stream (graph-capturable)."""
+        n, t = self._total_n_envs, self.horizon
+        buf, ro, env = self.samples_buf, self._rollout, self.env
+        self._uniforms.view(-1).copy_(self._uniforms_host, non_blocking=True)
+        self._st.done_count.zero_()
+        obs = buf.observations.view(n, t, *buf.observations.shape[1:])
+        obs[:, 0].copy_(self.step_obs)                         # worker.py:30-32
+        for s in range(t):
+            prob, value = self.policy.prob_value(self.step_obs)
+            _lib.env_act_step(self._game, self._state, ro, prob, value, self._uniforms[s], s,
+                              self.mid_batch_reset, self.max_path_length, self.discount)
+            _lib.env_frame_step(self._game, self._state, ro, s, env.max_start_noops)
+        if self.need_extra_obs:
+            buf.extra_observations.copy_(self.step_obs)        # sampler.py:147-151
+        if not self.mid_batch_reset:                           # worker.py:108-113
+            _lib.env_reset(self._game, self._state, ro, self._st.frozen, env.max_start_noops)
+
+    def _capture(self):
+        """Warm up on a side stream, then capture one batch into a hipGraph."""
+        snap = {k: v.clone() for k, v in self._st.items()}
+        obs_snap = self.step_obs.clone()
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._enqueue_batch()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._enqueue_batch()
+        # warm-up and capture-time work must not count: restore the state
+        for k, v in snap.items():
+            self._st[k].copy_(v)
+        self.step_obs.copy_(obs_snap)
+        torch.cuda.synchronize(self.device)
+        self._graph = graph
+
+    def _drain_traj_infos(self, itr_check=False):
+        """Completed episodes of this batch (the reference's traj_infos_queue)."""
+        n_streams = 2 * self.n_parallel
+        torch.cuda.current_stream(self.device).synchronize()
+        count = int(self._st.done_count.item())
+        infos = []
+        if count:
+            count = min(count, self._state.done_capacity)
+            ints = self._st.done_int[:count].cpu().numpy()
+            flts = self._st.done_flt[:count].cpu().numpy()
+            for (env_id, length, nonzero), (ret, raw, disc) in zip(ints, flts):
+                infos.append(TrajInfo(Length=int(length), Return=float(ret), RawReturn=float(raw),
+                                      NonzeroRewards=int(nonzero), DiscountedReturn=float(disc),
+                                      _env=int(env_id)))
+        if count or itr_check:
+            self._refill_noop_ring(n_streams)
+        return infos
+
+    def _refill_noop_ring(self, n_streams):
+        """Top the start-noop ring up with fresh draws from each worker stream."""
+        if self.env.max_start_noops <= 0:
+            return
+        parity = int(self._st.epoch.item()) & 1
+        cursor = self._st.noop_cursor[parity].cpu().numpy()
+        dirty = False
+        for w in range(n_streams):
+            n_new = int(cursor[w] + NOOP_RING - self._ring_produced[w])
+            if n_new >= NOOP_RING // 2:
+                draws = synth.draw_noops(self._worker_rngs[w], self.env.max_start_noops, size=n_new)
+                pos = (self._ring_produced[w] + np.arange(n_new)) % NOOP_RING
+                self._ring_host[w, pos] = draws
+                self._ring_produced[w] += n_new
+                dirty = True
+        if dirty:
+            self._st.noop_ring.copy_(torch.from_numpy(self._ring_host))
+
+    def _decorrelate(self):
+        """sampler/util.py:34-57: before the first batch every env takes a random number
+        (< max_decorrelation_steps) of random-action steps, resetting at episode ends.
+        The reference derives the count from wall-clock digits (non-deterministic); here
+        counts and actions come from a RandomState derived from the sampler seed."""
+        n, env, dev = self._total_n_envs, self.env, self.device
+        n_act = self.env_spec.action_space.n
+        rs = np.random.RandomState((self.seed + 7919) % 4294967294)
+        counts = torch.from_numpy((rs.rand(n) * self.max_decorrelation_steps).astype(np.int64)).to(dev)
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(rs.randint(2 ** 31)))
+        scratch = struct(
+            observations=self.step_obs, rewards=torch.zeros(n, device=dev),
+            dones=torch.zeros(n, dtype=torch.uint8, device=dev),
+            env_infos=dict(raw_reward=torch.zeros(n, device=dev),
+                           need_reset=torch.zeros(n, dtype=torch.uint8, device=dev)),
+            actions=torch.zeros(n, dtype=torch.uint8, device=dev),
+            agent_infos=dict(prob=torch.zeros((n, n_act), device=dev), value=torch.zeros(n, device=dev)))
+        ro = self._make_rollout(scratch)
+        ro.horizon = 1
+        prob = torch.full((n, n_act), 1. / n_act, dtype=torch.float32, device=dev)
+        value = torch.zeros(n, dtype=torch.float32, device=dev)
+        for k in range(int(counts.max().item()) if n else 0):
+            active = (counts > k).to(torch.uint8)
+            u = torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
+            _lib.env_act_step(self._game, self._state, ro, prob, value, u, 0, True,
+                              self.max_path_length, self.discount, active=active)
+            _lib.env_frame_step(self._game, self._state, ro, 0, env.max_start_noops)
+            if k % 256 == 255:
+                self._st.done_count.zero_()
+                self._refill_noop_ring(2 * self.n_parallel)
+        self._st.done_count.zero_()
+        self._refill_noop_ring(2 * self.n_parallel)

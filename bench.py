@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py -- the rollout + learner hot path on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: one
+`sampler.obtain_samples` (horizon x (policy forward, act_step, frame_step)) plus
+one `algo.optimize_policy` (bootstrap forward, GAE scan, PPO epochs x minibatches
+with the HIP flat-bucket optimiser; sync all-reduce when N > 1).
+Workload = BASELINE.json configs[1]: PPO "breakout", 256 envs per GPU, horizon 5,
+spec-1 CNN, minibatch 512 x 4 epochs  ->  1280 agent steps per GPU per step.
+Metric = the reference runner's SamplesPerSecond (accel_rl/runners/accel_rl.py:93-98).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  "roofline":     the GAE scan kernel at a bandwidth-bound sweep size (HIP events
+                  on the launch stream) + the at-config point, and
+  "kernels":      event-timed averages of every hand-written kernel of the step,
+  "cpu_baseline": the oracle's CPU sampler port timed on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+N_ENVS, HORIZON, GAME, CNN_SPEC = 256, 5, "breakout", 1
+GAMES_8 = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_rider", "enduro", "ms_pacman"]
+
+
+def build_workload(device, seed, rank, world, game, use_graph, quiet=True):
+    from accel_rl_amd.algos.pg.ppo import PPO, mPPO
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+    from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+    from accel_rl_amd.runners.accel_rl import AccelRL
+    from accel_rl_amd.runners.sync import AccelRLSync
+    from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
+    from accel_rl_amd.util import logger
+    logger.set_quiet(quiet)
+    sampler = GpuVecSampler(EnvCls=SynthAtariEnv, env_args=dict(game=game), horizon=HORIZON,
+                            n_parallel=16, envs_per=N_ENVS // 32, max_path_length=int(27e3),
+                            mid_batch_reset=True, max_decorrelation_steps=2000, device=device,
+                            use_graph=use_graph)
+    policy = AtariCnnPolicy(**cnn_specs[CNN_SPEC])
+    if world > 1:
+        algo = mPPO(discount=0.99, gae_lambda=0.95)
+        runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
+                             affinities=dict(gpu=device.index), log_interval_steps=1e8)
+    else:
+        algo = PPO(discount=0.99, gae_lambda=0.95)
+        runner = AccelRL(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
+                         affinities=dict(gpu=device.index), log_interval_steps=1e8)
+    runner.startup()
+    return runner, sampler, algo, policy
+
+
+def one_step(itr, sampler, algo):
+    samples, _ = sampler.obtain_samples(itr)
+    algo.optimize_policy(itr, samples)
+
+
+def event_time_ms(fn, reps, warm=3):
+    """Average device time of fn() over reps launches, HIP events on the current stream."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    start = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    stop = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    for i in range(reps):
+        start[i].record()
+        fn()
+        stop[i].record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in zip(start, stop))
+    return float(np.mean(ts)), float(ts[len(ts) // 2])
+
+
+def roofline_gae(device, log2_elems, reps):
+    """GAE scan at a bandwidth-bound size: algorithmic bytes = 17*N*T + 4*N."""
+    from accel_rl_amd import _lib
+    t = HORIZON
+    n = (1 << log2_elems) // t
+    gen = torch.Generator(device=device).manual_seed(1)
+    r = torch.randn(n * t, device=device, generator=gen)
+    v = torch.randn(n * t, device=device, generator=gen)
+    d = (torch.rand(n * t, device=device, generator=gen) < 0.05).to(torch.uint8)
+    lv = torch.randn(n, device=device, generator=gen)
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    mean_ms, med_ms = event_time_ms(
+        lambda: _lib.gae_scan(r, v, d, lv, 0.99, 0.95, n, t, adv, ret), reps)
+    nbytes = 17 * n * t + 4 * n
+    achieved = nbytes / (mean_ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="scan_lds_kernel<GAE,NEP50,256>", achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                bytes_per_launch=nbytes, n_env=n, horizon=t, launches=reps,
+                avg_launch_us=round(mean_ms * 1e3, 2), median_launch_us=round(med_ms * 1e3, 2))
+
+
+def kernel_table(device, sampler, algo, policy, reps=20):
+    """Event-timed averages of the step's hand-written kernels at the CONFIG sizes."""
+    from accel_rl_amd import _lib
+    n, t, a = N_ENVS, HORIZON, sampler.env_spec.action_space.n
+    buf = sampler.samples_buf
+    rows = []
+
+    def add(name, fn, nbytes, launches_per_step):
+        mean_ms, med_ms = event_time_ms(fn, reps)
+        gbs = nbytes / (mean_ms * 1e-3) / 1e9
+        rows.append(dict(kernel=name, avg_launch_us=round(mean_ms * 1e3, 2),
+                         median_launch_us=round(med_ms * 1e3, 2), bytes_per_launch=int(nbytes),
+                         achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4),
+                         launches_per_step=launches_per_step))
+
+    opt = algo._opt_buf
+    lv = torch.zeros(n, device=device)
+    add("gae_scan@config", lambda: _lib.gae_scan(buf.rewards, buf.agent_infos["value"], buf.dones, lv,
+                                                 0.99, 0.95, n, t, opt["advantages"], opt["returns"]),
+        17 * n * t + 4 * n, 1)
+    prob = torch.full((n, a), 1. / a, device=device)
+    val = torch.zeros(n, device=device)
+    u = torch.rand(n, dtype=torch.float64, device=device)
+    snap = {k: v.clone() for k, v in sampler._st.items()}
+    obs_snap = sampler.step_obs.clone()
+    ro, env = sampler._rollout, sampler.env
+    add("act_step", lambda: _lib.env_act_step(sampler._game, sampler._state, ro, prob, val, u, 0, True,
+                                              27e3, 0.99), n * (4 * a + 8 + 4 + 4 * a + 1 + 4 + 4 + 1 + 4 + 1), t)
+    # frame_step: 2 raw frames read + previous stack read + stacked obs written twice
+    add("frame_step(+epoch)", lambda: _lib.env_frame_step(sampler._game, sampler._state, ro, 0, env.max_start_noops),
+        n * (2 * 33600 + 3 * 8320 + 2 * 33280), t)
+    for k, v in snap.items():
+        sampler._st[k].copy_(v)
+    sampler.step_obs.copy_(obs_snap)
+    idx = torch.randperm(n * t, device=device)[:512].to(torch.int32)
+    out = torch.empty((512, 4, 104, 80), device=device)
+    add("gather_scale_obs", lambda: _lib.gather_scale_obs(buf.observations, idx, out, 1. / 255),
+        512 * 33280 * 5, 8)
+    optim = algo.optimizer
+    saved = [x.clone() for x in (policy.flat_params, optim._slot0, optim._slot1, optim._step_count)]
+    policy.flat_grads.normal_()
+    add("opt_step(sumsq+adam)", lambda: optim._apply_update(1.0), policy.flat_params.numel() * 32, 8)
+    for x, s in zip((policy.flat_params, optim._slot0, optim._slot1, optim._step_count), saved):
+        x.copy_(s)
+    return rows
+
+
+def cpu_baseline(device, policy, seconds=12.0):
+    """The oracle's CPU sampler port (per-env numpy env loop, as the reference's workers
+    do) + the oracle's process_samples, single process, actions served by the same
+    torch policy on the GPU (the reference serves actions from the GPU too)."""
+    from oracle import ref_port as P
+
+    class Served(object):
+        def get_actions(self, obs):
+            prob, value = policy.prob_value(torch.from_numpy(obs).to(device))
+            prob, value = prob.cpu().numpy(), value.cpu().numpy()
+            return P.sample_actions(prob, np.random.rand(len(prob))), dict(prob=prob, value=value)
+
+    smp = P.CpuSamplerPort(GAME, HORIZON, 16, N_ENVS // 32, max_path_length=int(27e3),
+                           mid_batch_reset=True)
+    np.random.seed(12345)
+    smp.initialize(12346, discount=0.99)
+    served = Served()
+    smp.obtain_samples(served)                       # warm-up batch
+    t0 = time.time()
+    batches = 0
+    while time.time() - t0 < seconds or batches < 3:
+        buf, _ = smp.obtain_samples(served)
+        lv = policy.value(torch.from_numpy(buf["extra_observations"]).to(device)).cpu().numpy()
+        P.process_samples(buf["rewards"].reshape(N_ENVS, HORIZON), buf["dones"].reshape(N_ENVS, HORIZON),
+                          buf["value"].reshape(N_ENVS, HORIZON), lv, None, 0.99, 0.95)
+        batches += 1
+    dt = time.time() - t0
+    return dict(value=round(batches * N_ENVS * HORIZON / dt, 1), unit="env-steps/s", cores=1,
+                kind="port",
+                sample="%d batches of the same workload's rollout + process_samples (256 envs x 5 "
+                       "steps, numpy port of the reference sampler/AtariEnv/GAE, one host process; "
+                       "no learner update); host has %d logical cores" % (batches, os.cpu_count()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-log2", type=int, default=26)
+    ap.add_argument("--suite", action="store_true", help="BASELINE config 4: one game per rank")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import __graft_entry__
+    __graft_entry__.build()
+
+    game = GAMES_8[rank % 8] if args.suite else GAME
+    runner, sampler, algo, policy = build_workload(device, 0, rank, world, game, not args.no_graph)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    itr = 0
+    for _ in range(args.warmup):
+        one_step(itr, sampler, algo)
+        itr += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(itr, sampler, algo)
+        itr += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    steps_per_gpu = args.steps * N_ENVS * HORIZON
+    line = {
+        "metric": "env-steps/sec (whole node), 256-env PPO Atari",
+        "value": round(world * steps_per_gpu / elapsed, 1),
+        "unit": "env-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PPO %s, %d envs/GPU, horizon %d, spec-%d CNN (fp32), minibatch 512 x 4 epochs, "
+                               "adam; synthetic fixed-frame emulator; %s" %
+                               ("8-game suite" if args.suite else GAME, N_ENVS, HORIZON, CNN_SPEC,
+                                "hipGraph rollout" if not args.no_graph else "eager"),
+                   "env_steps_per_step_per_gpu": N_ENVS * HORIZON,
+                   "parallelism": "dp%d sync all-reduce (RCCL)" % world if world > 1 else "single"},
+    }
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            line["roofline"] = roofline_gae(device, args.roofline_log2, 30)
+            line["kernels"] = kernel_table(device, sampler, algo, policy)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(device, policy)
+            line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 2)
+    runner.shutdown()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,261 @@
+/*
+ * accel_rl_hip.h -- C-ABI of libaccel_rl_hip.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * The reference (astooke/accel_rl) is pure Python and has NO FFI boundary of its
+ * own; its hot path is Python/numpy loops and Theano graphs.  The
+ * entry points below are what a binding for that path would bind: one function
+ * per reference routine on the path, each citing the reference code it replaces
+ * (paths relative to the reference root).  INTEGRATION.md shows the ctypes stub
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (no allocation
+ *     inside, no torch types); sizes are plain integers;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     call only ENQUEUES work on it and is hipGraph-capturable;
+ *   - return value: 0 = ok; < 0 = argument error (ARL_E_*); > 0 = hipError_t of
+ *     the failed launch.  arl_last_error() returns a thread-local message;
+ *   - batch arrays are "env-major": flat index = env * horizon + t
+ *     (accel_rl/buffers/batch.py:59-76);
+ *   - results: integer / byte / index outputs are bit-exact with the reference;
+ *     floating point follows the reference's own dtype walk (see `promo`).
+ */
+#ifndef ACCEL_RL_HIP_H
+#define ACCEL_RL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARL_ABI_VERSION 1
+
+#define ARL_E_ARG      (-1)   /* null pointer / non-positive size                 */
+#define ARL_E_RANGE    (-2)   /* size outside what the kernels support             */
+#define ARL_E_ALIGN    (-3)   /* pointer not aligned as documented                 */
+
+/* numpy promotion the reference arithmetic is reproduced under:
+ * NEP50  = numpy >= 2 (python float x float32 -> float32), bit-exact with the
+ *          reference as it runs today;
+ * LEGACY = numpy 1.x (python float x float32 scalar -> float64), as in 2018. */
+#define ARL_PROMO_NEP50   0
+#define ARL_PROMO_LEGACY  1
+
+int         arl_abi_version(void);
+const char* arl_last_error(void);
+
+/* ------------------------------------------------------------------------- *
+ * Return / advantage scans
+ * ------------------------------------------------------------------------- */
+
+/* GAE(lambda).  Replaces gen_adv_est, accel_rl/algos/pg/util.py:6-23, and the
+ * per-env Python loop around it, accel_rl/algos/pg/aac_base.py:122-127.
+ *   rewards, values  f32[n_env*horizon]   dones u8[n_env*horizon] (0/1)
+ *   last_values      f32[n_env]           (bootstrap V, aac_base.py:112)
+ *   advantages, returns  f32[n_env*horizon] (out; may not alias the inputs)   */
+int arl_gae_scan(const float* rewards, const float* values, const uint8_t* dones,
+                 const float* last_values, double discount, double gae_lambda,
+                 int64_t n_env, int32_t horizon, int32_t promo,
+                 float* advantages, float* returns, void* stream);
+
+/* n-step discounted return + advantage.  Replaces discount_returns,
+ * accel_rl/algos/pg/util.py:26-37, and `adv[:] = ret - v`, aac_base.py:115-121. */
+int arl_nstep_return(const float* rewards, const uint8_t* dones, const float* values,
+                     const float* last_values, double discount,
+                     int64_t n_env, int32_t horizon, int32_t promo,
+                     float* returns, float* advantages, void* stream);
+
+/* valids mask + zeroing.  Replaces update_valids / zero_after_reset,
+ * accel_rl/algos/pg/util.py:40-63 (loop at aac_base.py:129-134).
+ *   reset_flags u8[n_env*horizon] = env_infos.need_reset if present else dones
+ *   valids i8[n_env*horizon] (out); advantages/returns/values are zeroed IN
+ *   PLACE after the first set flag (any of the three may be NULL).            */
+int arl_valids_mask(const uint8_t* reset_flags, int64_t n_env, int32_t horizon,
+                    int8_t* valids, float* advantages, float* returns, float* values,
+                    void* stream);
+
+/* (adv - mean) / (std + eps), population std, over all n samples or over the
+ * valid ones.  Replaces accel_rl/algos/pg/aac_base.py:136-143.
+ *   workspace: >= arl_standardize_workspace_bytes() bytes of device scratch.  */
+int64_t arl_standardize_workspace_bytes(void);
+int arl_standardize(float* advantages, const int8_t* valids_or_null, int64_t n,
+                    double eps, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Categorical action sampling
+ * ------------------------------------------------------------------------- */
+
+/* k = #{j : cumsum_j(prob[b,:]) < u[b]} clamped to n_actions-1; fp32 sequential
+ * cumsum, fp64 compare.  Replaces weighted_sample_n, rllab/misc/special.py:22-27
+ * (called from accel_rl/spaces/discrete.py:67-68 and
+ * accel_rl/policies/pg/atari_cnn_policy.py:110).  The uniform variates the
+ * reference draws with np.random.rand(B) are an explicit input.
+ *   prob f32[batch*n_actions]  uniforms f64[batch]  actions u8[batch] (out)    */
+int arl_sample_categorical(const float* prob, const double* uniforms,
+                           int64_t batch, int32_t n_actions, uint8_t* actions,
+                           void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Vectorised environment step (synthetic fixed-frame emulator + AtariEnv
+ * wrapper + collector bookkeeping)
+ * ------------------------------------------------------------------------- */
+
+#define ARL_MAX_ACTIONS 18
+#define ARL_RAW_H 210
+#define ARL_RAW_W 160
+#define ARL_OBS_H 104     /* accel_rl/envs/atari_env.py:13 */
+#define ARL_OBS_W 80
+
+/* Static description of one game + AtariEnv constructor arguments
+ * (accel_rl/envs/atari_env.py:18-26).  Plain data, passed by pointer (host). */
+typedef struct arl_game {
+    const uint8_t* bank;        /* device u8[n_frames][210][160] frame bank      */
+    int32_t n_frames;
+    int32_t n_actions;
+    int32_t action_set[ARL_MAX_ACTIONS]; /* ALE action codes (getMinimalActionSet)*/
+    int32_t start_lives;
+    int32_t life_period;
+    int32_t frame_skip;         /* atari_env.py:20 */
+    int32_t n_stack;            /* num_img_obs, atari_env.py:21 */
+    int32_t clip_reward;        /* atari_env.py:22 */
+    int32_t episodic_lives;     /* atari_env.py:23 */
+} arl_game;
+
+/* Per-env mutable state, struct-of-arrays; every pointer is device memory of
+ * n_env elements unless noted.  Allocated and owned by the caller. */
+typedef struct arl_env_state {
+    int64_t  n_env;
+    int32_t* tick;          /* emulator frames since reset_game                  */
+    int32_t* emu_lives;     /* ale.lives()                                       */
+    int32_t* env_lives;     /* AtariEnv._lives (atari_env.py:179)                */
+    int32_t* phase;         /* per-emulator frame-bank phase                     */
+    uint8_t* over;          /* ale.game_over()                                   */
+    uint8_t* frozen;        /* NonResetCollector need_reset[i] (worker.py:75-95) */
+    /* TrajInfo accumulators (accel_rl/sampler/util.py:75-101) */
+    int32_t* traj_len;
+    int32_t* traj_nonzero;
+    float*   traj_ret;
+    float*   traj_raw;
+    float*   traj_disc;
+    double*  traj_curdisc;
+    /* per-step hand-off from arl_env_act_step to arl_env_frame_step */
+    int32_t* frame_a;       /* bank index of raw_frame_1, -1 = all-zero frame    */
+    int32_t* frame_b;       /* bank index of raw_frame_2                          */
+    uint8_t* frame_mode;    /* 0 skip, 1 shift+push, 2 blank+push                 */
+    uint8_t* reset_flag;    /* env must be reset by arl_env_frame_step            */
+    /* start-noop streams: one per simulated worker process
+     * (accel_rl/envs/atari_env.py:97 draws from the worker's numpy RNG)       */
+    const uint8_t* noop_ring;   /* u8[n_streams][noop_ring_len] pre-drawn counts */
+    int64_t* noop_cursor;       /* i64[2][n_streams], ping-pong by epoch parity  */
+    int32_t* epoch;             /* i32[1] number of frame_step launches so far   */
+    int32_t  noop_ring_len;
+    int32_t  envs_per_stream;
+    /* completed-trajectory records (the reference's traj_infos_queue,
+     * overlap/worker.py:147-148): appended with an atomic counter            */
+    int32_t* done_count;        /* i32[1]                                        */
+    int32_t* done_int;          /* i32[done_capacity][3] = env, Length, NonzeroRewards */
+    float*   done_flt;          /* f32[done_capacity][3] = Return, RawReturn, DiscountedReturn */
+    int32_t  done_capacity;
+} arl_env_state;
+
+/* Rollout batch buffer, env-major (accel_rl/sampler/act_server/buffers.py:7-38).
+ * Optional arrays may be NULL (raw_reward when !clip_reward, need_reset when
+ * !episodic_lives: the reference's env_infos then lack the key).               */
+typedef struct arl_rollout {
+    int32_t  horizon;
+    uint8_t* observations;  /* u8[n_env*horizon][n_stack][104][80]               */
+    float*   rewards;       /* f32[n_env*horizon]                                */
+    uint8_t* dones;         /* u8 (bool)                                         */
+    float*   raw_reward;    /* env_infos.raw_reward                              */
+    uint8_t* need_reset;    /* env_infos.need_reset                              */
+    uint8_t* actions;       /* u8                                                */
+    float*   prob;          /* agent_infos.prob f32[n_env*horizon][n_actions]    */
+    float*   value;         /* agent_infos.value                                 */
+    uint8_t* step_obs;      /* u8[n_env][n_stack][104][80] current observation   */
+} arl_rollout;
+
+/* One agent step for every env, scalar part (one lane per env): sample the
+ * action, write actions/prob/value at index env*horizon+step, advance the
+ * emulator frame_skip times, apply reward clipping / episodic-life / over-length
+ * / reset rules, accumulate TrajInfo, write rewards/dones/env_infos.
+ * Replaces: serve_actions' sample+scatter, overlap/sampler.py:139-145;
+ * AtariEnv.step minus pixels, envs/atari_env.py:65-78,165-191;
+ * ResetCollector / NonResetCollector.collect bookkeeping, overlap/worker.py:37-59,
+ * 75-106; TrajInfo.step, sampler/util.py:92-101.
+ *   prob f32[n_env][n_actions], value f32[n_env], uniforms f64[n_env] for THIS step
+ *   active_or_null u8[n_env]: envs with 0 sit this step out untouched (used for the
+ *   start-up decorrelation of sampler/util.py:34-57); NULL = every env steps    */
+int arl_env_act_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                     const float* prob, const float* value, const double* uniforms,
+                     const uint8_t* active_or_null,
+                     int32_t step, int32_t mid_batch_reset, double max_path_length,
+                     double discount, void* stream);
+
+/* Pixel part (one workgroup per env): resolve pending resets (start no-ops from
+ * the env's stream, in env order within the stream), max of the two raw frames,
+ * crop 2 rows, rounded 2x2 box to 104x80, shift/blank the frame stack, write
+ * step_obs and observations[env*horizon + step + 1] (if step+1 < horizon).
+ * Replaces AtariEnv._update_obs/_reset_obs/reset, envs/atari_env.py:93-100,
+ * 151-163, and the observation writes of overlap/worker.py:51-53.
+ *   max_start_noops: atari_env.py:24                                          */
+int arl_env_frame_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                       int32_t step, int32_t max_start_noops, void* stream);
+
+/* Reset every env whose flag is set (u8[n_env]; NULL = all): start_envs with
+ * max_decorrelation_steps == 0 (sampler/util.py:26-33) and
+ * NonResetCollector.reset_needed_envs (overlap/worker.py:108-113, flags =
+ * st->frozen, cleared afterwards).  Writes step_obs only.                      */
+int arl_env_reset(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                  const uint8_t* flags_or_null, int32_t max_start_noops, void* stream);
+
+/* Stand-alone preprocess of explicit raw frame pairs (testing / other
+ * emulators): out[i] = box2x(crop(max(a[i], b[i]))); a may be NULL (zeros).
+ * Replaces envs/atari_env.py:151-155.  a,b u8[n][210][160], out u8[n][104][80] */
+int arl_preprocess_frames(const uint8_t* raw_a_or_null, const uint8_t* raw_b,
+                          int64_t n, uint8_t* out, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Learner side: minibatch gather and the flat-bucket optimiser step
+ * ------------------------------------------------------------------------- */
+
+/* out[b] = float(obs[idx[b]]) * scale  (u8 -> f32 gather; the reference gathers
+ * on device with `s[idxs]`, accel_rl/optimizers/util.py:86-89, and scales by
+ * 1/255 in ScalarFixedScaleLayer, accel_rl/policies/layers.py:22-41).
+ *   obs u8[n_rows][row_bytes], idx i32[batch] (NULL = identity), out f32[batch][row_bytes] */
+int arl_gather_scale_obs(const uint8_t* obs, const int32_t* idx_or_null, int64_t batch,
+                         int64_t row_bytes, float scale, float* out, void* stream);
+
+/* Optimiser state for ONE flat fp32 parameter bucket (all trainable params in
+ * get_params order, accel_rl/optimizers/util.py:35-39). */
+typedef struct arl_opt_state {
+    int64_t n_params;
+    float*  params;         /* f32[P] flat parameter vector (updated in place)   */
+    float*  grads;          /* f32[P] flat gradient (after all-reduce in sync mode) */
+    float*  slot0;          /* adam m / rmsprop accu                             */
+    float*  slot1;          /* adam v / unused                                   */
+    float*  step_count;     /* f32[1] Lasagne's t (floatX)                       */
+    float*  lr_mult;        /* f32[1] device scalar (linear schedule, aac_base.py:165-168) */
+    double* partials;       /* f64[ARL_OPT_PARTIALS] scratch                     */
+    float*  grad_norm_log;  /* f32[norm_log_len] ring: norm of update k at k % len */
+    int32_t norm_log_len;
+} arl_opt_state;
+
+#define ARL_OPT_PARTIALS 1024
+#define ARL_OPT_ADAM     0
+#define ARL_OPT_RMSPROP  1
+
+/* grads *= avg_factor; norm = ||grads||_2; if clip > 0: grads *= clip(norm,0,clip)/(1e-7+norm);
+ * then adam / rmsprop.  Two launches (sum of squares, fused update).
+ * Replaces avg_grads_from_flat + apply_grad_norm_clip + lasagne update,
+ * accel_rl/optimizers/util.py:63-76, sync/sync_ppo_optimizer.py:27-34; update
+ * arithmetic as in accel_rl/optimizers/update_methods_stats.py:11-33 (rmsprop)
+ * and :55-87 (adam).  clip <= 0 means "no clip" (norm still logged).          */
+int arl_opt_step(const arl_opt_state* opt, int32_t method, float learning_rate,
+                 float avg_factor, float clip, float beta1_or_rho, float beta2,
+                 float epsilon, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACCEL_RL_HIP_H */

@@ -1,0 +1,72 @@
+"""CPU-only: the C-ABI library builds, loads, and exports exactly what
+include/accel_rl_hip.h declares; argument errors are reported without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from accel_rl_amd import _build, _lib
+    _build.build_extension()
+    return _lib.load()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "accel_rl_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(arl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(lib):
+    from accel_rl_amd import _lib
+    declared = _declared_functions()
+    assert len(declared) >= 14
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_every_declared_symbol_is_exported(lib):
+    raw = ctypes.CDLL(os.path.join(ROOT, "accel_rl_amd", "libaccel_rl_hip.so"))
+    for name in _declared_functions():
+        assert getattr(raw, name) is not None, name
+
+
+def test_abi_version_and_arg_errors(lib):
+    assert lib.arl_abi_version() == 1
+    # null pointers / bad sizes are rejected before any HIP call is made
+    assert lib.arl_gae_scan(None, None, None, None, 0.99, 0.95, 4, 5, 0, None, None, None) == -1
+    assert b"null" in lib.arl_last_error()
+    assert lib.arl_sample_categorical(None, None, 1, 4, None, None) == -1
+    assert lib.arl_valids_mask(None, 1, 1, None, None, None, None, None) == -1
+    assert lib.arl_standardize(None, None, 1, 1e-6, None, None) == -1
+    assert lib.arl_preprocess_frames(None, None, 1, None, None) == -1
+    assert lib.arl_standardize_workspace_bytes() >= 3 * 8
+
+
+def test_struct_layouts_match_header(lib):
+    """ctypes mirrors of the ABI structs have the C layout (sizes from gcc)."""
+    import subprocess
+    import tempfile
+    from accel_rl_amd import _lib
+    src = ('#include <stdio.h>\n#include "accel_rl_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
+           'sizeof(arl_game),sizeof(arl_env_state),sizeof(arl_rollout),sizeof(arl_opt_state));return 0;}')
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(_lib.ArlGame), ctypes.sizeof(_lib.ArlEnvState),
+                     ctypes.sizeof(_lib.ArlRollout), ctypes.sizeof(_lib.ArlOptState)]
+
+
+def test_no_cpu_fallback():
+    """Host tensors are refused: the product has no CPU path."""
+    import torch
+    from accel_rl_amd import _lib
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        _lib.ptr(torch.zeros(4))

@@ -1,0 +1,144 @@
+"""CPU-only tests of the host-side mirror of the reference interface: iteration
+arithmetic and minibatch index streams against the golden vectors, buffer
+construction, spaces' RNG draws, constructor-argument capture, logger."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_get_n_itr_matches_reference_table():
+    from accel_rl_amd.runners.accel_rl import AccelRLBase
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    for n_steps, sample_size, log_steps, n_itr, log_itrs in load_golden("g9_nitr")["table"]:
+        r = AccelRLBase.__new__(AccelRLBase)
+        r.n_steps, r._log_steps = int(n_steps), int(log_steps)
+        assert r.get_n_itr(int(sample_size)) == n_itr
+        assert r._log_interval_itrs == log_itrs
+
+
+def test_iterate_mb_idxs_matches_reference_stream():
+    from accel_rl_amd.optimizers.base import iterate_mb_idxs
+    g = load_golden("g8_mbidx")
+    for c in range(int(g["n_cases"])):
+        bs, n, seed = [int(x) for x in g["c%d_cfg" % c]]
+        np.random.seed(seed)
+        for ep in range(3):
+            got = list(iterate_mb_idxs(bs, n, shuffle=True))
+            want = g["c%d_idx" % c][ep]
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                np.testing.assert_array_equal(a, b)
+        ns = list(iterate_mb_idxs(bs, n, shuffle=False))
+        np.testing.assert_array_equal(
+            np.array([[m[0], m[-1] + 1] for m in ns], np.int64).reshape(-1, 2), g["c%d_noshuffle" % c])
+
+
+def test_parallelism_mismatch_raises_type_error():
+    from accel_rl_amd.runners.accel_rl import AccelRL
+    from accel_rl_amd.algos.pg.ppo import mPPO, PPO
+    with pytest.raises(TypeError, match="mismatched parallelism"):
+        AccelRL(algo=mPPO(), policy=None, sampler=None, n_steps=10)
+    AccelRL(algo=PPO(), policy=None, sampler=None, n_steps=10)
+
+
+def test_algo_defaults_match_reference():
+    from accel_rl_amd.algos.pg.a2c import A2C
+    from accel_rl_amd.algos.pg.ppo import PPO
+    a = A2C()
+    assert (a.discount, a.gae_lambda, a.v_loss_coeff, a.ent_loss_coeff) == (0.99, 1, 0.25, 0.01)
+    o = a.optimizer
+    assert (o._learning_rate, o._grad_norm_clip, o._update_method.name) == (7e-4, 0.5, "rmsprop")
+    assert o._update_args == dict(rho=0.9, epsilon=1e-6)
+    p = PPO()
+    assert (p.discount, p.gae_lambda, p.v_loss_coeff, p.clip_param) == (0.99, 0.95, 1, 0.2)
+    o = p.optimizer
+    assert (o._learning_rate, o._epochs, o._minibatch_size, o._shuffle, o._grad_norm_clip) == \
+        (1e-3, 4, 512, True, None)
+    assert o._update_args == dict(beta1=0.9, beta2=0.999, epsilon=1e-5)
+    with pytest.raises(ValueError):
+        PPO(lr_schedule="cosine")
+
+
+def test_buffers_layout_and_errors():
+    from accel_rl_amd import buffers as B
+    ex = dict(observations=np.zeros((4, 3, 2), np.uint8), rewards=np.float32(0), dones=False,
+              env_infos=dict(need_reset=False, raw_reward=np.float32(0)))
+    buf = B.buffer_with_segs_view(ex, 6 * 5, 5, "cpu")
+    assert buf.observations.shape == (30, 4, 3, 2) and buf.observations.dtype == torch.uint8
+    assert buf.dones.dtype == torch.bool and buf.env_infos["raw_reward"].dtype == torch.float32
+    assert B.buffer_length(buf) == 30 and len(buf.segs_view) == 6
+    buf.segs_view[2].rewards[3] = 7.0                     # views: flat index = env*T + t
+    assert buf.rewards[2 * 5 + 3] == 7.0
+    buf.segs_view[4].env_infos["need_reset"][0] = True
+    assert buf.env_infos["need_reset"][20]
+    pol = B.buffer_with_segs_view(dict(actions=np.uint8(0), agent_infos=dict(value=np.float32(0))), 30, 5, "cpu")
+    both = B.combine_distinct_buffers(buf, pol)
+    assert set(both.segs_view[0]) == {"observations", "rewards", "dones", "env_infos", "actions", "agent_infos"}
+    assert B.count_buffer_size(both) == 30 * (24 + 4 + 1 + 1 + 4 + 1 + 4)
+    with pytest.raises(ValueError):
+        B.view_segments(buf, 7)
+    with pytest.raises(TypeError):
+        B.build_array(np.array([object()]), 3, "cpu")
+    buf.extra_observations = torch.zeros(6, 4, 3, 2)
+    assert B.buffer_length(buf) == 30                     # "extra*" keys are exempt
+    buf.bad = torch.zeros(3)
+    with pytest.raises(RuntimeError):
+        B.buffer_length(buf)
+
+
+def test_spaces_draws_match_the_reference_calls():
+    from accel_rl_amd.spaces import Discrete, UintBox
+    d = Discrete(6)
+    assert d.dtype == "uint8" and Discrete(300).dtype == "uint16" and Discrete(70000).dtype == "uint32"
+    np.random.seed(4)
+    a = d.sample()
+    np.random.seed(4)
+    assert a == np.random.randint(6, dtype="uint8")
+    box = UintBox(shape=(4, 104, 80), bits=8)
+    np.random.seed(5)
+    x = box.sample()
+    np.random.seed(5)
+    np.testing.assert_array_equal(x, np.random.randint(low=0, high=255, size=(4, 104, 80), dtype="uint8"))
+    assert x.max() <= 254 and box.contains(x)
+
+
+def test_env_descriptor_consumes_reference_draws():
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv, K_FRAMES
+    from oracle.ref_port import PortedAtariEnv
+    np.random.seed(9)
+    env = SynthAtariEnv(game="seaquest", max_start_noops=7)
+    after = np.random.rand()
+    np.random.seed(9)
+    port = PortedAtariEnv(game="seaquest", max_start_noops=7)
+    assert np.random.rand() == after and env.phase == port.phase < K_FRAMES
+    assert env.action_space.n == 18 and env.observation_space.shape == (4, 104, 80)
+    assert env.env_info_keys == ["raw_reward", "need_reset"]
+    with pytest.raises(IOError):
+        SynthAtariEnv(game="nonexistent")
+
+
+def test_gpu_sampler_refuses_plain_envs_and_missing_gpu():
+    from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
+
+    class PlainEnv(object):
+        pass
+    s = GpuVecSampler(EnvCls=PlainEnv, env_args=dict(), horizon=5)
+    with pytest.raises(TypeError, match="batched device protocol"):
+        s.initialize(seed=1)
+    assert s.total_n_envs == 2 and s.alternating is False
+
+
+def test_logger_tabular_and_misc_stat(tmp_path):
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    logger.set_output(str(tmp_path))
+    logger.record_tabular("Iteration", 3)
+    logger.record_tabular_misc_stat("Return", [1.0, 2.0, 3.0])
+    row = logger.dump_tabular()
+    assert row["ReturnAverage"] == 2.0 and row["ReturnMedian"] == 2.0 and row["ReturnMax"] == 3.0
+    text = (tmp_path / "progress.csv").read_text().splitlines()
+    assert text[0].startswith("Iteration,ReturnAverage,ReturnStd")
+    logger.set_output(None)

@@ -1,0 +1,342 @@
+"""GPU parity tests: every HIP kernel, called through the C-ABI, against the
+oracle (oracle/ref_port.py) and the committed golden vectors.
+
+Bars: bit-exact for integer / byte / index outputs and for the scans (whose
+dtype walk is reproduced exactly); 1e-5 relative for the standardisation (mean /
+std are order-dependent reductions) and the optimiser step.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_port as P
+from oracle import synth_ale
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def L():
+    from accel_rl_amd import _lib
+    _lib.load()
+    return _lib
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def run_gae(L, r, v, d, lv, gam, lam, promo=0):
+    n, t = r.shape
+    adv = torch.empty(n * t, dtype=torch.float32, device=DEV)
+    ret = torch.empty(n * t, dtype=torch.float32, device=DEV)
+    L.gae_scan(dev(r.reshape(-1)), dev(v.reshape(-1)), dev(d.reshape(-1).astype(np.uint8)), dev(lv),
+               gam, lam, n, t, adv, ret, promo=promo)
+    return adv.cpu().numpy().reshape(n, t), ret.cpu().numpy().reshape(n, t)
+
+
+def run_nstep(L, r, d, v, lv, gam, promo=0):
+    n, t = r.shape
+    adv = torch.empty(n * t, dtype=torch.float32, device=DEV)
+    ret = torch.empty(n * t, dtype=torch.float32, device=DEV)
+    L.nstep_return(dev(r.reshape(-1)), dev(d.reshape(-1).astype(np.uint8)), dev(v.reshape(-1)), dev(lv),
+                   gam, n, t, ret, adv, promo=promo)
+    return ret.cpu().numpy().reshape(n, t), adv.cpu().numpy().reshape(n, t)
+
+
+# ----------------------------------------------------------------------------- scans
+
+def test_gae_golden_bit_exact(L):
+    g = load_golden("g1_g2_scans")
+    for i in range(int(g["n_inputs"])):
+        ik = "i%02d" % i
+        for pi, (gam, lam) in enumerate(g["params"]):
+            key = "%s_p%d" % (ik, pi)
+            adv, ret = run_gae(L, g[ik + "_r"], g[ik + "_v"], g[ik + "_d"], g[ik + "_lv"], float(gam), float(lam))
+            np.testing.assert_array_equal(adv, g[key + "_adv"], err_msg=key)
+            np.testing.assert_array_equal(ret, g[key + "_ret"], err_msg=key)
+            adv_l, _ = run_gae(L, g[ik + "_r"], g[ik + "_v"], g[ik + "_d"], g[ik + "_lv"], float(gam), float(lam), promo=1)
+            np.testing.assert_array_equal(adv_l, g[key + "_adv_legacy"], err_msg=key + " legacy")
+
+
+def test_nstep_golden_bit_exact(L):
+    g = load_golden("g1_g2_scans")
+    n = 0
+    for i in range(int(g["n_inputs"])):
+        ik = "i%02d" % i
+        for pi, (gam, lam) in enumerate(g["params"]):
+            key = "%s_p%d" % (ik, pi)
+            if key + "_nret" not in g:
+                continue
+            ret, adv = run_nstep(L, g[ik + "_r"], g[ik + "_d"], g[ik + "_v"], g[ik + "_lv"], float(gam))
+            np.testing.assert_array_equal(ret, g[key + "_nret"], err_msg=key)
+            np.testing.assert_array_equal(adv, g[key + "_nadv"], err_msg=key)
+            ret_l, _ = run_nstep(L, g[ik + "_r"], g[ik + "_d"], g[ik + "_v"], g[ik + "_lv"], float(gam), promo=1)
+            np.testing.assert_array_equal(ret_l, g[key + "_nret_legacy"], err_msg=key + " legacy")
+            n += 1
+    assert n == 54
+
+
+@pytest.mark.parametrize("n,t", [(256, 5), (1024, 5), (2048, 5), (1, 5), (257, 5), (1000, 1),
+                                 (513, 2), (300, 8), (129, 9), (640, 16), (77, 17), (200, 32),
+                                 (65, 34), (50, 35), (40, 128), (3, 1000)])
+def test_scans_vs_oracle_shapes(L, n, t):
+    """Ragged tiles, every kernel variant (LDS 256/128/64-lane tiles, direct), both scans."""
+    rs = np.random.RandomState(n * 1000 + t)
+    r = rs.randn(n, t).astype(np.float32)
+    v = (rs.randn(n, t) * 2).astype(np.float32)
+    d = rs.rand(n, t) < 0.15
+    lv = rs.randn(n).astype(np.float32)
+    for promo, pname in ((0, "nep50"), (1, "legacy")):
+        adv, ret = run_gae(L, r, v, d, lv, 0.99, 0.95, promo)
+        a0, r0 = P.gae_scan(r, v, d, lv, 0.99, 0.95, pname)
+        np.testing.assert_array_equal(adv, a0)
+        np.testing.assert_array_equal(ret, r0)
+        ret, adv = run_nstep(L, r, d, v, lv, 0.99, promo)
+        r1, a1 = P.nstep_returns(r, d, v, lv, 0.99, pname)
+        np.testing.assert_array_equal(ret, r1)
+        np.testing.assert_array_equal(adv, a1)
+
+
+def test_scan_unaligned_views_take_the_direct_path(L):
+    rs = np.random.RandomState(5)
+    n, t = 100, 5
+    r = rs.randn(n, t).astype(np.float32)
+    v = rs.randn(n, t).astype(np.float32)
+    d = rs.rand(n, t) < 0.2
+    lv = rs.randn(n).astype(np.float32)
+    pad = torch.zeros(n * t + 1, dtype=torch.float32, device=DEV)
+    pad[1:] = dev(r.reshape(-1))
+    adv = torch.empty(n * t, dtype=torch.float32, device=DEV)
+    ret = torch.empty(n * t, dtype=torch.float32, device=DEV)
+    L.gae_scan(pad[1:], dev(v.reshape(-1)), dev(d.reshape(-1).astype(np.uint8)), dev(lv), 0.99, 0.95, n, t, adv, ret)
+    a0, r0 = P.gae_scan(r, v, d, lv, 0.99, 0.95)
+    np.testing.assert_array_equal(adv.cpu().numpy().reshape(n, t), a0)
+    np.testing.assert_array_equal(ret.cpu().numpy().reshape(n, t), r0)
+
+
+def test_gae_full_size_properties(L):
+    """BASELINE-scale and sweep-scale inputs: size-independent properties.
+    (a) done everywhere => adv = r - v exactly; (b) lambda=0 => adv = delta_t;
+    (c) linearity in rewards for done=0 (within fp32 rounding); (d) a random
+    window re-checked against the oracle."""
+    n, t = 1 << 20, 5
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    r = torch.randn(n * t, device=DEV, generator=gen)
+    v = torch.randn(n * t, device=DEV, generator=gen)
+    lv = torch.randn(n, device=DEV, generator=gen)
+    ones = torch.ones(n * t, dtype=torch.uint8, device=DEV)
+    zeros = torch.zeros(n * t, dtype=torch.uint8, device=DEV)
+    adv = torch.empty_like(r)
+    ret = torch.empty_like(r)
+    L.gae_scan(r, v, ones, lv, 0.99, 0.95, n, t, adv, ret)
+    assert torch.equal(adv, (r.double() - v.double()).float())
+    assert torch.equal(ret, adv + v)
+    d = (torch.rand(n * t, device=DEV, generator=gen) < 0.1).to(torch.uint8)
+    L.gae_scan(r, v, d, lv, 0.99, 0.95, n, t, adv, ret)
+    lo = 12345
+    a0, r0 = P.gae_scan(r.view(n, t)[lo:lo + 4096].cpu().numpy(), v.view(n, t)[lo:lo + 4096].cpu().numpy(),
+                        d.view(n, t)[lo:lo + 4096].cpu().numpy(), lv[lo:lo + 4096].cpu().numpy(), 0.99, 0.95)
+    np.testing.assert_array_equal(adv.view(n, t)[lo:lo + 4096].cpu().numpy(), a0)
+    np.testing.assert_array_equal(ret.view(n, t)[lo:lo + 4096].cpu().numpy(), r0)
+    # last tile too
+    a1, _ = P.gae_scan(r.view(n, t)[-300:].cpu().numpy(), v.view(n, t)[-300:].cpu().numpy(),
+                       d.view(n, t)[-300:].cpu().numpy(), lv[-300:].cpu().numpy(), 0.99, 0.95)
+    np.testing.assert_array_equal(adv.view(n, t)[-300:].cpu().numpy(), a1)
+    # linearity: scan(2r, 2v, 2lv) == 2 * scan(r, v, lv) exactly (powers of two commute with rounding)
+    adv2 = torch.empty_like(r)
+    ret2 = torch.empty_like(r)
+    L.gae_scan(r * 2, v * 2, d, lv * 2, 0.99, 0.95, n, t, adv2, ret2)
+    assert torch.equal(adv2, adv * 2)
+    del zeros
+
+
+# ----------------------------------------------------------------------------- valids / standardise
+
+def test_valids_golden(L):
+    g = load_golden("g3_valids")
+    for c in range(int(g["n_cases"])):
+        k = "c%02d" % c
+        n, t = g[k + "_flags"].shape
+        valids = torch.full((n * t,), 9, dtype=torch.int8, device=DEV)
+        a, r, v = (dev(g[k + x].reshape(-1)) for x in ("_adv", "_ret", "_val"))
+        L.valids_mask(dev(g[k + "_flags"].reshape(-1).astype(np.uint8)), n, t, valids, a, r, v)
+        np.testing.assert_array_equal(valids.cpu().numpy().reshape(n, t), g[k + "_valids"], err_msg=k)
+        np.testing.assert_array_equal(a.cpu().numpy().reshape(n, t), g[k + "_adv_z"])
+        np.testing.assert_array_equal(r.cpu().numpy().reshape(n, t), g[k + "_ret_z"])
+        np.testing.assert_array_equal(v.cpu().numpy().reshape(n, t), g[k + "_val_z"])
+
+
+@pytest.mark.parametrize("n", [1, 5, 1280, 5120, 100003, 1 << 22])
+@pytest.mark.parametrize("masked", [False, True])
+def test_standardize_vs_oracle(L, n, masked):
+    rs = np.random.RandomState(n % 9973)
+    x = (rs.randn(n) * 3 + 1.5).astype(np.float32)
+    valids = (rs.rand(n) < 0.7).astype(np.int8) if masked else None
+    if masked:
+        valids[0] = 1
+    want = P.standardize(x, valids)
+    xt = dev(x)
+    ws = L.standardize_workspace(DEV)
+    L.standardize(xt, None if valids is None else dev(valids), ws, 1e-6)
+    got = xt.cpu().numpy()
+    tol = 1e-5 * np.maximum(1.0, np.abs(want)) if n > 1 else 1e-5
+    assert np.all(np.abs(got - want) <= tol), np.abs(got - want).max()
+    if masked:
+        np.testing.assert_array_equal(got[valids == 0], x[valids == 0])   # untouched
+
+
+def test_process_samples_golden_pipeline(L):
+    """scan -> valids -> standardise chained on the device == the reference's
+    AdvActorCriticBase.process_samples (fixture G4)."""
+    g = load_golden("g4_process_samples")
+    ws = L.standardize_workspace(DEV)
+    for c in range(int(g["n_cases"])):
+        k = "c%02d" % c
+        gam, lam, use_valids, std_adv = g[k + "_cfg"]
+        n, t = g[k + "_r"].shape
+        r, v, lv = dev(g[k + "_r"].reshape(-1)), dev(g[k + "_v"].reshape(-1)), dev(g[k + "_lv"])
+        d = dev(g[k + "_d"].reshape(-1).astype(np.uint8))
+        adv = torch.empty(n * t, dtype=torch.float32, device=DEV)
+        ret = torch.empty(n * t, dtype=torch.float32, device=DEV)
+        if lam == 1:
+            L.nstep_return(r, d, v, lv, float(gam), n, t, ret, adv)
+        else:
+            L.gae_scan(r, v, d, lv, float(gam), float(lam), n, t, adv, ret)
+        valids = None
+        if use_valids:
+            valids = torch.empty(n * t, dtype=torch.int8, device=DEV)
+            L.valids_mask(dev(g[k + "_need"].reshape(-1).astype(np.uint8)), n, t, valids, adv, ret, v)
+            np.testing.assert_array_equal(valids.cpu().numpy().reshape(n, t), g[k + "_valids"])
+            np.testing.assert_array_equal(v.cpu().numpy().reshape(n, t), g[k + "_value_after"])
+        np.testing.assert_array_equal(ret.cpu().numpy().reshape(n, t), g[k + "_ret"], err_msg=k)
+        if std_adv:
+            L.standardize(adv, valids, ws, 1e-6)
+            want = g[k + "_adv"]
+            got = adv.cpu().numpy().reshape(n, t)
+            assert np.all(np.abs(got - want) <= 1e-5 * np.maximum(1, np.abs(want))), k
+        else:
+            np.testing.assert_array_equal(adv.cpu().numpy().reshape(n, t), g[k + "_adv"], err_msg=k)
+
+
+# ----------------------------------------------------------------------------- sampling
+
+def test_sampling_golden_bit_exact(L):
+    g = load_golden("g5_sampling")
+    for c in range(int(g["n_cases"])):
+        k = "c%02d" % c
+        p, u = g[k + "_prob"], g[k + "_u"]
+        act = torch.full((len(u),), 255, dtype=torch.uint8, device=DEV)
+        L.sample_categorical(dev(p), dev(u), act)
+        np.testing.assert_array_equal(act.cpu().numpy(), g[k + "_act"], err_msg=k)
+
+
+def test_sampling_large_vs_oracle(L):
+    rs = np.random.RandomState(0)
+    for b, a in ((1 << 18, 4), (100001, 18), (4099, 6)):
+        p = rs.dirichlet(np.ones(a) * 0.3, size=b).astype(np.float32)
+        u = rs.rand(b)
+        u[:8] = [0.0, 1.0 - 1e-17, 0.999999999, 1e-300, 0.5, 0.25, 0.75, 0.9999]
+        act = torch.empty(b, dtype=torch.uint8, device=DEV)
+        L.sample_categorical(dev(p), dev(u), act)
+        np.testing.assert_array_equal(act.cpu().numpy(), P.sample_actions(p, u))
+
+
+# ----------------------------------------------------------------------------- pixels
+
+def test_preprocess_vs_oracle(L):
+    rs = np.random.RandomState(4)
+    n = 37
+    a = rs.randint(0, 256, size=(n, 210, 160), dtype=np.uint8)
+    b = rs.randint(0, 256, size=(n, 210, 160), dtype=np.uint8)
+    a[0] = 255; b[0] = 255          # saturation: (4*255+2)>>2 == 255
+    a[1] = 0; b[1] = 0
+    b[2] = a[2]
+    out = torch.empty((n, 104, 80), dtype=torch.uint8, device=DEV)
+    L.preprocess_frames(dev(a), dev(b), out)
+    want = np.stack([P.preprocess_pair(a[i], b[i]) for i in range(n)])
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    L.preprocess_frames(None, dev(b), out)
+    want = np.stack([P.preprocess_pair(None, b[i]) for i in range(n)])
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+def test_preprocess_bank_frames(L):
+    bank = synth_ale.frame_bank(1)
+    out = torch.empty((64, 104, 80), dtype=torch.uint8, device=DEV)
+    L.preprocess_frames(dev(bank), dev(np.roll(bank, 1, axis=0)), out)
+    want = np.stack([P.preprocess_pair(bank[i], bank[i - 1]) for i in range(64)])
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+def test_gather_scale(L):
+    rs = np.random.RandomState(8)
+    obs = rs.randint(0, 256, size=(1280, 4, 104, 80), dtype=np.uint8)
+    idx = rs.permutation(1280)[:512].astype(np.int32)
+    out = torch.empty((512, 4, 104, 80), dtype=torch.float32, device=DEV)
+    L.gather_scale_obs(dev(obs), dev(idx), out, 1. / 255)
+    want = obs[idx].astype(np.float32) * np.float32(1. / 255)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    out2 = torch.empty((1280, 4, 104, 80), dtype=torch.float32, device=DEV)
+    L.gather_scale_obs(dev(obs), None, out2, 1. / 255)
+    np.testing.assert_array_equal(out2.cpu().numpy(), obs.astype(np.float32) * np.float32(1. / 255))
+
+
+# ----------------------------------------------------------------------------- optimiser
+
+def _opt_state(L, p, g, with_v=True, log_len=16):
+    n = p.numel()
+    st = L.ArlOptState()
+    keep = dict(p=p, g=g, m=torch.zeros_like(p), v=torch.zeros_like(p) if with_v else None,
+                t=torch.zeros(1, device=DEV), lr=torch.ones(1, device=DEV),
+                part=torch.zeros(L.OPT_PARTIALS, dtype=torch.float64, device=DEV),
+                log=torch.zeros(log_len, device=DEV))
+    st.n_params = n
+    st.params, st.grads, st.slot0 = p.data_ptr(), g.data_ptr(), keep["m"].data_ptr()
+    st.slot1 = keep["v"].data_ptr() if with_v else None
+    st.step_count, st.lr_mult = keep["t"].data_ptr(), keep["lr"].data_ptr()
+    st.partials, st.grad_norm_log, st.norm_log_len = keep["part"].data_ptr(), keep["log"].data_ptr(), log_len
+    return st, keep
+
+
+@pytest.mark.parametrize("n", [3, 1000, 898613, 3620005])
+@pytest.mark.parametrize("clip", [None, 0.5])
+def test_adam_vs_oracle(L, n, clip):
+    rs = np.random.RandomState(n % 1000)
+    p0 = rs.randn(n).astype(np.float32)
+    p, g = dev(p0), torch.zeros(n, device=DEV)
+    st, keep = _opt_state(L, p, g)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); t = np.float32(0); pw = p0.copy()
+    for it in range(3):
+        gh = (rs.randn(n) * (0.01 if it else 3.0)).astype(np.float32)
+        g.copy_(dev(gh))
+        keep["lr"].fill_(1.0 - 0.25 * it)
+        L.opt_step(st, L.OPT_ADAM, 1e-3, 0.5, clip, 0.9, 0.999, 1e-5)
+        gavg = (gh * np.float32(0.5)).astype(np.float32)
+        gc, norm = P.clip_by_total_norm(gavg, clip)
+        pw, m, v, t = P.adam_step(pw, gc, m, v, t, np.float32(1e-3) * np.float32(1.0 - 0.25 * it), eps=1e-5)
+        got = p.cpu().numpy()
+        assert np.allclose(got, pw, rtol=1e-5, atol=1e-6), (it, np.abs(got - pw).max())
+        assert abs(keep["log"][it].item() - norm) <= 1e-5 * max(1, norm)
+    assert keep["t"].item() == 3.0
+
+
+@pytest.mark.parametrize("clip", [None, 0.5])
+def test_rmsprop_vs_oracle(L, clip):
+    n = 898613
+    rs = np.random.RandomState(2)
+    p0 = rs.randn(n).astype(np.float32)
+    p, g = dev(p0), torch.zeros(n, device=DEV)
+    st, keep = _opt_state(L, p, g, with_v=False)
+    acc = np.zeros(n, np.float32); pw = p0.copy()
+    for it in range(3):
+        gh = rs.randn(n).astype(np.float32)
+        g.copy_(dev(gh))
+        L.opt_step(st, L.OPT_RMSPROP, 7e-4, 1.0, clip, 0.9, 0.0, 1e-6)
+        gc, norm = P.clip_by_total_norm(gh, clip)
+        pw, acc = P.rmsprop_step(pw, gc, acc, 7e-4)
+        got = p.cpu().numpy()
+        assert np.allclose(got, pw, rtol=1e-5, atol=1e-6), (it, np.abs(got - pw).max())

@@ -1,0 +1,181 @@
+"""GPU parity of the whole rollout: GpuVecSampler (HIP env + sampling kernels
+behind the reference's sampler interface) against
+  (1) the golden rollouts recorded from the reference's real multi-process
+      sampler + AtariEnv (fixture G7), and
+  (2) the oracle's sequential sampler port at BASELINE sizes (256 / 1024 envs).
+Everything compared here is integer / byte / copied-float data: bit-exact.
+"""
+import ast
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import ref_port as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def crc_rows(t):
+    a = np.ascontiguousarray(t.cpu().numpy())
+    return np.array([zlib.crc32(a[i].tobytes()) for i in range(len(a))], np.uint32)
+
+
+class DeviceTablePolicy(object):
+    """Device twin of the fixtures' table policy: key = pixel sum mod 64."""
+    recurrent = False
+
+    def __init__(self, prob_table, value_table):
+        self.prob_table = torch.from_numpy(prob_table).to(DEV)
+        self.value_table = torch.from_numpy(value_table).to(DEV)
+
+    def _keys(self, obs):
+        return obs.reshape(obs.shape[0], -1).sum(dim=1, dtype=torch.int64) % 64
+
+    def reset(self, n_batch):
+        pass
+
+    def prob_value(self, obs):
+        k = self._keys(obs)
+        return self.prob_table[k].contiguous(), self.value_table[k].contiguous()
+
+    def get_action(self, ob):
+        np.random.rand()             # the reference policy samples one action here
+        return None, None
+
+
+class HostTablePolicy(object):
+    """numpy twin for the oracle sampler (same tables, global numpy RNG)."""
+
+    def __init__(self, prob_table, value_table):
+        self.prob_table, self.value_table = prob_table, value_table
+
+    def get_actions(self, obs):
+        k = obs.reshape(obs.shape[0], -1).astype(np.int64).sum(axis=1) % 64
+        prob, value = self.prob_table[k], self.value_table[k]
+        return P.sample_actions(prob, np.random.rand(len(k))), dict(prob=prob, value=value)
+
+
+def make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, mid_batch_reset, max_path_length,
+                     env_kwargs, tables, discount, use_graph):
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    env_args = dict(env_kwargs)
+    env_args["game"] = game
+    smp = GpuVecSampler(EnvCls=SynthAtariEnv, env_args=env_args, horizon=horizon,
+                        n_parallel=n_parallel, envs_per=envs_per, mid_batch_reset=mid_batch_reset,
+                        max_path_length=max_path_length, max_decorrelation_steps=0,
+                        device=DEV, use_graph=use_graph)
+    np.random.seed(seed)                                   # runner: set_seed(seed)
+    smp.initialize(seed=seed + 1, affinities=dict(), discount=discount, need_extra_obs=True)
+    smp.policy_init(DeviceTablePolicy(*tables))
+    return smp
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("tag", ["breakout", "pong_maxlen", "seaquest_nomid", "breakout_noop0"])
+def test_gpu_sampler_matches_reference_rollout(tag, use_graph):
+    g = load_golden("g7_rollout_" + tag)
+    n_parallel, envs_per, horizon, n_batches, seed, mbr, maxlen = [int(x) for x in g["cfg"]]
+    smp = make_gpu_sampler(str(g["game"]), horizon, n_parallel, envs_per, seed, bool(mbr),
+                           np.inf if maxlen < 0 else maxlen,
+                           dict(ast.literal_eval(str(g["env_args"]))),
+                           (g["prob_table"], g["value_table"]), float(g["discount"]), use_graph)
+    t = horizon
+    traj = []
+    for b in range(n_batches):
+        buf, infos = smp.obtain_samples(b)
+        msg = "%s batch %d" % (tag, b)
+        np.testing.assert_array_equal(buf.actions.cpu().numpy(), g["actions"][b], err_msg=msg)
+        np.testing.assert_array_equal(buf.agent_infos["prob"].cpu().numpy(), g["prob"][b], err_msg=msg)
+        np.testing.assert_array_equal(buf.agent_infos["value"].cpu().numpy(), g["value"][b], err_msg=msg)
+        need = buf.env_infos["need_reset"].cpu().numpy().astype(bool)
+        if mbr:
+            valid = np.ones(len(need), bool)
+        else:   # NonResetCollector leaves stale rows: compare under the valids mask
+            valid = P.valid_mask(g["need_reset"][b].reshape(-1, t)).reshape(-1).astype(bool)
+            np.testing.assert_array_equal(P.valid_mask(need.reshape(-1, t)).reshape(-1).astype(bool), valid)
+        np.testing.assert_array_equal(buf.rewards.cpu().numpy()[valid], g["rewards"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(buf.dones.cpu().numpy().astype(bool)[valid], g["dones"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(buf.env_infos["raw_reward"].cpu().numpy()[valid], g["raw_reward"][b][valid])
+        np.testing.assert_array_equal(need[valid], g["need_reset"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(crc_rows(buf.observations)[valid], g["obs_crc"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(crc_rows(buf.extra_observations), g["extra_crc"][b], err_msg=msg)
+        if b == 0:
+            np.testing.assert_array_equal(buf.observations[:, -1].cpu().numpy(),
+                                          g["first_batch_newest_frames"])
+        for ti in infos:
+            traj.append((b, float(ti.Length), float(ti.Return), float(ti.RawReturn),
+                         float(ti.NonzeroRewards), float(ti.DiscountedReturn)))
+    want = sorted((int(b),) + tuple(float(x) for x in row) for b, row in zip(g["traj_batch"], g["traj"]))
+    assert len(want) > 0 and sorted(traj) == want
+    smp.shutdown()
+
+
+@pytest.mark.parametrize("n_parallel,envs_per,game,n_batches", [
+    (16, 8, "breakout", 4),       # BASELINE config 2: 256 envs, T=5
+    (64, 8, "breakout", 2),       # BASELINE config 3: 1024 envs
+    (4, 2, "pong", 3),            # config 1 size (16 envs), 6 actions
+    (3, 5, "seaquest", 3),        # 18 actions, odd group sizes
+])
+def test_gpu_sampler_matches_oracle_at_baseline_sizes(n_parallel, envs_per, game, n_batches):
+    seed, horizon = 17, 5
+    rs = np.random.RandomState(77)
+    n_act = {"breakout": 4, "pong": 6, "seaquest": 18}[game]
+    logits = rs.randn(64, n_act) * 1.5
+    p = np.exp(logits - logits.max(1, keepdims=True))
+    tables = ((p / p.sum(1, keepdims=True)).astype(np.float32), (rs.randn(64) * 2).astype(np.float32))
+    # short episodes so that resets, life losses and over-length all occur within a few batches
+    kw = dict(max_start_noops=30)
+    smp = make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, True, 9, kw, tables, 0.99, True)
+
+    ora = P.CpuSamplerPort(game, horizon, n_parallel, envs_per, max_path_length=9,
+                           mid_batch_reset=True, env_kwargs=kw)
+    np.random.seed(seed)
+    ora.initialize(seed + 1, discount=0.99)
+    shape = ora.step_obs.shape[1:]
+    for _ in range(2):
+        np.random.randint(low=0, high=255, size=shape, dtype=np.uint8)
+        np.random.randint(n_act, dtype=np.uint8)
+    np.random.randint(low=0, high=255, size=shape, dtype=np.uint8)
+    np.random.rand()
+    host_policy = HostTablePolicy(*tables)
+    state = np.random.get_state()
+    for b in range(n_batches):
+        # both sides draw the batch's uniforms from the same global stream position
+        np.random.set_state(state)
+        buf, infos = smp.obtain_samples(b)
+        np.random.set_state(state)
+        want, completed = ora.obtain_samples(host_policy)
+        state = np.random.get_state()
+        for key, got in (("actions", buf.actions), ("rewards", buf.rewards), ("dones", buf.dones),
+                         ("raw_reward", buf.env_infos["raw_reward"]), ("need_reset", buf.env_infos["need_reset"]),
+                         ("prob", buf.agent_infos["prob"]), ("value", buf.agent_infos["value"])):
+            np.testing.assert_array_equal(got.cpu().numpy().astype(want[key].dtype), want[key],
+                                          err_msg="%s batch %d" % (key, b))
+        np.testing.assert_array_equal(buf.observations.cpu().numpy(), want["observations"])
+        np.testing.assert_array_equal(buf.extra_observations.cpu().numpy(), want["extra_observations"])
+        got_t = sorted((ti.Length, ti.Return, ti.RawReturn, ti.NonzeroRewards, ti.DiscountedReturn) for ti in infos)
+        want_t = sorted(ti.as_tuple() for ti in completed)
+        assert got_t == want_t and len(want_t) > 0
+    smp.shutdown()
+
+
+def test_decorrelation_runs_and_desynchronises():
+    rs = np.random.RandomState(1)
+    p = np.full((64, 4), 0.25, np.float32)
+    smp = make_gpu_sampler("breakout", 5, 8, 4, 3, True, np.inf, dict(), (p, rs.randn(64).astype(np.float32)), 0.99, False)
+    ticks0 = smp._st.tick.cpu().numpy().copy()
+    smp.max_decorrelation_steps = 300
+    with torch.cuda.device(smp.device):
+        smp._decorrelate()
+    ticks = smp._st.tick.cpu().numpy()
+    assert len(np.unique(ticks)) > len(np.unique(ticks0))
+    assert smp._st.traj_len.cpu().numpy().max() > 10
+    buf, _ = smp.obtain_samples(0)
+    assert buf.observations.shape == (64 * 5, 4, 104, 80)
