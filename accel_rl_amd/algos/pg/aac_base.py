@@ -29,7 +29,7 @@ def valids_mean(expression, valids=None):
 class AdvActorCriticBase(RLAlgorithm):
 
     def __init__(self, discount, gae_lambda, v_loss_coeff=1, ent_loss_coeff=0.01,
-                 standardize_adv=False, lr_schedule=None, promo="nep50"):
+                 standardize_adv=False, lr_schedule=None, promo="nep50", use_graph=True):
         if lr_schedule is not None and lr_schedule not in LR_SCHEDULES:
             raise ValueError("Unrecognized lr_schedule: {}, should be None (for constant) or "
                              "in: {}".format(lr_schedule, LR_SCHEDULES))
@@ -59,14 +59,49 @@ class AdvActorCriticBase(RLAlgorithm):
         self._horizon = horizon
         self._n_env = sample_size // horizon
         self._std_ws = _lib.standardize_workspace(dev)
+        self._lr_mult_host = torch.ones(1, dtype=torch.float32).pin_memory()
+        self._graph = None
+        self._graph_out = None
+        self._graph_samples = None
+        self._warm_calls = 0
 
     def set_n_itr(self, n_itr):
         self.n_itr = n_itr
 
     def optimize_policy(self, itr, samples_data):
+        """reference: aac_base.py:102-106.  Host-side draws (minibatch permutations, lr
+        schedule) are made first; the device work (bootstrap forward, scan, epochs x
+        minibatches of forward/backward/update) is static-shape and, after two eager
+        warm-up calls, is replayed from one hipGraph."""
+        if self.lr_schedule == "linear":                             # aac_base.py:165-168
+            self._lr_mult_host.fill_(max((self.n_itr - itr) / self.n_itr, 0.))
+        if hasattr(self.optimizer, "prepare_host"):
+            self.optimizer.prepare_host(self._batch_size)
+        graphable = self.use_graph and hasattr(self.optimizer, "device_updates") and \
+            getattr(self.optimizer, "_n_gpu", 1) == 1
+        if not graphable:
+            return self._device_optimize(itr, samples_data)
+        if self._graph is None:
+            self._warm_calls += 1
+            if self._warm_calls <= 2:
+                return self._device_optimize(itr, samples_data)
+            torch.cuda.synchronize(self.policy.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._graph_out = self._device_optimize(itr, samples_data)
+            self._graph, self._graph_samples = graph, samples_data
+        assert samples_data is self._graph_samples, "the sampler must hand over the same buffer"
+        self._graph.replay()
+        return self._graph_out
+
+    def _device_optimize(self, itr, samples_data):
+        self._lr_mult.copy_(self._lr_mult_host, non_blocking=True)
         opt_data = self.process_samples(itr, samples_data)
         opt_input_values = self.prep_opt_inputs(itr, samples_data, opt_data)
-        _, grad_norm = self.optimizer.optimize(opt_input_values)
+        if hasattr(self.optimizer, "device_updates"):
+            _, grad_norm = self.optimizer.device_updates(opt_input_values)
+        else:
+            _, grad_norm = self.optimizer.optimize(opt_input_values)
         return opt_data, dict(GradNorm=grad_norm)
 
     def process_samples(self, itr, samples_data):
@@ -99,8 +134,6 @@ class AdvActorCriticBase(RLAlgorithm):
         values += tuple(agent_infos[k] for k in self._dist_info_keys)
         if self._use_valids:
             values += (opt_data["valids"],)
-        if self.lr_schedule == "linear":
-            self._lr_mult.fill_(max((self.n_itr - itr) / self.n_itr, 0.))
         return values
 
     # ---- loss graph (aac_base.py:60-70) ---------------------------------------

@@ -81,11 +81,16 @@ class BaseOptimizer(object):
                       avg_factor, self._grad_norm_clip, b1, b2, eps)
         self._n_updates += 1
 
+    def _set_updates_per_call(self, count):
+        """The update kernel logs the grad norm of update number t at slot (t-1) % len.
+        With len == updates per optimize() call, update k of EVERY call lands on slot k,
+        so a captured hipGraph can read fixed slots."""
+        count = max(1, min(int(count), NORM_LOG_LEN))
+        if self._opt_state.norm_log_len != count:
+            assert self._n_updates % count == 0 or self._n_updates == 0
+            self._opt_state.norm_log_len = count
+
     def _recent_grad_norms(self, count):
-        """Device tensor [count] with the global grad norms of the last `count` updates
-        (the update kernel logs them into a ring; no host sync here)."""
-        assert 0 < count <= NORM_LOG_LEN
-        first = (self._n_updates - count) % NORM_LOG_LEN
-        if first + count <= NORM_LOG_LEN:
-            return self._norm_log[first:first + count].clone()
-        return torch.cat([self._norm_log[first:], self._norm_log[:first + count - NORM_LOG_LEN]])
+        """Device tensor [count]: global grad norms of this call's updates (no host sync)."""
+        assert 0 < count <= self._opt_state.norm_log_len
+        return self._norm_log[:count].clone()

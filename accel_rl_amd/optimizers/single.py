@@ -21,6 +21,13 @@ class A2cOptimizer(BaseOptimizer):
         self._setup_bucket(target, lr_mult)
 
     def optimize(self, inputs):
+        self.prepare_host(len(inputs[0]))
+        return self.device_updates(inputs)
+
+    def prepare_host(self, data_length):
+        self._set_updates_per_call(1)
+
+    def device_updates(self, inputs):
         minibatch = dict(zip(self._input_names, inputs))
         minibatch["idx"] = None
         loss = self._backward(self._losses, minibatch)
@@ -61,22 +68,35 @@ class PpoOptimizer(BaseOptimizer):
         self._idx_host = None
 
     def optimize(self, inputs):
-        data = dict(zip(self._input_names, inputs))      # "_f_load": already on the device
-        return self._do_updates(data, len(inputs[0]))
+        self.prepare_host(len(inputs[0]))
+        return self.device_updates(inputs)
 
-    def _do_updates(self, data, data_length):
+    # Split for hipGraph capture: everything that draws from the host RNG happens in
+    # prepare_host(); device_updates() only enqueues static-shape device work.
+    def prepare_host(self, data_length):
+        """Minibatch permutations for ALL epochs up front, into one pinned buffer: same
+        RNG consumption order as the reference (np.random.shuffle once per epoch,
+        optimizers/util.py:10-11; nothing else draws inside optimize)."""
         bs = self._minibatch_size
-        # all epochs' permutations up front: same RNG consumption order as the reference
-        # (nothing else draws from the global stream inside optimize), one H2D copy
-        per_epoch = [list(iterate_mb_idxs(bs, data_length, self._shuffle)) for _ in range(self._epochs)]
-        flat = [mb for ep in per_epoch for mb in ep]
-        if not flat:
+        flat = [mb for _ in range(self._epochs)
+                for mb in iterate_mb_idxs(bs, data_length, self._shuffle)]
+        if self._idx_host is None:
+            shape = (max(len(flat), 1), bs)
+            self._idx_host = torch.zeros(shape, dtype=torch.int32).pin_memory()
+            self._idx_dev = torch.zeros(shape, dtype=torch.int32, device=self._target.device)
+        self._n_minibatches = len(flat)
+        self._set_updates_per_call(len(flat))
+        if flat:
+            self._idx_host.copy_(torch.from_numpy(np.stack(flat).astype(np.int32)))
+
+    def device_updates(self, inputs):
+        data = dict(zip(self._input_names, inputs))      # "_f_load": already on the device
+        if not self._n_minibatches:
             return [], []
-        host = torch.from_numpy(np.stack(flat).astype(np.int32))
-        idx_dev = host.to(self._target.device, non_blocking=True)
+        self._idx_dev.copy_(self._idx_host, non_blocking=True)
         losses = []
-        for k in range(len(flat)):
-            idx = idx_dev[k]
+        for k in range(self._n_minibatches):
+            idx = self._idx_dev[k]
             mb = dict(idx=idx, observations=data["observations"])
             idx64 = idx.long()
             for name, tensor in data.items():
@@ -85,7 +105,7 @@ class PpoOptimizer(BaseOptimizer):
             losses.append(self._backward(self._losses, mb))
             self._share_grad()
             self._apply_update(self._avg_factor())
-        return losses, self._recent_grad_norms(len(flat))
+        return losses, self._recent_grad_norms(self._n_minibatches)
 
     def _share_grad(self):
         pass

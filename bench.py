@@ -101,9 +101,22 @@ def roofline_gae(device, log2_elems, reps):
     nbytes = 17 * n * t + 4 * n
     achieved = nbytes / (mean_ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel="scan_lds_kernel<GAE,NEP50,256>", achieved=round(achieved, 1),
-                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=pmc_traffic(log2_elems),
                 bytes_per_launch=nbytes, n_env=n, horizon=t, launches=reps,
                 avg_launch_us=round(mean_ms * 1e3, 2), median_launch_us=round(med_ms * 1e3, 2))
+
+
+def pmc_traffic(log2_elems):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (bench.py cannot
+    read PMC counters itself); None if no profile for this size is committed."""
+    path = os.path.join(ROOT, "profiles", "gae_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        return rec["hbm_bytes_per_launch"] if rec.get("log2_elems") == log2_elems else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def kernel_table(device, sampler, algo, policy, reps=20):
@@ -196,6 +209,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-log2", type=int, default=26)
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the GAE-scan roofline leg (used for the rocprofv3 --pmc passes)")
     ap.add_argument("--suite", action="store_true", help="BASELINE config 4: one game per rank")
     args = ap.parse_args()
 
@@ -214,6 +229,9 @@ def main():
 
     import __graft_entry__
     __graft_entry__.build()
+    if args.roofline_only:
+        print(json.dumps({"roofline": roofline_gae(device, args.roofline_log2, 30)}), flush=True)
+        return
 
     game = GAMES_8[rank % 8] if args.suite else GAME
     runner, sampler, algo, policy = build_workload(device, 0, rank, world, game, not args.no_graph)
@@ -256,13 +274,30 @@ def main():
                    "env_steps_per_step_per_gpu": N_ENVS * HORIZON,
                    "parallelism": "dp%d sync all-reduce (RCCL)" % world if world > 1 else "single"},
     }
+    # phase split of the same workload (after the timed region): rollout only / learner only
+    def timed(fn, reps):
+        barrier()
+        t = time.perf_counter()
+        for i in range(reps):
+            fn(i)
+        barrier()
+        return (time.perf_counter() - t) / reps
+    reps = max(10, min(50, args.steps))
+    t_roll = timed(lambda i: sampler.obtain_samples(itr + i), reps)
+    samples = sampler.samples_buf
+    t_learn = timed(lambda i: algo.optimize_policy(itr + i, samples), reps)
+    line["phases"] = {"rollout_ms": round(t_roll * 1e3, 4), "learner_ms": round(t_learn * 1e3, 4),
+                      "rollout_only_env_steps_per_s": round(N_ENVS * HORIZON / t_roll, 1)}
     if rank == 0 and world == 1:
         if not args.no_roofline:
             line["roofline"] = roofline_gae(device, args.roofline_log2, 30)
             line["kernels"] = kernel_table(device, sampler, algo, policy)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(device, policy)
-            line["gpu_over_cpu"] = round(line["value"] / line["cpu_baseline"]["value"], 2)
+            line["gpu_over_cpu"] = {
+                "rollout_only": round(line["phases"]["rollout_only_env_steps_per_s"] / line["cpu_baseline"]["value"], 2),
+                "note": "like for like: GPU rollout (sampler only) vs CPU sampler port; `value` additionally "
+                        "contains the PPO learner, which the CPU baseline does not run"}
     runner.shutdown()
     if rank == 0:
         print(json.dumps(line), flush=True)
