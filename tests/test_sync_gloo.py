@@ -1,0 +1,178 @@
+"""World-size-2 `gloo` tests (CPU) of the synchronous multi-GPU protocol:
+flat-bucket all-reduce + 1/n averaging in the optimizers, and AccelRLSync's
+rank seeding, parameter broadcast, lock-step iteration count and trajectory
+gather.  The device kernels are replaced by trivial stand-ins HERE (test doubles
+inside this file only); the protocol code under test is the product's."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+class _Target(object):
+    """Stand-in for the policy's flat buckets (CPU tensors)."""
+    def __init__(self, n):
+        self.device = torch.device("cpu")
+        self.flat_params = torch.zeros(n)
+        self.flat_grads = torch.zeros(n)
+
+
+def _optimizer_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from accel_rl_amd.optimizers import update_methods
+    from accel_rl_amd.optimizers.sync import SyncPpoOptimizer, SyncA2cOptimizer
+    for cls, kw in ((SyncPpoOptimizer, dict(update_method_args=None, epochs=1, minibatch_size=4)),
+                    (SyncA2cOptimizer, dict())):
+        opt = cls(learning_rate=1e-3, update_method=update_methods.adam, **kw)
+        assert opt.parallelism_tag == "synchronous"
+        opt._target = _Target(10)
+        opt.init_comm(None, rank, world)
+        opt._target.flat_grads.copy_(torch.arange(10.) * (rank + 1))
+        opt._share_grad()                                   # all-reduce SUM of the ONE flat vector
+        want = torch.arange(10.) * sum(r + 1 for r in range(world))
+        assert torch.equal(opt._target.flat_grads, want)
+        assert opt._avg_factor() == 1.0 / world             # applied AFTER the sum (sync/base.py:14-16)
+    out.put((rank, "ok"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_optimizer_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    out, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_optimizer_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
+# ----------------------------------------------------------------------------- runner
+
+class _FakePolicy(object):
+    recurrent = False
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+
+    def initialize(self, env_spec, device=None):
+        g = torch.Generator().manual_seed(int(np.random.randint(1 << 30)))   # differs per rank seed
+        self.flat_params = torch.randn(16, generator=g)
+        self.flat_grads = torch.zeros(16)
+        self.n_params = 16
+
+    def get_param_values(self):
+        return self.flat_params.numpy().copy()
+
+    def reset(self, n_batch=None):
+        pass
+
+
+class _FakeSampler(object):
+    device = "cpu"
+
+    def initialize(self, seed, affinities, discount, need_extra_obs):
+        self.seed = seed
+        return None, 20, 5, True
+
+    def policy_init(self, policy):
+        pass
+
+    def obtain_samples(self, itr):
+        from accel_rl_amd.sampler.util import TrajInfo
+        rank = int(os.environ["RANK"])
+        infos = [TrajInfo(Length=10 + rank, Return=float(itr))] if itr % 2 == rank else []
+        return dict(), infos
+
+    def shutdown(self):
+        pass
+
+
+class _FakeAlgo(object):
+    need_extra_obs = True
+    discount = 0.99
+    opt_info_keys = ["GradNorm"]
+
+    def __init__(self):
+        from accel_rl_amd.optimizers import update_methods
+        from accel_rl_amd.optimizers.sync import SyncA2cOptimizer
+        self.optimizer = SyncA2cOptimizer(learning_rate=1e-3, update_method=update_methods.rmsprop)
+        self.calls = 0
+
+    def initialize(self, policy, env_spec, sample_size, horizon, mid_batch_reset):
+        self.policy = policy
+        self.optimizer._target = policy
+
+    def set_n_itr(self, n):
+        self.n_itr = n
+
+    def optimize_policy(self, itr, samples):
+        self.calls += 1
+        self.policy.flat_grads.fill_(float(int(os.environ["RANK"]) + 1))
+        self.optimizer._share_grad()
+        self.policy.flat_params.sub_(self.policy.flat_grads * self.optimizer._avg_factor() * 0.1)
+        return None, dict(GradNorm=torch.tensor([1.0]))
+
+
+def _runner_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from accel_rl_amd.runners.sync import AccelRLSync
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    algo, policy, sampler = _FakeAlgo(), _FakePolicy(), _FakeSampler()
+    runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, n_steps=200, seed=7,
+                         log_interval_steps=80, backend="gloo")
+    runner.init_policy = lambda env_spec: policy.initialize(env_spec)
+    runner.save_itr_snapshot = lambda itr: None
+    runner._log_entropy = False
+    orig_init_logging = runner.init_logging
+
+    def init_logging():
+        orig_init_logging()
+        runner._log_entropy = False
+    runner.init_logging = init_logging
+    runner.train()
+    out.put(dict(rank=rank, seed=runner.seed, sampler_seed=sampler.seed, n_itr=runner._n_itr,
+                 calls=algo.calls, params=policy.flat_params.numpy().copy(),
+                 trajs=runner._cum_completed_trajs,
+                 tab=getattr(runner, "last_tabular", None) and dict(runner.last_tabular)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_runner_world2():
+    ctx = mp.get_context("spawn")
+    out, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((out.get(timeout=180) for _ in range(2)), key=lambda d: d["rank"])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    r0, r1 = res
+    assert (r0["seed"], r1["seed"]) == (7, 107)                  # seed + 100*rank (multigpu_rl_base.py:28)
+    assert (r0["sampler_seed"], r1["sampler_seed"]) == (8, 108)  # sampler gets seed + 1
+    # n_itr counts sample_size * n_runners per iteration (:62-63): 200 // 40 = 5 -> log every 2 -> 4 (+1)
+    assert r0["n_itr"] == r1["n_itr"] == 5 and r0["calls"] == r1["calls"] == 5
+    # params were broadcast from rank 0 and stay identical under identical averaged updates
+    np.testing.assert_array_equal(r0["params"], r1["params"])
+    # rank 0 saw both ranks' completed trajectories at log time; rank 1 logs nothing
+    assert r0["trajs"] == 4 and r1["trajs"] == 0      # itrs 0..3 contribute one episode each (gather at itr 1, 3)
+    assert r0["tab"] is not None and r0["tab"]["CumTotalSteps"] == 4 * 40 and r1["tab"] is None
