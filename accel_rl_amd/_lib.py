@@ -70,6 +70,12 @@ _SIGNATURES = {
                              _vp, _i32, _vp]),
     "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "arl_gather_scale_obs": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "arl_gather_scale_obs_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "arl_bias_relu": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "arl_relu_bwd_workspace_bytes": (_i64, []),
+    "arl_relu_bwd_bias_grad": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "arl_pg_head_infer": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32] + [_vp] * 7),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -230,3 +236,55 @@ def opt_step(opt, method, learning_rate, avg_factor, clip, beta1_or_rho, beta2, 
     _check(load().arl_opt_step(C.byref(opt), method, learning_rate, avg_factor,
                                0.0 if clip is None else clip, beta1_or_rho, beta2, epsilon,
                                stream_ptr(stream)), "arl_opt_step")
+
+
+# ---------------------------------------------------------------------------
+# learner glue (csrc/learner.hip)
+# ---------------------------------------------------------------------------
+
+def gather_scale_obs_nhwc(obs, idx, out, scale, stream=None):
+    """obs u8[n,4,H,W] -> out f32 with NHWC memory ([B,H,W,4] contiguous)."""
+    _want(obs, torch.uint8, "obs")
+    _want(out, torch.float32, "out")
+    if idx is not None:
+        _want(idx, torch.int32, "idx")
+    batch = out.shape[0]
+    channels, plane = obs.shape[1], obs.shape[2] * obs.shape[3]
+    assert out.numel() == batch * channels * plane
+    _check(load().arl_gather_scale_obs_nhwc(ptr(obs), ptr(idx), batch, channels, plane, float(scale),
+                                            out.data_ptr(), stream_ptr(stream)),
+           "arl_gather_scale_obs_nhwc")
+
+
+def bias_relu(x, bias, rows, channels, stream=None):
+    _check(load().arl_bias_relu(x.data_ptr(), bias.data_ptr(), rows, channels, stream_ptr(stream)),
+           "arl_bias_relu")
+
+
+def relu_bwd_workspace(device):
+    return torch.empty(load().arl_relu_bwd_workspace_bytes() // 4, dtype=torch.float32, device=device)
+
+
+def relu_bwd_bias_grad(dy, y, rows, channels, dbias, workspace, stream=None):
+    _check(load().arl_relu_bwd_bias_grad(dy.data_ptr(), y.data_ptr(), rows, channels,
+                                         dbias.data_ptr(), ptr(workspace), stream_ptr(stream)),
+           "arl_relu_bwd_bias_grad")
+
+
+def pg_head_infer(h, w_head, b_head, prob, value, stream=None):
+    batch, hid = h.shape
+    n_act = prob.shape[1]
+    _check(load().arl_pg_head_infer(ptr(h), w_head.data_ptr(), b_head.data_ptr(), batch, hid, n_act,
+                                    ptr(prob), ptr(value), stream_ptr(stream)), "arl_pg_head_infer")
+
+
+def pg_head_loss(h, w_head, b_head, actions, advantages, returns, old_prob, valids, idx, lr_mult,
+                 inv_count, n_actions, kind, clip_param, v_loss_coeff, ent_loss_coeff,
+                 dout, dh, dw_head, db_head, loss4, workspace, stream=None):
+    batch, hid = h.shape
+    _check(load().arl_pg_head_loss(
+        ptr(h), w_head.data_ptr(), b_head.data_ptr(), ptr(actions), ptr(advantages), ptr(returns),
+        ptr(old_prob), ptr(valids), ptr(idx), ptr(lr_mult), ptr(inv_count), batch, hid, n_actions,
+        kind, float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), ptr(dout), ptr(dh),
+        dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), stream_ptr(stream)),
+        "arl_pg_head_loss")

@@ -17,6 +17,8 @@ class BaseA2C(AdvActorCriticBase):
         super().__init__(discount=discount, gae_lambda=gae_lambda, v_loss_coeff=v_loss_coeff,
                          **kwargs)
 
+    loss_kind = 0
+
     def pi_loss(self, policy, act, adv, old_dist_info, new_dist_info, valids):
         logli = policy.distribution.log_likelihood_sym(act, new_dist_info)
         return - valids_mean(logli * adv, valids)

@@ -51,8 +51,11 @@ class AdvActorCriticBase(RLAlgorithm):
         if self._use_valids:
             input_names.append("valids")
             opt_examples["valids"] = np.int8(1)
-        self.optimizer.initialize(inputs=input_names, losses=self._losses, constraints=None,
-                                  target=policy, lr_mult=self._lr_mult)
+        self._explicit = bool(getattr(policy, "explicit", False))
+        self.optimizer.initialize(inputs=input_names,
+                                  losses=self._explicit_losses if self._explicit else self._losses,
+                                  constraints=None, target=policy,
+                                  givens=dict(explicit_grads=self._explicit), lr_mult=self._lr_mult)
         self._opt_buf = buffer_with_segs_view(opt_examples, sample_size, horizon, dev)
         self._batch_size = sample_size
         self._mid_batch_reset = mid_batch_reset
@@ -148,6 +151,21 @@ class AdvActorCriticBase(RLAlgorithm):
         pi_loss = self.pi_loss(policy, mb["actions"], mb["advantages"], old_dist_info,
                                new_dist_info, valids)
         return pi_loss, v_loss, ent_loss
+
+    def _explicit_losses(self, mb):
+        """Same losses, fused: the policy's explicit forward + csrc/learner.hip head kernel
+        compute (pi_loss, v_loss, ent_loss) and write every gradient into flat_grads."""
+        inv_count = None
+        valids = mb.get("valids")
+        if valids is not None:
+            v = valids if mb.get("idx") is None else valids.index_select(0, mb["idx"].long())
+            inv_count = (1. / v.sum(dtype=torch.float32)).reshape(1)
+        loss4 = self.policy.loss_and_grads(mb, self.loss_kind, getattr(self, "clip_param", 0.),
+                                           self.v_loss_coeff, self.ent_loss_coeff, self._lr_mult,
+                                           inv_count)
+        return loss4[0], loss4[1], loss4[2]
+
+    loss_kind = None        # 0 = A2C, 1 = PPO (selects the fused kernel's pi_loss)
 
     def pi_loss(self, policy, act, adv, old_dist_info, new_dist_info, valids):
         raise NotImplementedError

@@ -21,6 +21,8 @@ class BasePPO(AdvActorCriticBase):
         self.clip_param = clip_param
         super().__init__(discount=discount, gae_lambda=gae_lambda, **kwargs)
 
+    loss_kind = 1
+
     def pi_loss(self, policy, act, adv, old_dist_info, new_dist_info, valids):
         ratio = policy.distribution.likelihood_ratio_sym(act, old_dist_info, new_dist_info)
         clip = self.clip_param * self._lr_mult                 # ppo.py:46 (anneals with lr)

@@ -1,0 +1,408 @@
+// Learner glue for gfx950: everything around the policy's conv / GEMM calls that
+// the reference expresses as Theano graph nodes (and PyTorch would run as ~150
+// tiny elementwise / reduction launches per minibatch), as a handful of fused,
+// HBM-bound streaming kernels over channels-last activations.
+//
+//   arl_gather_scale_obs_nhwc  minibatch gather + u8 -> f32 * (1/255), NCHW u8 -> NHWC f32
+//                              (optimizers/util.py:86-89 `s[idxs]`, policies/layers.py:22-41)
+//   arl_bias_relu              x[M][C] = relu(x + b[c])          (Lasagne Conv2D/Dense b + rectify)
+//   arl_relu_bwd_bias_grad     dy *= (y > 0); db[c] = sum_m dy   (their backward), deterministic
+//   arl_pg_head_loss           policy/value heads + softmax + A2C / PPO / value / entropy losses
+//                              and their gradients in one pass
+//                              (policies/pg/networks/pg_cnn.py:70-86; algos/pg/aac_base.py:60-70;
+//                               a2c.py:43-46; ppo.py:42-51; distributions/categorical.py:35-88)
+//   arl_pg_head_wgrad          dW_head = dout^T h, db_head = colsum(dout)
+//   arl_pg_head_infer          heads + softmax for action serving (atari_cnn_policy.py:67,109)
+//
+// All fp32 (the reference's floatX); compiled with -ffp-contract=off.
+
+#include "arl_common.h"
+
+namespace {
+
+constexpr int HID_MAX = 1024;      // hidden width supported by the head kernels
+constexpr int K_MAX = ARL_MAX_ACTIONS + 1;
+
+// ---------------------------------------------------------------- gather NCHW u8 -> NHWC f32 (C = 4)
+// one lane: 4 consecutive pixels of all 4 planes -> 4 float4 (64 B) stores
+__global__ __launch_bounds__(256) void gather_nhwc4_kernel(const uint8_t* __restrict__ obs,
+                                                           const int32_t* __restrict__ idx,
+                                                           int64_t batch, int plane, float scale,
+                                                           float* __restrict__ out) {
+    const int q_per_row = plane >> 2;                       // 4-pixel groups per plane
+    const int64_t total = batch * q_per_row;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t b = i / q_per_row;
+        const int q = (int)(i - b * q_per_row);
+        const int64_t src = (idx ? (int64_t)idx[b] : b) * 4 * plane;
+        uint32_t w[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            w[c] = *reinterpret_cast<const uint32_t*>(obs + src + (int64_t)c * plane + (q << 2));
+        float4* o = reinterpret_cast<float4*>(out) + (b * plane + (q << 2));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int sh = p * 8;
+            o[p] = make_float4((float)((w[0] >> sh) & 255u) * scale, (float)((w[1] >> sh) & 255u) * scale,
+                               (float)((w[2] >> sh) & 255u) * scale, (float)((w[3] >> sh) & 255u) * scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- bias + relu, in place
+__global__ __launch_bounds__(256) void bias_relu_kernel(float4* __restrict__ x,
+                                                        const float4* __restrict__ bias,
+                                                        int64_t total4, int c4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        const float4 b = bias[i % c4];
+        float4 v = x[i];
+        v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
+        v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+        x[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------- relu backward + bias grad
+// thread -> (row lane rl, float4 column cg); fixed-order reductions => deterministic.
+__global__ __launch_bounds__(256) void relu_bwd_bias_kernel(float4* __restrict__ dy,
+                                                            const float4* __restrict__ y, int64_t m,
+                                                            int c4, float4* __restrict__ partials) {
+    __shared__ float4 lds[256];
+    const int rows_per_iter = 256 / c4;
+    const int cg = threadIdx.x % c4, rl = threadIdx.x / c4;
+    float4 acc = make_float4(0, 0, 0, 0);
+    if (rl < rows_per_iter) {
+        for (int64_t row = (int64_t)blockIdx.x * rows_per_iter + rl; row < m;
+             row += (int64_t)gridDim.x * rows_per_iter) {
+            const int64_t i = row * c4 + cg;
+            float4 g = dy[i];
+            const float4 a = y[i];
+            g.x = a.x > 0.f ? g.x : 0.f; g.y = a.y > 0.f ? g.y : 0.f;
+            g.z = a.z > 0.f ? g.z : 0.f; g.w = a.w > 0.f ? g.w : 0.f;
+            dy[i] = g;
+            acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+        }
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        float4 s = make_float4(0, 0, 0, 0);
+        for (int r = 0; r < rows_per_iter; ++r) {
+            const float4 v = lds[r * c4 + cg];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        partials[(int64_t)blockIdx.x * c4 + cg] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials,
+                                                            int n_partials, int width,
+                                                            float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= width) return;
+    float s = 0.f;
+    for (int g = 0; g < n_partials; ++g) s += partials[(int64_t)g * width + c];
+    out[c] = s;
+}
+
+// ---------------------------------------------------------------- heads
+__device__ __forceinline__ float wave_sum_f(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+struct HeadLossArgs {
+    const float* h;          // [B][hid] post-relu hidden activations
+    const float* w_head;     // [K][hid], rows 0..A-1 = pi, row A = value
+    const float* b_head;     // [K]
+    const uint8_t* actions;  // [n_rows]
+    const float* adv;        // [n_rows]
+    const float* ret;        // [n_rows]
+    const float* old_prob;   // [n_rows][A]
+    const int8_t* valids;    // [n_rows] or null
+    const int32_t* idx;      // [B] rows of this minibatch, or null (identity)
+    const float* lr_mult;    // device scalar (PPO clip anneals with it, ppo.py:46)
+    const float* inv_count;  // device scalar 1/sum(valids) or null -> 1/B
+    float* dout;             // [B][K] gradient wrt (logits, value)
+    float* dh;               // [B][hid] gradient wrt h (before the relu mask)
+    float* loss_partials;    // [gridDim][4] = pi, v, ent, unused
+    int batch, hid, n_act, kind;
+    float clip_param, v_coeff, ent_coeff;
+};
+
+// one wave per row (looping); lanes split the hidden dimension.  Every per-action
+// array is indexed with compile-time indices only (fully unrolled loops with
+// `k < n_act` guards) so that it lives in VGPRs, not scratch.
+constexpr int HV = HID_MAX / 64;
+
+template <bool TRAIN>
+__global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __restrict__ prob_out,
+                                                   float* __restrict__ value_out) {
+    extern __shared__ __attribute__((aligned(16))) float s_w[];     // [K][hid]
+    __shared__ float s_loss[4][4];
+    const int A = a.n_act, K = A + 1, hid = a.hid, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < K * hid; i += blockDim.x) s_w[i] = a.w_head[i];
+    __syncthreads();
+    const float TINY = 1e-8f;                                        // categorical.py:6
+    const float inv_n = TRAIN ? (a.inv_count ? a.inv_count[0] : 1.f / (float)a.batch) : 0.f;
+    const float clip = TRAIN ? a.clip_param * a.lr_mult[0] : 0.f;
+    float l_pi = 0.f, l_v = 0.f, l_ent = 0.f;
+    const int waves = (gridDim.x * blockDim.x) >> 6;
+    for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < a.batch; b += waves) {
+        const float* hrow = a.h + (int64_t)b * hid;
+        float hv[HV];
+#pragma unroll
+        for (int j = 0; j < HV; ++j) hv[j] = (lane + 64 * j < hid) ? hrow[lane + 64 * j] : 0.f;
+        float out[K_MAX];
+#pragma unroll
+        for (int k = 0; k < K_MAX; ++k) {
+            out[k] = 0.f;
+            if (k < K) {
+                float sdot = 0.f;
+#pragma unroll
+                for (int j = 0; j < HV; ++j)
+                    if (lane + 64 * j < hid) sdot += hv[j] * s_w[k * hid + lane + 64 * j];
+                out[k] = wave_sum_f(sdot) + a.b_head[k];
+            }
+        }
+        float v = 0.f, mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < K_MAX; ++k) {
+            if (k < A) mx = fmaxf(mx, out[k]);
+            if (k == A) v = out[k];
+        }
+        float p[ARL_MAX_ACTIONS], z = 0.f;
+#pragma unroll
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) {
+            p[k] = (k < A) ? expf(out[k] - mx) : 0.f;
+            z += p[k];
+        }
+#pragma unroll
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) p[k] = p[k] / z;
+        if (!TRAIN) {
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
+                    if (k < A) prob_out[(int64_t)b * A + k] = p[k];
+                value_out[b] = v;
+            }
+            continue;
+        }
+        const int64_t row = a.idx ? (int64_t)a.idx[b] : b;
+        const float w = (a.valids ? (a.valids[row] != 0 ? 1.f : 0.f) : 1.f) * inv_n;   // valids_mean
+        const int act = a.actions[row];
+        const float adv = a.adv[row], ret = a.ret[row];
+        float pa = 0.f;
+#pragma unroll
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) pa = (k == act) ? p[k] : pa;
+        // ---- d loss / d p_k : entropy term for every action (categorical.py:76-78)
+        float g[ARL_MAX_ACTIONS];
+        float ent = 0.f;
+#pragma unroll
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) {
+            g[k] = 0.f;
+            if (k < A) {
+                const float lg = logf(p[k] + TINY);
+                ent -= p[k] * lg;
+                g[k] = a.ent_coeff * w * (lg + p[k] / (p[k] + TINY));    // d(-c_e * ent)/dp_k
+            }
+        }
+        float pi_term, g_act;
+        if (a.kind == 1) {                                               // PPO, ppo.py:42-51
+            const float old_pa = a.old_prob[row * A + act];
+            const float ratio = (pa + TINY) / (old_pa + TINY);           // categorical.py:66-70
+            const float lo = 1.f - clip, hi = 1.f + clip;
+            const float rc = fminf(fmaxf(ratio, lo), hi);
+            const float s1 = ratio * adv, s2 = rc * adv;
+            pi_term = fminf(s1, s2);
+            const bool in_range = (ratio >= lo) && (ratio <= hi);
+            const float g_ratio = in_range ? adv : (s1 < s2 ? adv : 0.f);
+            g_act = -w * g_ratio / (old_pa + TINY);
+        } else {                                                         // A2C, a2c.py:43-46
+            pi_term = logf(pa + TINY) * adv;
+            g_act = -w * adv / (pa + TINY);
+        }
+        const float dv = 2.f * a.v_coeff * w * (v - ret);                // aac_base.py:60-61
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) {
+            g[k] += (k == act) ? g_act : 0.f;
+            dot += g[k] * p[k];
+        }
+        float dl[K_MAX];                                                 // softmax backward
+#pragma unroll
+        for (int k = 0; k < K_MAX; ++k) {
+            dl[k] = 0.f;
+            if (k < ARL_MAX_ACTIONS && k < A) dl[k] = p[k < ARL_MAX_ACTIONS ? k : 0] * (g[k < ARL_MAX_ACTIONS ? k : 0] - dot);
+            if (k == A) dl[k] = dv;
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < K_MAX; ++k)
+                if (k < K) a.dout[(int64_t)b * K + k] = dl[k];
+            l_pi += -w * pi_term;
+            l_v += a.v_coeff * w * (v - ret) * (v - ret);
+            l_ent += -a.ent_coeff * w * ent;
+        }
+        // dh[b][c] = sum_k dl_k W[k][c]
+        float* dhrow = a.dh + (int64_t)b * hid;
+#pragma unroll
+        for (int j = 0; j < HV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < hid) {
+                float sdh = 0.f;
+#pragma unroll
+                for (int k = 0; k < K_MAX; ++k)
+                    if (k < K) sdh += dl[k] * s_w[k * hid + c];
+                dhrow[c] = sdh;
+            }
+        }
+    }
+    if (TRAIN) {
+        if (lane == 0) { s_loss[wave][0] = l_pi; s_loss[wave][1] = l_v; s_loss[wave][2] = l_ent; s_loss[wave][3] = 0.f; }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float sl = 0.f;
+            for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) sl += s_loss[wv][threadIdx.x];
+            a.loss_partials[blockIdx.x * 4 + threadIdx.x] = sl;
+        }
+    }
+}
+
+// dW[k][c] = sum_b dout[b][k] h[b][c]; db[k] = sum_b dout[b][k].  Block = 64-column tile,
+// 4 waves split the rows, fixed-order fold => deterministic.
+__global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dout,
+                                                         const float* __restrict__ h, int batch,
+                                                         int hid, int K, float* __restrict__ dw,
+                                                         float* __restrict__ db) {
+    __shared__ float lds[4][K_MAX][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float acc[K_MAX];
+    for (int k = 0; k < K_MAX; ++k) acc[k] = 0.f;
+    if (c < hid) {
+        for (int b = wave; b < batch; b += 4) {
+            const float hv = h[(int64_t)b * hid + c];
+            for (int k = 0; k < K; ++k) acc[k] += dout[(int64_t)b * K + k] * hv;
+        }
+    }
+    for (int k = 0; k < K; ++k) lds[wave][k][lane] = acc[k];
+    __syncthreads();
+    if (wave == 0 && c < hid)
+        for (int k = 0; k < K; ++k)
+            dw[(int64_t)k * hid + c] = ((lds[0][k][lane] + lds[1][k][lane]) + lds[2][k][lane]) + lds[3][k][lane];
+    if (blockIdx.x == 0 && threadIdx.x < K) {
+        float s = 0.f;
+        for (int b = 0; b < batch; ++b) s += dout[(int64_t)b * K + threadIdx.x];
+        db[threadIdx.x] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" int arl_gather_scale_obs_nhwc(const uint8_t* obs, const int32_t* idx_or_null,
+                                         int64_t batch, int32_t channels, int32_t plane_bytes,
+                                         float scale, float* out, void* stream) {
+    ARL_REQUIRE(obs && out, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(batch >= 0 && plane_bytes > 0, ARL_E_ARG, "bad batch/plane");
+    ARL_REQUIRE(channels == 4, ARL_E_RANGE, "NHWC gather is specialised for 4 stacked frames");
+    ARL_REQUIRE((plane_bytes & 3) == 0, ARL_E_RANGE, "plane_bytes must be a multiple of 4");
+    ARL_REQUIRE(arl::aligned4(obs) && arl::aligned16(out), ARL_E_ALIGN, "obs 4-byte, out 16-byte aligned");
+    if (batch == 0) return 0;
+    hipLaunchKernelGGL(gather_nhwc4_kernel, dim3(arl::stream_grid(batch * (plane_bytes >> 2), 256)),
+                       dim3(256), 0, (hipStream_t)stream, obs, idx_or_null, batch, (int)plane_bytes,
+                       scale, out);
+    return arl::check_launch("gather_nhwc4_kernel");
+}
+
+extern "C" int arl_bias_relu(float* x, const float* bias, int64_t rows, int32_t channels, void* stream) {
+    ARL_REQUIRE(x && bias, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(rows >= 0 && channels > 0 && (channels & 3) == 0, ARL_E_RANGE, "channels must be a multiple of 4");
+    ARL_REQUIRE(arl::aligned16(x) && arl::aligned16(bias), ARL_E_ALIGN, "x/bias must be 16-byte aligned");
+    if (rows == 0) return 0;
+    const int64_t total4 = rows * (channels >> 2);
+    hipLaunchKernelGGL(bias_relu_kernel, dim3(arl::stream_grid(total4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, (float4*)x, (const float4*)bias, total4, (int)(channels >> 2));
+    return arl::check_launch("bias_relu_kernel");
+}
+
+extern "C" int64_t arl_relu_bwd_workspace_bytes(void) { return (int64_t)256 * HID_MAX * sizeof(float); }
+
+extern "C" int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, int32_t channels,
+                                      float* dbias, void* workspace, void* stream) {
+    ARL_REQUIRE(dy && y && dbias && workspace, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(rows > 0 && channels > 0 && (channels & 3) == 0 && channels <= HID_MAX, ARL_E_RANGE,
+                "channels must be a multiple of 4 and <= 1024");
+    ARL_REQUIRE(arl::aligned16(dy) && arl::aligned16(y) && arl::aligned16(workspace), ARL_E_ALIGN, "16-byte alignment");
+    const int c4 = channels >> 2, rows_per_iter = 256 / c4;
+    int64_t grid = (rows + rows_per_iter - 1) / rows_per_iter;
+    if (grid > 256) grid = 256;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3((unsigned)grid), dim3(256), 0, s, (float4*)dy,
+                       (const float4*)y, rows, c4, (float4*)workspace);
+    int rc = arl::check_launch("relu_bwd_bias_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((channels + 255) / 256), dim3(256), 0, s,
+                       (const float*)workspace, (int)grid, (int)channels, dbias);
+    return arl::check_launch("fold_partials_kernel");
+}
+
+static int check_head(int64_t batch, int32_t hid, int32_t n_act) {
+    if (batch <= 0 || hid <= 0 || hid > HID_MAX || n_act <= 0 || n_act > ARL_MAX_ACTIONS) {
+        arl::set_error("head: bad batch/hidden/n_actions");
+        return ARL_E_RANGE;
+    }
+    return 0;
+}
+
+extern "C" int arl_pg_head_infer(const float* h, const float* w_head, const float* b_head,
+                                 int64_t batch, int32_t hid, int32_t n_actions, float* prob,
+                                 float* value, void* stream) {
+    ARL_REQUIRE(h && w_head && b_head && prob && value, ARL_E_ARG, "null pointer");
+    int rc = check_head(batch, hid, n_actions);
+    if (rc) return rc;
+    HeadLossArgs a = {};
+    a.h = h; a.w_head = w_head; a.b_head = b_head; a.batch = (int)batch; a.hid = hid; a.n_act = n_actions;
+    const int grid = (int)((batch + 3) / 4 < 1024 ? (batch + 3) / 4 : 1024);
+    hipLaunchKernelGGL((head_kernel<false>), dim3(grid), dim3(256), (size_t)(n_actions + 1) * hid * 4,
+                       (hipStream_t)stream, a, prob, value);
+    return arl::check_launch("head_kernel<infer>");
+}
+
+extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
+                                const uint8_t* actions, const float* advantages, const float* returns,
+                                const float* old_prob, const int8_t* valids_or_null,
+                                const int32_t* idx_or_null, const float* lr_mult,
+                                const float* inv_count_or_null, int64_t batch, int32_t hid,
+                                int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
+                                float ent_loss_coeff, float* dout, float* dh, float* dw_head,
+                                float* db_head, float* loss4, void* workspace, void* stream) {
+    ARL_REQUIRE(h && w_head && b_head && actions && advantages && returns && lr_mult && dout && dh &&
+                    dw_head && db_head && loss4 && workspace, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(kind == 0 || (kind == 1 && old_prob), ARL_E_ARG, "kind must be 0 (A2C) or 1 (PPO, needs old_prob)");
+    int rc = check_head(batch, hid, n_actions);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    HeadLossArgs a = {};
+    a.h = h; a.w_head = w_head; a.b_head = b_head; a.actions = actions; a.adv = advantages;
+    a.ret = returns; a.old_prob = old_prob; a.valids = valids_or_null; a.idx = idx_or_null;
+    a.lr_mult = lr_mult; a.inv_count = inv_count_or_null; a.dout = dout; a.dh = dh;
+    a.loss_partials = (float*)workspace;
+    a.batch = (int)batch; a.hid = hid; a.n_act = n_actions; a.kind = kind;
+    a.clip_param = clip_param; a.v_coeff = v_loss_coeff; a.ent_coeff = ent_loss_coeff;
+    const int grid = (int)((batch + 3) / 4 < 256 ? (batch + 3) / 4 : 256);
+    const int K = n_actions + 1;
+    hipLaunchKernelGGL((head_kernel<true>), dim3(grid), dim3(256), (size_t)K * hid * 4, s, a,
+                       (float*)nullptr, (float*)nullptr);
+    rc = arl::check_launch("head_kernel<train>");
+    if (rc) return rc;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, grid, 4, loss4);
+    rc = arl::check_launch("fold_partials_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((hid + 63) / 64), dim3(256), 0, s, dout, h, (int)batch,
+                       (int)hid, K, dw_head, db_head);
+    return arl::check_launch("head_wgrad_kernel");
+}

@@ -38,8 +38,9 @@ class BaseOptimizer(object):
         raise NotImplementedError
 
     # ---- shared: flat bucket + HIP update ------------------------------------
-    def _setup_bucket(self, target, lr_mult):
+    def _setup_bucket(self, target, lr_mult, givens=None):
         self._target = target
+        self._explicit_grads = bool((givens or dict()).get("explicit_grads", False))
         dev = target.device
         n = target.flat_params.numel()
         self._slot0 = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -68,7 +69,12 @@ class BaseOptimizer(object):
             self._kernel_args = (a["rho"], 0.0, a["epsilon"])
 
     def _backward(self, losses, minibatch):
-        """Gradient of the summed loss into the flat gradient bucket."""
+        """Gradient of the summed loss into the flat gradient bucket.  With
+        `givens=dict(explicit_grads=True)` the loss callable runs the policy's explicit
+        forward/backward itself and OVERWRITES the bucket; otherwise autograd accumulates
+        into the (zeroed) bucket views."""
+        if self._explicit_grads:
+            return sum(losses(minibatch))
         self._target.flat_grads.zero_()
         loss = sum(losses(minibatch))
         loss.backward()

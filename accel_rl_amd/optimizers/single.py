@@ -18,7 +18,7 @@ class A2cOptimizer(BaseOptimizer):
     def initialize(self, inputs, losses, constraints, target, givens=None, lr_mult=1):
         self._input_names = list(inputs)
         self._losses = losses
-        self._setup_bucket(target, lr_mult)
+        self._setup_bucket(target, lr_mult, givens)
 
     def optimize(self, inputs):
         self.prepare_host(len(inputs[0]))
@@ -64,7 +64,7 @@ class PpoOptimizer(BaseOptimizer):
     def initialize(self, inputs, losses, constraints, target, givens=None, lr_mult=1):
         self._input_names = list(inputs)
         self._losses = losses
-        self._setup_bucket(target, lr_mult)
+        self._setup_bucket(target, lr_mult, givens)
         self._idx_host = None
 
     def optimize(self, inputs):
@@ -97,11 +97,14 @@ class PpoOptimizer(BaseOptimizer):
         losses = []
         for k in range(self._n_minibatches):
             idx = self._idx_dev[k]
-            mb = dict(idx=idx, observations=data["observations"])
-            idx64 = idx.long()
-            for name, tensor in data.items():
-                if name != "observations":
-                    mb[name] = tensor.index_select(0, idx64)
+            if self._explicit_grads:             # kernels gather rows by idx themselves
+                mb = dict(data, idx=idx)
+            else:
+                mb = dict(idx=idx, observations=data["observations"])
+                idx64 = idx.long()
+                for name, tensor in data.items():
+                    if name != "observations":
+                        mb[name] = tensor.index_select(0, idx64)
             losses.append(self._backward(self._losses, mb))
             self._share_grad()
             self._apply_update(self._avg_factor())

@@ -2,22 +2,27 @@
 
 Mirror of the reference's AtariCnnPolicy / PgCnn
 (accel_rl/policies/pg/atari_cnn_policy.py:15-119, pg/networks/pg_cnn.py:11-119,
-policies/layers.py:11-41) with PyTorch-ROCm as the dense-contraction engine (the
-only MFMA-shaped stage of the path).  What is specific to this build:
+policies/layers.py:11-41).  PyTorch-ROCm supplies the dense contractions
+(conv2d / convolution_backward via MIOpen, mm via hipBLASLt: fp32 MFMA) -- the
+only MFMA-shaped stage of the path; everything between them is hand-written HIP
+(csrc/learner.hip) on channels-last activations:
 
-* all trainable parameters live in ONE flat fp32 HBM bucket (`flat_params`) and
-  all gradients in another (`flat_grads`); the nn.Parameters are views.  That is
-  the vector the reference all-reduces (optimizers/util.py:35-39) and the HIP
-  optimiser kernel updates in two launches (csrc/optim.hip).
-* uint8 observations are converted by the gather/scale HIP kernel
-  (x * 1/255, layers.py:22-41) instead of a host-side cast + H2D copy.
-* action sampling runs on the device (csrc/batch_ops.hip) from numpy's uniforms.
+  forward :  gather+scale (u8 NCHW -> f32 NHWC)  ->  [conv -> bias+relu] x n
+             -> mm -> bias+relu -> heads+softmax (infer) | heads+losses+grads (train)
+  backward:  head wgrad -> [relu-bwd+bias-grad -> mm dW / mm dx] -> [relu-bwd+bias-grad ->
+             convolution_backward] x n, every gradient written straight into ONE flat
+             fp32 bucket (`flat_grads`) that the HIP optimiser / RCCL all-reduce consume.
 
-Flat-vector convention of get/set_param_values = the reference's (Lasagne):
-order conv_i.W, conv_i.b, hidden_i.W, hidden_i.b, output_pi.W, .b, output_v.W, .b
-(pg_cnn.py:47-86,118-119); conv W (out,in,kh,kw) for a *flipped* (true)
-convolution, dense W (in,out).  Internally torch uses correlation kernels and
-(out,in) matrices; get/set convert.
+No autograd graph is built on the hot path (`explicit=True`, default).  The
+autograd formulation of the same network (`forward`) is kept for A/B tests.
+
+Internal parameter layout (the bucket is ours to define): conv W as (K,kh,kw,C)
+= channels-last correlation kernels; first dense W with its input columns in
+(h,w,c) order; both heads fused in one matrix W_head[(A+1), hid].
+get/set_param_values convert to/from the reference's flat vector: order conv_i.W,
+conv_i.b, hidden_i.W, hidden_i.b, output_pi.W, .b, output_v.W, .b
+(pg_cnn.py:47-86,118-119), conv W (out,in,kh,kw) for a flipped (true) convolution,
+dense W (in,out) with (c,h,w) input order.
 """
 import numpy as np
 import torch
@@ -27,6 +32,9 @@ from accel_rl_amd import _lib
 from accel_rl_amd.distributions import Categorical
 from accel_rl_amd.spaces import Discrete
 from accel_rl_amd.util.seed import layer_rng
+
+aten = torch.ops.aten
+KIND_A2C, KIND_PPO = 0, 1
 
 
 def _glorot_uniform(shape):
@@ -47,12 +55,15 @@ def _norm_c(shape, std):
 class AtariCnnPolicy(object):
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads,
-                 hidden_sizes=(), pixel_scale=255., initial_param_values=None):
+                 hidden_sizes=(), pixel_scale=255., initial_param_values=None, explicit=True):
         self.conv_filters, self.conv_filter_sizes = list(conv_filters), list(conv_filter_sizes)
         self.conv_strides, self.conv_pads = list(conv_strides), list(conv_pads)
         self.hidden_sizes = list(hidden_sizes)
+        if not self.hidden_sizes:
+            raise NotImplementedError("at least one hidden dense layer is required")
         self.pixel_scale = pixel_scale
         self.initial_param_values = initial_param_values
+        self.explicit = explicit
         self._scratch = dict()
 
     recurrent = property(lambda self: False)
@@ -68,92 +79,192 @@ class AtariCnnPolicy(object):
         self.env_spec = env_spec
         self.action_space = env_spec.action_space
         c, h, w = env_spec.observation_space.shape
-        n_act = self.action_space.n
+        n_act = self.n_act = self.action_space.n
         self._obs_shape = (c, h, w)
-        shapes, names, inits = [], [], []
-        for i, (nf, sz, st, pad) in enumerate(zip(self.conv_filters, self.conv_filter_sizes,
-                                                  self.conv_strides, self.conv_pads)):
-            wshape = (nf, c, sz, sz)
-            # stored as a correlation kernel: flip Lasagne's convolution filter spatially
-            inits += [_glorot_uniform(wshape)[:, :, ::-1, ::-1].copy(), np.zeros(nf, np.float32)]
-            shapes += [wshape, (nf,)]
-            names += ["Conv%dW" % i, "Conv%db" % i]
-            c = nf
+        # ---- reference-layout initial values, drawn in the reference's order
+        ref, self._conv_geom = [], []
+        for nf, sz, st, pad in zip(self.conv_filters, self.conv_filter_sizes, self.conv_strides,
+                                   self.conv_pads):
+            ref += [_glorot_uniform((nf, c, sz, sz)), np.zeros(nf, np.float32)]
             h = (h + 2 * pad[0] - sz) // st + 1
             w = (w + 2 * pad[1] - sz) // st + 1
+            self._conv_geom.append((nf, c, sz, st, tuple(pad), h, w))
+            c = nf
         self._conv_out = (c, h, w)
         fan = c * h * w
-        for i, hs in enumerate(self.hidden_sizes):
-            inits += [_norm_c((fan, hs), 1.0).T.copy(), np.zeros(hs, np.float32)]
-            shapes += [(hs, fan), (hs,)]
-            names += ["FC%dW" % i, "FC%db" % i]
+        self._hid_geom = []
+        for hs in self.hidden_sizes:
+            ref += [_norm_c((fan, hs), 1.0), np.zeros(hs, np.float32)]
+            self._hid_geom.append((hs, fan))
             fan = hs
-        inits += [_norm_c((fan, n_act), 0.01).T.copy(), np.zeros(n_act, np.float32)]
-        shapes += [(n_act, fan), (n_act,)]
-        names += ["OutputW", "Outputb"]
-        inits += [_norm_c((fan, 1), 1.0).T.copy(), np.zeros(1, np.float32)]
-        shapes += [(1, fan), (1,)]
-        names += ["OutputW", "Outputb"]
-        self.param_short_names = names
+        ref += [_norm_c((fan, n_act), 0.01), np.zeros(n_act, np.float32)]
+        ref += [_norm_c((fan, 1), 1.0), np.zeros(1, np.float32)]
+        self._ref_shapes = [a.shape for a in ref]
+        self.param_short_names = (["Conv%d%s" % (i, s) for i in range(len(self._conv_geom)) for s in "Wb"] +
+                                  ["FC%d%s" % (i, s) for i in range(len(self._hid_geom)) for s in "Wb"] +
+                                  ["OutputW", "Outputb", "OutputW", "Outputb"])
+        self.n_params = int(sum(a.size for a in ref))
+        # ---- internal bucket: [conv W, b]... [hidden W, b]... W_head, b_head
+        shapes = []
+        for nf, ci, sz, st, pad, ho, wo in self._conv_geom:
+            shapes += [(nf, sz, sz, ci), (nf,)]
+        for hs, fan_in in self._hid_geom:
+            shapes += [(hs, fan_in), (hs,)]
+        shapes += [(n_act + 1, fan), (n_act + 1,)]
         self._shapes = shapes
         sizes = [int(np.prod(s)) for s in shapes]
-        # every tensor starts on a 16-byte boundary inside the bucket (float4 kernels)
         self._offsets, off = [], 0
-        for n in sizes:
+        for n in sizes:                       # every tensor starts on a 16-byte boundary
             self._offsets.append(off)
             off += (n + 3) // 4 * 4
-        self.n_params = int(sum(sizes))
         self._bucket_len = off
         self.flat_params = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.flat_grads = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.params = []
-        for o, n, s, init in zip(self._offsets, sizes, shapes, inits):
-            p = torch.nn.Parameter(self.flat_params[o:o + n].view(s))
-            p.data.copy_(torch.from_numpy(np.ascontiguousarray(init)))
-            p.grad = self.flat_grads[o:o + n].view(s)
-            self.params.append(p)
-        self._n_conv = len(self.conv_filters)
+
+        def views(flat):
+            out = []
+            for o, n, s in zip(self._offsets, sizes, shapes):
+                v = flat[o:o + n].view(s)
+                out.append(v.permute(0, 3, 1, 2) if len(s) == 4 else v)   # logical (K,C,kh,kw)
+            return out
+        self.params = [torch.nn.Parameter(v) for v in views(self.flat_params)]
+        self.grads = views(self.flat_grads)
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        self._n_conv, self._n_hid = len(self._conv_geom), len(self._hid_geom)
         self._dist = Categorical(n_act)
         self._scale = float(np.float32(1. / self.pixel_scale))
+        self._relu_ws = _lib.relu_bwd_workspace(self.device)
+        self._loss_ws = torch.zeros(256 * 4, dtype=torch.float32, device=self.device)
+        self._set_from_reference_arrays(ref)
         if self.initial_param_values is not None:
             self.set_param_values(self.initial_param_values)
 
     # -------------------------------------------------------------- forward
+    def _buffer(self, key, shape, channels_last=False):
+        """Static scratch tensor (re-used across calls; fresh inside a graph capture)."""
+        capturing = torch.cuda.is_current_stream_capturing()
+        buf = None if capturing else self._scratch.get(key)
+        if buf is None:
+            buf = torch.empty(shape, dtype=torch.float32, device=self.device)
+            if channels_last:
+                buf = buf.contiguous(memory_format=torch.channels_last)
+            if not capturing:
+                self._scratch[key] = buf
+        return buf
+
     def _scaled(self, obs_u8, idx=None):
-        """u8 [B,C,H,W] (optionally gathered by idx) -> f32 * (1/pixel_scale)."""
+        """u8 [n,C,H,W] (rows optionally gathered by idx) -> f32 * (1/pixel_scale),
+        logical [B,C,H,W] in channels-last memory."""
         b = obs_u8.shape[0] if idx is None else idx.shape[0]
-        key = (b, torch.is_grad_enabled())
-        out = self._scratch.get(key)
-        if out is None or torch.cuda.is_current_stream_capturing():
-            out = torch.empty((b,) + self._obs_shape, dtype=torch.float32, device=self.device)
-            if not torch.cuda.is_current_stream_capturing():
-                self._scratch[key] = out
+        c, h, w = self._obs_shape
+        if c == 4:
+            out = self._buffer(("x", b), (b, c, h, w), channels_last=True)
+            _lib.gather_scale_obs_nhwc(obs_u8, idx, out, self._scale)
+            return out
+        out = self._buffer(("x", b), (b, c, h, w))
         _lib.gather_scale_obs(obs_u8, idx, out, self._scale)
-        return out
+        return out.contiguous(memory_format=torch.channels_last)
+
+    def _trunk(self, x):
+        """Explicit conv/dense stack (no autograd).  Returns (conv activations, hidden
+        activations); every activation is post bias+relu."""
+        b = x.shape[0]
+        acts, a = [], x
+        for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
+            z = F.conv2d(a, self.params[2 * i], None, stride=st, padding=pad)
+            if not z.is_contiguous(memory_format=torch.channels_last):
+                z = z.contiguous(memory_format=torch.channels_last)
+            _lib.bias_relu(z, self.params[2 * i + 1], b * ho * wo, nf)
+            acts.append(z)
+            a = z
+        cur = a.permute(0, 2, 3, 1).reshape(b, -1)             # NHWC memory viewed as [B, H*W*C]
+        hids, k = [], 2 * self._n_conv
+        for j, (hs, fan_in) in enumerate(self._hid_geom):
+            hcur = torch.mm(cur, self.params[k].t())
+            _lib.bias_relu(hcur, self.params[k + 1], b, hs)
+            hids.append(hcur)
+            cur = hcur
+            k += 2
+        return acts, hids
 
     def forward(self, x):
-        """f32 scaled pixels -> (prob [B,A], value [B])."""
+        """Autograd formulation of the same network (A/B reference)."""
         p = self.params
-        for i in range(self._n_conv):
-            x = F.relu(F.conv2d(x, p[2 * i], p[2 * i + 1], stride=self.conv_strides[i],
-                                padding=tuple(self.conv_pads[i])))
-        x = x.flatten(1)
+        for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
+            x = F.relu(F.conv2d(x, p[2 * i], p[2 * i + 1], stride=st, padding=pad))
+        x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
         k = 2 * self._n_conv
-        for _ in self.hidden_sizes:
+        for _ in self._hid_geom:
             x = F.relu(F.linear(x, p[k], p[k + 1]))
             k += 2
-        prob = torch.softmax(F.linear(x, p[k], p[k + 1]), dim=1)
-        value = F.linear(x, p[k + 2], p[k + 3]).reshape(-1)
-        return prob, value
+        out = F.linear(x, p[k], p[k + 1])
+        return torch.softmax(out[:, :self.n_act], dim=1), out[:, self.n_act]
 
     def prob_value(self, observations):
         """Batched inference on device uint8 observations (the sampler's hot call;
         reference: _f_prob_value, atari_cnn_policy.py:67,109)."""
         with torch.no_grad():
-            return self.forward(self._scaled(observations))
+            x = self._scaled(observations)
+            if not self.explicit:
+                return self.forward(x)
+            b = x.shape[0]
+            _, hids = self._trunk(x)
+            prob = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
+            value = torch.empty(b, dtype=torch.float32, device=self.device)
+            _lib.pg_head_infer(hids[-1], self.params[-2], self.params[-1], prob, value)
+            return prob, value
+
+    # ------------------------------------------------------------- training
+    def loss_and_grads(self, mb, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult,
+                       inv_count=None):
+        """One minibatch: forward, losses (a2c.py:43-46 / ppo.py:42-51 + aac_base.py:60-66)
+        and the full backward pass into `flat_grads` (overwritten, not accumulated).
+        mb: observations u8[n,...], idx i32[B] or None, actions, advantages, returns,
+        old_prob, valids (full-batch arrays, rows selected by idx).  Returns loss4 =
+        (pi_loss, v_loss, ent_loss, 0) as a device tensor."""
+        with torch.no_grad():
+            idx = mb.get("idx")
+            x = self._scaled(mb["observations"], idx)
+            b = x.shape[0]
+            acts, hids = self._trunk(x)
+            g, k_head = self.grads, 2 * (self._n_conv + self._n_hid)
+            hid = self._hid_geom[-1][0]
+            dout = self._buffer(("dout", b), (b, self.n_act + 1))
+            dh = self._buffer(("dh", b), (b, hid))
+            loss4 = self._buffer(("loss", b), (4,))
+            _lib.pg_head_loss(hids[-1], self.params[k_head], self.params[k_head + 1], mb["actions"],
+                              mb["advantages"], mb["returns"], mb.get("old_prob"), mb.get("valids"),
+                              idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
+                              ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws)
+            # ---- dense layers, last to first
+            conv_flat = acts[-1].permute(0, 2, 3, 1).reshape(b, -1)
+            d_cur = dh
+            for j in range(self._n_hid - 1, -1, -1):
+                k = 2 * (self._n_conv + j)
+                hs, fan_in = self._hid_geom[j]
+                _lib.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._relu_ws)
+                inp = hids[j - 1] if j > 0 else conv_flat
+                torch.mm(d_cur.t(), inp, out=g[k])
+                d_cur = torch.mm(d_cur, self.params[k])
+            # ---- conv layers, last to first
+            co, ho, wo = self._conv_out
+            d_act = d_cur.view(b, ho, wo, co).permute(0, 3, 1, 2)         # NHWC memory, logical NCHW
+            for i in range(self._n_conv - 1, -1, -1):
+                nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
+                if not d_act.is_contiguous(memory_format=torch.channels_last):
+                    d_act = d_act.contiguous(memory_format=torch.channels_last)
+                _lib.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._relu_ws)
+                inp = acts[i - 1] if i > 0 else x
+                d_in, d_w, _ = aten.convolution_backward(
+                    d_act, inp, self.params[2 * i], None, [st, st], list(pad), [1, 1], False, [0, 0], 1,
+                    [i > 0, True, False])
+                g[2 * i].copy_(d_w)
+                d_act = d_in
+            return loss4
 
     def dist_info_value_sym(self, obs_u8, idx=None):
-        """Training-time forward (autograd) on a gathered minibatch."""
+        """Training-time forward through autograd (explicit=False path)."""
         prob, value = self.forward(self._scaled(obs_u8, idx))
         return dict(prob=prob), value
 
@@ -181,10 +292,7 @@ class AtariCnnPolicy(object):
 
     def get_action(self, observation, deterministic=False):
         prob, value = self.prob_value(observation[None])
-        if deterministic:
-            action = torch.argmax(prob[0])
-        else:
-            action = self._sample(prob)[0]
+        action = torch.argmax(prob[0]) if deterministic else self._sample(prob)[0]
         return action, dict(prob=prob[0], value=value[0])
 
     def reset(self, n_batch=None):
@@ -197,31 +305,58 @@ class AtariCnnPolicy(object):
     def get_params(self, trainable=True):
         return list(self.params)
 
-    def _to_reference_layout(self, i, arr):
-        if arr.ndim == 4:
-            return arr[:, :, ::-1, ::-1]
-        if arr.ndim == 2:
-            return arr.T
-        return arr
+    def _internal_arrays(self):
+        host = self.flat_params.detach().cpu().numpy()
+        return [host[o:o + int(np.prod(s))].reshape(s) for o, s in zip(self._offsets, self._shapes)]
 
     def get_param_values(self, trainable=True):
-        """Flat fp32 vector in the reference's order/layout (host numpy)."""
-        host = self.flat_params.detach().cpu().numpy()
-        parts = []
-        for i, (o, s) in enumerate(zip(self._offsets, self._shapes)):
-            n = int(np.prod(s))
-            parts.append(np.ascontiguousarray(self._to_reference_layout(i, host[o:o + n].reshape(s))).reshape(-1))
-        return np.concatenate(parts)
+        """Flat fp32 vector in the reference's order and layout (host numpy)."""
+        arr = self._internal_arrays()
+        out, k = [], 0
+        for _ in range(self._n_conv):
+            out += [arr[k].transpose(0, 3, 1, 2)[:, :, ::-1, ::-1], arr[k + 1]]
+            k += 2
+        co, ho, wo = self._conv_out
+        for j, (hs, fan_in) in enumerate(self._hid_geom):
+            w = arr[k]
+            if j == 0:      # (hs, h*w*c) -> (c*h*w, hs)
+                w = w.reshape(hs, ho, wo, co).transpose(3, 1, 2, 0).reshape(fan_in, hs)
+            else:
+                w = w.T
+            out += [w, arr[k + 1]]
+            k += 2
+        wh, bh, a = arr[k], arr[k + 1], self.n_act
+        out += [wh[:a].T, bh[:a], wh[a:].T, bh[a:]]
+        return np.concatenate([np.ascontiguousarray(x).reshape(-1) for x in out]).astype(np.float32)
+
+    def _set_from_reference_arrays(self, ref):
+        host = np.zeros(self._bucket_len, np.float32)
+        internal, k = [], 0
+        for _ in range(self._n_conv):
+            internal += [ref[k][:, :, ::-1, ::-1].transpose(0, 2, 3, 1), ref[k + 1]]
+            k += 2
+        co, ho, wo = self._conv_out
+        for j, (hs, fan_in) in enumerate(self._hid_geom):
+            w = ref[k]
+            if j == 0:      # (c*h*w, hs) -> (hs, h*w*c)
+                w = w.reshape(co, ho, wo, hs).transpose(3, 1, 2, 0).reshape(hs, fan_in)
+            else:
+                w = w.T
+            internal += [w, ref[k + 1]]
+            k += 2
+        internal += [np.concatenate([ref[k].T, ref[k + 2].T], axis=0),
+                     np.concatenate([ref[k + 1], ref[k + 3]])]
+        for o, s, a in zip(self._offsets, self._shapes, internal):
+            assert tuple(a.shape) == tuple(s), (a.shape, s)
+            host[o:o + a.size] = np.ascontiguousarray(a).reshape(-1)
+        self.flat_params.copy_(torch.from_numpy(host))
 
     def set_param_values(self, flat, trainable=True):
         flat = np.asarray(flat, np.float32)
         assert flat.size == self.n_params
-        host = np.zeros(self._bucket_len, np.float32)
-        pos = 0
-        for i, (o, s) in enumerate(zip(self._offsets, self._shapes)):
+        ref, pos = [], 0
+        for s in self._ref_shapes:
             n = int(np.prod(s))
-            ref_shape = s if len(s) != 2 else s[::-1]
-            arr = self._to_reference_layout(i, flat[pos:pos + n].reshape(ref_shape))
-            host[o:o + n] = np.ascontiguousarray(arr).reshape(-1)
+            ref.append(flat[pos:pos + n].reshape(s))
             pos += n
-        self.flat_params.copy_(torch.from_numpy(host))
+        self._set_from_reference_arrays(ref)

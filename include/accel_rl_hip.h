@@ -226,6 +226,54 @@ int arl_preprocess_frames(const uint8_t* raw_a_or_null, const uint8_t* raw_b,
 int arl_gather_scale_obs(const uint8_t* obs, const int32_t* idx_or_null, int64_t batch,
                          int64_t row_bytes, float scale, float* out, void* stream);
 
+/* Channels-last variant of arl_gather_scale_obs for the conv stack:
+ * obs u8[n_rows][channels][plane_bytes] -> out f32[batch][plane_bytes][channels].
+ * channels must be 4 (the 4-frame stack, atari_env.py:21).                      */
+int arl_gather_scale_obs_nhwc(const uint8_t* obs, const int32_t* idx_or_null, int64_t batch,
+                              int32_t channels, int32_t plane_bytes, float scale, float* out,
+                              void* stream);
+
+/* x[rows][channels] = relu(x + bias[c]) in place: the bias + rectify of Lasagne's
+ * Conv2DLayer / DenseLayer (accel_rl/policies/pg/networks/pg_cnn.py:47-68) on a
+ * channels-last activation.  channels % 4 == 0.                                 */
+int arl_bias_relu(float* x, const float* bias, int64_t rows, int32_t channels, void* stream);
+
+/* Backward of the above: dy *= (y > 0) in place, dbias[c] = sum_rows dy (fixed
+ * summation order).  workspace >= arl_relu_bwd_workspace_bytes().               */
+int64_t arl_relu_bwd_workspace_bytes(void);
+int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, int32_t channels,
+                           float* dbias, void* workspace, void* stream);
+
+/* Policy / value heads + softmax for action serving: prob = softmax(h W_pi^T + b),
+ * value = h w_v + b_v.  Replaces the output layers of _f_prob_value,
+ * accel_rl/policies/pg/atari_cnn_policy.py:63-67 (pg_cnn.py:70-86).
+ *   h f32[batch][hid]; w_head f32[n_actions+1][hid] (rows 0..A-1 pi, row A value);
+ *   b_head f32[n_actions+1]; prob f32[batch][A]; value f32[batch]               */
+int arl_pg_head_infer(const float* h, const float* w_head, const float* b_head, int64_t batch,
+                      int32_t hid, int32_t n_actions, float* prob, float* value, void* stream);
+
+/* Training-time heads: forward, the three losses and every gradient up to dh in
+ * one pass.  kind 0 = A2C  pi_loss = -mean(log(pi[a]+1e-8) adv)    (a2c.py:43-46)
+ *            kind 1 = PPO  pi_loss = -mean(min(r adv, clip(r, 1 -+ clip_param*lr_mult) adv)),
+ *                          r = (pi[a]+1e-8)/(old[a]+1e-8)          (ppo.py:42-51)
+ * v_loss = c_v mean((V-R)^2); ent_loss = -c_e mean(-sum pi log(pi+1e-8))
+ * (aac_base.py:60-66, categorical.py:66-78); means are valids_mean when valids
+ * is given (algos/pg/util.py:49-53; inv_count = 1/sum(valids) over the minibatch).
+ * Rows of the batch arrays are selected by idx (NULL = identity).  Where the
+ * min() ties (ratio inside the clip range) the gradient is adv, as in any
+ * autograd that splits ties to sum 1 (Theano's tie rule is unpinned).
+ *   out: dout f32[batch][A+1], dh f32[batch][hid] (before the hidden relu mask),
+ *        dw_head f32[A+1][hid], db_head f32[A+1], loss4 f32[4] = pi, v, ent, 0
+ *   workspace >= 256*4 floats                                                   */
+int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
+                     const uint8_t* actions, const float* advantages, const float* returns,
+                     const float* old_prob, const int8_t* valids_or_null,
+                     const int32_t* idx_or_null, const float* lr_mult,
+                     const float* inv_count_or_null, int64_t batch, int32_t hid, int32_t n_actions,
+                     int32_t kind, float clip_param, float v_loss_coeff, float ent_loss_coeff,
+                     float* dout, float* dh, float* dw_head, float* db_head, float* loss4,
+                     void* workspace, void* stream);
+
 /* Optimiser state for ONE flat fp32 parameter bucket (all trainable params in
  * get_params order, accel_rl/optimizers/util.py:35-39). */
 typedef struct arl_opt_state {

@@ -340,3 +340,101 @@ def test_rmsprop_vs_oracle(L, clip):
         pw, acc = P.rmsprop_step(pw, gc, acc, 7e-4)
         got = p.cpu().numpy()
         assert np.allclose(got, pw, rtol=1e-5, atol=1e-6), (it, np.abs(got - pw).max())
+
+
+# ----------------------------------------------------------------------------- learner glue
+
+def test_gather_scale_nhwc(L):
+    rs = np.random.RandomState(9)
+    obs = rs.randint(0, 256, size=(300, 4, 104, 80), dtype=np.uint8)
+    idx = rs.permutation(300)[:77].astype(np.int32)
+    out = torch.empty((77, 104, 80, 4), dtype=torch.float32, device=DEV)
+    L.gather_scale_obs_nhwc(dev(obs), dev(idx), out, 1. / 255)
+    want = obs[idx].transpose(0, 2, 3, 1).astype(np.float32) * np.float32(1. / 255)
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    out2 = torch.empty((300, 104, 80, 4), dtype=torch.float32, device=DEV)
+    L.gather_scale_obs_nhwc(dev(obs), None, out2, 1. / 255)
+    np.testing.assert_array_equal(out2.cpu().numpy(), obs.transpose(0, 2, 3, 1).astype(np.float32) * np.float32(1. / 255))
+
+
+@pytest.mark.parametrize("rows,ch", [(512 * 475, 32), (512 * 108, 64), (512, 512), (7, 4), (1000, 256), (3, 1024)])
+def test_bias_relu_and_backward(L, rows, ch):
+    rs = np.random.RandomState(rows % 97)
+    x = rs.randn(rows, ch).astype(np.float32)
+    b = rs.randn(ch).astype(np.float32)
+    xt, bt = dev(x), dev(b)
+    L.bias_relu(xt, bt, rows, ch)
+    y = np.maximum(x + b, np.float32(0))
+    np.testing.assert_array_equal(xt.cpu().numpy(), y)
+    dy = rs.randn(rows, ch).astype(np.float32)
+    dyt, db = dev(dy), torch.full((ch,), 7.0, device=DEV)
+    ws = L.relu_bwd_workspace(DEV)
+    L.relu_bwd_bias_grad(dyt, xt, rows, ch, db, ws)
+    want = dy * (y > 0)
+    np.testing.assert_array_equal(dyt.cpu().numpy(), want)
+    ref = want.astype(np.float64).sum(axis=0)
+    assert np.allclose(db.cpu().numpy(), ref, rtol=1e-4, atol=1e-3 * np.sqrt(rows))
+    db2 = torch.zeros(ch, device=DEV)                     # deterministic: bit-identical on a re-run
+    dyt2 = dev(dy)
+    L.relu_bwd_bias_grad(dyt2, xt, rows, ch, db2, ws)
+    assert torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("n_act,hid,batch", [(4, 512, 512), (6, 256, 100), (18, 512, 64), (4, 64, 5), (9, 1024, 33)])
+@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("masked", [False, True])
+def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, masked):
+    """heads + softmax + A2C/PPO/value/entropy losses and all gradients vs PyTorch autograd
+    on the reference's formulas (aac_base.py:60-70, a2c.py:43-46, ppo.py:42-51)."""
+    gen = torch.Generator(device=DEV).manual_seed(n_act * 1000 + hid + batch)
+    n_rows = batch * 3
+    h = torch.relu(torch.randn(batch, hid, device=DEV, generator=gen)).requires_grad_()
+    w = (torch.randn(n_act + 1, hid, device=DEV, generator=gen) * 0.05).requires_grad_()
+    bh = (torch.randn(n_act + 1, device=DEV, generator=gen) * 0.1).requires_grad_()
+    act = torch.randint(0, n_act, (n_rows,), device=DEV, generator=gen).to(torch.uint8)
+    adv = torch.randn(n_rows, device=DEV, generator=gen)
+    ret = torch.randn(n_rows, device=DEV, generator=gen)
+    old = torch.softmax(torch.randn(n_rows, n_act, device=DEV, generator=gen), 1)
+    idx = torch.randperm(n_rows, device=DEV, generator=gen)[:batch].to(torch.int32)
+    valids = (torch.rand(n_rows, device=DEV, generator=gen) < 0.7).to(torch.int8) if masked else None
+    lr_mult = torch.full((1,), 0.6, device=DEV)
+    clip, c_v, c_e = 0.2, 0.25 if kind == 0 else 1.0, 0.01
+    sel = idx.long()
+    if masked:
+        valids[sel[0]] = 1
+        inv = (1. / valids[sel].sum(dtype=torch.float32)).reshape(1)
+        wgt = valids[sel].float() * inv
+    else:
+        inv, wgt = None, torch.full((batch,), 1. / batch, device=DEV)
+    # --- autograd reference
+    out = h @ w.t() + bh
+    prob, value = torch.softmax(out[:, :n_act], 1), out[:, n_act]
+    a = act[sel].long()
+    pa = prob[torch.arange(batch), a]
+    if kind == 1:
+        # make a good share of the ratios leave the clip range
+        old_sel = old[sel]
+        ratio = (pa + 1e-8) / (old_sel[torch.arange(batch), a] + 1e-8)
+        c = clip * 0.6
+        pi = -torch.sum(wgt * torch.minimum(ratio * adv[sel], torch.clamp(ratio, 1 - c, 1 + c) * adv[sel]))
+    else:
+        pi = -torch.sum(wgt * torch.log(pa + 1e-8) * adv[sel])
+    vl = c_v * torch.sum(wgt * (value - ret[sel]) ** 2)
+    el = -c_e * torch.sum(wgt * -torch.sum(prob * torch.log(prob + 1e-8), dim=1))
+    gh, gw, gb = torch.autograd.grad(pi + vl + el, [h, w, bh])
+    # --- kernel
+    dout = torch.empty(batch, n_act + 1, device=DEV)
+    dh = torch.empty(batch, hid, device=DEV)
+    dw, db, loss4 = torch.empty_like(w), torch.empty_like(bh), torch.zeros(4, device=DEV)
+    ws = torch.zeros(1024, device=DEV)
+    L.pg_head_loss(h.detach(), w.detach(), bh.detach(), act, adv, ret, old, valids, idx, lr_mult, inv,
+                   n_act, kind, clip, c_v, c_e, dout, dh, dw, db, loss4, ws)
+    assert torch.allclose(loss4[:3], torch.stack([pi, vl, el]).detach(), rtol=1e-4, atol=1e-6)
+    for got, want, name in ((dh, gh, "dh"), (dw, gw, "dw"), (db, gb, "db")):
+        scale = max(want.abs().max().item(), 1e-6)
+        assert torch.allclose(got, want, rtol=1e-3, atol=1e-5 * scale), (name, (got - want).abs().max().item(), scale)
+    # --- inference twin
+    p2 = torch.empty(batch, n_act, device=DEV)
+    v2 = torch.empty(batch, device=DEV)
+    L.pg_head_infer(h.detach(), w.detach(), bh.detach(), p2, v2)
+    assert torch.allclose(p2, prob.detach(), rtol=1e-5, atol=1e-7) and torch.allclose(v2, value.detach(), rtol=1e-5, atol=1e-6)

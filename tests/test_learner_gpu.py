@@ -17,17 +17,32 @@ DEV = "cuda:0"
 TINY = 1e-8
 
 
-def ref_forward(params, spec, x):
+def ref_forward(rp, spec, x):
+    """Plain PyTorch network on parameters held in the REFERENCE's layout/order
+    (conv W (out,in,kh,kw) of a flipped convolution, dense W (in,out), (c,h,w) flatten):
+    an independent restatement of pg_cnn.py:45-86."""
     n_conv = len(spec["conv_filters"])
+    k = 0
     for i in range(n_conv):
-        x = F.relu(F.conv2d(x, params[2 * i], params[2 * i + 1], stride=spec["conv_strides"][i],
+        x = F.relu(F.conv2d(x, rp[k].flip(2, 3), rp[k + 1], stride=spec["conv_strides"][i],
                             padding=tuple(spec["conv_pads"][i])))
-    x = x.flatten(1)
-    k = 2 * n_conv
-    for _ in spec["hidden_sizes"]:
-        x = F.relu(F.linear(x, params[k], params[k + 1]))
         k += 2
-    return torch.softmax(F.linear(x, params[k], params[k + 1]), 1), F.linear(x, params[k + 2], params[k + 3]).reshape(-1)
+    x = x.flatten(1)
+    for _ in spec["hidden_sizes"]:
+        x = F.relu(x @ rp[k] + rp[k + 1])
+        k += 2
+    return torch.softmax(x @ rp[k] + rp[k + 1], 1), (x @ rp[k + 2] + rp[k + 3]).reshape(-1)
+
+
+def ref_params_from(policy):
+    flat = policy.get_param_values()
+    out, pos = [], 0
+    for shape in policy._ref_shapes:
+        n = int(np.prod(shape))
+        out.append(torch.from_numpy(flat[pos:pos + n].reshape(shape).copy()).to(DEV).requires_grad_())
+        pos += n
+    assert pos == flat.size
+    return out
 
 
 def ref_loss(kind, params, spec, mb, clip, v_coeff, ent_coeff=0.01):
@@ -88,8 +103,8 @@ def test_learner_matches_plain_torch(kind, use_graph):
     n_env, horizon = 16, 5
     policy, algo, buf, spec = make(kind, n_env, horizon, use_graph)
     rs = np.random.RandomState(0)
-    # independent copies for the reference side
-    ref_params = [p.detach().clone().requires_grad_() for p in policy.params]
+    # independent copies for the reference side, in the reference's own layout
+    ref_params = ref_params_from(policy)
     n_par = sum(p.numel() for p in ref_params)
     m = np.zeros(n_par, np.float32); v = np.zeros(n_par, np.float32); t = np.float32(0)
     for itr in range(4):                                   # calls 3+ replay the hipGraph
@@ -142,23 +157,75 @@ def test_learner_matches_plain_torch(kind, use_graph):
         got_norms = infos["GradNorm"].cpu().numpy()
         assert got_norms.shape == (len(mbs),)
         assert np.allclose(got_norms, norms, rtol=2e-3), (itr, got_norms, norms)
-        for pr, pp in zip(ref_params, policy.params):
-            a, b = host(pr), host(pp)
-            assert np.allclose(a, b, rtol=2e-4, atol=2e-5), (itr, np.abs(a - b).max())
+        a = np.concatenate([host(x).reshape(-1) for x in ref_params])
+        b = policy.get_param_values()
+        assert np.allclose(a, b, rtol=2e-4, atol=2e-5), (itr, np.abs(a - b).max())
 
 
 def test_param_vector_roundtrip_and_reference_layout():
     policy, algo, buf, spec = make("ppo", 4, 5, False, spec_id=1)
     flat = policy.get_param_values()
     assert flat.shape == (3617953 + 513 * 6,) and flat.dtype == np.float32      # SURVEY a-9
-    # dense W is exposed as (in, out), conv W flipped: check one element of each
-    w_fc = policy.params[6].detach().cpu().numpy()                  # (512, 6912) torch layout
-    off = sum(int(np.prod(s)) for s in policy._shapes[:6])
-    np.testing.assert_array_equal(flat[off:off + w_fc.size].reshape(6912, 512), w_fc.T)
-    w0 = policy.params[0].detach().cpu().numpy()
-    np.testing.assert_array_equal(flat[:w0.size].reshape(w0.shape), w0[:, :, ::-1, ::-1])
     policy.set_param_values(flat * 2)
     np.testing.assert_array_equal(policy.get_param_values(), flat * 2)
-    # NormCInit: unit column norms on the (in, out) matrix (policies/layers.py:16-19)
-    norms = np.sqrt((w_fc.T ** 2).sum(axis=0)) / 2 * 2
-    assert np.allclose(norms, 1.0, atol=1e-4)
+    policy.set_param_values(flat)
+    # NormCInit: unit column norms of the (in, out) dense matrix (policies/layers.py:16-19)
+    rp = ref_params_from(policy)
+    w_fc = rp[6].detach().cpu().numpy()
+    assert w_fc.shape == (6912, 512)
+    assert np.allclose(np.sqrt((w_fc ** 2).sum(axis=0)), 1.0, atol=1e-4)
+    assert np.allclose(np.sqrt((rp[8].detach().cpu().numpy() ** 2).sum(axis=0)), 0.01, atol=1e-5)
+    # the explicit channels-last forward == the plain NCHW network on the reference-layout vector
+    rs = np.random.RandomState(1)
+    obs = torch.from_numpy(rs.randint(0, 256, size=(37, 4, 104, 80), dtype=np.uint8)).to(DEV)
+    prob, value = policy.prob_value(obs)
+    with torch.no_grad():
+        p0, v0 = ref_forward(rp, spec, obs.float() * np.float32(1. / 255))
+    assert torch.allclose(prob, p0, rtol=1e-4, atol=1e-6) and torch.allclose(value, v0, rtol=1e-4, atol=1e-5)
+    # and the autograd formulation of the same internal network agrees too
+    with torch.no_grad():
+        p1, v1 = policy.forward(policy._scaled(obs))
+    assert torch.allclose(prob, p1, rtol=1e-4, atol=1e-6) and torch.allclose(value, v1, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("kind", ["ppo", "a2c"])
+def test_explicit_backward_matches_autograd(kind):
+    """flat_grads from the explicit HIP/aten backward == autograd on the same network."""
+    n_env, horizon = 16, 5
+    policy, algo, buf, spec = make(kind, n_env, horizon, False)
+    rs = np.random.RandomState(5)
+    fill(buf, policy, rs, n_env, horizon)
+    n = n_env * horizon
+    adv = torch.randn(n, device=DEV)
+    ret = torch.randn(n, device=DEV)
+    idx = torch.from_numpy(rs.permutation(n)[:32].astype(np.int32)).to(DEV)
+    valids = torch.from_numpy((rs.rand(n) < 0.8).astype(np.int8)).to(DEV)
+    lr_mult = torch.full((1,), 0.7, device=DEV)
+    for use_valids in (False, True):
+        mb = dict(observations=buf.observations, idx=idx, actions=buf.actions, advantages=adv, returns=ret,
+                  old_prob=buf.agent_infos["prob"] * 0.9 + 0.1 / 6, valids=valids if use_valids else None)
+        sel = idx.long()
+        inv = (1. / valids[sel].sum(dtype=torch.float32)).reshape(1) if use_valids else None
+        kid, v_c = (1, 1.0) if kind == "ppo" else (0, 0.25)
+        loss4 = policy.loss_and_grads(mb, kid, 0.2, v_c, 0.01, lr_mult, inv).clone()
+        got = policy.flat_grads.clone()
+        # autograd on the same internal parameters
+        policy.flat_grads.zero_()
+        prob, value = policy.forward(policy._scaled(buf.observations, idx))
+        w = (valids[sel].float() * inv) if use_valids else torch.full((32,), 1. / 32, device=DEV)
+        act = buf.actions[sel].long()
+        pa = prob[torch.arange(32), act]
+        if kind == "ppo":
+            ratio = (pa + TINY) / (mb["old_prob"][sel][torch.arange(32), act] + TINY)
+            c = 0.2 * 0.7
+            pi = -torch.sum(w * torch.minimum(ratio * adv[sel], torch.clamp(ratio, 1 - c, 1 + c) * adv[sel]))
+        else:
+            pi = -torch.sum(w * torch.log(pa + TINY) * adv[sel])
+        vl = v_c * torch.sum(w * (value - ret[sel]) ** 2)
+        el = -0.01 * torch.sum(w * -torch.sum(prob * torch.log(prob + TINY), dim=1))
+        (pi + vl + el).backward()
+        want = policy.flat_grads.clone()
+        assert torch.allclose(loss4[:3], torch.stack([pi, vl, el]).detach(), rtol=1e-4, atol=1e-6)
+        scale = want.abs().max().item()
+        assert torch.allclose(got, want, rtol=2e-3, atol=2e-5 * max(scale, 1e-3)), \
+            (kind, use_valids, (got - want).abs().max().item(), scale)
