@@ -74,6 +74,7 @@ _SIGNATURES = {
     "arl_bias_relu": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "arl_relu_bwd_workspace_bytes": (_i64, []),
     "arl_relu_bwd_bias_grad": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "arl_pg_head_workspace_bytes": (_i64, []),
     "arl_pg_head_infer": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32] + [_vp] * 7),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
@@ -269,6 +270,10 @@ def relu_bwd_bias_grad(dy, y, rows, channels, dbias, workspace, stream=None):
     _check(load().arl_relu_bwd_bias_grad(dy.data_ptr(), y.data_ptr(), rows, channels,
                                          dbias.data_ptr(), ptr(workspace), stream_ptr(stream)),
            "arl_relu_bwd_bias_grad")
+
+
+def pg_head_workspace(device):
+    return torch.zeros(load().arl_pg_head_workspace_bytes() // 4, dtype=torch.float32, device=device)
 
 
 def pg_head_infer(h, w_head, b_head, prob, value, stream=None):

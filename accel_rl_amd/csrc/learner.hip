@@ -97,14 +97,33 @@ __global__ __launch_bounds__(256) void relu_bwd_bias_kernel(float4* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void fold_partials_kernel(const float* __restrict__ partials,
-                                                            int n_partials, int width,
-                                                            float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= width) return;
-    float s = 0.f;
-    for (int g = 0; g < n_partials; ++g) s += partials[(int64_t)g * width + c];
-    out[c] = s;
+// out[c] = sum_g partials[g][c].  Block = 64 columns x 16 waves: wave w sums the rows
+// g = w, w+16, ... (coalesced 256-B loads, independent accumulators), then the 16 wave
+// sums are folded in a fixed order => deterministic and ~16x shorter dependency chains
+// than one thread walking all partials.
+__global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __restrict__ partials,
+                                                             int n_partials, int width,
+                                                             float* __restrict__ out) {
+    __shared__ float lds[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < width) {
+        int g = wave;
+        for (; g + 16 < n_partials; g += 32) {
+            s0 += partials[(int64_t)g * width + c];
+            s1 += partials[(int64_t)(g + 16) * width + c];
+        }
+        if (g < n_partials) s0 += partials[(int64_t)g * width + c];
+    }
+    lds[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && c < width) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += lds[w][lane];
+        out[c] = s;
+    }
 }
 
 // ---------------------------------------------------------------- heads
@@ -272,32 +291,52 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
     }
 }
 
-// dW[k][c] = sum_b dout[b][k] h[b][c]; db[k] = sum_b dout[b][k].  Block = 64-column tile,
-// 4 waves split the rows, fixed-order fold => deterministic.
+// Partial head weight gradient: part[rs][k][c] = sum_{b in row split rs} dout[b][k] h[b][c],
+// k == K holds the bias gradient (h := 1).  grid = (hid/64 column tiles, row splits); the
+// 4 waves of a block take rows b = wave, wave+4, ... of the split; dout rows sit in LDS.
+// Folded over row splits by fold_partials_kernel => deterministic.
+constexpr int WG_SPLITS = 16;
+
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dout,
                                                          const float* __restrict__ h, int batch,
-                                                         int hid, int K, float* __restrict__ dw,
-                                                         float* __restrict__ db) {
+                                                         int hid, int K, float* __restrict__ part) {
     __shared__ float lds[4][K_MAX][64];
+    extern __shared__ __attribute__((aligned(16))) float s_dout[];   // [rows_in_split][K]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
+    const int rows_per = (batch + WG_SPLITS - 1) / WG_SPLITS;
+    const int b0 = blockIdx.y * rows_per;
+    const int b1 = (b0 + rows_per < batch) ? b0 + rows_per : batch;
+    const int n_rows = b1 > b0 ? b1 - b0 : 0;
+    for (int i = threadIdx.x; i < n_rows * K; i += blockDim.x) s_dout[i] = dout[(int64_t)b0 * K + i];
+    __syncthreads();
     float acc[K_MAX];
+#pragma unroll
     for (int k = 0; k < K_MAX; ++k) acc[k] = 0.f;
     if (c < hid) {
-        for (int b = wave; b < batch; b += 4) {
-            const float hv = h[(int64_t)b * hid + c];
-            for (int k = 0; k < K; ++k) acc[k] += dout[(int64_t)b * K + k] * hv;
+        for (int r = wave; r < n_rows; r += 4) {
+            const float hv = h[(int64_t)(b0 + r) * hid + c];
+#pragma unroll
+            for (int k = 0; k < K_MAX; ++k)
+                if (k < K) acc[k] += s_dout[r * K + k] * hv;
         }
     }
-    for (int k = 0; k < K; ++k) lds[wave][k][lane] = acc[k];
+#pragma unroll
+    for (int k = 0; k < K_MAX; ++k) lds[wave][k][lane] = acc[k];
     __syncthreads();
-    if (wave == 0 && c < hid)
+    if (wave == 0 && c < hid) {
         for (int k = 0; k < K; ++k)
-            dw[(int64_t)k * hid + c] = ((lds[0][k][lane] + lds[1][k][lane]) + lds[2][k][lane]) + lds[3][k][lane];
-    if (blockIdx.x == 0 && threadIdx.x < K) {
-        float s = 0.f;
-        for (int b = 0; b < batch; ++b) s += dout[(int64_t)b * K + threadIdx.x];
-        db[threadIdx.x] = s;
+            part[((int64_t)blockIdx.y * (K + 1) + k) * hid + c] =
+                ((lds[0][k][lane] + lds[1][k][lane]) + lds[2][k][lane]) + lds[3][k][lane];
+    }
+    // bias gradient rides along as row K of the partial: column c < K holds sum_b dout[b][c]
+    if (blockIdx.x == 0 && wave == 1) {
+        for (int cc = lane; cc < hid; cc += 64) {
+            float sb = 0.f;
+            if (cc < K)
+                for (int r = 0; r < n_rows; ++r) sb += s_dout[r * K + cc];
+            part[((int64_t)blockIdx.y * (K + 1) + K) * hid + cc] = sb;
+        }
     }
 }
 
@@ -330,6 +369,9 @@ extern "C" int arl_bias_relu(float* x, const float* bias, int64_t rows, int32_t 
 }
 
 extern "C" int64_t arl_relu_bwd_workspace_bytes(void) { return (int64_t)256 * HID_MAX * sizeof(float); }
+extern "C" int64_t arl_pg_head_workspace_bytes(void) {
+    return (int64_t)(256 * 4 + WG_SPLITS * (K_MAX + 1) * HID_MAX + (K_MAX + 1) * HID_MAX) * sizeof(float);
+}
 
 extern "C" int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, int32_t channels,
                                       float* dbias, void* workspace, void* stream) {
@@ -345,7 +387,7 @@ extern "C" int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, i
                        (const float4*)y, rows, c4, (float4*)workspace);
     int rc = arl::check_launch("relu_bwd_bias_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((channels + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((channels + 63) / 64), dim3(1024), 0, s,
                        (const float*)workspace, (int)grid, (int)channels, dbias);
     return arl::check_launch("fold_partials_kernel");
 }
@@ -399,10 +441,27 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
                        (float*)nullptr, (float*)nullptr);
     rc = arl::check_launch("head_kernel<train>");
     if (rc) return rc;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(256), 0, s, (const float*)workspace, grid, 4, loss4);
+    float* ws = (float*)workspace;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, grid, 4, loss4);
     rc = arl::check_launch("fold_partials_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3((hid + 63) / 64), dim3(256), 0, s, dout, h, (int)batch,
-                       (int)hid, K, dw_head, db_head);
-    return arl::check_launch("head_wgrad_kernel");
+    // head weight / bias gradient: row-split partials, then one fold into a staging
+    // matrix [(K+1)][hid]; rows 0..K-1 -> dw_head, row K (first K columns) -> db_head
+    float* part = ws + 256 * 4;
+    float* staged = part + (size_t)WG_SPLITS * (K + 1) * hid;
+    const int rows_per = ((int)batch + WG_SPLITS - 1) / WG_SPLITS;
+    hipLaunchKernelGGL(head_wgrad_kernel, dim3((hid + 63) / 64, WG_SPLITS), dim3(256),
+                       (size_t)rows_per * K * 4, s, dout, h, (int)batch, (int)hid, K, part);
+    rc = arl::check_launch("head_wgrad_kernel");
+    if (rc) return rc;
+    const int width = (K + 1) * hid;
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((width + 63) / 64), dim3(1024), 0, s,
+                       (const float*)part, WG_SPLITS, width, staged);
+    rc = arl::check_launch("fold_partials_kernel");
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(dw_head, staged, (size_t)K * hid * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(db_head, staged + (size_t)K * hid, (size_t)K * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) { arl::set_error("head grads copy: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
 }

@@ -135,7 +135,7 @@ class AtariCnnPolicy(object):
         self._dist = Categorical(n_act)
         self._scale = float(np.float32(1. / self.pixel_scale))
         self._relu_ws = _lib.relu_bwd_workspace(self.device)
-        self._loss_ws = torch.zeros(256 * 4, dtype=torch.float32, device=self.device)
+        self._loss_ws = _lib.pg_head_workspace(self.device)
         self._set_from_reference_arrays(ref)
         if self.initial_param_values is not None:
             self.set_param_values(self.initial_param_values)
@@ -146,9 +146,9 @@ class AtariCnnPolicy(object):
         capturing = torch.cuda.is_current_stream_capturing()
         buf = None if capturing else self._scratch.get(key)
         if buf is None:
-            buf = torch.empty(shape, dtype=torch.float32, device=self.device)
-            if channels_last:
-                buf = buf.contiguous(memory_format=torch.channels_last)
+            buf = torch.empty(shape, dtype=torch.float32, device=self.device,
+                              memory_format=torch.channels_last if channels_last
+                              else torch.contiguous_format)
             if not capturing:
                 self._scratch[key] = buf
         return buf

@@ -426,7 +426,7 @@ def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, masked):
     dout = torch.empty(batch, n_act + 1, device=DEV)
     dh = torch.empty(batch, hid, device=DEV)
     dw, db, loss4 = torch.empty_like(w), torch.empty_like(bh), torch.zeros(4, device=DEV)
-    ws = torch.zeros(1024, device=DEV)
+    ws = L.pg_head_workspace(DEV)
     L.pg_head_loss(h.detach(), w.detach(), bh.detach(), act, adv, ret, old, valids, idx, lr_mult, inv,
                    n_act, kind, clip, c_v, c_e, dout, dh, dw, db, loss4, ws)
     assert torch.allclose(loss4[:3], torch.stack([pi, vl, el]).detach(), rtol=1e-4, atol=1e-6)
