@@ -81,7 +81,7 @@ class AdvActorCriticBase(RLAlgorithm):
         if hasattr(self.optimizer, "prepare_host"):
             self.optimizer.prepare_host(self._batch_size)
         graphable = self.use_graph and hasattr(self.optimizer, "device_updates") and \
-            getattr(self.optimizer, "_n_gpu", 1) == 1
+            self.optimizer.parallelism_tag == "single"
         if not graphable:
             return self._device_optimize(itr, samples_data)
         if self._graph is None:

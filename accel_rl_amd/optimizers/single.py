@@ -94,18 +94,51 @@ class PpoOptimizer(BaseOptimizer):
         if not self._n_minibatches:
             return [], []
         self._idx_dev.copy_(self._idx_host, non_blocking=True)
+        if self._explicit_grads and self._graph_minibatch:
+            return self._graphed_minibatches(data)
         losses = []
         for k in range(self._n_minibatches):
-            idx = self._idx_dev[k]
-            if self._explicit_grads:             # kernels gather rows by idx themselves
-                mb = dict(data, idx=idx)
+            losses.append(self._backward(self._losses, self._minibatch(data, self._idx_dev[k])))
+            self._share_grad()
+            self._apply_update(self._avg_factor())
+        return losses, self._recent_grad_norms(self._n_minibatches)
+
+    def _minibatch(self, data, idx):
+        if self._explicit_grads:                 # kernels gather rows by idx themselves
+            return dict(data, idx=idx)
+        mb = dict(idx=idx, observations=data["observations"])
+        idx64 = idx.long()
+        for name, tensor in data.items():
+            if name != "observations":
+                mb[name] = tensor.index_select(0, idx64)
+        return mb
+
+    # Multi-GPU: the collective stays an ordinary eager call between two replays of ONE
+    # reusable per-minibatch hipGraph (forward + backward into flat_grads, reading its row
+    # indices from a fixed buffer), so RCCL never has to be captured.
+    _graph_minibatch = False
+    _mb_graph = None
+
+    def _graphed_minibatches(self, data):
+        if self._mb_graph is None:
+            self._idx_cur = torch.zeros_like(self._idx_dev[0])
+            self._mb_warm = getattr(self, "_mb_warm", 0) + 1
+            if self._mb_warm > 2:
+                torch.cuda.synchronize(self._target.device)
+                graph = torch.cuda.CUDAGraph()
+                self._idx_cur.copy_(self._idx_dev[0])
+                with torch.cuda.graph(graph):
+                    self._mb_loss = self._backward(self._losses, self._minibatch(data, self._idx_cur))
+                self._mb_graph, self._mb_data = graph, data
+        losses = []
+        for k in range(self._n_minibatches):
+            if self._mb_graph is None:
+                losses.append(self._backward(self._losses, self._minibatch(data, self._idx_dev[k])))
             else:
-                mb = dict(idx=idx, observations=data["observations"])
-                idx64 = idx.long()
-                for name, tensor in data.items():
-                    if name != "observations":
-                        mb[name] = tensor.index_select(0, idx64)
-            losses.append(self._backward(self._losses, mb))
+                assert all(data[n] is self._mb_data[n] for n in data), "static buffers expected"
+                self._idx_cur.copy_(self._idx_dev[k])
+                self._mb_graph.replay()
+                losses.append(self._mb_loss)
             self._share_grad()
             self._apply_update(self._avg_factor())
         return losses, self._recent_grad_norms(self._n_minibatches)

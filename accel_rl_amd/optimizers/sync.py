@@ -16,6 +16,8 @@ class _SyncMixin(object):
     _comm = None
     _n_gpu = 1
     _rank = 0
+    _graph_minibatch = True     # per-minibatch hipGraph around the eager all-reduce
+    _force_collective = False   # issue the all-reduce even with one rank (plumbing tests)
 
     def init_comm(self, gpu_comm, rank, n_gpu):
         """`gpu_comm`: a torch.distributed process group (None = default group)."""
@@ -24,7 +26,7 @@ class _SyncMixin(object):
         self._n_gpu = n_gpu
 
     def _share_grad(self):
-        if self._n_gpu > 1:
+        if self._n_gpu > 1 or self._force_collective:
             dist.all_reduce(self._target.flat_grads, op=dist.ReduceOp.SUM, group=self._comm)
 
     def _avg_factor(self):

@@ -52,8 +52,9 @@ def build_workload(device, seed, rank, world, game, use_graph, quiet=True):
                             mid_batch_reset=True, max_decorrelation_steps=2000, device=device,
                             use_graph=use_graph)
     policy = AtariCnnPolicy(**cnn_specs[CNN_SPEC])
-    if world > 1:
+    if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
         algo = mPPO(discount=0.99, gae_lambda=0.95)
+        algo.optimizer._force_collective = True
         runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
                              affinities=dict(gpu=device.index), log_interval_steps=1e8)
     else:
@@ -223,9 +224,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    if world > 1:
+    if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import __graft_entry__
     __graft_entry__.build()
@@ -301,7 +303,7 @@ def main():
     runner.shutdown()
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
