@@ -39,6 +39,10 @@ struct GatherDesc {
     int out_h, out_w;
     int mul, add_y, add_x;
     int taps_x, step;
+    // fast path only: taps_y; rmin = smallest tap-origin element offset of a valid row,
+    // dmin = smallest tap displacement; origin = rmin + dmin (descriptor base shift, <= 0);
+    // src_bytes is then the descriptor size measured from src + origin
+    int taps_y, rmin, dmin, origin;
 };
 
 // The weight operand.  B_KC:  element (n, r) at w[n*ld + r]                (r contiguous)
@@ -65,6 +69,8 @@ struct GemmArgs {
     int M, N, K;
     int k_per_split;        // multiple of BK; gridDim.z splits
     int64_t split_stride;   // elements between split outputs (dense M*N)
+    int debug;              // tuning aid: bit 0 = no global loads (all offsets out of range), bit 1 = no barriers
+    unsigned long long* trace;  // tuning aid: per-workgroup timestamps (arl_conv_trace_buffer), or null
 };
 
 // Hardware-bounds-checked 16-byte loads: a raw buffer load whose byte offset lies outside
@@ -80,6 +86,36 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
 __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+// Row-major epilogue of one wave's TM x TN accumulator tiles: D[row][col] with col = lane & 31,
+// row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5).  Each store instruction writes two 128-byte row
+// segments; the row part of the address is a compile-time multiple of the row pitch and rides
+// in the scalar offset, so the epilogue costs no address arithmetic on the vector unit.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tiles_rowmajor(const f32x16 (&acc)[TM][TN], float* out, int rows_total,
+                                                     int N, int row_base, int col_base, int lane,
+                                                     const float* bias, int relu) {
+    const int l31 = lane & 31, half = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(out, (unsigned)rows_total * (unsigned)N * 4u);
+    const int row0 = row_base + 4 * half;
+    const bool full = row_base + TM * 32 <= rows_total;                 // uniform per wave
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = col_base + j * 32 + l31;
+        const float bj = (bias && n < N) ? bias[n] : 0.f;
+        const unsigned voff = n < N ? (unsigned)(row0 * N + n) << 2 : OOB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int rc = i * 32 + (v & 3) + 8 * (v >> 2);
+                float val = acc[i][j][v] + bj;
+                if (relu) val = fmaxf(val, 0.f);
+                if (full || row0 + rc < rows_total)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, voff, (unsigned)(rc * N) << 2, 0);
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -134,7 +170,7 @@ __global__ __launch_bounds__(256) void rowgather_gemm_kernel(const GemmArgs a) {
             const int ty = tap / a.g.taps_x, tx = tap - ty * a.g.taps_x;
             const int dy = a.g.step * ty, dx = a.g.step * tx;
             const int delta = (dy * a.g.Ws + dx) * a.g.Cs + ch;
-            const int kval = r < kend;
+            const int kval = (r < kend) & !(a.debug & 1);
 #pragma unroll
             for (int p = 0; p < RA; ++p) {
                 const int ok = kval & ((unsigned)(ry[p] + dy) < (unsigned)a.g.Hs) & ((unsigned)(rx[p] + dx) < (unsigned)a.g.Ws);
@@ -147,7 +183,7 @@ __global__ __launch_bounds__(256) void rowgather_gemm_kernel(const GemmArgs a) {
                 const int idx = tid + p * 256;
                 const int nl = idx / CH, chunk = idx - nl * CH;
                 const int n = n0 + nl, r = kb + chunk * 4;
-                const int ok = (NB4 % 256 == 0 || idx < NB4) & (n < a.N) & (r < kend);
+                const int ok = (NB4 % 256 == 0 || idx < NB4) & (n < a.N) & (r < kend) & !(a.debug & 1);
                 offB[p] = ok ? (unsigned)(n * a.b.ld + r) << 2 : OOB;
             }
         } else {
@@ -256,7 +292,7 @@ __global__ __launch_bounds__(256) void rowgather_gemm_kernel(const GemmArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         store_tiles(buf ^ 1);
-        __syncthreads();
+        if (!(a.debug & 2)) __syncthreads();
     }
 
     // ---- epilogue: D[row][col], col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
@@ -302,6 +338,7 @@ struct WgradArgs {
     unsigned dy_bytes;
     int K_out, N, Mred;
     int m_per_split;        // multiple of BK
+    int adv_b, adv_y, adv_x;    // fast path: 256 rows = adv_b images + adv_y output rows + adv_x pixels
 };
 
 template <int WGM, int WGN, int TM, int TN, int BK>
@@ -452,6 +489,403 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// ==========================================================================================
+// Scalar-addressed fast path.
+//
+// On gfx950 the fp32-input MFMA runs at the fp32 VECTOR rate and shares the SIMD's VALU issue:
+// every VALU instruction in the k-loop is time taken from the MFMAs (measured on MI355X,
+// tools/mfma_mix.hip: 6 v_add per MFMA drop 144 -> 93 TF/s; ds_read / buffer_load cost nothing).
+// The kernels below therefore keep the per-tile addressing entirely on the scalar unit: a k-tile
+// never straddles filter taps, so its address is   per-thread constant (voffset)  +  per-tile
+// uniform (soffset, SALU);  padding taps are switched off with one v_bfe_i32 + v_and_or per row
+// from a per-row bit mask built once in the prologue.  Requirements (else the generic kernels
+// above are used): K % BK == 0 and either Cs % BK == 0 (one tap per tile) or BK % Cs == 0 with
+// whole taps of one filter row per tile (MULTI_TAP: conv 1, 4 channels x 8 taps = 32).
+// ==========================================================================================
+__device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned voff) {
+    // imask bit set = tap invalid for this row -> force the offset out of range
+    return ((unsigned)__builtin_amdgcn_sbfe(imask, bit, 1) & OOB) | voff;
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD>
+__global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, CH = BK / 4;
+    constexpr int LDA = BK + 4;
+    constexpr int LDB = B_KC ? BK + 4 : BN;
+    constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
+    constexpr int ROWS_PER_PASS = 256 / CH;
+    constexpr int RA = BM / ROWS_PER_PASS;
+    constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
+    constexpr int RB = (NB4 + 255) / 256;
+    static_assert(WGM * WGN == 4 && BM % ROWS_PER_PASS == 0 && BK % 8 == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;
+    float* sB = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int kbeg = blockIdx.z * a.k_per_split;
+    const int kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
+    const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
+    if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    // descriptor origins: the smallest element offset a valid (row, tap) pair can produce
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
+
+    // ---- per-thread constants -------------------------------------------------------------
+    const int a_chunk = tid % CH, a_row0 = tid / CH;
+    int tpt = 0, chl = a_chunk * 4;                 // tap within the tile / channel within the tap
+    if (MULTI_TAP) { tpt = chl / Cs; chl -= tpt * Cs; }
+    unsigned voffA[RA], imask[RA], voffB[RB];
+#pragma unroll
+    for (int p = 0; p < RA; ++p) {
+        const int m = m0 + a_row0 + p * ROWS_PER_PASS;
+        const int t = m / a.g.out_w, ox = m - t * a.g.out_w;
+        const int b = t / a.g.out_h, oy = t - b * a.g.out_h;
+        const int ry = oy * a.g.mul + a.g.add_y, rx = ox * a.g.mul + a.g.add_x;
+        const int rbase = ((b * a.g.Hs + ry) * Ws + rx) * Cs;
+        voffA[p] = m < a.M ? (unsigned)(rbase - a.g.rmin + tpt * Cs + chl) << 2 : OOB;
+        imask[p] = 0;
+        if (HAS_PAD) {                              // bit (ty*taps_x + tx) set <=> that tap is outside the image
+            unsigned xbad = 0, im = 0;
+            for (int tx = 0; tx < taps_x; ++tx)
+                xbad |= (unsigned)!((unsigned)(rx + step * (tx + tpt)) < (unsigned)Ws) << tx;
+            const unsigned row_all = (1u << taps_x) - 1u;
+            for (int ty = 0; ty < a.g.taps_y; ++ty) {
+                const bool yok = (unsigned)(ry + step * ty) < (unsigned)a.g.Hs;
+                im |= (yok ? xbad : row_all) << (ty * taps_x);
+            }
+            imask[p] = im;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < RB; ++p) {
+        const int idx = tid + p * 256;
+        if (B_KC) {
+            const int nl = idx / CH, chunk = idx - nl * CH;
+            const int n = n0 + nl;
+            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && n < a.N) ? (unsigned)(n * a.b.ld + chunk * 4) << 2 : OOB;
+        } else {
+            constexpr int NC4 = BN / 4;
+            const int kl = idx / NC4, nch = idx - kl * NC4;
+            const int n = n0 + nch * 4;
+            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && n < a.N) ? (unsigned)(kl * a.b.ld + n) << 2 : OOB;
+        }
+    }
+
+    // ---- uniform per-tile state (scalar unit) ------------------------------------------------
+    int ty, tx, ch0;
+    {
+        const int tap = kbeg / Cs;
+        ch0 = kbeg - tap * Cs;
+        ty = tap / taps_x;
+        tx = tap - ty * taps_x;
+    }
+    float4 va[RA], vb[RB];
+    auto issue_loads = [&](int kk) {                // tile starting at reduction index kk, tap state (ty, tx, ch0)
+        const unsigned soffA = (unsigned)(step * (ty * Ws + tx) * Cs + ch0 - a.g.dmin) << 2;
+        unsigned soffB;
+        if (B_KC) soffB = (unsigned)kk << 2;
+        else soffB = (unsigned)(ch0 * a.b.ld + ((a.b.i0 + a.b.si * ty) * a.b.kw + (a.b.j0 + a.b.si * tx)) * a.b.c) << 2;
+        const int bit = ty * taps_x + tx;
+#pragma unroll
+        for (int p = 0; p < RA; ++p)
+            va[p] = buf_ld4s(rsA, HAS_PAD ? mask_off(imask[p], bit, voffA[p]) : voffA[p], soffA);
+#pragma unroll
+        for (int p = 0; p < RB; ++p) vb[p] = buf_ld4s(rsB, voffB[p], soffB);
+    };
+    auto next_tile = [&]() {
+        if (MULTI_TAP) {
+            tx += BK / Cs;
+            if (tx >= taps_x) { tx = 0; ++ty; }
+        } else {
+            ch0 += BK;
+            if (ch0 >= Cs) {
+                ch0 = 0;
+                if (++tx >= taps_x) { tx = 0; ++ty; }
+            }
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* dA = sA + buf * A_SZ;
+        float* dB = sB + buf * B_SZ;
+#pragma unroll
+        for (int p = 0; p < RA; ++p)
+            *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) = va[p];
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int idx = tid + p * 256;
+            if (NB4 % 256 != 0 && idx >= NB4) continue;
+            if (B_KC) {
+                const int nl = idx / CH, chunk = idx - nl * CH;
+                *reinterpret_cast<float4*>(dB + nl * LDB + chunk * 4) = vb[p];
+            } else {
+                constexpr int NC4 = BN / 4;
+                const int kl = idx / NC4, nch = idx - kl * NC4;
+                *reinterpret_cast<float4*>(dB + kl * LDB + nch * 4) = vb[p];
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const int nk = (kend - kbeg) / BK;
+    issue_loads(kbeg);
+    store_tiles(0);
+    __syncthreads();
+    if (a.trace) tr1 = __builtin_readcyclecounter();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {                          // uniform branch: the last tile prefetches nothing
+            next_tile();
+            issue_loads(kbeg + (kt + 1) * BK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
+        const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
+                               : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
+                fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (B_KC) {
+                    const float4 t = *reinterpret_cast<const float4*>(cB + j * 32 * LDB + ks * 8);
+                    fb[j][0] = t.x; fb[j][1] = t.y; fb[j][2] = t.z; fb[j][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fb[j][q] = cB[(ks * 8 + q) * LDB + j * 32];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (a.trace) tr2 = __builtin_readcyclecounter();
+    float* out = a.o.out + (int64_t)blockIdx.z * a.split_stride;
+    if (a.o.dense && !a.o.mask) {
+        store_tiles_rowmajor<TM, TN>(acc, out, a.M, a.N, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, a.o.bias, a.o.relu);
+    } else {
+        // strided (stride-parity data gradient) or masked output: per-row address decode
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+                if (m >= a.M) continue;
+                int64_t orow;
+                if (a.o.dense) {
+                    orow = (int64_t)m * a.N;
+                } else {
+                    const int t = m / a.g.out_w, ox = m - t * a.g.out_w;
+                    const int b = t / a.g.out_h, oy = t - b * a.g.out_h;
+                    orow = ((int64_t)(b * a.o.OH + oy * a.o.omul + a.o.oadd_y) * a.o.OW + ox * a.o.omul + a.o.oadd_x) * a.N;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + l31;
+                    if (n >= a.N) continue;
+                    float val = acc[i][j][v];
+                    if (a.o.bias) val += a.o.bias[n];
+                    if (a.o.relu) val = fmaxf(val, 0.f);
+                    if (a.o.mask && !(a.o.mask[orow + n] > 0.f)) val = 0.f;
+                    out[orow + n] = val;
+                }
+            }
+        }
+    }
+    if (a.trace && tid == 0) {
+        unsigned long long* t = a.trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_readcyclecounter();
+        t[4] = rt0; t[5] = __builtin_amdgcn_s_memrealtime();
+        t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+        t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+    }
+}
+
+// Weight gradient, scalar-addressed: dy advances by a uniform stride per tile (soffset); the
+// gathered rows change every tile, so their element offsets and padding masks come from an LDS
+// table that all 256 threads refresh together, 256 rows (= 256 / BK tiles) at a time, each
+// thread walking its own row's (b, oy, ox) incrementally (no divisions in the loop).
+// Requirements: Mred % 256 == 0 is NOT needed, but Mred % BK == 0 and m_per_split % BK == 0.
+constexpr int WG_ROWS = 256;
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD>
+__global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
+    constexpr int NA4 = BK * BM / 4, RA = (NA4 + 255) / 256, MC4 = BM / 4;
+    constexpr int NC4 = BN / 4, KROWS = 256 / NC4, RB = BK / KROWS;
+    constexpr int TILES_PER_GROUP = WG_ROWS / BK;
+    static_assert(WGM * WGN == 4 && 256 % NC4 == 0 && BK % KROWS == 0 && BK % 8 == 0 && WG_ROWS % BK == 0, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ uint2 s_row[2][WG_ROWS];     // per gathered row: byte offset of its tap origin, inverted tap mask
+    float* sA = smem;
+    float* sB = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.x * BN, i0 = blockIdx.y * BM;
+    const int mbeg = blockIdx.z * a.m_per_split;
+    const int mend = (mbeg + a.m_per_split < a.Mred) ? mbeg + a.m_per_split : a.Mred;
+    const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.dy, a.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
+
+    // ---- per-thread constants: dy fragment offsets, gather column
+    unsigned voffA[RA];
+#pragma unroll
+    for (int p = 0; p < RA; ++p) {
+        const int idx = tid + p * 256;
+        const int kl = idx / MC4, c4 = idx - kl * MC4;
+        const int ko = i0 + c4 * 4;
+        voffA[p] = ((NA4 % 256 == 0 || idx < NA4) && ko < a.K_out) ? (unsigned)(kl * a.K_out + ko) << 2 : OOB;
+    }
+    const int b_c4 = tid % NC4, b_k0 = tid / NC4;
+    const int r = n0 + b_c4 * 4;
+    const int tap = r / Cs, ch = r - tap * Cs;
+    const int cty = tap / taps_x, ctx = tap - cty * taps_x;
+    const unsigned cdelta = r < a.N ? (unsigned)(step * (cty * Ws + ctx) * Cs + ch - a.g.dmin) << 2 : OOB;
+
+    // ---- row producer state: thread t owns row t of every 256-row group
+    int pm = mbeg + tid, pb, poy, pox;
+    {
+        const int t = pm / a.g.out_w;
+        pox = pm - t * a.g.out_w;
+        pb = t / a.g.out_h;
+        poy = t - pb * a.g.out_h;
+    }
+    auto produce_rows = [&](int slot) {
+        const int ry = poy * a.g.mul + a.g.add_y, rx = pox * a.g.mul + a.g.add_x;
+        unsigned off = OOB, im = ~0u;
+        if (pm < mend) {
+            off = (unsigned)(((pb * a.g.Hs + ry) * Ws + rx) * Cs - a.g.rmin) << 2;
+            im = 0;
+            if (HAS_PAD) {
+                unsigned xbad = 0;
+                for (int tx = 0; tx < taps_x; ++tx) xbad |= (unsigned)!((unsigned)(rx + step * tx) < (unsigned)Ws) << tx;
+                const unsigned row_all = (1u << taps_x) - 1u;
+                for (int ty = 0; ty < a.g.taps_y; ++ty)
+                    im |= (((unsigned)(ry + step * ty) < (unsigned)a.g.Hs) ? xbad : row_all) << (ty * taps_x);
+            }
+        }
+        s_row[slot][tid] = make_uint2(off, im);
+        // advance this thread's row by 256 (host-provided decomposition 256 = qb*out_h*out_w + qw*out_w + rw)
+        pm += WG_ROWS;
+        pb += a.adv_b; poy += a.adv_y; pox += a.adv_x;
+        if (pox >= a.g.out_w) { pox -= a.g.out_w; ++poy; }
+        if (poy >= a.g.out_h) { poy -= a.g.out_h; ++pb; }
+    };
+
+    float4 va[RA], vb[RB];
+    auto issue_loads = [&](int tile) {              // tile index within the split
+        const unsigned soffA = (unsigned)((mbeg + tile * BK) * a.K_out) << 2;
+        const int grp = tile / TILES_PER_GROUP, tin = tile - grp * TILES_PER_GROUP;
+        const uint2* rows = &s_row[grp & 1][tin * BK + b_k0];
+#pragma unroll
+        for (int p = 0; p < RA; ++p) va[p] = buf_ld4s(rsA, voffA[p], soffA);
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const uint2 e = rows[p * KROWS];
+            const unsigned off = e.x + cdelta;      // either term may be the OOB marker (sum stays >= OOB, < 2^32)
+            vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        float* dA = sA + buf * A_SZ;
+        float* dB = sB + buf * B_SZ;
+#pragma unroll
+        for (int p = 0; p < RA; ++p) {
+            const int idx = tid + p * 256;
+            if (NA4 % 256 != 0 && idx >= NA4) continue;
+            *reinterpret_cast<float4*>(dA + idx * 4) = va[p];
+        }
+#pragma unroll
+        for (int p = 0; p < RB; ++p)
+            *reinterpret_cast<float4*>(dB + (b_k0 + p * KROWS) * BN + b_c4 * 4) = vb[p];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    // Row groups: group g (tiles g*T .. g*T+T-1) lives in slot g & 1.  Groups 0 and 1 are produced
+    // up front; group g+2 is produced in the first iteration of group g+1's ... see loop.
+    const int nk = (mend - mbeg) / BK;
+    produce_rows(0);
+    produce_rows(1);
+    __syncthreads();
+    issue_loads(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue_loads(kt + 1);
+        // tile kt+1 was the last reader of group (kt+1)/T when it is that group's last tile; the
+        // slot is rewritten (group + 2) one iteration later, after this iteration's barrier.
+        if (kt % TILES_PER_GROUP == 0 && kt >= TILES_PER_GROUP) produce_rows(((kt / TILES_PER_GROUP) + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* cA = sA + buf * A_SZ + (half * 4) * BM + wm * TM * 32 + l31;
+        const float* cB = sB + buf * B_SZ + (half * 4) * BN + wn * TN * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < BK / 8; ++ks) {
+            float fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[i][q] = cA[(ks * 8 + q) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[j][q] = cB[(ks * 8 + q) * BN + j * 32];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = a.part + (int64_t)blockIdx.z * a.K_out * a.N;
+    store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
+}
+
 // out[i] = act(sum_z part[z][i] + bias[i % n_bias]) with a fixed summation order; float4 lanes.
 __global__ __launch_bounds__(256) void fold_splits_kernel(const float4* __restrict__ part, int splits,
                                                           int64_t total4, const float4* __restrict__ bias,
@@ -491,6 +925,54 @@ int launch_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
     return arl::check_launch("wgrad_kernel");
 }
 
+template <typename K>
+int allow_big_lds(K kernel, size_t lds) {           // > 64 KiB of dynamic LDS needs an explicit opt-in
+    if (lds <= 65536) return 0;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { arl::set_error("hipFuncSetAttribute(LDS %zu): %s", lds, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC>
+int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hipStream_t s) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * BN;
+    const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, splits);
+    int rc = 0;
+#define ARL_IGEMM(MT, HP)                                                                                  \
+    do {                                                                                                   \
+        auto k = igemm_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP>;                                         \
+        rc = allow_big_lds(k, lds);                                                                        \
+        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
+    } while (0)
+    if (multi_tap && has_pad) ARL_IGEMM(true, true);
+    else if (multi_tap) ARL_IGEMM(true, false);
+    else if (has_pad) ARL_IGEMM(false, true);
+    else ARL_IGEMM(false, false);
+#undef ARL_IGEMM
+    return rc ? rc : arl::check_launch("igemm_kernel");
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK>
+int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t s) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
+    dim3 grid((a.N + BN - 1) / BN, (a.K_out + BM - 1) / BM, splits);
+    int rc;
+    if (has_pad) {
+        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, true>;
+        rc = allow_big_lds(k, lds + 4096);
+        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    } else {
+        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, false>;
+        rc = allow_big_lds(k, lds + 4096);
+        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    }
+    return rc ? rc : arl::check_launch("wgrad_fast_kernel");
+}
+
 int launch_fold(const float* part, int splits, int64_t total, const float* bias, int n_bias, int relu,
                 float* out, hipStream_t s) {
     const int64_t total4 = total >> 2;
@@ -505,6 +987,16 @@ constexpr int BKT = 32;             // k-tile of the skinny configurations (host
 int tuning_bk() {                   // ARL_CONV_BK=16|32 overrides the k-tile (tuning aid)
     static int bk = [] { const char* e = getenv("ARL_CONV_BK"); return e ? atoi(e) : 0; }();
     return bk;
+}
+unsigned long long* g_trace = nullptr;
+
+int tuning_debug() {
+    static int t = [] { const char* e = getenv("ARL_CONV_DEBUG"); return e ? atoi(e) : 0; }();
+    return t;
+}
+int tuning_wgs() {                  // ARL_CONV_WGS: workgroups targeted by the split planner
+    static int t = [] { const char* e = getenv("ARL_CONV_WGS"); return e ? atoi(e) : 0; }();
+    return t;
 }
 int tuning_tile() {                 // ARL_CONV_TILE=1: halve the row tile of the skinny configurations (tuning aid)
     static int t = [] { const char* e = getenv("ARL_CONV_TILE"); return e ? atoi(e) : 0; }();
@@ -543,8 +1035,9 @@ int check_geom(const arl_conv_geom* g, Geom* o) {
 int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 // split the reduction so that tiles * splits ~ TARGET_WGS, each split a multiple of BKT
-void plan_split(int tiles, int red, int* splits, int* per) {
-    int s = tiles >= TARGET_WGS ? 1 : TARGET_WGS / tiles;
+void plan_split(int tiles, int red, int* splits, int* per, int want = TARGET_WGS) {
+    const int target = tuning_wgs() > 0 ? tuning_wgs() : want;
+    int s = tiles >= target ? 1 : target / tiles;
     const int max_s = (red + 4 * BKT - 1) / (4 * BKT);          // at least 4 k-tiles per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -555,6 +1048,8 @@ void plan_split(int tiles, int red, int* splits, int* per) {
 }  // namespace
 
 extern "C" int64_t arl_conv_workspace_bytes(void) { return (int64_t)64 << 20; }
+
+extern "C" void arl_conv_trace_buffer(void* device_u64_or_null) { g_trace = (unsigned long long*)device_u64_or_null; }
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {
@@ -571,10 +1066,10 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.kh * g.kw * g.C;
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.b.w = w; a.b.ld = a.K; a.b.w_bytes = (unsigned)((int64_t)a.N * a.K * 4);
-    a.o.dense = 1;
+    a.o.dense = 1; a.debug = tuning_debug(); a.trace = g_trace;
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
-    if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per);
+    if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 2 * TARGET_WGS);
     a.k_per_split = per;
     if (splits > 1) {
         ARL_REQUIRE((int64_t)splits * a.M * a.N * 4 <= arl_conv_workspace_bytes(), ARL_E_RANGE, "workspace too small");
@@ -582,15 +1077,31 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     } else {
         a.o.out = y; a.o.bias = bias_or_null; a.o.relu = relu;
     }
-    const bool bk16 = tuning_bk() == 16;
-    const int tt = tuning_tile();
-    if (a.N <= 32 && tt == 1) rc = bk16 ? launch_rowgather<4, 1, 1, 1, 16, true>(a, splits, s) : launch_rowgather<4, 1, 1, 1, 32, true>(a, splits, s);
-    else if (a.N <= 32) rc = bk16 ? launch_rowgather<4, 1, 2, 1, 16, true>(a, splits, s) : launch_rowgather<4, 1, 2, 1, 32, true>(a, splits, s);
-    else if (a.N <= 64 && tt == 1) rc = bk16 ? launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s) : launch_rowgather<2, 2, 1, 1, 32, true>(a, splits, s);
-    else if (a.N <= 64 && tt == 2) rc = bk16 ? launch_rowgather<4, 1, 1, 2, 16, true>(a, splits, s) : launch_rowgather<4, 1, 1, 2, 32, true>(a, splits, s);
-    else if (a.N <= 64) rc = bk16 ? launch_rowgather<2, 2, 2, 1, 16, true>(a, splits, s) : launch_rowgather<2, 2, 2, 1, 32, true>(a, splits, s);
-    else if (small) rc = bk16 ? launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s) : launch_rowgather<2, 2, 1, 1, 32, true>(a, splits, s);
-    else rc = launch_rowgather<2, 2, 2, 2, 16, true>(a, splits, s);
+    // scalar-addressed fast path (k-tile of 32 inside one filter row)
+    constexpr int FBK = 32;
+    const bool single_tap = g.C % FBK == 0;
+    const bool multi_tap = !single_tap && FBK % g.C == 0 && g.kw % (FBK / g.C) == 0;
+    const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
+    const bool fast = tuning_debug() != 4 && a.K % FBK == 0 && per % FBK == 0 && (single_tap || multi_tap) &&
+                      (!has_pad || g.kh * g.kw <= 32);
+    if (fast) {
+        a.g.taps_y = g.kh; a.g.dmin = 0;
+        a.g.rmin = (a.g.add_y * g.W + a.g.add_x) * g.C;
+        a.g.origin = a.g.rmin + a.g.dmin;
+        a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4 - (int64_t)a.g.origin * 4);
+        // 128-row tiles keep the LDS footprint small enough for >= 2 workgroups per CU: with one wave
+        // per SIMD the barrier and LDS latencies of each k-tile would sit exposed between MFMA bursts
+        if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        else if (a.N <= 64) rc = launch_igemm<2, 2, 2, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        else rc = launch_igemm<2, 2, 2, 2, FBK, true>(a, splits, multi_tap, has_pad, s);
+    } else {
+        const bool bk16 = tuning_bk() == 16;
+        if (a.N <= 32) rc = bk16 ? launch_rowgather<4, 1, 2, 1, 16, true>(a, splits, s) : launch_rowgather<4, 1, 2, 1, 32, true>(a, splits, s);
+        else if (a.N <= 64) rc = bk16 ? launch_rowgather<2, 2, 2, 1, 16, true>(a, splits, s) : launch_rowgather<2, 2, 2, 1, 32, true>(a, splits, s);
+        else if (small) rc = bk16 ? launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s) : launch_rowgather<2, 2, 1, 1, 32, true>(a, splits, s);
+        else rc = launch_rowgather<2, 2, 2, 2, 16, true>(a, splits, s);
+    }
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, bias_or_null, a.N, relu, y, s);
 }
@@ -625,21 +1136,24 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
             a.o.out = dx; a.o.mask = mask_or_null; a.o.dense = (st == 1);
             a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
             a.k_per_split = round_up(a.K, BKT);
-            const bool bk16 = tuning_bk() == 16;
-            const bool uni = g.K % 32 == 0;                 // a k-tile never straddles two filter taps
-            const int tt = tuning_tile();
-            if (a.N <= 32 && uni && tt == 1) {
-                rc = bk16 ? launch_rowgather<4, 1, 1, 1, 16, false, true>(a, 1, s) : launch_rowgather<4, 1, 1, 1, 32, false, true>(a, 1, s);
-            } else if (a.N <= 64 && a.N > 32 && uni && tt == 1) {
-                rc = bk16 ? launch_rowgather<2, 2, 1, 1, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 1, 1, 32, false, true>(a, 1, s);
-            } else if (a.N <= 32) {
-                if (!uni) rc = launch_rowgather<4, 1, 2, 1, 16, false, false>(a, 1, s);
-                else rc = bk16 ? launch_rowgather<4, 1, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<4, 1, 2, 1, 32, false, true>(a, 1, s);
-            } else if (a.N <= 64) {
-                if (!uni) rc = launch_rowgather<2, 2, 2, 1, 16, false, false>(a, 1, s);
-                else rc = bk16 ? launch_rowgather<2, 2, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 1, 32, false, true>(a, 1, s);
+            a.debug = tuning_debug(); a.trace = g_trace;
+            constexpr int FBK = 32;
+            const bool has_pad = !(g.kh == 1 && g.kw == 1 && g.pad_h == 0 && g.pad_w == 0);
+            const bool fast = tuning_debug() != 4 && g.K % FBK == 0 && (g.kh / st) * (g.kw / st) <= 32;
+            if (fast) {
+                a.g.taps_y = g.kh / st;
+                a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
+                a.g.dmin = -((a.g.taps_y - 1) * g.Wo + (a.g.taps_x - 1)) * g.K;
+                a.g.origin = a.g.rmin + a.g.dmin;
+                a.g.src_bytes = (unsigned)(g.batch * g.Ho * g.Wo * g.K * 4 - (int64_t)a.g.origin * 4);
+                if (a.N <= 32) rc = launch_igemm<4, 1, 2, 1, FBK, false>(a, 1, false, has_pad, s);
+                else if (a.N <= 64) rc = launch_igemm<2, 2, 2, 1, FBK, false>(a, 1, false, has_pad, s);
+                else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
             } else {
-                rc = uni ? launch_rowgather<2, 2, 2, 2, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 2, 16, false, false>(a, 1, s);
+                const bool uni = g.K % 16 == 0;                 // a 16-wide k-tile never straddles two filter taps
+                if (a.N <= 32) rc = uni ? launch_rowgather<4, 1, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<4, 1, 2, 1, 16, false, false>(a, 1, s);
+                else if (a.N <= 64) rc = uni ? launch_rowgather<2, 2, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 1, 16, false, false>(a, 1, s);
+                else rc = uni ? launch_rowgather<2, 2, 2, 2, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 2, 16, false, false>(a, 1, s);
             }
             if (rc) return rc;
         }
@@ -678,10 +1192,26 @@ extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw,
     } else {
         a.part = dw;
     }
-    const bool bk16 = tuning_bk() == 16;
-    if (g.K <= 32) rc = bk16 ? launch_wgrad<1, 4, 1, 1, 16>(a, splits, s) : launch_wgrad<1, 4, 1, 1, 32>(a, splits, s);
-    else if (g.K <= 64) rc = bk16 ? launch_wgrad<2, 2, 1, 1, 16>(a, splits, s) : launch_wgrad<2, 2, 1, 1, 32>(a, splits, s);
-    else rc = launch_wgrad<2, 2, 2, 2, 16>(a, splits, s);        // 128x128 at BK=32 would exceed 64 KB of LDS
+    constexpr int FBK = 32;
+    const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
+    const bool fast = tuning_debug() != 4 && a.Mred % FBK == 0 && per % FBK == 0 && (!has_pad || g.kh * g.kw <= 32);
+    if (fast) {
+        a.g.taps_y = g.kh; a.g.dmin = 0;
+        a.g.rmin = (a.g.add_y * g.W + a.g.add_x) * g.C;
+        a.g.origin = a.g.rmin;
+        a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4 - (int64_t)a.g.origin * 4);
+        const int img = g.Ho * g.Wo;
+        a.adv_b = WG_ROWS / img;
+        a.adv_y = (WG_ROWS % img) / g.Wo;
+        a.adv_x = (WG_ROWS % img) % g.Wo;
+        if (g.K <= 32) rc = launch_wgrad_fast<1, 4, 1, 1, FBK>(a, splits, has_pad, s);
+        else if (g.K <= 64) rc = launch_wgrad_fast<2, 2, 1, 1, FBK>(a, splits, has_pad, s);
+        else rc = launch_wgrad_fast<2, 2, 2, 2, FBK>(a, splits, has_pad, s);
+    } else {
+        if (g.K <= 32) rc = launch_wgrad<1, 4, 1, 1, 16>(a, splits, s);
+        else if (g.K <= 64) rc = launch_wgrad<2, 2, 1, 1, 16>(a, splits, s);
+        else rc = launch_wgrad<2, 2, 2, 2, 16>(a, splits, s);
+    }
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, total, nullptr, 4, 0, dw, s);
 }

@@ -292,6 +292,12 @@ typedef struct arl_conv_geom {
 /* Scratch for the split reductions below (fixed; the caller allocates once). */
 int64_t arl_conv_workspace_bytes(void);
 
+/* Diagnostic hook (tools/conv_trace.py): while a device buffer of u64[workgroups][8] is set,
+ * the forward / data-gradient kernels record per-workgroup shader-clock timestamps
+ * (start, main loop begin, main loop end, end), two 100 MHz wall-clock samples, HW_ID and XCC_ID.
+ * NULL (the default) disables it.  Not thread-safe; not for production use.             */
+void arl_conv_trace_buffer(void* device_u64_or_null);
+
 /* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
  * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,
  * policies/layers.py:22-41; the reference's flipped filters are stored pre-flipped).

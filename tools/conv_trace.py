@@ -1,0 +1,55 @@
+"""Per-workgroup timeline of one fp32-MFMA conv kernel launch (arl_conv_trace_buffer):
+how long prologue / main loop / epilogue take in shader clocks, the effective clock,
+how the dispatcher spread the workgroups over CUs.  usage: python tools/conv_trace.py [batch]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import collections
+import numpy as np
+import torch
+from accel_rl_amd import _lib
+
+DEV = "cuda:0"
+
+
+def main():
+    b = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    layers = [("conv1", 104, 80, 4, 32, 8, 4, 0), ("conv2", 25, 19, 32, 64, 4, 2, 1),
+              ("conv3", 12, 9, 64, 64, 3, 1, 1), ("dense", 1, 1, 6912, 512, 1, 1, 0)]
+    ws = _lib.conv_workspace(DEV)
+    lib = _lib.load()
+    for name, h, w, c, k, ks, st, p in layers:
+        geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p)
+        ho, wo = _lib.conv_out_hw(geom)
+        x = torch.randn(b, h, w, c, device=DEV)
+        wt = torch.randn(k, ks, ks, c, device=DEV) * 0.05
+        bias = torch.randn(k, device=DEV)
+        y = torch.empty(b, ho, wo, k, device=DEV)
+        for _ in range(3):
+            _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+        torch.cuda.synchronize()
+        tr = torch.zeros(8192 * 8, dtype=torch.int64, device=DEV)
+        lib.arl_conv_trace_buffer(tr.data_ptr())
+        _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+        torch.cuda.synchronize()
+        lib.arl_conv_trace_buffer(None)
+        t = tr.cpu().numpy().reshape(-1, 8)
+        t = t[t[:, 0] != 0]
+        n = len(t)
+        t0 = t[:, 0].min()
+        start, pro, loop, epi = t[:, 0] - t0, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
+        end = t[:, 3] - t0
+        real = (t[:, 5].max() - t[:, 4].min()) / 100.0          # us (100 MHz)
+        clk = (t[:, 3].max() - t0) / real / 1e3                 # GHz if s_memtime ticks at shader clock
+        hw, xcc = t[:, 6], t[:, 7] & 0xf
+        cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
+        per_cu = collections.Counter(cu.tolist())
+        hist = collections.Counter(per_cu.values())
+        print("%s fwd: %d WGs, wall %.1f us, counter/wall = %.2f ticks/ns; start skew p50/max %d/%d; prologue p50 %d, "
+              "loop p50/max %d/%d, epilogue p50 %d, end max %d; CUs used %d, WGs/CU histogram %s" %
+              (name, n, real, clk, np.median(start), start.max(), np.median(pro), np.median(loop), loop.max(),
+               np.median(epi), end.max(), len(per_cu), dict(sorted(hist.items()))))
+
+
+if __name__ == "__main__":
+    main()
