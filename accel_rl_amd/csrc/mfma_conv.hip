@@ -71,6 +71,13 @@ struct GemmArgs {
     int64_t split_stride;   // elements between split outputs (dense M*N)
     int debug;              // tuning aid: bit 0 = no global loads (all offsets out of range), bit 1 = no barriers
     unsigned long long* trace;  // tuning aid: per-workgroup timestamps (arl_conv_trace_buffer), or null
+    // stride-s data gradient: the s*s input-pixel parity classes are independent implicit GEMMs that
+    // differ only in the fields below; one launch runs them all, blockIdx.z = class (igemm_kernel only)
+    int n_par;
+    struct Parity {
+        int M, out_h, out_w, add_y, add_x, rmin, dmin, origin, i0, j0, oadd_y, oadd_x;
+        unsigned src_bytes;
+    } par[4];
 };
 
 // Hardware-bounds-checked 16-byte loads: a raw buffer load whose byte offset lies outside
@@ -530,13 +537,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * a.k_per_split;
+    GatherDesc g = a.g;
+    int M = a.M, w_i0 = a.b.i0, w_j0 = a.b.j0, oadd_y = a.o.oadd_y, oadd_x = a.o.oadd_x;
+    if (a.n_par) {                                  // uniform: this workgroup's parity class
+        const GemmArgs::Parity& q = a.par[blockIdx.z];
+        M = q.M; g.out_h = q.out_h; g.out_w = q.out_w; g.add_y = q.add_y; g.add_x = q.add_x;
+        g.rmin = q.rmin; g.dmin = q.dmin; g.origin = q.origin; g.src_bytes = q.src_bytes;
+        w_i0 = q.i0; w_j0 = q.j0; oadd_y = q.oadd_y; oadd_x = q.oadd_x;
+        if (m0 >= M) return;
+    }
+    const int kbeg = a.n_par ? 0 : blockIdx.z * a.k_per_split;
     const int kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
-    const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
+    const int Cs = g.Cs, taps_x = g.taps_x, Ws = g.Ws, step = g.step;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
     if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     // descriptor origins: the smallest element offset a valid (row, tap) pair can produce
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src + g.origin, g.src_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
 
     // ---- per-thread constants -------------------------------------------------------------
@@ -547,19 +563,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < RA; ++p) {
         const int m = m0 + a_row0 + p * ROWS_PER_PASS;
-        const int t = m / a.g.out_w, ox = m - t * a.g.out_w;
-        const int b = t / a.g.out_h, oy = t - b * a.g.out_h;
-        const int ry = oy * a.g.mul + a.g.add_y, rx = ox * a.g.mul + a.g.add_x;
-        const int rbase = ((b * a.g.Hs + ry) * Ws + rx) * Cs;
-        voffA[p] = m < a.M ? (unsigned)(rbase - a.g.rmin + tpt * Cs + chl) << 2 : OOB;
+        const int t = m / g.out_w, ox = m - t * g.out_w;
+        const int b = t / g.out_h, oy = t - b * g.out_h;
+        const int ry = oy * g.mul + g.add_y, rx = ox * g.mul + g.add_x;
+        const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
+        voffA[p] = m < M ? (unsigned)(rbase - g.rmin + tpt * Cs + chl) << 2 : OOB;
         imask[p] = 0;
         if (HAS_PAD) {                              // bit (ty*taps_x + tx) set <=> that tap is outside the image
             unsigned xbad = 0, im = 0;
             for (int tx = 0; tx < taps_x; ++tx)
                 xbad |= (unsigned)!((unsigned)(rx + step * (tx + tpt)) < (unsigned)Ws) << tx;
             const unsigned row_all = (1u << taps_x) - 1u;
-            for (int ty = 0; ty < a.g.taps_y; ++ty) {
-                const bool yok = (unsigned)(ry + step * ty) < (unsigned)a.g.Hs;
+            for (int ty = 0; ty < g.taps_y; ++ty) {
+                const bool yok = (unsigned)(ry + step * ty) < (unsigned)g.Hs;
                 im |= (yok ? xbad : row_all) << (ty * taps_x);
             }
             imask[p] = im;
@@ -590,10 +606,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     }
     float4 va[RA], vb[RB];
     auto issue_loads = [&](int kk) {                // tile starting at reduction index kk, tap state (ty, tx, ch0)
-        const unsigned soffA = (unsigned)(step * (ty * Ws + tx) * Cs + ch0 - a.g.dmin) << 2;
+        const unsigned soffA = (unsigned)(step * (ty * Ws + tx) * Cs + ch0 - g.dmin) << 2;
         unsigned soffB;
         if (B_KC) soffB = (unsigned)kk << 2;
-        else soffB = (unsigned)(ch0 * a.b.ld + ((a.b.i0 + a.b.si * ty) * a.b.kw + (a.b.j0 + a.b.si * tx)) * a.b.c) << 2;
+        else soffB = (unsigned)(ch0 * a.b.ld + ((w_i0 + a.b.si * ty) * a.b.kw + (w_j0 + a.b.si * tx)) * a.b.c) << 2;
         const int bit = ty * taps_x + tx;
 #pragma unroll
         for (int p = 0; p < RA; ++p)
@@ -689,9 +705,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     }
 
     if (a.trace) tr2 = __builtin_readcyclecounter();
-    float* out = a.o.out + (int64_t)blockIdx.z * a.split_stride;
+    float* out = a.o.out + (a.n_par ? 0 : (int64_t)blockIdx.z * a.split_stride);
     if (a.o.dense && !a.o.mask) {
-        store_tiles_rowmajor<TM, TN>(acc, out, a.M, a.N, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, a.o.bias, a.o.relu);
+        store_tiles_rowmajor<TM, TN>(acc, out, M, a.N, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, a.o.bias, a.o.relu);
     } else {
         // strided (stride-parity data gradient) or masked output: per-row address decode
 #pragma unroll
@@ -699,14 +715,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int m = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
-                if (m >= a.M) continue;
+                if (m >= M) continue;
                 int64_t orow;
                 if (a.o.dense) {
                     orow = (int64_t)m * a.N;
                 } else {
-                    const int t = m / a.g.out_w, ox = m - t * a.g.out_w;
-                    const int b = t / a.g.out_h, oy = t - b * a.g.out_h;
-                    orow = ((int64_t)(b * a.o.OH + oy * a.o.omul + a.o.oadd_y) * a.o.OW + ox * a.o.omul + a.o.oadd_x) * a.N;
+                    const int t = m / g.out_w, ox = m - t * g.out_w;
+                    const int b = t / g.out_h, oy = t - b * g.out_h;
+                    orow = ((int64_t)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N;
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
@@ -886,15 +902,28 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
     store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
 }
 
-// out[i] = act(sum_z part[z][i] + bias[i % n_bias]) with a fixed summation order; float4 lanes.
+// out[i] = act(sum_z part[z][i] + bias[i % n_bias]), float4 lanes, fixed summation order:
+// 16 threads share one output float4 (thread zg sums splits zg, zg+16, ...), then the 16
+// partial sums are added in index order -- enough parallelism for the small, many-split
+// weight gradients (conv 1: 2048 float4 x 128 splits) without giving up determinism.
 __global__ __launch_bounds__(256) void fold_splits_kernel(const float4* __restrict__ part, int splits,
                                                           int64_t total4, const float4* __restrict__ bias,
                                                           int bias4, int relu, float4* __restrict__ out) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        float4 s = part[i];
-        for (int z = 1; z < splits; ++z) {
+    __shared__ float4 lds[16][16];
+    const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 16 + o;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4)
+        for (int z = zg; z < splits; z += 16) {
             const float4 v = part[(int64_t)z * total4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    lds[zg][o] = s;
+    __syncthreads();
+    if (zg == 0 && i < total4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float4 v = lds[k][o];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
         if (bias) {
@@ -939,7 +968,7 @@ int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hi
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * BN;
     const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, splits);
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
     int rc = 0;
 #define ARL_IGEMM(MT, HP)                                                                                  \
     do {                                                                                                   \
@@ -976,7 +1005,7 @@ int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t 
 int launch_fold(const float* part, int splits, int64_t total, const float* bias, int n_bias, int relu,
                 float* out, hipStream_t s) {
     const int64_t total4 = total >> 2;
-    hipLaunchKernelGGL(fold_splits_kernel, dim3(arl::stream_grid(total4, 256)), dim3(256), 0, s,
+    hipLaunchKernelGGL(fold_splits_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, s,
                        (const float4*)part, splits, total4, (const float4*)bias, n_bias >> 2, relu, (float4*)out);
     return arl::check_launch("fold_splits_kernel");
 }
@@ -1092,6 +1121,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         // 128-row tiles keep the LDS footprint small enough for >= 2 workgroups per CU: with one wave
         // per SIMD the barrier and LDS latencies of each k-tile would sit exposed between MFMA bursts
         if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        else if (a.N <= 64 && a.M < 128 * 384) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 2, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, true>(a, splits, multi_tap, has_pad, s);
@@ -1118,43 +1148,64 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
                     (!mask_or_null || arl::aligned16(mask_or_null)), ARL_E_ALIGN, "16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     const int st = g.stride;
+    constexpr int FBK = 32;
+    const int taps_y = g.kh / st, taps_x = g.kw / st;
+    const bool has_pad = !(g.kh == 1 && g.kw == 1 && g.pad_h == 0 && g.pad_w == 0);
+    const bool fast = tuning_debug() != 4 && g.K % FBK == 0 && taps_y * taps_x <= 32 && st * st <= 4;
+    // One implicit GEMM per input-pixel parity class (ph, pw): pixels (h, w) = (st*oy + ph, st*ox + pw)
+    // only see the taps i = i0 + st*ti, j = j0 + st*tj, which reach output row
+    // (h + pad - i) / st = oy + (ph + pad - i0)/st - ti.
+    auto describe = [&](int ph, int pw) {
+        const int i0 = (ph + g.pad_h) % st, j0 = (pw + g.pad_w) % st;
+        GemmArgs a = {};
+        a.g.src = dy; a.g.Hs = g.Ho; a.g.Ws = g.Wo; a.g.Cs = g.K;
+        a.g.out_h = (g.H - ph + st - 1) / st; a.g.out_w = (g.W - pw + st - 1) / st;
+        a.g.mul = 1; a.g.add_y = (ph + g.pad_h - i0) / st; a.g.add_x = (pw + g.pad_w - j0) / st;
+        a.g.taps_x = taps_x; a.g.taps_y = taps_y; a.g.step = -1;
+        a.M = (int)(g.batch * a.g.out_h * a.g.out_w); a.N = g.C; a.K = taps_y * taps_x * g.K;
+        a.g.src_bytes = (unsigned)(g.batch * g.Ho * g.Wo * g.K * 4);
+        a.b.w_bytes = (unsigned)((int64_t)g.K * g.kh * g.kw * g.C * 4);
+        a.b.w = w; a.b.ld = g.kh * g.kw * g.C; a.b.kc = g.K; a.b.taps_x = taps_x;
+        a.b.i0 = i0; a.b.j0 = j0; a.b.si = st; a.b.kw = g.kw; a.b.c = g.C;
+        a.o.out = dx; a.o.mask = mask_or_null; a.o.dense = (st == 1);
+        a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
+        a.k_per_split = round_up(a.K, BKT);
+        a.debug = tuning_debug(); a.trace = g_trace;
+        if (fast) {
+            a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
+            a.g.dmin = -((taps_y - 1) * g.Wo + (taps_x - 1)) * g.K;
+            a.g.origin = a.g.rmin + a.g.dmin;
+            a.g.src_bytes = (unsigned)(g.batch * g.Ho * g.Wo * g.K * 4 - (int64_t)a.g.origin * 4);
+        }
+        return a;
+    };
+    if (fast) {
+        GemmArgs a = describe(0, 0);
+        if (st > 1) {                       // all parity classes in one launch (blockIdx.z = class)
+            int n = 0, max_m = 0;
+            for (int ph = 0; ph < st && ph < g.H; ++ph)
+                for (int pw = 0; pw < st && pw < g.W; ++pw) {
+                    const GemmArgs q = describe(ph, pw);
+                    GemmArgs::Parity& e = a.par[n++];
+                    e.M = q.M; e.out_h = q.g.out_h; e.out_w = q.g.out_w; e.add_y = q.g.add_y; e.add_x = q.g.add_x;
+                    e.rmin = q.g.rmin; e.dmin = q.g.dmin; e.origin = q.g.origin; e.src_bytes = q.g.src_bytes;
+                    e.i0 = q.b.i0; e.j0 = q.b.j0; e.oadd_y = q.o.oadd_y; e.oadd_x = q.o.oadd_x;
+                    if (q.M > max_m) max_m = q.M;
+                }
+            a.n_par = n; a.M = max_m;       // grid covers the largest class; smaller ones exit early
+        }
+        if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, false>(a, 1, false, has_pad, s);
+        else if (a.N <= 64) rc = launch_igemm<2, 2, 2, 1, FBK, false>(a, 1, false, has_pad, s);
+        else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
+        return rc;
+    }
     for (int ph = 0; ph < st && ph < g.H; ++ph) {
         for (int pw = 0; pw < st && pw < g.W; ++pw) {
-            // input pixels (h, w) = (st*oy + ph, st*ox + pw); taps i = i0 + st*ti reach
-            // output row (h + pad - i) / st = oy + (ph + pad - i0)/st - ti
-            const int i0 = (ph + g.pad_h) % st, j0 = (pw + g.pad_w) % st;
-            GemmArgs a = {};
-            a.g.src = dy; a.g.Hs = g.Ho; a.g.Ws = g.Wo; a.g.Cs = g.K;
-            a.g.out_h = (g.H - ph + st - 1) / st; a.g.out_w = (g.W - pw + st - 1) / st;
-            a.g.mul = 1; a.g.add_y = (ph + g.pad_h - i0) / st; a.g.add_x = (pw + g.pad_w - j0) / st;
-            a.g.taps_x = g.kw / st; a.g.step = -1;
-            a.M = (int)(g.batch * a.g.out_h * a.g.out_w); a.N = g.C; a.K = (g.kh / st) * (g.kw / st) * g.K;
-            a.g.src_bytes = (unsigned)(g.batch * g.Ho * g.Wo * g.K * 4);
-            a.b.w_bytes = (unsigned)((int64_t)g.K * g.kh * g.kw * g.C * 4);
-            a.b.w = w; a.b.ld = g.kh * g.kw * g.C; a.b.kc = g.K; a.b.taps_x = g.kw / st;
-            a.b.i0 = i0; a.b.j0 = j0; a.b.si = st; a.b.kw = g.kw; a.b.c = g.C;
-            a.o.out = dx; a.o.mask = mask_or_null; a.o.dense = (st == 1);
-            a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
-            a.k_per_split = round_up(a.K, BKT);
-            a.debug = tuning_debug(); a.trace = g_trace;
-            constexpr int FBK = 32;
-            const bool has_pad = !(g.kh == 1 && g.kw == 1 && g.pad_h == 0 && g.pad_w == 0);
-            const bool fast = tuning_debug() != 4 && g.K % FBK == 0 && (g.kh / st) * (g.kw / st) <= 32;
-            if (fast) {
-                a.g.taps_y = g.kh / st;
-                a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
-                a.g.dmin = -((a.g.taps_y - 1) * g.Wo + (a.g.taps_x - 1)) * g.K;
-                a.g.origin = a.g.rmin + a.g.dmin;
-                a.g.src_bytes = (unsigned)(g.batch * g.Ho * g.Wo * g.K * 4 - (int64_t)a.g.origin * 4);
-                if (a.N <= 32) rc = launch_igemm<4, 1, 2, 1, FBK, false>(a, 1, false, has_pad, s);
-                else if (a.N <= 64) rc = launch_igemm<2, 2, 2, 1, FBK, false>(a, 1, false, has_pad, s);
-                else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
-            } else {
-                const bool uni = g.K % 16 == 0;                 // a 16-wide k-tile never straddles two filter taps
-                if (a.N <= 32) rc = uni ? launch_rowgather<4, 1, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<4, 1, 2, 1, 16, false, false>(a, 1, s);
-                else if (a.N <= 64) rc = uni ? launch_rowgather<2, 2, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 1, 16, false, false>(a, 1, s);
-                else rc = uni ? launch_rowgather<2, 2, 2, 2, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 2, 16, false, false>(a, 1, s);
-            }
+            const GemmArgs a = describe(ph, pw);
+            const bool uni = g.K % 16 == 0;                 // a 16-wide k-tile never straddles two filter taps
+            if (a.N <= 32) rc = uni ? launch_rowgather<4, 1, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<4, 1, 2, 1, 16, false, false>(a, 1, s);
+            else if (a.N <= 64) rc = uni ? launch_rowgather<2, 2, 2, 1, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 1, 16, false, false>(a, 1, s);
+            else rc = uni ? launch_rowgather<2, 2, 2, 2, 16, false, true>(a, 1, s) : launch_rowgather<2, 2, 2, 2, 16, false, false>(a, 1, s);
             if (rc) return rc;
         }
     }
