@@ -163,7 +163,7 @@ class AdvActorCriticBase(RLAlgorithm):
         loss4 = self.policy.loss_and_grads(mb, self.loss_kind, getattr(self, "clip_param", 0.),
                                            self.v_loss_coeff, self.ent_loss_coeff, self._lr_mult,
                                            inv_count)
-        return loss4[0], loss4[1], loss4[2]
+        return loss4            # (pi_loss, v_loss, ent_loss, their sum): the optimizer reads [3]
 
     loss_kind = None        # 0 = A2C, 1 = PPO (selects the fused kernel's pi_loss)
 

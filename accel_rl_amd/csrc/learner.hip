@@ -147,7 +147,7 @@ struct HeadLossArgs {
     const float* inv_count;  // device scalar 1/sum(valids) or null -> 1/B
     float* dout;             // [B][K] gradient wrt (logits, value)
     float* dh;               // [B][hid] gradient wrt h (before the relu mask)
-    float* loss_partials;    // [gridDim][4] = pi, v, ent, unused
+    float* loss_partials;    // [gridDim][4] = pi, v, ent, their sum
     int batch, hid, n_act, kind;
     float clip_param, v_coeff, ent_coeff;
 };
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
         }
     }
     if (TRAIN) {
-        if (lane == 0) { s_loss[wave][0] = l_pi; s_loss[wave][1] = l_v; s_loss[wave][2] = l_ent; s_loss[wave][3] = 0.f; }
+        if (lane == 0) { s_loss[wave][0] = l_pi; s_loss[wave][1] = l_v; s_loss[wave][2] = l_ent; s_loss[wave][3] = (l_pi + l_v) + l_ent; }
         __syncthreads();
         if (threadIdx.x < 4) {
             float sl = 0.f;

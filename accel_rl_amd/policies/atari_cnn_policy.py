@@ -249,7 +249,7 @@ class AtariCnnPolicy(object):
         and the full backward pass into `flat_grads` (overwritten, not accumulated).
         mb: observations u8[n,...], idx i32[B] or None, actions, advantages, returns,
         old_prob, valids (full-batch arrays, rows selected by idx).  Returns loss4 =
-        (pi_loss, v_loss, ent_loss, 0) as a device tensor."""
+        (pi_loss, v_loss, ent_loss, pi+v+ent) as a device tensor."""
         with torch.no_grad():
             idx = mb.get("idx")
             x = self._scaled(mb["observations"], idx)

@@ -16,7 +16,8 @@ Metric = the reference runner's SamplesPerSecond (accel_rl/runners/accel_rl.py:9
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   "roofline":     the GAE scan kernel at a bandwidth-bound sweep size (HIP events
                   on the launch stream) + the at-config point, and
-  "kernels":      event-timed averages of every hand-written kernel of the step,
+  "kernels":      event-timed averages of the hand-written HBM-bound kernels of the step,
+  "mfma":         the policy's fp32-MFMA conv / dense kernels at the PPO minibatch vs the MFMA peak,
   "cpu_baseline": the oracle's CPU sampler port timed on this box's host cores.
 """
 import argparse
@@ -33,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
 N_ENVS, HORIZON, GAME, CNN_SPEC = 256, 5, "breakout", 1
 GAMES_8 = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_rider", "enduro", "ms_pacman"]
 
@@ -155,8 +157,8 @@ def kernel_table(device, sampler, algo, policy, reps=20):
         sampler._st[k].copy_(v)
     sampler.step_obs.copy_(obs_snap)
     idx = torch.randperm(n * t, device=device)[:512].to(torch.int32)
-    out = torch.empty((512, 4, 104, 80), device=device)
-    add("gather_scale_obs", lambda: _lib.gather_scale_obs(buf.observations, idx, out, 1. / 255),
+    out = torch.empty((512, 4, 104, 80), device=device).contiguous(memory_format=torch.channels_last)
+    add("gather_scale_obs_nhwc", lambda: _lib.gather_scale_obs_nhwc(buf.observations, idx, out, 1. / 255),
         512 * 33280 * 5, 8)
     optim = algo.optimizer
     saved = [x.clone() for x in (policy.flat_params, optim._slot0, optim._slot1, optim._step_count)]
@@ -167,23 +169,57 @@ def kernel_table(device, sampler, algo, policy, reps=20):
     return rows
 
 
-def cpu_baseline(device, policy, seconds=12.0):
-    """The oracle's CPU sampler port (per-env numpy env loop, as the reference's workers
-    do) + the oracle's process_samples, single process, actions served by the same
-    torch policy on the GPU (the reference serves actions from the GPU too)."""
+def mfma_table(device, policy, batch=512, reps=20):
+    """The policy's dense contractions (fp32 MFMA implicit GEMM, csrc/mfma_conv.hip) at the PPO
+    minibatch: event-timed per call, 2*MACs/time against the fp32 MFMA peak."""
+    from accel_rl_amd import _lib
+    conv_g, dense_g = policy._layer_geoms(batch)
+    ws = policy._conv_ws
+    rows = []
+    gen = torch.Generator(device=device).manual_seed(3)
+    k = 0
+    for name, g in [("conv%d" % (i + 1), g) for i, g in enumerate(conv_g)] + \
+                   [("dense%d" % (i + 1), g) for i, g in enumerate(dense_g)]:
+        ho, wo = _lib.conv_out_hw(g)
+        x = torch.randn(batch, g.in_h, g.in_w, g.in_c, device=device, generator=gen)
+        dy = torch.randn(batch, ho, wo, g.out_c, device=device, generator=gen)
+        y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(policy._w[k])
+        w, b = policy._w[k], policy._w[k + 1]
+        flops = 2.0 * batch * ho * wo * g.out_c * g.kh * g.kw * g.in_c
+        calls = [("fwd", lambda: _lib.conv2d_fwd(x, w, b, y, g, True, ws)),
+                 ("wgrad", lambda: _lib.conv2d_bwd_weight(dy, x, dw, g, ws))]
+        if k > 0:                                   # the first layer's input needs no gradient
+            calls.append(("dgrad", lambda: _lib.conv2d_bwd_data(dy, w, None, dx, g)))
+        for tag, fn in calls:
+            mean_ms, med_ms = event_time_ms(fn, reps)
+            tfs = flops / (mean_ms * 1e-3) / 1e12
+            rows.append(dict(kernel="%s %s" % (name, tag), avg_launch_us=round(mean_ms * 1e3, 2),
+                             flops_per_launch=int(flops), achieved_TFs=round(tfs, 1),
+                             frac_mfma_f32=round(tfs / MFMA_F32_PEAK_TFS, 4), launches_per_step=8))
+        k += 2
+    total_us = sum(r["avg_launch_us"] for r in rows)
+    total_fl = sum(r["flops_per_launch"] for r in rows)
+    return dict(bound="mfma", dtype="f32", peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", batch=batch,
+                achieved=round(total_fl / total_us / 1e6, 1),
+                frac=round(total_fl / total_us / 1e6 / MFMA_F32_PEAK_TFS, 4), kernels=rows)
+
+
+def _served(device, policy):
+    """The action server of the CPU baselines: H2D of the u8 observations, the SAME torch policy
+    on the GPU, D2H, categorical sampling on the host (the reference's master does exactly this
+    with Theano, overlap/sampler.py:129-145, rllab/misc/special.py:22-27)."""
     from oracle import ref_port as P
 
     class Served(object):
         def get_actions(self, obs):
-            prob, value = policy.prob_value(torch.from_numpy(obs).to(device))
+            prob, value = policy.prob_value(torch.from_numpy(np.ascontiguousarray(obs)).to(device))
             prob, value = prob.cpu().numpy(), value.cpu().numpy()
             return P.sample_actions(prob, np.random.rand(len(prob))), dict(prob=prob, value=value)
+    return Served()
 
-    smp = P.CpuSamplerPort(GAME, HORIZON, 16, N_ENVS // 32, max_path_length=int(27e3),
-                           mid_batch_reset=True)
-    np.random.seed(12345)
-    smp.initialize(12346, discount=0.99)
-    served = Served()
+
+def _time_sampler(smp, served, device, policy, seconds):
+    from oracle import ref_port as P
     smp.obtain_samples(served)                       # warm-up batch
     t0 = time.time()
     batches = 0
@@ -193,12 +229,53 @@ def cpu_baseline(device, policy, seconds=12.0):
         P.process_samples(buf["rewards"].reshape(N_ENVS, HORIZON), buf["dones"].reshape(N_ENVS, HORIZON),
                           buf["value"].reshape(N_ENVS, HORIZON), lv, None, 0.99, 0.95)
         batches += 1
-    dt = time.time() - t0
-    return dict(value=round(batches * N_ENVS * HORIZON / dt, 1), unit="env-steps/s", cores=1,
-                kind="port",
-                sample="%d batches of the same workload's rollout + process_samples (256 envs x 5 "
-                       "steps, numpy port of the reference sampler/AtariEnv/GAE, one host process; "
-                       "no learner update); host has %d logical cores" % (batches, os.cpu_count()))
+    return batches, time.time() - t0
+
+
+def start_cpu_pool():
+    """Fork the CPU baseline's worker processes BEFORE this process touches HIP (a forked child of an
+    initialised HIP runtime is not safe; the reference forks its workers before Theano's first call too).
+    They sit on a barrier, using no CPU, until cpu_baseline() runs."""
+    from oracle.cpu_sampler_mp import CpuSamplerMP
+    logical = os.cpu_count() or 2
+    physical = max(1, logical // 2)
+    half = N_ENVS // 2
+    n_par = max(d for d in range(1, half + 1) if half % d == 0 and d <= max(1, physical - 1))
+    smp = CpuSamplerMP(GAME, HORIZON, n_par, half // n_par, max_path_length=int(27e3), mid_batch_reset=True,
+                       start_method="fork", pin=True)
+    smp.initialize(12346, discount=0.99, master_rng=np.random.RandomState(12345))
+    return smp
+
+
+def cpu_baseline(device, policy, smp, seconds=10.0):
+    """The reference's CPU sampler restated (oracle/, pinned to the real reference by the golden
+    fixtures) on this box's host cores, same workload's rollout + process_samples, no learner update:
+      * multi-process, as the reference runs it: master + 2*n_parallel workers in two alternating
+        groups (oracle/cpu_sampler_mp.py), n_parallel = the largest divisor of N/2 that fits the
+        physical cores minus one (scripts/launching/affinities.py:63-69) -> `value`, `cores`;
+      * the same arithmetic walked by ONE process (oracle/ref_port.CpuSamplerPort) -> `single_core`."""
+    from oracle import ref_port as P
+    served = _served(device, policy)
+    logical = os.cpu_count() or 2
+    n_par, half = smp.n_parallel, N_ENVS // 2
+    np.random.seed(12345)
+    try:
+        batches, dt = _time_sampler(smp, served, device, policy, seconds)
+    finally:
+        smp.shutdown()
+    multi = batches * N_ENVS * HORIZON / dt
+    one = P.CpuSamplerPort(GAME, HORIZON, 16, N_ENVS // 32, max_path_length=int(27e3), mid_batch_reset=True)
+    np.random.seed(12345)
+    one.initialize(12346, discount=0.99)
+    b1, dt1 = _time_sampler(one, served, device, policy, seconds * 0.6)
+    return dict(value=round(multi, 1), unit="env-steps/s", cores=n_par + 1, kind="port",
+                single_core=round(b1 * N_ENVS * HORIZON / dt1, 1),
+                sample="%d batches (%.1f s) of the same workload's rollout + process_samples (256 envs x 5 steps): "
+                       "numpy restatement of the reference sampler / AtariEnv / GAE, master + %d worker "
+                       "processes (2 alternating groups x %d, %d envs each, pinned), actions served by the "
+                       "same policy on the GPU, no learner update; single_core = the same walked by one "
+                       "process (%d batches); host has %d logical cores" %
+                       (batches, dt, 2 * n_par, n_par, half // n_par, b1, logical))
 
 
 def main():
@@ -220,6 +297,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+    cpu_pool = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.roofline_only:
+        cpu_pool = start_cpu_pool()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     device = torch.device("cuda", local)
@@ -294,8 +374,9 @@ def main():
         if not args.no_roofline:
             line["roofline"] = roofline_gae(device, args.roofline_log2, 30)
             line["kernels"] = kernel_table(device, sampler, algo, policy)
+            line["mfma"] = mfma_table(device, policy)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(device, policy)
+            line["cpu_baseline"] = cpu_baseline(device, policy, cpu_pool)
             line["gpu_over_cpu"] = {
                 "rollout_only": round(line["phases"]["rollout_only_env_steps_per_s"] / line["cpu_baseline"]["value"], 2),
                 "note": "like for like: GPU rollout (sampler only) vs CPU sampler port; `value` additionally "

@@ -263,7 +263,7 @@ int arl_pg_head_infer(const float* h, const float* w_head, const float* b_head, 
  * min() ties (ratio inside the clip range) the gradient is adv, as in any
  * autograd that splits ties to sum 1 (Theano's tie rule is unpinned).
  *   out: dout f32[batch][A+1], dh f32[batch][hid] (before the hidden relu mask),
- *        dw_head f32[A+1][hid], db_head f32[A+1], loss4 f32[4] = pi, v, ent, 0
+ *        dw_head f32[A+1][hid], db_head f32[A+1], loss4 f32[4] = pi, v, ent, pi+v+ent
  *   workspace >= arl_pg_head_workspace_bytes()                                  */
 int64_t arl_pg_head_workspace_bytes(void);
 int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
