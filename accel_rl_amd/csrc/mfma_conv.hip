@@ -58,6 +58,7 @@ struct OutDesc {
     float* out;
     const float* bias;      // [N] or null
     const float* mask;      // same layout as out; out = 0 where mask <= 0 (relu backward), or null
+    unsigned out_bytes;     // size of the whole output tensor (strided epilogue's buffer descriptor)
     int relu, dense;        // dense: out[m*N + n]
     int OH, OW, omul, oadd_y, oadd_x;   // else out[((b*OH + oy*omul + oadd_y)*OW + ox*omul + oadd_x)*N + n]
 };
@@ -709,30 +710,42 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     if (a.o.dense && !a.o.mask) {
         store_tiles_rowmajor<TM, TN>(acc, out, M, a.N, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, a.o.bias, a.o.relu);
     } else {
-        // strided (stride-parity data gradient) or masked output: per-row address decode
+        // Strided (stride-parity data gradient) or masked output: rows map to scattered pixels.  Only the
+        // lane's first row is decoded with divisions; the other rows of the 32-row tile are at most 31 + 32*TM
+        // pixels further on, so their carries into (oy, b) are one multiply-shift each (exact for the
+        // small operands involved: x < 2^12, divisor < 2^10).
+        const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out, a.o.out_bytes);
+        const unsigned inv_w = 65536u / (unsigned)g.out_w + 1u, inv_h = 65536u / (unsigned)g.out_h + 1u;
+        const int mb = m0 + wm * TM * 32 + 4 * half;
+        const int t0 = mb / g.out_w, ox0 = mb - t0 * g.out_w;
+        const int b0 = t0 / g.out_h, oy0 = t0 - b0 * g.out_h;
+        const bool small = g.out_w < 1024 && g.out_h < 1024;           // uniform
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int m = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
-                if (m >= M) continue;
-                int64_t orow;
-                if (a.o.dense) {
-                    orow = (int64_t)m * a.N;
+                const int rc = i * 32 + (v & 3) + 8 * (v >> 2);
+                const int m = mb + rc;
+                int b, oy, ox;
+                if (small) {
+                    const unsigned x = (unsigned)(ox0 + rc), qx = (x * inv_w) >> 16;
+                    const unsigned y = (unsigned)oy0 + qx, qy = (y * inv_h) >> 16;
+                    ox = (int)(x - qx * (unsigned)g.out_w); oy = (int)(y - qy * (unsigned)g.out_h); b = b0 + (int)qy;
                 } else {
-                    const int t = m / g.out_w, ox = m - t * g.out_w;
-                    const int b = t / g.out_h, oy = t - b * g.out_h;
-                    orow = ((int64_t)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N;
+                    const int t = m / g.out_w;
+                    ox = m - t * g.out_w; b = t / g.out_h; oy = t - b * g.out_h;
                 }
+                const int orow = a.o.dense ? m * a.N
+                                           : ((b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int n = n0 + wn * TN * 32 + j * 32 + l31;
-                    if (n >= a.N) continue;
                     float val = acc[i][j][v];
-                    if (a.o.bias) val += a.o.bias[n];
+                    if (a.o.bias && n < a.N) val += a.o.bias[n];
                     if (a.o.relu) val = fmaxf(val, 0.f);
-                    if (a.o.mask && !(a.o.mask[orow + n] > 0.f)) val = 0.f;
-                    out[orow + n] = val;
+                    const bool ok = m < M && n < a.N;
+                    if (a.o.mask && ok && !(a.o.mask[orow + n] > 0.f)) val = 0.f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsO, ok ? (unsigned)(orow + n) << 2 : OOB, 0, 0);
                 }
             }
         }
@@ -1168,6 +1181,7 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
         a.b.w = w; a.b.ld = g.kh * g.kw * g.C; a.b.kc = g.K; a.b.taps_x = taps_x;
         a.b.i0 = i0; a.b.j0 = j0; a.b.si = st; a.b.kw = g.kw; a.b.c = g.C;
         a.o.out = dx; a.o.mask = mask_or_null; a.o.dense = (st == 1);
+        a.o.out_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
         a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
         a.k_per_split = round_up(a.K, BKT);
         a.debug = tuning_debug(); a.trace = g_trace;
