@@ -307,6 +307,7 @@ def main():
     if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")        # no INFO/VERSION chatter on stdout
         dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import __graft_entry__
@@ -382,11 +383,15 @@ def main():
                 "note": "like for like: GPU rollout (sampler only) vs CPU sampler port; `value` additionally "
                         "contains the PPO learner, which the CPU baseline does not run"}
     runner.shutdown()
-    if rank == 0:
-        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner to C stdout (block-buffered when piped): flush it first so that
+        # the JSON line is the LAST line this process prints
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -95,6 +95,32 @@ def test_backward_matches_autograd(case):
     assert torch.equal(dw, dw2)                                 # split reduction is deterministic
 
 
+@pytest.mark.parametrize("case", [(512, 104, 80, 4, 32, 8, 4, 0), (512, 25, 19, 32, 64, 4, 2, 1),
+                                  (512, 12, 9, 64, 64, 3, 1, 1), (512, 1, 1, 6912, 512, 1, 1, 0),
+                                  (5120, 12, 9, 64, 64, 3, 1, 1)])
+def test_adjoint_identities_at_full_size(case):
+    """Size-independent property at the PPO minibatch (B = 512) and the A2C batch (5120) of BASELINE
+    configs 2-3: the three kernels are one bilinear form,
+        <conv(x; w), dy> = <x, bwd_data(dy; w)> = <w, bwd_weight(dy; x)>,
+    evaluated in fp64 from the fp32 outputs (no reference convolution needed at this size)."""
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = case
+    x, wt, bias, geom, ws = _mk(case, seed=3)
+    ho, wo = _lib.conv_out_hw(geom)
+    dy = torch.randn(b, ho, wo, k, device=DEV, generator=torch.Generator(device=DEV).manual_seed(9))
+    y, dw = torch.empty_like(dy), torch.empty_like(wt)
+    _lib.conv2d_fwd(x, wt, None, y, geom, False, ws)
+    _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+    dot = lambda a, b_: torch.dot(a.double().reshape(-1), b_.double().reshape(-1)).item()     # noqa: E731
+    ref = dot(y, dy)
+    scale = np.sqrt(dot(y, y) * dot(dy, dy))
+    assert abs(dot(wt, dw) - ref) <= 1e-5 * scale, (case, ref, dot(wt, dw))
+    if ks % st == 0:
+        dx = torch.empty_like(x)
+        _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
+        assert abs(dot(x, dx) - ref) <= 1e-5 * scale, (case, ref, dot(x, dx))
+
+
 def test_argument_errors():
     from accel_rl_amd import _lib
     x, wt, bias, geom, ws = _mk((2, 12, 9, 64, 64, 3, 1, 1))
