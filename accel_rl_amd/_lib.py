@@ -16,6 +16,7 @@ ARL_ABI_VERSION = 1
 PROMO_NEP50, PROMO_LEGACY = 0, 1
 OPT_ADAM, OPT_RMSPROP = 0, 1
 MAX_ACTIONS = 18
+REPLAY_MAX_HORIZON = 16
 RAW_H, RAW_W, OBS_H, OBS_W = 210, 160, 104, 80
 OPT_PARTIALS = 1024
 
@@ -50,6 +51,12 @@ class ArlRollout(C.Structure):
 class ArlConvGeom(C.Structure):
     _fields_ = [("batch", _i64), ("in_h", _i32), ("in_w", _i32), ("in_c", _i32), ("out_c", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad_h", _i32), ("pad_w", _i32)]
+
+
+class ArlReplay(C.Structure):
+    _fields_ = [("n_env", _i64), ("size", _i32), ("n_stack", _i32), ("frame_bytes", _i32),
+                ("reward_horizon", _i32), ("frames", _vp), ("n_blanks", _vp), ("acts", _vp),
+                ("terminals", _vp), ("rewards", _vp), ("returns", _vp)]
 
 
 class ArlOptState(C.Structure):
@@ -87,6 +94,11 @@ _SIGNATURES = {
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
+    "arl_replay_append": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _vp, _vp, _i32, _i32, _f64, _i32, _vp]),
+    "arl_replay_extract": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "arl_sumtree_find": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
+    "arl_sumtree_add": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp]),
+    "arl_sumtree_gather": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -354,3 +366,48 @@ def conv2d_bwd_weight(dy, x, dw, geom, workspace, stream=None):
     assert dw.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "dw size"
     _check(load().arl_conv2d_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(geom),
                                         ptr(workspace), stream_ptr(stream)), "arl_conv2d_bwd_weight")
+
+
+# ---------------------------------------------------------------------------
+# replay memory + sum tree (csrc/replay.hip)
+# ---------------------------------------------------------------------------
+
+def replay_append(rb, observations, actions, rewards, dones, horizon, idx, discount, promo=PROMO_NEP50,
+                  stream=None):
+    _want(observations, torch.uint8, "observations")
+    _want(actions, torch.uint8, "actions")
+    _want(rewards, torch.float32, "rewards")
+    _check(load().arl_replay_append(C.byref(rb), ptr(observations), ptr(actions), ptr(rewards), ptr(dones),
+                                    horizon, idx, float(discount), promo, stream_ptr(stream)), "arl_replay_append")
+
+
+def replay_extract(rb, env_idxs, step_idxs, obs, next_obs, actions, returns, terminals, stream=None):
+    _want(env_idxs, torch.int32, "env_idxs")
+    _want(step_idxs, torch.int32, "step_idxs")
+    _check(load().arl_replay_extract(C.byref(rb), ptr(env_idxs), ptr(step_idxs), env_idxs.numel(), ptr(obs),
+                                     ptr(next_obs), ptr(actions), ptr(returns), ptr(terminals),
+                                     stream_ptr(stream)), "arl_replay_extract")
+
+
+def sumtree_find(tree, levels, uniforms, out, stream=None):
+    _want(tree, torch.float64, "tree")
+    _want(uniforms, torch.float64, "uniforms")
+    _want(out, torch.int32, "out")
+    _check(load().arl_sumtree_find(ptr(tree), levels, ptr(uniforms), uniforms.numel(), ptr(out),
+                                   stream_ptr(stream)), "arl_sumtree_find")
+
+
+def sumtree_add(tree, levels, idxs, diffs, stream=None):
+    _want(tree, torch.float64, "tree")
+    _want(idxs, torch.int32, "idxs")
+    _want(diffs, torch.float64, "diffs")
+    _check(load().arl_sumtree_add(ptr(tree), levels, ptr(idxs), ptr(diffs), idxs.numel(), stream_ptr(stream)),
+           "arl_sumtree_add")
+
+
+def sumtree_gather(tree, idxs, out, scale=1.0, stream=None):
+    _want(tree, torch.float64, "tree")
+    _want(idxs, torch.int32, "idxs")
+    _want(out, torch.float64, "out")
+    _check(load().arl_sumtree_gather(ptr(tree), ptr(idxs), idxs.numel(), float(scale), ptr(out),
+                                     stream_ptr(stream)), "arl_sumtree_gather")

@@ -1,0 +1,282 @@
+// Device replay memory for the DQN family: frame-dedup ring buffers for all
+// environments in HBM, n-step return back-fill, batch extraction, and the f64 parted sum tree of
+// prioritized replay.  HBM-bound byte / index work, no MFMA.
+//
+//   arl_replay_append     FrameReplayBuffer.append_data / EnvBuffer.write_samples
+//                         (accel_rl/algos/dqn/replay_buffers/frame.py:57-60,121-166)
+//   arl_replay_extract    extract_batch / extract_observations            (frame.py:69-90)
+//   arl_sumtree_find      PartedSumTree.find                              (sum_tree.py:88-98)
+//   arl_sumtree_add       PartedSumTree.reconstruct (np.add.at, in input order, :54-57)
+//   arl_sumtree_gather    tree[idxs]                                      (:83,:65)
+//
+// Layout (struct arl_replay): per environment a ring of `size` states; frames are stored ONCE
+// each, u8[n_env][size + F - 1][frame_bytes] (the last F-1 slots mirror the first after a wrap),
+// so a stacked observation is F consecutive slots = one contiguous F*frame_bytes run.
+
+#include "arl_common.h"
+
+namespace {
+
+struct AppendArgs {
+    arl_replay rb;
+    const uint8_t* observations;   // [n_env*T][F][frame_bytes]
+    const uint8_t* actions;        // [n_env*T]
+    const float* rewards;
+    const uint8_t* dones;
+    int horizon, idx, promo;
+    double disc_pow[ARL_REPLAY_MAX_HORIZON];    // discount^i (NEP50: already rounded to f32)
+};
+
+__device__ __forceinline__ void copy_bytes16(uint8_t* dst, const uint8_t* src, int bytes, int tid, int nthreads) {
+    const uint4* s = reinterpret_cast<const uint4*>(src);
+    uint4* d = reinterpret_cast<uint4*>(dst);
+    for (int i = tid; i < bytes / 16; i += nthreads) d[i] = s[i];
+}
+
+// one workgroup per environment
+__global__ __launch_bounds__(256) void replay_append_kernel(const AppendArgs a) {
+    const int e = blockIdx.x, tid = threadIdx.x;
+    const int S = a.rb.size, F = a.rb.n_stack, P = a.rb.frame_bytes, T = a.horizon, idx = a.idx, h_r = a.rb.reward_horizon;
+    const int ring = S + F - 1;
+    uint8_t* frames = a.rb.frames + (int64_t)e * ring * P;
+    uint8_t* nb = a.rb.n_blanks + (int64_t)e * ring;
+    uint8_t* acts = a.rb.acts + (int64_t)e * S;
+    uint8_t* term = a.rb.terminals + (int64_t)e * S;
+    float* rew = a.rb.rewards + (int64_t)e * S;
+    float* ret = a.rb.returns + (int64_t)e * S;
+    if (idx == 0) {                                   // mirror the ring's tail (frame.py:134-137)
+        copy_bytes16(frames, frames + (int64_t)S * P, (F - 1) * P, tid, 256);
+        if (tid < F - 1) nb[tid] = nb[S + tid];
+    }
+    for (int t = 0; t < T; ++t)                       // newest frame of every step (:142-143)
+        copy_bytes16(frames + (int64_t)(idx + F - 1 + t) * P,
+                     a.observations + ((int64_t)(e * T + t) * F + (F - 1)) * P, P, tid, 256);
+    if (tid < T) {
+        acts[idx + tid] = a.actions[e * T + tid];
+        rew[idx + tid] = a.rewards[e * T + tid];
+        term[idx + tid] = a.dones[e * T + tid] ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {                                   // blank-history marks (:144-155), in step order
+        for (int t = 0; t < T; ++t) {
+            const int p = idx + t;
+            if (a.dones[e * T + t]) {                 // the sampler's dones, not the propagated terminals
+                for (int k = 1; k < F; ++k) nb[p + k] = (uint8_t)(F - k);
+            } else if (nb[p + 1] && nb[p + 1] >= nb[p]) {
+                nb[p + 1] = 0;
+            }
+        }
+    }
+    if (tid == 64) {                                  // n-step returns h_r - 1 behind (:156-166), in step order
+        for (int t = 0; t < T; ++t) {
+            int j = idx - (h_r - 1) + t;
+            if (j < 0) j += S;
+            float r32 = rew[j];
+            double r64 = (double)rew[j];
+            if (!term[j]) {
+                for (int i = 1; i < h_r; ++i) {
+                    int k = j + i;
+                    if (k >= S) k -= S;
+                    if (a.promo == ARL_PROMO_NEP50) r32 = r32 + (float)a.disc_pow[i] * rew[k];
+                    else r64 = r64 + a.disc_pow[i] * (double)rew[k];
+                    if (term[k]) { term[j] = 1; break; }
+                }
+            }
+            ret[j] = a.promo == ARL_PROMO_NEP50 ? r32 : (float)r64;
+        }
+    }
+}
+
+struct ExtractArgs {
+    arl_replay rb;
+    const int32_t* env_idxs;
+    const int32_t* step_idxs;
+    uint8_t* obs;          // [batch][F][frame_bytes]
+    uint8_t* next_obs;
+    uint8_t* actions;
+    float* returns;
+    uint8_t* terminals;
+    int64_t batch;
+};
+
+// grid (batch, 2): one workgroup copies one stacked observation (F * frame_bytes contiguous)
+// and zeroes its leading n_blanks frames (frame.py:81-90)
+__global__ __launch_bounds__(256) void replay_extract_kernel(const ExtractArgs a) {
+    const int64_t j = blockIdx.x;
+    const int which = blockIdx.y, tid = threadIdx.x;
+    const int S = a.rb.size, F = a.rb.n_stack, P = a.rb.frame_bytes, ring = S + F - 1;
+    const int e = a.env_idxs[j];
+    int i = a.step_idxs[j];
+    if (which) { i += a.rb.reward_horizon; if (i >= S) i -= S; }     // frame.py:70
+    const uint8_t* src = a.rb.frames + ((int64_t)e * ring + i) * P;
+    uint8_t* dst = (which ? a.next_obs : a.obs) + j * F * P;
+    const int blanks = a.rb.n_blanks[(int64_t)e * ring + i];
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    const int per_frame = P / 16, total = F * per_frame, zero_upto = blanks * per_frame;
+    for (int q = tid; q < total; q += 256) d4[q] = q < zero_upto ? make_uint4(0, 0, 0, 0) : s4[q];
+    if (!which && tid == 0) {
+        a.actions[j] = a.rb.acts[(int64_t)e * S + a.step_idxs[j]];
+        a.returns[j] = a.rb.returns[(int64_t)e * S + a.step_idxs[j]];
+        a.terminals[j] = a.rb.terminals[(int64_t)e * S + a.step_idxs[j]];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ sum tree
+__global__ __launch_bounds__(256) void sumtree_find_kernel(const double* __restrict__ tree, int levels,
+                                                           const double* __restrict__ uniforms, int64_t n,
+                                                           int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double v = uniforms[i] * tree[0];
+    int idx = 0;
+    for (int l = 0; l < levels - 1; ++l) {
+        idx = 2 * idx + 1;
+        const double left = tree[idx];
+        if (v > left) { v -= left; idx += 1; }
+    }
+    out[i] = idx;
+}
+
+__global__ __launch_bounds__(256) void sumtree_gather_kernel(const double* __restrict__ tree,
+                                                             const int32_t* __restrict__ idxs, int64_t n,
+                                                             double scale, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = scale * tree[idxs[i]];
+}
+
+// np.add.at(tree, idxs >> level, diffs) for every level, several updates of one node applied in INPUT
+// order (that fixes the f64 rounding, sum_tree.py:54-57).  One workgroup, n <= 4096: per level the
+// (node, position) pairs are bitonic-sorted in LDS, which makes each node's updates a contiguous run in
+// input order; the first lane of a run adds it sequentially.
+constexpr int ADD_MAX = 4096;
+
+__global__ __launch_bounds__(1024) void sumtree_add_kernel(double* __restrict__ tree, int levels,
+                                                           const int32_t* __restrict__ idxs,
+                                                           const double* __restrict__ diffs, int n) {
+    __shared__ unsigned long long keys[ADD_MAX];
+    __shared__ double s_diff[ADD_MAX];
+    const int tid = threadIdx.x;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < n; i += 1024) s_diff[i] = diffs[i];
+    for (int l = 0; l < levels; ++l) {
+        for (int i = tid; i < np2; i += 1024) {
+            unsigned long long k = ~0ull;                        // padding sorts last
+            if (i < n) {
+                const unsigned node = (unsigned)((idxs[i] + 1) >> l) - 1u;      // parent = (i - 1) / 2, l times
+                k = ((unsigned long long)node << 32) | (unsigned)i;
+            }
+            keys[i] = k;
+        }
+        __syncthreads();
+        for (int size = 2; size <= np2; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < np2 / 2; i += 1024) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const unsigned long long a = keys[lo], b = keys[hi];
+                    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < n; i += 1024) {
+            const unsigned node = (unsigned)(keys[i] >> 32);
+            if (i == 0 || (unsigned)(keys[i - 1] >> 32) != node) {
+                double t = tree[node];
+                for (int q = i; q < n && (unsigned)(keys[q] >> 32) == node; ++q) t += s_diff[(unsigned)keys[q]];
+                tree[node] = t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int check_replay(const arl_replay* rb) {
+    if (!rb || !rb->frames || !rb->acts || !rb->n_blanks || !rb->terminals || !rb->rewards || !rb->returns) {
+        arl::set_error("replay: null pointer");
+        return ARL_E_ARG;
+    }
+    if (rb->n_env <= 0 || rb->size <= 0 || rb->n_stack < 2 || rb->frame_bytes <= 0 || (rb->frame_bytes & 15) ||
+        rb->reward_horizon < 1 || rb->reward_horizon > ARL_REPLAY_MAX_HORIZON || rb->reward_horizon > rb->size) {
+        arl::set_error("replay: need n_stack >= 2, frame_bytes %% 16 == 0, 1 <= reward_horizon <= %d", ARL_REPLAY_MAX_HORIZON);
+        return ARL_E_RANGE;
+    }
+    if (!arl::aligned16(rb->frames)) { arl::set_error("replay: frames must be 16-byte aligned"); return ARL_E_ALIGN; }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int arl_replay_append(const arl_replay* rb, const uint8_t* observations, const uint8_t* actions,
+                                 const float* rewards, const uint8_t* dones, int32_t horizon, int32_t idx,
+                                 double discount, int32_t promo, void* stream) {
+    int rc = check_replay(rb);
+    if (rc) return rc;
+    ARL_REQUIRE(observations && actions && rewards && dones, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(horizon > 0 && horizon <= 256 && rb->size % horizon == 0 && idx >= 0 && idx + horizon <= rb->size &&
+                    idx % horizon == 0, ARL_E_RANGE, "size must be a multiple of horizon (<= 256), idx a multiple of it");
+    ARL_REQUIRE(promo == ARL_PROMO_NEP50 || promo == ARL_PROMO_LEGACY, ARL_E_ARG, "bad promo");
+    ARL_REQUIRE(arl::aligned16(observations), ARL_E_ALIGN, "observations must be 16-byte aligned");
+    AppendArgs a = {};
+    a.rb = *rb; a.observations = observations; a.actions = actions; a.rewards = rewards; a.dones = dones;
+    a.horizon = horizon; a.idx = idx; a.promo = promo;
+    double p = 1.0;
+    for (int i = 0; i < ARL_REPLAY_MAX_HORIZON; ++i) {       // discount ** i, as Python computes it (repeated
+        a.disc_pow[i] = promo == ARL_PROMO_NEP50 ? (double)(float)p : p;     // multiplication == pow for i <= 2;
+        p = pow(discount, i + 1);                                            // use pow() itself to be exact)
+    }
+    hipLaunchKernelGGL(replay_append_kernel, dim3((unsigned)rb->n_env), dim3(256), 0, (hipStream_t)stream, a);
+    return arl::check_launch("replay_append_kernel");
+}
+
+extern "C" int arl_replay_extract(const arl_replay* rb, const int32_t* env_idxs, const int32_t* step_idxs,
+                                  int64_t batch, uint8_t* obs, uint8_t* next_obs, uint8_t* actions,
+                                  float* returns, uint8_t* terminals, void* stream) {
+    int rc = check_replay(rb);
+    if (rc) return rc;
+    ARL_REQUIRE(env_idxs && step_idxs && obs && next_obs && actions && returns && terminals, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(batch >= 0 && batch < ((int64_t)1 << 31), ARL_E_RANGE, "bad batch");
+    ARL_REQUIRE(arl::aligned16(obs) && arl::aligned16(next_obs), ARL_E_ALIGN, "obs buffers must be 16-byte aligned");
+    if (batch == 0) return 0;
+    ExtractArgs a = {};
+    a.rb = *rb; a.env_idxs = env_idxs; a.step_idxs = step_idxs; a.obs = obs; a.next_obs = next_obs;
+    a.actions = actions; a.returns = returns; a.terminals = terminals; a.batch = batch;
+    hipLaunchKernelGGL(replay_extract_kernel, dim3((unsigned)batch, 2), dim3(256), 0, (hipStream_t)stream, a);
+    return arl::check_launch("replay_extract_kernel");
+}
+
+extern "C" int arl_sumtree_find(const double* tree, int32_t levels, const double* uniforms, int64_t n,
+                                int32_t* tree_idxs, void* stream) {
+    ARL_REQUIRE(tree && uniforms && tree_idxs, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(levels >= 1 && levels <= 31 && n >= 0, ARL_E_RANGE, "bad levels / n");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(sumtree_find_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       tree, levels, uniforms, n, tree_idxs);
+    return arl::check_launch("sumtree_find_kernel");
+}
+
+extern "C" int arl_sumtree_gather(const double* tree, const int32_t* tree_idxs, int64_t n, double scale,
+                                  double* out, void* stream) {
+    ARL_REQUIRE(tree && tree_idxs && out, ARL_E_ARG, "null pointer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sumtree_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       tree, tree_idxs, n, scale, out);
+    return arl::check_launch("sumtree_gather_kernel");
+}
+
+extern "C" int arl_sumtree_add(double* tree, int32_t levels, const int32_t* tree_idxs, const double* diffs,
+                               int64_t n, void* stream) {
+    ARL_REQUIRE(tree && tree_idxs && diffs, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(levels >= 1 && levels <= 31 && n >= 0, ARL_E_RANGE, "bad levels / n");
+    // consecutive chunks are exact: levels touch disjoint nodes and a node sees chunk A's updates before B's
+    for (int64_t lo = 0; lo < n; lo += ADD_MAX) {
+        const int m = (int)((n - lo < ADD_MAX) ? n - lo : ADD_MAX);
+        hipLaunchKernelGGL(sumtree_add_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree, levels,
+                           tree_idxs + lo, diffs + lo, m);
+        int rc = arl::check_launch("sumtree_add_kernel");
+        if (rc) return rc;
+    }
+    return 0;
+}

@@ -318,6 +318,61 @@ int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_nu
 int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
                           void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Replay memory of the DQN family
+ * ------------------------------------------------------------------------- */
+
+#define ARL_REPLAY_MAX_HORIZON 16
+
+/* Frame-dedup replay storage for all environments, struct-of-arrays in HBM.
+ * Replaces FrameReplayBuffer + one EnvBuffer per environment,
+ * accel_rl/algos/dqn/replay_buffers/frame.py:23-119.  Per environment `size`
+ * states; every frame is stored once in a ring of size + n_stack - 1 slots. */
+typedef struct arl_replay {
+    int64_t  n_env;
+    int32_t  size;            /* states per environment (env_replay_size, frame.py:44) */
+    int32_t  n_stack;         /* frames per observation (num_img_obs), >= 2            */
+    int32_t  frame_bytes;     /* bytes of one frame, multiple of 16 (104*80 = 8320)    */
+    int32_t  reward_horizon;  /* n of the n-step return                                */
+    uint8_t* frames;          /* u8[n_env][size + n_stack - 1][frame_bytes]            */
+    uint8_t* n_blanks;        /* u8[n_env][size + n_stack - 1] blank frames after a reset */
+    uint8_t* acts;            /* u8[n_env][size]                                       */
+    uint8_t* terminals;       /* u8[n_env][size] (0/1)                                 */
+    float*   rewards;         /* f32[n_env][size]                                      */
+    float*   returns;         /* f32[n_env][size] n-step discounted return             */
+} arl_replay;
+
+/* One sampler batch into the ring at state index idx: newest frame of every step,
+ * actions / rewards / dones, blank-history marks after terminals, and the n-step
+ * returns of the `horizon` states that now have all their rewards, with a terminal
+ * inside the window propagated back.  Replaces append_data / write_samples,
+ * frame.py:57-60,121-166.  Sampler layout, env-major: observations
+ * u8[n_env*horizon][n_stack][frame_bytes], actions u8, rewards f32, dones u8.
+ * promo as for the scans (the reference accumulates python-float x float32). */
+int arl_replay_append(const arl_replay* rb, const uint8_t* observations, const uint8_t* actions,
+                      const float* rewards, const uint8_t* dones, int32_t horizon, int32_t idx,
+                      double discount, int32_t promo, void* stream);
+
+/* Batch extraction: obs / next_obs (reward_horizon states later) as stacked u8 frames with
+ * the post-reset blank frames zeroed, plus actions, n-step returns, terminals.
+ * Replaces extract_batch / extract_observations, frame.py:69-90. */
+int arl_replay_extract(const arl_replay* rb, const int32_t* env_idxs, const int32_t* step_idxs,
+                       int64_t batch, uint8_t* obs, uint8_t* next_obs, uint8_t* actions,
+                       float* returns, uint8_t* terminals, void* stream);
+
+/* Parted sum tree of prioritized replay, f64[2^levels - 1], root at 0, children 2i+1 / 2i+2
+ * (accel_rl/algos/dqn/replay_buffers/sum_tree.py:12-98).
+ * find:   descend by prefix mass, uniforms in [0,1] scaled by the root       (:88-98)
+ * add:    np.add.at along every leaf-to-root path; several updates of one node are
+ *         applied in INPUT order, so the f64 rounding equals the reference's (:54-57)
+ * gather: out[i] = scale * tree[idxs[i]]                                      (:65,:83) */
+int arl_sumtree_find(const double* tree, int32_t levels, const double* uniforms, int64_t n,
+                     int32_t* tree_idxs, void* stream);
+int arl_sumtree_add(double* tree, int32_t levels, const int32_t* tree_idxs, const double* diffs,
+                    int64_t n, void* stream);
+int arl_sumtree_gather(const double* tree, const int32_t* tree_idxs, int64_t n, double scale,
+                       double* out, void* stream);
+
 /* Optimiser state for ONE flat fp32 parameter bucket (all trainable params in
  * get_params order, accel_rl/optimizers/util.py:35-39). */
 typedef struct arl_opt_state {

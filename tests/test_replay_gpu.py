@@ -1,0 +1,169 @@
+"""Device replay memory + sum tree (csrc/replay.hip, accel_rl_amd/algos/dqn/replay_buffers/) against
+vectors recorded from the reference's own classes (g11 / g12) and against the oracle at
+BASELINE config 5's frame size: every stored array after every append, the sampled indices,
+the extracted batches and the f64 tree -- bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import replay_port as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+HERE = os.path.dirname(os.path.abspath(__file__))
+G11 = np.load(os.path.join(HERE, "golden", "g11_replay.npz"))
+G12 = np.load(os.path.join(HERE, "golden", "g12_sumtree.npz"))
+
+
+class _Space(object):
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class _Spec(object):
+    def __init__(self, shape):
+        self.observation_space = _Space(shape)
+
+
+def _samples(obs, acts, rews, dones, b):
+    """Sampler layout: env-major flat arrays on the device.  Frames are padded to a multiple of
+    16 bytes (the golden frames are 6x5; the product's are 104x80)."""
+    n_env, t = obs.shape[1], obs.shape[2]
+    o = torch.from_numpy(obs[b].reshape((n_env * t,) + obs.shape[3:])).to(DEV)
+    return dict(observations=o, actions=torch.from_numpy(acts[b].reshape(-1)).to(DEV),
+                rewards=torch.from_numpy(rews[b].reshape(-1)).to(DEV),
+                dones=torch.from_numpy(dones[b].reshape(-1)).to(DEV))
+
+
+def _pad(frames):
+    """6x5 golden frames -> 6x8 (48 bytes, multiple of 16); extra pixels are zero."""
+    out = np.zeros(frames.shape[:-1] + (8,), np.uint8)
+    out[..., :5] = frames
+    return out
+
+
+@pytest.mark.parametrize("tag", ["f4", "f2", "f4h5"])
+def test_uniform_buffer_matches_reference(tag):
+    from accel_rl_amd.algos.dqn.replay_buffers.uniform import UniformReplayBuffer
+    n_env, horizon, n_batches, n_frames, h, w, h_r, s = [int(x) for x in G11[tag + "_cfg"]]
+    obs = _pad(G11[tag + "_in_obs"])
+    acts, rews, dones = (G11["%s_in_%s" % (tag, k)] for k in ("acts", "rews", "dones"))
+    buf = UniformReplayBuffer(env_spec=_Spec((n_frames, h, 8)), size=60, reward_horizon=h_r,
+                              sampling_horizon=horizon, n_environments=n_env,
+                              discount=float(G11[tag + "_discount"]), device=DEV)
+    assert buf.env_replay_size == s
+    for b in range(n_batches):
+        buf.append_data(_samples(obs, acts, rews, dones, b))
+        want = {k: G11["%s_b%02d_%s" % (tag, b, k)] for k in ("frames", "acts", "n_blanks", "terminals", "rewards", "returns")}
+        np.testing.assert_array_equal(buf.frames.cpu().numpy()[..., :5], want["frames"])
+        assert not buf.frames.cpu().numpy()[..., 5:].any()
+        np.testing.assert_array_equal(buf.acts.cpu().numpy(), want["acts"])
+        np.testing.assert_array_equal(buf.n_blanks.cpu().numpy(), want["n_blanks"])
+        np.testing.assert_array_equal(buf.terminals.cpu().numpy().astype(bool), want["terminals"])
+        np.testing.assert_array_equal(buf.rewards.cpu().numpy(), want["rewards"])
+        np.testing.assert_array_equal(buf.returns.cpu().numpy(), want["returns"])
+        idx, full = G11["%s_b%02d_idx_full" % (tag, b)]
+        assert (buf.idx, int(buf._buffer_full)) == (idx, full)
+        key = "%s_b%02d_env_idxs" % (tag, b)
+        if key in G11.files:
+            np.random.seed(1000 + b)
+            o, no, a, r, term = buf.sample_batch(16)
+            np.testing.assert_array_equal(o.cpu().numpy()[..., :5], G11["%s_b%02d_x_obs" % (tag, b)])
+            np.testing.assert_array_equal(no.cpu().numpy()[..., :5], G11["%s_b%02d_x_next_obs" % (tag, b)])
+            np.testing.assert_array_equal(a.cpu().numpy(), G11["%s_b%02d_x_actions" % (tag, b)])
+            np.testing.assert_array_equal(r.cpu().numpy(), G11["%s_b%02d_x_returns" % (tag, b)])
+            np.testing.assert_array_equal(term.cpu().numpy(), G11["%s_b%02d_x_terminals" % (tag, b)])
+
+
+def test_sum_tree_matches_reference():
+    from accel_rl_amd.algos.dqn.replay_buffers.sum_tree import PartedSumTree
+    part, parts, zf, zb, n_adv, level, size, shift = [int(x) for x in G12["cfg"]]
+    tree = PartedSumTree(part, parts, zf, zb, float(G12["default_value"]), n_adv, device=DEV)
+    assert (tree.tree_level, tree.tree_size, tree.t_l_shift) == (level, size, shift)
+    np.testing.assert_array_equal(tree.tree.cpu().numpy(), G12["tree_init"])
+    for s in range(int(G12["n_steps"])):
+        p = "s%02d_" % s
+        if p + "advance_tree" in G12.files:
+            tree.advance()
+            np.testing.assert_array_equal(tree.tree.cpu().numpy(), G12[p + "advance_tree"])
+            assert tree.step_cursor == int(G12[p + "cursor"])
+        elif p + "sample_env" in G12.files:
+            np.random.seed(int(G12[p + "sample_seed"]))
+            e, st, pr = tree.sample_n(8)
+            np.testing.assert_array_equal(e, G12[p + "sample_env"])
+            np.testing.assert_array_equal(st, G12[p + "sample_step"])
+            np.testing.assert_array_equal(pr, G12[p + "sample_probs"])
+        else:
+            tree.update_last_samples(G12[p + "update_values"])
+            np.testing.assert_array_equal(tree.tree.cpu().numpy(), G12[p + "update_tree"])
+    tree.tree.copy_(torch.from_numpy(G12["find_tree"]))
+    np.testing.assert_array_equal(tree.find(G12["find_u"]), G12["find_idx"])
+
+
+def test_prioritized_buffer_matches_reference():
+    from accel_rl_amd.algos.dqn.replay_buffers.prioritized import PrioritizedReplayBuffer
+    obs = _pad(G12["pri_in_obs"])
+    acts, rews, dones = (G12["pri_in_%s" % k] for k in ("acts", "rews", "dones"))
+    buf = PrioritizedReplayBuffer(alpha=0.6, beta_initial=0.4, default_priority=1., env_spec=_Spec((4, 6, 8)),
+                                  size=60, reward_horizon=3, sampling_horizon=5, n_environments=3,
+                                  discount=0.99, device=DEV)
+    for b in range(9):
+        buf.append_data(_samples(obs, acts, rews, dones, b))
+        if b >= 1:
+            np.random.seed(3000 + b)
+            o, no, a, r, term, isw = buf.sample_batch(6)
+            np.testing.assert_array_equal(o.cpu().numpy()[..., :5], G12["pri_b%d_obs" % b])
+            np.testing.assert_array_equal(no.cpu().numpy()[..., :5], G12["pri_b%d_next_obs" % b])
+            np.testing.assert_array_equal(r.cpu().numpy(), G12["pri_b%d_returns" % b])
+            np.testing.assert_array_equal(isw, G12["pri_b%d_is_weights" % b])
+            buf.update_batch_priorities(G12["pri_b%d_new_priorities" % b])
+        np.testing.assert_array_equal(buf.priority_tree.tree.cpu().numpy(), G12["pri_b%d_tree" % b])
+
+
+@pytest.mark.parametrize("promo", ["nep50", "legacy"])
+def test_config5_shapes_against_oracle(promo):
+    """Seaquest-shaped frames (4 x 104 x 80), 64 envs, many wraps, both numpy promotions; a large
+    random tree update exercises the chunked in-order add (n > 4096)."""
+    from accel_rl_amd import _lib
+    from accel_rl_amd.algos.dqn.replay_buffers.uniform import UniformReplayBuffer
+    from accel_rl_amd.algos.dqn.replay_buffers.sum_tree import PartedSumTree
+    rs = np.random.RandomState(5)
+    n_env, t, f, h_r, size = 64, 4, 4, 3, 64 * 40
+    buf = UniformReplayBuffer(env_spec=_Spec((f, 104, 80)), size=size, reward_horizon=h_r, sampling_horizon=t,
+                              n_environments=n_env, discount=0.99, device=DEV,
+                              promo=_lib.PROMO_NEP50 if promo == "nep50" else _lib.PROMO_LEGACY)
+    port = R.ReplayPort(n_env, f, (104, 80), size, h_r, t, 0.99, promo=promo)
+    for b in range(25):
+        obs = rs.randint(0, 256, size=(n_env, t, f, 104, 80), dtype=np.uint8)
+        acts = rs.randint(0, 18, size=(n_env, t)).astype(np.uint8)
+        rews = rs.randn(n_env, t).astype(np.float32)
+        dones = rs.rand(n_env, t) < 0.1
+        port.append(obs, acts, rews, dones)
+        buf.append_data(dict(observations=torch.from_numpy(obs.reshape(n_env * t, f, 104, 80)).to(DEV),
+                             actions=torch.from_numpy(acts.reshape(-1)).to(DEV),
+                             rewards=torch.from_numpy(rews.reshape(-1)).to(DEV),
+                             dones=torch.from_numpy(dones.reshape(-1)).to(DEV)))
+    for k in ("frames", "n_blanks", "acts", "rewards", "returns"):
+        np.testing.assert_array_equal(getattr(buf, k).cpu().numpy(), getattr(port, k), err_msg=k)
+    np.testing.assert_array_equal(buf.terminals.cpu().numpy().astype(bool), port.terminals)
+    np.random.seed(9)
+    e, s = buf.sample_idxs(512)
+    got = buf.extract_batch(e, s)
+    want = port.extract_batch(e, s)
+    for g, w_ in zip(got, want):
+        np.testing.assert_array_equal(g.cpu().numpy(), w_)
+    # sum tree: 6000 updates with many repeated leaves, in-order accumulation across chunks
+    tree = PartedSumTree(size // n_env, n_env, f, h_r, 1.0, t, device=DEV)
+    ref = R.SumTreePort(size // n_env, n_env, f, h_r, 1.0, t)
+    for _ in range(3):
+        tree.advance()
+        ref.advance()
+    idxs = rs.randint(0, size, size=6000) + ref.shift
+    diffs = rs.randn(6000)
+    tree.reconstruct(idxs, diffs)
+    ref.add(idxs, diffs)
+    np.testing.assert_array_equal(tree.tree.cpu().numpy(), ref.tree)
+    u = rs.rand(1000)
+    np.testing.assert_array_equal(tree.find(u), ref.find(u))
