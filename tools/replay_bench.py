@@ -1,0 +1,79 @@
+"""BASELINE config 5 shape: 1M-transition device replay (Seaquest frames 4 x 104 x 80), event-timed
+append / extract / sum-tree operations with their algorithmic HBM bytes.
+usage: python tools/replay_bench.py [n_env] [size]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from accel_rl_amd import _lib
+from accel_rl_amd.algos.dqn.replay_buffers.prioritized import PrioritizedReplayBuffer
+
+DEV = "cuda:0"
+
+
+class _Space(object):
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class _Spec(object):
+    observation_space = _Space((4, 104, 80))
+
+
+def ev(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    for i in range(reps):
+        s[i].record(); fn(); e[i].record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in zip(s, e)])) * 1e3
+
+
+def main():
+    n_env = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    size = int(sys.argv[2]) if len(sys.argv) > 2 else 1000000
+    t, h_r, frame = 4, 3, 104 * 80
+    buf = PrioritizedReplayBuffer(alpha=0.6, beta_initial=0.4, default_priority=1., env_spec=_Spec(), size=size,
+                                  reward_horizon=h_r, sampling_horizon=t, n_environments=n_env, discount=0.99,
+                                  device=DEV)
+    print("replay: %d envs x %d states = %d transitions, frames %.2f GB, tree %d levels (%.1f MB)" %
+          (n_env, buf.env_replay_size, n_env * buf.env_replay_size, buf.frames.numel() / 1e9,
+           buf.priority_tree.tree_level, buf.priority_tree.tree.numel() * 8 / 1e6))
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    samples = dict(observations=torch.randint(0, 256, (n_env * t, 4, 104, 80), dtype=torch.uint8, device=DEV, generator=gen),
+                   actions=torch.randint(0, 18, (n_env * t,), dtype=torch.uint8, device=DEV, generator=gen),
+                   rewards=torch.randn(n_env * t, device=DEV, generator=gen),
+                   dones=(torch.rand(n_env * t, device=DEV, generator=gen) < 0.02))
+    for _ in range(40):
+        buf.append_data(samples)
+    us = ev(lambda: _lib.replay_append(buf._rb, samples["observations"], samples["actions"], samples["rewards"],
+                                       samples["dones"].view(torch.uint8), t, 8, 0.99))
+    nbytes = n_env * t * (2 * frame + 2 * (1 + 4 + 1)) + n_env * t * 8
+    print("append  (%d env-steps): %7.1f us  %6.1f GB/s algorithmic (%.1f MB)" % (n_env * t, us, nbytes / us / 1e3, nbytes / 1e6))
+    tree = buf.priority_tree
+    us = ev(lambda: tree.advance(), reps=10)
+    print("tree advance (%d leaf updates x %d levels, in input order): %7.1f us" % (2 * tree.n_ons, tree.tree_level, us))
+    for b in (32, 512, 4096):
+        e_idx = torch.randint(0, n_env, (b,), dtype=torch.int32, device=DEV, generator=gen)
+        s_idx = torch.randint(0, buf.env_replay_size - 8, (b,), dtype=torch.int32, device=DEV, generator=gen)
+        outs = [torch.empty((b, 4, 104, 80), dtype=torch.uint8, device=DEV) for _ in range(2)]
+        a, r, tm = (torch.empty(b, dtype=torch.uint8, device=DEV), torch.empty(b, device=DEV),
+                    torch.empty(b, dtype=torch.uint8, device=DEV))
+        us = ev(lambda: _lib.replay_extract(buf._rb, e_idx, s_idx, outs[0], outs[1], a, r, tm))
+        nbytes = b * 2 * 2 * 4 * frame
+        print("extract batch %4d: %7.1f us  %7.1f GB/s algorithmic (%.1f MB read + written)" % (b, us, nbytes / us / 1e3, nbytes / 1e6))
+        u = torch.rand(b, dtype=torch.float64, device=DEV, generator=gen)
+        out = torch.empty(b, dtype=torch.int32, device=DEV)
+        us = ev(lambda: _lib.sumtree_find(tree.tree, tree.tree_level, u, out))
+        print("tree find    %4d: %7.1f us" % (b, us))
+        d = torch.randn(b, dtype=torch.float64, device=DEV, generator=gen)
+        us = ev(lambda: _lib.sumtree_add(tree.tree, tree.tree_level, out, d))
+        print("tree update  %4d: %7.1f us" % (b, us))
+
+
+if __name__ == "__main__":
+    main()
