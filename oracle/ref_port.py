@@ -357,7 +357,16 @@ class CpuSamplerPort(object):
     (step, group, worker, env) order reproduces them exactly."""
 
     def __init__(self, game, horizon, n_parallel=1, envs_per=1,
-                 max_path_length=np.inf, mid_batch_reset=True, env_kwargs=None):
+                 max_path_length=np.inf, mid_batch_reset=True, env_kwargs=None,
+                 eval_steps=None, eval_envs_per=None):
+        """eval_envs_per / eval_steps: the AAOEvalSampler variant (sampler_with_eval.py:6-54,
+        worker_with_eval.py): extra evaluation envs per worker, and the over-length rule of
+        BOTH collectors becomes Length >= max_path_length (worker_with_eval.py:48,123,159)
+        where the plain worker has > (worker.py:42)."""
+        self.eval_envs_per = eval_envs_per
+        if eval_envs_per is not None:
+            self.n_eval_envs = eval_envs_per * n_parallel * 2
+            self.eval_horizon = eval_steps // self.n_eval_envs
         self.game = game
         self.horizon = horizon
         self.n_parallel = n_parallel
@@ -392,12 +401,14 @@ class CpuSamplerPort(object):
             extra_observations=np.zeros((n, f, OBS_H, OBS_W), np.uint8),
         )
         self.step_obs = np.zeros((n, f, OBS_H, OBS_W), np.uint8)
-        self.envs, self.trajs = [], []
+        self.envs, self.trajs, self.eval_envs = [], [], []
         for w in range(2 * self.n_parallel):
             rng = np.random.RandomState((seed + w) % 4294967294)   # ext.set_seed
             for _ in range(self.envs_per):
                 env = PortedAtariEnv(game=self.game, rng=rng, **self.env_kwargs)
                 self.envs.append(env)
+            for _ in range(self.eval_envs_per or 0):                # worker_with_eval.py:200
+                self.eval_envs.append(PortedAtariEnv(game=self.game, rng=rng, **self.env_kwargs))
             for i in range(self.envs_per):                          # start_envs
                 e = w * self.envs_per + i
                 self.step_obs[e] = self.envs[e].reset()
@@ -429,7 +440,8 @@ class CpuSamplerPort(object):
                     env, traj = self.envs[e], self.trajs[e]
                     o, r, d, info = env.step(acts[e - lo])
                     traj.step(r, info)
-                    over_len = traj["Length"] > self.max_path_length
+                    over_len = (traj["Length"] >= self.max_path_length) if self.eval_envs_per is not None \
+                        else (traj["Length"] > self.max_path_length)
                     hit = over_len or (d and info.get("need_reset", True))
                     if hit:                                         # worker.py:42-50
                         d = True
@@ -457,6 +469,30 @@ class CpuSamplerPort(object):
                 if frozen[e]:
                     self.step_obs[e] = self.envs[e].reset()
         return b, completed
+
+
+    def evaluate_policy(self, policy):
+        """AAOEvalSampler.evaluate_policy + collect_eval (sampler_with_eval.py:20-54,
+        worker_with_eval.py:148-176): fresh resets of the evaluation envs, eval_horizon served
+        steps, nothing stored; returns the completed TrajInfos (fresh ones per call)."""
+        ne, half = self.n_eval_envs, self.n_eval_envs // 2
+        obs = np.stack([env.reset() for env in self.eval_envs])
+        trajs = [PortedTrajInfo(self.discount) for _ in range(ne)]
+        completed = []
+        for _ in range(self.eval_horizon):
+            for j in (0, 1):
+                lo, hi = j * half, (j + 1) * half
+                acts, _ = policy.get_actions(obs[lo:hi])
+                for e in range(lo, hi):
+                    env = self.eval_envs[e]
+                    o, r, d, info = env.step(acts[e - lo])
+                    trajs[e].step(r, info)
+                    if trajs[e]["Length"] >= self.max_path_length or (d and info.get("need_reset", True)):
+                        o = env.reset()
+                        completed.append(trajs[e])
+                        trajs[e] = PortedTrajInfo(self.discount)
+                    obs[e] = o
+        return completed
 
 
 # =============================================================================

@@ -165,17 +165,21 @@ class TablePolicyPort(object):
 
 
 def replay_rollout(g, sampler_factory=None):
-    n_parallel, envs_per, horizon, n_batches, seed, mbr, maxlen = [int(x) for x in g["cfg"]]
+    n_parallel, envs_per, horizon, n_batches, seed, mbr, maxlen = [int(x) for x in g["cfg"][:7]]
     env_kwargs = dict(ast.literal_eval(str(g["env_args"])))
+    extra = dict()
+    if len(g["cfg"]) > 7:                               # G13: the evaluation-sampler variant
+        extra = dict(eval_steps=int(g["cfg"][7]), eval_envs_per=int(g["cfg"][8]))
     smp = P.CpuSamplerPort(str(g["game"]), horizon, n_parallel, envs_per,
                            max_path_length=np.inf if maxlen < 0 else maxlen,
-                           mid_batch_reset=bool(mbr), env_kwargs=env_kwargs)
+                           mid_batch_reset=bool(mbr), env_kwargs=env_kwargs, **extra)
     np.random.seed(seed)
     n_act, sample_size = smp.initialize(seed + 1, discount=float(g["discount"]))
     # master-side draws the reference makes between initialize and the first serve
-    # (build_step_buffer x2: act_server/buffers.py:24-30; build_policy_buffer: :33-38)
+    # (build_step_buffer x2 [+ x2 for the eval step buffers, sampler.py:204-206]:
+    #  act_server/buffers.py:24-30; build_policy_buffer: :33-38)
     obs_shape = smp.step_obs.shape[1:]
-    for _ in range(2):
+    for _ in range(4 if extra else 2):
         np.random.randint(low=0, high=255, size=obs_shape, dtype=np.uint8)
         np.random.randint(n_act, dtype=np.uint8)
     np.random.randint(low=0, high=255, size=obs_shape, dtype=np.uint8)
@@ -222,6 +226,39 @@ def test_sampler_port_matches_reference_sampler(tag):
     got = sorted((b,) + tuple(float(x) for x in row) for (b, *row) in traj)
     assert len(want) > 0
     assert got == want
+
+
+# -- G13: evaluation sampler ---------------------------------------------------
+
+@pytest.mark.parametrize("tag", ["breakout", "pong_nomid"])
+def test_eval_sampler_port_matches_reference(tag):
+    """Training batches interleaved with evaluate_policy calls, recorded from the reference's own
+    AAOEvalSampler: the evaluation trajectories AND every later training array must match (the
+    eval resets and eval action draws advance the worker / master RNG streams)."""
+    g = load_golden("g13_eval_" + tag)
+    smp, policy, n_batches = replay_rollout(g)
+    assert smp.eval_horizon == int(g["cfg"][9])
+    mbr, t = bool(g["cfg"][5]), smp.horizon
+    eval_at = set(int(x) for x in g["eval_batches"])
+    traj, eval_traj = [], []
+    for b in range(n_batches):
+        if b in eval_at:
+            eval_traj += [(b,) + ti.as_tuple() for ti in smp.evaluate_policy(policy)]
+        buf, completed = smp.obtain_samples(policy)
+        np.testing.assert_array_equal(buf["actions"], g["actions"][b], err_msg="b%d" % b)
+        np.testing.assert_array_equal(buf["prob"], g["prob"][b])
+        valid = np.ones(len(buf["rewards"]), bool)
+        if not mbr:
+            valid = P.valid_mask(g["need_reset"][b].reshape(-1, t)).reshape(-1).astype(bool)
+        for key in ("rewards", "dones", "raw_reward", "need_reset"):
+            np.testing.assert_array_equal(buf[key][valid], g[key][b][valid], err_msg="b%d %s" % (b, key))
+        np.testing.assert_array_equal(_crc_rows(buf["observations"])[valid], g["obs_crc"][b][valid])
+        np.testing.assert_array_equal(_crc_rows(buf["extra_observations"]), g["extra_crc"][b])
+        traj += [(b,) + ti.as_tuple() for ti in completed]
+    as_rows = lambda bs, rows: sorted((int(b),) + tuple(float(x) for x in r) for b, r in zip(bs, rows))     # noqa: E731
+    assert sorted((b,) + tuple(float(x) for x in r) for (b, *r) in traj) == as_rows(g["traj_batch"], g["traj"])
+    got = sorted((b,) + tuple(float(x) for x in r) for (b, *r) in eval_traj)
+    assert got == as_rows(g["eval_at"], g["eval_traj"]) and len(got) >= 10
 
 
 # -- G8 / G9 ------------------------------------------------------------------
