@@ -188,3 +188,72 @@ class AccelRL(AccelRLBase):
         self._new_completed_trajs = 0
         if itr < self._n_itr - 1:
             logger.log("optimizing over {} iterations".format(self._log_interval_itrs))
+
+
+class AccelRLEval(AccelRLBase):
+    """Runs RL; tracks learning performance offline using evaluation trajectories
+    (reference: accel_rl/runners/accel_rl.py:108-180).  Needs a sampler with
+    `evaluate_policy(itr)` (GpuVecEvalSampler); the algorithm's optional `prep_eval(itr)` /
+    `post_eval(itr)` hooks (dqn.py:209-216: epsilon switch) are called around it."""
+
+    def __init__(self, eval_interval_steps=1e6, **kwargs):
+        super().__init__(**kwargs)
+        self._log_steps = int(eval_interval_steps)
+
+    def train(self):
+        n_itr = self.startup()
+        for itr in range(n_itr):
+            with logger.prefix("itr #%d | " % itr):
+                if itr % self._log_interval_itrs == 0:
+                    eval_traj_infos, eval_time = self.eval_policy(itr)
+                    self.log_diagnostics(itr, eval_traj_infos, eval_time)
+                samples_data, traj_infos = self.sampler.obtain_samples(itr)
+                opt_data, opt_infos = self.algo.optimize_policy(itr, samples_data)
+                self.store_diagnostics(itr, samples_data, opt_data, traj_infos, opt_infos)
+        self.shutdown()
+
+    def init_logging(self):
+        self._cum_train_time = 0
+        self._cum_eval_time = 0
+        self._cum_total_time = 0
+        super().init_logging()
+
+    def eval_policy(self, itr):
+        logger.log("evaluating policy...")
+        start = time.time()
+        getattr(self.algo, "prep_eval", lambda itr: None)(itr)
+        traj_infos = self.sampler.evaluate_policy(itr)
+        getattr(self.algo, "post_eval", lambda itr: None)(itr)
+        logger.log("evaluation run complete")
+        return traj_infos, time.time() - start
+
+    def store_diagnostics(self, itr, samples_data, opt_data, traj_infos, opt_infos):
+        for k, v in opt_infos.items():
+            self._opt_infos[k].extend(v if isinstance(v, list) else [v])
+
+    def log_diagnostics(self, itr, eval_traj_infos, eval_time):
+        """reference: accel_rl.py:150-180"""
+        self.save_itr_snapshot(itr)
+        if not eval_traj_infos:
+            logger.log("ERROR: had no complete trajectories in eval.")
+        logger.record_tabular("Iteration", itr)
+        logger.record_tabular("CumCompletedSteps", itr * self._sample_size)
+        logger.record_tabular("StepsInEval", sum(info["Length"] for info in eval_traj_infos))
+        logger.record_tabular("TrajsInEval", len(eval_traj_infos))
+        self._log_infos(eval_traj_infos)
+        if torch.device(self.policy.device).type == "cuda":
+            torch.cuda.synchronize(self.policy.device)
+        new_time = time.time()
+        log_interval_time = new_time - self._last_time
+        new_train_time = log_interval_time - eval_time
+        self._cum_train_time += new_train_time
+        self._cum_eval_time += eval_time
+        self._cum_total_time += log_interval_time
+        self._last_time = new_time
+        train_speed = float("nan") if itr == 0 else self._log_interval_itrs * self._sample_size / new_train_time
+        logger.record_tabular("CumTrainTime", self._cum_train_time)
+        logger.record_tabular("CumEvalTime", self._cum_eval_time)
+        logger.record_tabular("CumTotalTime", self._cum_total_time)
+        logger.record_tabular("SamplesPerSecond", train_speed)
+        self.last_tabular = logger.dump_tabular(with_prefix=False)
+        logger.log("optimizing over {} iterations".format(self._log_interval_itrs))

@@ -85,7 +85,8 @@ class GpuVecSampler(BaseMbSampler):
             self.envs_buf.extra_observations = batch_buffer(obs_example, n, dev)
         # step buffers: observation_space.sample() + action_space.sample() per group
         # (act_server/buffers.py:24-30) -- drawn only to keep the RNG stream aligned
-        for _ in range(2):
+        eval_per = getattr(self, "eval_envs_per", None)            # set by GpuVecEvalSampler
+        for _ in range(4 if eval_per is not None else 2):          # (+ 2 eval step buffers, sampler.py:204-206)
             env.observation_space.sample()
             env.action_space.sample()
         self.step_obs = torch.zeros((n, f, synth.OBS_H, synth.OBS_W), dtype=torch.uint8, device=dev)
@@ -117,12 +118,16 @@ class GpuVecSampler(BaseMbSampler):
             epoch=i32(1), done_count=i32(1), done_int=i32(n * t, 3), done_flt=f32(n * t, 3),
         )
         self._worker_rngs = []
+        self._eval_phases = np.zeros(n_streams * (eval_per or 0), np.int32)
         phases = np.zeros(n, np.int32)
         ring = np.zeros((n_streams, NOOP_RING), np.uint8)
         for w in range(n_streams):                       # group-major worker order
             rs = np.random.RandomState((seed + w) % 4294967294)   # initialize_worker -> set_seed
             for i in range(self.envs_per):               # envs = [EnvCls(...) ...] (worker.py:122)
                 phases[w * self.envs_per + i] = synth.draw_phase(rs)
+                synth.draw_noops(rs, env.max_start_noops)
+            for i in range(eval_per or 0):               # eval_envs = [...] (worker_with_eval.py:200)
+                self._eval_phases[w * eval_per + i] = synth.draw_phase(rs)
                 synth.draw_noops(rs, env.max_start_noops)
             if env.max_start_noops > 0:
                 ring[w] = synth.draw_noops(rs, env.max_start_noops, size=NOOP_RING)
@@ -222,12 +227,16 @@ class GpuVecSampler(BaseMbSampler):
         for s in range(t):
             prob, value = self.policy.prob_value(self.step_obs)
             _lib.env_act_step(self._game, self._state, ro, prob, value, self._uniforms[s], s,
-                              self.mid_batch_reset, self.max_path_length, self.discount)
+                              self.mid_batch_reset, self._kernel_max_path_length(), self.discount)
             _lib.env_frame_step(self._game, self._state, ro, s, env.max_start_noops)
         if self.need_extra_obs:
             buf.extra_observations.copy_(self.step_obs)        # sampler.py:147-151
         if not self.mid_batch_reset:                           # worker.py:108-113
             _lib.env_reset(self._game, self._state, ro, self._st.frozen, env.max_start_noops)
+
+    def _kernel_max_path_length(self):
+        """The kernels end an episode when Length > limit (worker.py:42)."""
+        return self.max_path_length
 
     def _capture(self):
         """Warm up on a side stream, then capture one batch into a hipGraph."""

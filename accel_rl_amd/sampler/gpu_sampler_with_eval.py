@@ -1,0 +1,106 @@
+"""GpuVecEvalSampler: the GPU sampler plus offline evaluation on separate environments.
+
+Drop-in for the reference's AAOEvalSampler
+(accel_rl/sampler/act_server/alternating/overlap/sampler_with_eval.py:6-54 and its workers,
+worker_with_eval.py:20-239): `evaluate_policy(itr)` resets `eval_envs_per` evaluation envs per
+(simulated) worker, serves `eval_steps // n_eval_envs` steps of the current policy on them without
+storing anything, and returns the completed TrajInfos.  As in the reference the evaluation envs share
+their worker's RNG stream with its training envs (construction-time phase draws, start no-ops at
+every reset -- consumed from the same device ring in launch order), the evaluation action draws come
+from the master's global numpy RNG, and the over-length rule of this sampler family is
+Length >= max_path_length (worker_with_eval.py:48,123,159) where the plain sampler has >.
+"""
+import numpy as np
+import torch
+
+from accel_rl_amd import _lib
+from accel_rl_amd.envs import synthetic_atari as synth
+from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
+from accel_rl_amd.sampler.util import TrajInfo
+from accel_rl_amd.util.misc import struct
+
+
+class GpuVecEvalSampler(GpuVecSampler):
+
+    def __init__(self, eval_steps, eval_envs_per, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.eval_envs_per = eval_envs_per
+        self._total_n_eval_envs = eval_envs_per * self.n_parallel * 2
+        self.eval_horizon = eval_steps // self._total_n_eval_envs
+
+    def _kernel_max_path_length(self):
+        return self.max_path_length - 1          # Length > L - 1  <=>  Length >= L
+
+    def initialize(self, *args, **kwargs):
+        ret = super().initialize(*args, **kwargs)
+        dev, ne, f = self.device, self._total_n_eval_envs, self.env.num_img_obs
+        n_act = self.env_spec.action_space.n
+        i32 = lambda *s: torch.zeros(s, dtype=torch.int32, device=dev)      # noqa: E731
+        u8 = lambda *s: torch.zeros(s, dtype=torch.uint8, device=dev)       # noqa: E731
+        f32 = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)    # noqa: E731
+        cap = max(1, ne * self.eval_horizon)
+        st = self._st
+        self._eval_st = struct(
+            tick=i32(ne), emu_lives=i32(ne), env_lives=i32(ne),
+            phase=torch.from_numpy(self._eval_phases).to(dev), over=u8(ne), frozen=u8(ne),
+            traj_len=i32(ne), traj_nonzero=i32(ne), traj_ret=f32(ne), traj_raw=f32(ne), traj_disc=f32(ne),
+            traj_curdisc=torch.ones(ne, dtype=torch.float64, device=dev),
+            frame_a=i32(ne), frame_b=i32(ne), frame_mode=u8(ne), reset_flag=u8(ne),
+            # the worker's RNG stream is shared with its training envs: same ring, cursors, launch epoch
+            noop_ring=st.noop_ring, noop_cursor=st.noop_cursor, epoch=st.epoch,
+            done_count=i32(1), done_int=i32(cap, 3), done_flt=f32(cap, 3))
+        s = _lib.ArlEnvState()
+        s.n_env = ne
+        for k in ("tick", "emu_lives", "env_lives", "phase", "over", "frozen", "traj_len", "traj_nonzero",
+                  "traj_ret", "traj_raw", "traj_disc", "traj_curdisc", "frame_a", "frame_b", "frame_mode",
+                  "reset_flag", "noop_ring", "noop_cursor", "epoch", "done_count", "done_int", "done_flt"):
+            setattr(s, k, self._eval_st[k].data_ptr())
+        s.noop_ring_len, s.envs_per_stream, s.done_capacity = self._state.noop_ring_len, self.eval_envs_per, cap
+        self._eval_state = s
+        self.eval_step_obs = torch.zeros((ne, f, synth.OBS_H, synth.OBS_W), dtype=torch.uint8, device=dev)
+        # nothing is stored: a one-step scratch rollout receives the per-step writes
+        self._eval_scratch = struct(
+            observations=self.eval_step_obs, rewards=f32(ne), dones=u8(ne),
+            env_infos=dict(raw_reward=f32(ne), need_reset=u8(ne)), actions=u8(ne),
+            agent_infos=dict(prob=f32(ne, n_act), value=f32(ne)))
+        ro = _lib.ArlRollout()
+        sc = self._eval_scratch
+        ro.horizon = 1
+        ro.step_obs = self.eval_step_obs.data_ptr()
+        ro.observations, ro.rewards, ro.dones = sc.observations.data_ptr(), sc.rewards.data_ptr(), sc.dones.data_ptr()
+        ro.raw_reward, ro.need_reset = sc.env_infos["raw_reward"].data_ptr(), sc.env_infos["need_reset"].data_ptr()
+        ro.actions = sc.actions.data_ptr()
+        ro.prob, ro.value = sc.agent_infos["prob"].data_ptr(), sc.agent_infos["value"].data_ptr()
+        self._eval_rollout = ro
+        self._eval_uniforms_host = torch.empty(max(1, self.eval_horizon * ne), dtype=torch.float64).pin_memory()
+        self._eval_uniforms = torch.empty((max(1, self.eval_horizon), ne), dtype=torch.float64, device=dev)
+        return ret
+
+    def evaluate_policy(self, itr):
+        """sampler_with_eval.py:20-54 + collect_eval (worker_with_eval.py:148-176)."""
+        ne, te, est, env = self._total_n_eval_envs, self.eval_horizon, self._eval_st, self.env
+        # one np.random.rand(B) per (step, group) in the reference == one flat draw here
+        self._eval_uniforms_host.copy_(torch.from_numpy(np.random.rand(te * ne)))
+        with torch.cuda.device(self.device):
+            self._eval_uniforms.view(-1).copy_(self._eval_uniforms_host, non_blocking=True)
+            for k in ("traj_len", "traj_nonzero", "traj_ret", "traj_raw", "traj_disc", "done_count"):
+                est[k].zero_()                                   # fresh TrajInfos (worker_with_eval.py:158)
+            est.traj_curdisc.fill_(1.)
+            _lib.env_reset(self._game, self._eval_state, self._eval_rollout, None, env.max_start_noops)
+            for s in range(te):
+                prob, value = self.policy.prob_value(self.eval_step_obs)
+                _lib.env_act_step(self._game, self._eval_state, self._eval_rollout, prob, value,
+                                  self._eval_uniforms[s], 0, True, self._kernel_max_path_length(), self.discount)
+                _lib.env_frame_step(self._game, self._eval_state, self._eval_rollout, 0, env.max_start_noops)
+            torch.cuda.current_stream(self.device).synchronize()
+            count = min(int(est.done_count.item()), self._eval_state.done_capacity)
+            infos = []
+            if count:
+                ints = est.done_int[:count].cpu().numpy()
+                flts = est.done_flt[:count].cpu().numpy()
+                for (env_id, length, nonzero), (ret, raw, disc) in zip(ints, flts):
+                    infos.append(TrajInfo(Length=int(length), Return=float(ret), RawReturn=float(raw),
+                                          NonzeroRewards=int(nonzero), DiscountedReturn=float(disc),
+                                          _env=int(env_id)))
+            self._refill_noop_ring(2 * self.n_parallel)
+        return infos

@@ -182,3 +182,80 @@ def test_decorrelation_runs_and_desynchronises():
     assert smp._st.traj_len.cpu().numpy().max() > 10
     buf, _ = smp.obtain_samples(0)
     assert buf.observations.shape == (64 * 5, 4, 104, 80)
+
+
+# ---- evaluation sampler + AccelRLEval ------------------------------------------
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("tag", ["breakout", "pong_nomid"])
+def test_gpu_eval_sampler_matches_reference(tag, use_graph):
+    """Training batches interleaved with evaluate_policy calls, recorded from the reference's own
+    AAOEvalSampler (G13): the evaluation trajectories and every later training array are bit-identical
+    (evaluation resets and action draws advance the shared worker / master RNG streams)."""
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.sampler.gpu_sampler_with_eval import GpuVecEvalSampler
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    g = load_golden("g13_eval_" + tag)
+    n_parallel, envs_per, horizon, n_batches, seed, mbr, maxlen, eval_steps, eval_per, eval_h = [int(x) for x in g["cfg"]]
+    env_args = dict(ast.literal_eval(str(g["env_args"])))
+    env_args["game"] = str(g["game"])
+    smp = GpuVecEvalSampler(eval_steps=eval_steps, eval_envs_per=eval_per, EnvCls=SynthAtariEnv, env_args=env_args,
+                            horizon=horizon, n_parallel=n_parallel, envs_per=envs_per, mid_batch_reset=bool(mbr),
+                            max_path_length=np.inf if maxlen < 0 else maxlen, max_decorrelation_steps=0,
+                            device=DEV, use_graph=use_graph)
+    assert smp.eval_horizon == eval_h
+    np.random.seed(seed)
+    smp.initialize(seed=seed + 1, affinities=dict(), discount=float(g["discount"]), need_extra_obs=True)
+    smp.policy_init(DeviceTablePolicy(g["prob_table"], g["value_table"]))
+    eval_at = set(int(x) for x in g["eval_batches"])
+    t, traj, eval_traj = horizon, [], []
+    row = lambda b, ti: (b, float(ti.Length), float(ti.Return), float(ti.RawReturn), float(ti.NonzeroRewards),     # noqa: E731
+                         float(ti.DiscountedReturn))
+    for b in range(n_batches):
+        if b in eval_at:
+            eval_traj += [row(b, ti) for ti in smp.evaluate_policy(b)]
+        buf, infos = smp.obtain_samples(b)
+        msg = "%s batch %d" % (tag, b)
+        np.testing.assert_array_equal(buf.actions.cpu().numpy(), g["actions"][b], err_msg=msg)
+        np.testing.assert_array_equal(buf.agent_infos["prob"].cpu().numpy(), g["prob"][b], err_msg=msg)
+        need = buf.env_infos["need_reset"].cpu().numpy().astype(bool)
+        valid = np.ones(len(need), bool)
+        if not mbr:
+            valid = P.valid_mask(g["need_reset"][b].reshape(-1, t)).reshape(-1).astype(bool)
+        np.testing.assert_array_equal(buf.rewards.cpu().numpy()[valid], g["rewards"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(buf.dones.cpu().numpy().astype(bool)[valid], g["dones"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(need[valid], g["need_reset"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(crc_rows(buf.observations)[valid], g["obs_crc"][b][valid], err_msg=msg)
+        np.testing.assert_array_equal(crc_rows(buf.extra_observations), g["extra_crc"][b], err_msg=msg)
+        traj += [row(b, ti) for ti in infos]
+    as_rows = lambda bs, rows: sorted((int(b),) + tuple(float(x) for x in r) for b, r in zip(bs, rows))     # noqa: E731
+    assert sorted(traj) == as_rows(g["traj_batch"], g["traj"])
+    assert sorted(eval_traj) == as_rows(g["eval_at"], g["eval_traj"]) and len(eval_traj) >= 10
+    smp.shutdown()
+
+
+def test_eval_runner_trains_and_logs():
+    """AccelRLEval (accel_rl/runners/accel_rl.py:108-180): evaluation every log interval, its tabular keys."""
+    from accel_rl_amd.algos.pg.ppo import PPO
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+    from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+    from accel_rl_amd.runners.accel_rl import AccelRLEval
+    from accel_rl_amd.sampler.gpu_sampler_with_eval import GpuVecEvalSampler
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    sampler = GpuVecEvalSampler(eval_steps=16 * 60, eval_envs_per=2, EnvCls=SynthAtariEnv,
+                                env_args=dict(game="breakout"), horizon=5, n_parallel=4, envs_per=4,
+                                max_path_length=30, max_decorrelation_steps=0, device=DEV)
+    algo = PPO(optimizer_args=dict(minibatch_size=64, epochs=2))
+    runner = AccelRLEval(algo=algo, policy=AtariCnnPolicy(**cnn_specs[0]), sampler=sampler, n_steps=160 * 8,
+                         seed=3, eval_interval_steps=640)
+    runner.train()
+    tab = runner.last_tabular
+    for key in ("Iteration", "CumCompletedSteps", "StepsInEval", "TrajsInEval", "LengthAverage", "ReturnAverage",
+                "GradNormAverage", "ParamsNorm", "NormFromInit", "CumTrainTime", "CumEvalTime", "CumTotalTime",
+                "SamplesPerSecond"):
+        assert key in tab, key
+    assert tab["Iteration"] == 8 and tab["TrajsInEval"] >= 16 and tab["LengthAverage"] == 30
+    assert tab["StepsInEval"] == tab["TrajsInEval"] * 30 and tab["SamplesPerSecond"] > 0
