@@ -142,3 +142,55 @@ def test_logger_tabular_and_misc_stat(tmp_path):
     text = (tmp_path / "progress.csv").read_text().splitlines()
     assert text[0].startswith("Iteration,ReturnAverage,ReturnStd")
     logger.set_output(None)
+
+
+def test_affinity_codes_match_the_reference():
+    """G10: encode / decode / build for six machine shapes, recorded from the reference's own
+    accel_rl/scripts/launching/affinities.py (tests/golden/gen_golden_affinities.py)."""
+    import json
+    import os
+    from accel_rl_amd.scripts.launching import affinities as A
+    with open(os.path.join(os.path.dirname(__file__), "golden", "g10_affinities.json")) as f:
+        cases = json.load(f)
+    norm = lambda x: json.loads(json.dumps(x))          # noqa: E731  (tuples -> lists, as stored)
+    for c in cases:
+        kw = c["kwargs"]
+        assert A.encode_affinity_params(**kw) == c["code"]
+        assert A.decode_affinity_params(c["code"]) == c["decoded"]
+        for s in c["slots"]:
+            assert norm(A.get_affinities(s["code"])) == s["affinities"], s["code"]
+        assert norm(A.build_all_affinities(**kw)) == c["all"]
+    with pytest.raises(ValueError):
+        A.decode_affinity_params("8gpu_3xyz")
+
+
+def test_logger_context_files_and_snapshots(tmp_path, monkeypatch):
+    """accel_rl/util/logging.py:24-49 + rllab snapshot modes: progress.csv, debug.log, params.json,
+    itr_N.pkl under <log_dir>/<name>_<run_ID>/; a snapshot restores the parameter vector."""
+    import json
+    import os
+    from accel_rl_amd.util import logger
+    from accel_rl_amd.util import logging as arl_logging
+    monkeypatch.setattr(arl_logging, "LOG_DIR", str(tmp_path))
+    logger.set_quiet(True)
+    with arl_logging.logger_context(str(tmp_path / "exp"), "ppo", 7, dict(game="pong"), snapshot_mode="gap") as exp_dir:
+        logger.set_snapshot_gap(2)
+        for itr in range(5):
+            logger.log("hello %d" % itr)
+            logger.record_tabular("Iteration", itr)
+            logger.record_tabular_misc_stat("Return", [itr, itr + 1.])
+            logger.dump_tabular()
+            logger.save_itr_params(itr, dict(itr=itr, cum_samples=itr * 1280,
+                                             policy_param_values=np.arange(4, dtype=np.float32) + itr))
+    assert exp_dir == str(tmp_path / "exp" / "ppo_7")
+    assert json.load(open(os.path.join(exp_dir, "params.json"))) == dict(game="pong", name="ppo", run_ID=7)
+    rows = open(os.path.join(exp_dir, "progress.csv")).read().strip().split("\n")
+    assert rows[0].startswith("Iteration,ReturnAverage,ReturnStd") and len(rows) == 6
+    text = open(os.path.join(exp_dir, "debug.log")).read()
+    assert "ppo_7 hello 3" in text and "ReturnAverage" in text
+    assert sorted(f for f in os.listdir(exp_dir) if f.endswith(".pkl")) == ["itr_0.pkl", "itr_2.pkl", "itr_4.pkl"]
+    snap = logger.load_itr_params(os.path.join(exp_dir, "itr_4.pkl"))
+    assert snap["itr"] == 4 and snap["cum_samples"] == 5120
+    np.testing.assert_array_equal(snap["policy_param_values"], np.arange(4, dtype=np.float32) + 4)
+    logger.set_snapshot_mode("none")
+    logger.set_snapshot_dir(None)

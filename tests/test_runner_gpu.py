@@ -59,3 +59,29 @@ def test_seeded_runs_are_reproducible():
         runner.train()
         out.append(policy.get_param_values())
     np.testing.assert_array_equal(out[0], out[1])       # deterministic kernels + seeded RNG streams
+
+
+def test_snapshot_resume_restores_the_policy(tmp_path, monkeypatch):
+    """itr_N.pkl content (accel_rl_base.py:108-113) and resuming from it through the
+    policy's `initial_param_values`, as a reference script would."""
+    import os
+    from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+    from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+    from accel_rl_amd.util import logger
+    from accel_rl_amd.util import logging as arl_logging
+    monkeypatch.setattr(arl_logging, "LOG_DIR", str(tmp_path))
+    runner, sampler, algo, policy = _build("ppo", 160 * 4, max_path_length=30)
+    with arl_logging.logger_context(str(tmp_path / "run"), "ppo_breakout", 0, snapshot_mode="last") as exp_dir:
+        runner.train()
+    logger.set_snapshot_mode("none")
+    logger.set_snapshot_dir(None)
+    snap = logger.load_itr_params(os.path.join(exp_dir, "params.pkl"))
+    assert set(snap) == {"itr", "cum_samples", "policy_param_values"} and snap["cum_samples"] == snap["itr"] * 160
+    resumed = AtariCnnPolicy(initial_param_values=snap["policy_param_values"], **cnn_specs[0])
+    resumed.initialize(sampler.env_spec, device="cuda:0")
+    np.testing.assert_array_equal(resumed.get_param_values(), snap["policy_param_values"])
+    obs = sampler.samples_buf.observations[:32]
+    p0, v0 = policy.prob_value(obs)
+    if snap["itr"] == runner._n_itr - 1:            # the last snapshot is the final policy
+        p1, v1 = resumed.prob_value(obs)
+        assert torch.equal(p0, p1) and torch.equal(v0, v1)
