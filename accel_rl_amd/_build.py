@@ -25,9 +25,22 @@ def _stale():
 
 
 def build_extension(force=False, verbose=False):
-    """Compile every HIP source for gfx950 into one shared library."""
+    """Compile every HIP source for gfx950 into one shared library.  Serialised by a file lock:
+    under torch.distributed.run every rank calls this at start-up."""
     if not force and not _stale():
         return LIB_PATH
+    import fcntl
+    with open(os.path.join(PKG_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():          # another rank built it while we waited
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libaccel_rl_hip.so")
@@ -49,10 +62,12 @@ def build_extension(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()        # link aside, then rename: readers never see a partial file
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if out.returncode != 0:
         raise RuntimeError("link failed:\n%s" % out.stdout.decode(errors="replace"))
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 
