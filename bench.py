@@ -39,7 +39,8 @@ N_ENVS, HORIZON, GAME, CNN_SPEC = 256, 5, "breakout", 1
 GAMES_8 = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_rider", "enduro", "ms_pacman"]
 
 
-def build_workload(device, seed, rank, world, game, use_graph, quiet=True):
+def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind="ppo"):
+    from accel_rl_amd.algos.pg.a2c import A2C, mA2C
     from accel_rl_amd.algos.pg.ppo import PPO, mPPO
     from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
     from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
@@ -54,13 +55,18 @@ def build_workload(device, seed, rank, world, game, use_graph, quiet=True):
                             mid_batch_reset=True, max_decorrelation_steps=2000, device=device,
                             use_graph=use_graph)
     policy = AtariCnnPolicy(**cnn_specs[CNN_SPEC])
-    if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
+    multi = world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1"
+    if kind == "a2c":
+        algo = (mA2C if multi else A2C)(discount=0.99, gae_lambda=1)
+    elif multi:
         algo = mPPO(discount=0.99, gae_lambda=0.95)
+    else:
+        algo = PPO(discount=0.99, gae_lambda=0.95)
+    if multi:
         algo.optimizer._force_collective = True
         runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
                              affinities=dict(gpu=device.index), log_interval_steps=1e8)
     else:
-        algo = PPO(discount=0.99, gae_lambda=0.95)
         runner = AccelRL(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
                          affinities=dict(gpu=device.index), log_interval_steps=1e8)
     runner.startup()
@@ -290,8 +296,15 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the GAE-scan roofline leg (used for the rocprofv3 --pmc passes)")
     ap.add_argument("--suite", action="store_true", help="BASELINE config 4: one game per rank")
+    ap.add_argument("--workload", choices=["ppo256", "a2c1024"], default="ppo256",
+                    help="ppo256 = BASELINE config 2 (the metric's config, default); a2c1024 = config 3 "
+                         "(A2C, 1024 envs, 5-step returns, spec-0 CNN, one rmsprop step per batch)")
     args = ap.parse_args()
 
+    global N_ENVS, CNN_SPEC
+    if args.workload == "a2c1024":
+        N_ENVS, CNN_SPEC = 1024, 0
+        args.no_cpu_baseline = args.no_roofline = True
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -317,7 +330,8 @@ def main():
         return
 
     game = GAMES_8[rank % 8] if args.suite else GAME
-    runner, sampler, algo, policy = build_workload(device, 0, rank, world, game, not args.no_graph)
+    runner, sampler, algo, policy = build_workload(device, 0, rank, world, game, not args.no_graph,
+                                                   kind="a2c" if args.workload == "a2c1024" else "ppo")
 
     def barrier():
         torch.cuda.synchronize()
@@ -343,15 +357,18 @@ def main():
 
     steps_per_gpu = args.steps * N_ENVS * HORIZON
     line = {
-        "metric": "env-steps/sec (whole node), 256-env PPO Atari",
+        "metric": "env-steps/sec (whole node), 256-env PPO Atari" if args.workload == "ppo256"
+                  else "env-steps/sec (whole node), 1024-env A2C Atari (BASELINE config 3, not the headline metric)",
         "value": round(world * steps_per_gpu / elapsed, 1),
         "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "PPO %s, %d envs/GPU, horizon %d, spec-%d CNN (fp32), minibatch 512 x 4 epochs, "
-                               "adam; synthetic fixed-frame emulator; %s" %
+        "config": {"workload": ("A2C %s, %d envs/GPU, horizon %d (5-step returns), spec-%d CNN (fp32), one "
+                                "rmsprop step per batch; synthetic fixed-frame emulator; %s" if args.workload == "a2c1024"
+                                else "PPO %s, %d envs/GPU, horizon %d, spec-%d CNN (fp32), minibatch 512 x 4 epochs, "
+                                "adam; synthetic fixed-frame emulator; %s") %
                                ("8-game suite" if args.suite else GAME, N_ENVS, HORIZON, CNN_SPEC,
                                 "hipGraph rollout" if not args.no_graph else "eager"),
                    "env_steps_per_step_per_gpu": N_ENVS * HORIZON,
