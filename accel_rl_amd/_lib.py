@@ -99,6 +99,8 @@ _SIGNATURES = {
     "arl_sumtree_find": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "arl_sumtree_add": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp]),
     "arl_sumtree_gather": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
+    "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -411,3 +413,24 @@ def sumtree_gather(tree, idxs, out, scale=1.0, stream=None):
     _want(out, torch.float64, "out")
     _check(load().arl_sumtree_gather(ptr(tree), ptr(idxs), idxs.numel(), float(scale), ptr(out),
                                      stream_ptr(stream)), "arl_sumtree_gather")
+
+
+# ---------------------------------------------------------------------------
+# categorical DQN output stage (csrc/dqn.hip)
+# ---------------------------------------------------------------------------
+
+def catdqn_act(logits, z, override, n_actions, n_atoms, onehot, greedy=None, stream=None):
+    batch = onehot.shape[0]
+    stride = logits.numel() // (batch * n_actions)
+    _check(load().arl_catdqn_act(ptr(logits), ptr(z), ptr(override), batch, n_actions, n_atoms, stride,
+                                 ptr(onehot), ptr(greedy), stream_ptr(stream)), "arl_catdqn_act")
+
+
+def catdqn_loss(pred_logits, tgt_next_logits, pol_next_logits, z, actions, returns, terminals, is_weights,
+                n_actions, n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl, stream=None):
+    batch = actions.numel()
+    stride = pred_logits.numel() // (batch * n_actions)
+    _check(load().arl_catdqn_loss(ptr(pred_logits), ptr(tgt_next_logits), ptr(pol_next_logits), ptr(z),
+                                  ptr(actions), ptr(returns), ptr(terminals), ptr(is_weights), batch, n_actions,
+                                  n_atoms, stride, float(v_min), float(v_max), float(gamma_n), ptr(dlogits),
+                                  ptr(loss_rows), ptr(kl), stream_ptr(stream)), "arl_catdqn_loss")

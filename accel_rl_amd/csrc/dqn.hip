@@ -1,0 +1,175 @@
+// Categorical DQN ("C51") output stage for gfx950: everything after the network's last dense
+// layer, which the reference expresses as Theano graph nodes.
+//
+//   arl_catdqn_act    per-action softmax over atoms, Q = sum_i p_i z_i, greedy action (first
+//                     maximum, as T.argmax), epsilon-greedy override, served as a one-hot row so
+//                     that the sampler's categorical kernel picks exactly that action
+//                     (policies/dqn/atari_cat_dqn_policy.py:84-126, catdqn_cnn.py:94-99)
+//   arl_catdqn_loss   distributional Bellman target projected on the fixed support, cross-entropy
+//                     loss, KL priorities, and d loss / d logits in one pass
+//                     (algos/dqn/cat_dqn.py:40-109)
+//
+// Layout: logits f32[batch][n_actions][atom_stride], atom_stride = n_atoms rounded up to a
+// multiple of 4 (the dense layer producing them is an MFMA kernel with 16-byte rows); the padding
+// columns are ignored on input and receive zero gradient.  One wave per sample; lane i owns atom i
+// (n_atoms <= 64).  fp32, compiled with -ffp-contract=off.
+
+#include "arl_common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+    return x;
+}
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// softmax over the atoms of one action; lane i returns p_i (0 for i >= n_atoms)
+__device__ __forceinline__ float atom_softmax(const float* row, int lane, int n_atoms) {
+    const float x = lane < n_atoms ? row[lane] : -3.0e38f;
+    const float m = wave_max(x);
+    const float e = lane < n_atoms ? expf(x - m) : 0.f;
+    return e / wave_sum(e);
+}
+
+// greedy action of one sample under `logits`: argmax_a sum_i softmax(logits[a])_i z_i, first maximum
+__device__ __forceinline__ int greedy_action(const float* logits, int lane, int n_actions, int n_atoms,
+                                             int stride, float z_lane) {
+    int best = 0;
+    float best_q = -3.0e38f;
+    for (int a = 0; a < n_actions; ++a) {
+        const float q = wave_sum(atom_softmax(logits + a * stride, lane, n_atoms) * z_lane);
+        if (q > best_q) { best_q = q; best = a; }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void catdqn_act_kernel(const float* __restrict__ logits,
+                                                         const float* __restrict__ z,
+                                                         const int32_t* __restrict__ override_or_null,
+                                                         int64_t batch, int n_actions, int n_atoms, int stride,
+                                                         float* __restrict__ onehot, uint8_t* __restrict__ greedy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= batch) return;
+    const float z_lane = lane < n_atoms ? z[lane] : 0.f;
+    const int g = greedy_action(logits + b * n_actions * stride, lane, n_actions, n_atoms, stride, z_lane);
+    int act = g;
+    if (override_or_null && override_or_null[b] >= 0) act = override_or_null[b];
+    if (lane < n_actions) onehot[b * n_actions + lane] = lane == act ? 1.f : 0.f;
+    if (lane == 0 && greedy) greedy[b] = (uint8_t)g;
+}
+
+struct CatLossArgs {
+    const float* pred_logits;       // policy net on obs              [B][A][S]
+    const float* tgt_next_logits;   // target net on next_obs         [B][A][S]
+    const float* pol_next_logits;   // policy net on next_obs (double DQN) or null
+    const float* z;                 // [n_atoms] support
+    const uint8_t* actions;         // [B]
+    const float* returns;           // [B] n-step discounted return
+    const uint8_t* terminals;       // [B]
+    const float* is_weights;        // [B] or null
+    float* dlogits;                 // [B][A][S]
+    float* loss_rows;               // [B] per-sample (weighted) loss / B
+    float* kl;                      // [B] priorities
+    int64_t batch;
+    int n_actions, n_atoms, stride;
+    float v_min, v_max, gamma_n;    // gamma_n = discount ** reward_horizon (rounded to f32 on the host)
+};
+
+__global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
+    __shared__ float s_next[4][64], s_znext[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= a.batch) return;
+    const int A = a.n_actions, n = a.n_atoms, S = a.stride;
+    const float z_lane = lane < n ? a.z[lane] : 0.f;
+    const float* tgt = a.tgt_next_logits + b * A * S;
+    // greedy next action: under the policy net (double DQN) or the target net (cat_dqn.py:77-81)
+    const int a_next = greedy_action(a.pol_next_logits ? a.pol_next_logits + b * A * S : tgt, lane, A, n, S, z_lane);
+    const float next_p = atom_softmax(tgt + a_next * S, lane, n);
+    // shifted support, clipped to [v_min, v_max] (:56-62)
+    const float keep = a.terminals[b] ? 0.f : 1.f;
+    float zn = a.returns[b] + keep * (a.gamma_n * z_lane);
+    zn = fminf(fmaxf(zn, a.v_min), a.v_max);
+    s_next[wave][lane] = next_p;        // wave-private LDS rows: in-order LDS access of one wave needs no barrier
+    s_znext[wave][lane] = zn;
+    __builtin_amdgcn_wave_barrier();
+    // projection on the base support (:63-70,88-90): proj_i = sum_j next_p_j clip(1 - |zn_j - z_i| / dz, 0, 1)
+    const float dz = (a.v_max - a.v_min) / (float)(n - 1);
+    float proj = 0.f;
+    if (lane < n)
+        for (int j = 0; j < n; ++j) {
+            const float c = 1.f - fabsf(s_znext[wave][j] - z_lane) / dz;
+            proj += s_next[wave][j] * fminf(fmaxf(c, 0.f), 1.f);
+        }
+    // prediction, cross-entropy with NaN guard (:92-94)
+    const int act = a.actions[b];
+    const float pred = atom_softmax(a.pred_logits + (b * A + act) * S, lane, n);
+    const float pc = fminf(fmaxf(pred, 1e-6f), 1.f);
+    const float w = (a.is_weights ? a.is_weights[b] : 1.f) / (float)a.batch;
+    const float ce = lane < n ? -(proj * logf(pc)) : 0.f;
+    const float loss_b = wave_sum(ce);
+    // KL priority (:100-105)
+    const float pj = fminf(fmaxf(proj, 1e-6f), 1.f);
+    const float kl_b = wave_sum(lane < n ? pj * logf(pj / pc) : 0.f);
+    // gradient: d loss / d pred_i = -w proj_i / pred_i inside the clip range, then softmax backward
+    const float g = (lane < n && pred >= 1e-6f && pred <= 1.f) ? -w * proj / pred : 0.f;
+    const float dot = wave_sum(g * pred);
+    float* dl = a.dlogits + b * A * S;
+    for (int q = lane; q < A * S; q += 64) {                           // every other action (and the padding) gets 0
+        const int qa = q / S, qi = q - qa * S;
+        if (qa != act || qi >= n) dl[q] = 0.f;
+    }
+    if (lane < n) dl[act * S + lane] = pred * (g - dot);
+    if (lane == 0) {
+        a.loss_rows[b] = w * loss_b;
+        a.kl[b] = fminf(fmaxf(kl_b, 1e-6f), 1e6f);
+    }
+}
+
+}  // namespace
+
+static int check_cat(int64_t batch, int n_actions, int n_atoms, int stride) {
+    if (batch <= 0 || n_actions <= 0 || n_actions > 64 || n_atoms < 2 || n_atoms > 64 || stride < n_atoms || (stride & 3)) {
+        arl::set_error("catdqn: need batch > 0, 1 <= n_actions <= 64, 2 <= n_atoms <= 64, atom_stride >= n_atoms and %% 4 == 0");
+        return ARL_E_RANGE;
+    }
+    return 0;
+}
+
+extern "C" int arl_catdqn_act(const float* logits, const float* z, const int32_t* override_or_null, int64_t batch,
+                              int32_t n_actions, int32_t n_atoms, int32_t atom_stride, float* onehot,
+                              uint8_t* greedy_or_null, void* stream) {
+    ARL_REQUIRE(logits && z && onehot, ARL_E_ARG, "null pointer");
+    int rc = check_cat(batch, n_actions, n_atoms, atom_stride);
+    if (rc) return rc;
+    hipLaunchKernelGGL(catdqn_act_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       logits, z, override_or_null, batch, n_actions, n_atoms, atom_stride, onehot, greedy_or_null);
+    return arl::check_launch("catdqn_act_kernel");
+}
+
+extern "C" int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_logits, const float* pol_next_logits_or_null,
+                               const float* z, const uint8_t* actions, const float* returns, const uint8_t* terminals,
+                               const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t n_atoms,
+                               int32_t atom_stride, float v_min, float v_max, float gamma_n, float* dlogits,
+                               float* loss_rows, float* kl, void* stream) {
+    ARL_REQUIRE(pred_logits && tgt_next_logits && z && actions && returns && terminals && dlogits && loss_rows && kl,
+                ARL_E_ARG, "null pointer");
+    int rc = check_cat(batch, n_actions, n_atoms, atom_stride);
+    if (rc) return rc;
+    ARL_REQUIRE(v_max > v_min, ARL_E_ARG, "v_max must exceed v_min");
+    CatLossArgs a = {};
+    a.pred_logits = pred_logits; a.tgt_next_logits = tgt_next_logits; a.pol_next_logits = pol_next_logits_or_null;
+    a.z = z; a.actions = actions; a.returns = returns; a.terminals = terminals; a.is_weights = is_weights_or_null;
+    a.dlogits = dlogits; a.loss_rows = loss_rows; a.kl = kl; a.batch = batch;
+    a.n_actions = n_actions; a.n_atoms = n_atoms; a.stride = atom_stride;
+    a.v_min = v_min; a.v_max = v_max; a.gamma_n = gamma_n;
+    hipLaunchKernelGGL(catdqn_loss_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return arl::check_launch("catdqn_loss_kernel");
+}

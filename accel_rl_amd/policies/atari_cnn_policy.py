@@ -104,12 +104,12 @@ class AtariCnnPolicy(object):
             ref += [_norm_c((fan, hs), 1.0), np.zeros(hs, np.float32)]
             self._hid_geom.append((hs, fan))
             fan = hs
-        ref += [_norm_c((fan, n_act), 0.01), np.zeros(n_act, np.float32)]
-        ref += [_norm_c((fan, 1), 1.0), np.zeros(1, np.float32)]
+        head_ref, head_names = self._head_reference_init(fan, n_act)
+        ref += head_ref
         self._ref_shapes = [a.shape for a in ref]
         self.param_short_names = (["Conv%d%s" % (i, s) for i in range(len(self._conv_geom)) for s in "Wb"] +
                                   ["FC%d%s" % (i, s) for i in range(len(self._hid_geom)) for s in "Wb"] +
-                                  ["OutputW", "Outputb", "OutputW", "Outputb"])
+                                  head_names)
         self.n_params = int(sum(a.size for a in ref))
         # ---- internal bucket: [conv W, b]... [hidden W, b]... W_head, b_head
         shapes = []
@@ -117,7 +117,7 @@ class AtariCnnPolicy(object):
             shapes += [(nf, sz, sz, ci), (nf,)]
         for hs, fan_in in self._hid_geom:
             shapes += [(hs, fan_in), (hs,)]
-        shapes += [(n_act + 1, fan), (n_act + 1,)]
+        shapes += self._head_internal_shapes(fan, n_act)
         self._shapes = shapes
         sizes = [int(np.prod(s)) for s in shapes]
         self._offsets, off = [], 0
@@ -152,6 +152,22 @@ class AtariCnnPolicy(object):
         if self.initial_param_values is not None:
             self.set_param_values(self.initial_param_values)
 
+    # ---- output layers: policy + value heads fused in one matrix W_head[(A+1), hid]
+    #      (pg_cnn.py:70-86); subclasses with other output layers override these four
+    def _head_reference_init(self, fan, n_act):
+        return ([_norm_c((fan, n_act), 0.01), np.zeros(n_act, np.float32),
+                 _norm_c((fan, 1), 1.0), np.zeros(1, np.float32)], ["OutputW", "Outputb", "OutputW", "Outputb"])
+
+    def _head_internal_shapes(self, fan, n_act):
+        return [(n_act + 1, fan), (n_act + 1,)]
+
+    def _head_to_reference(self, wh, bh):
+        a = self.n_act
+        return [wh[:a].T, bh[:a], wh[a:].T, bh[a:]]
+
+    def _head_to_internal(self, ref_tail):
+        return [np.concatenate([ref_tail[0].T, ref_tail[2].T], axis=0), np.concatenate([ref_tail[1], ref_tail[3]])]
+
     # -------------------------------------------------------------- forward
     def _buffer(self, key, shape, channels_last=False):
         """Static scratch tensor (re-used across calls; fresh inside a graph capture)."""
@@ -165,18 +181,18 @@ class AtariCnnPolicy(object):
                 self._scratch[key] = buf
         return buf
 
-    def _scaled(self, obs_u8, idx=None):
+    def _scaled(self, obs_u8, idx=None, tag=""):
         """u8 [n,C,H,W] (rows optionally gathered by idx) -> f32 * (1/pixel_scale),
         logical [B,C,H,W] in channels-last memory."""
         b = obs_u8.shape[0] if idx is None else idx.shape[0]
         c, h, w = self._obs_shape
         if c == 4:
-            out = self._buffer(("x", b), (b, c, h, w), channels_last=True)
+            out = self._buffer(("x" + tag, b), (b, c, h, w), channels_last=True)
             _lib.gather_scale_obs_nhwc(obs_u8, idx, out, self._scale)
             return out
-        tmp = self._buffer(("x_nchw", b), (b, c, h, w))
+        tmp = self._buffer(("x_nchw" + tag, b), (b, c, h, w))
         _lib.gather_scale_obs(obs_u8, idx, tmp, self._scale)
-        out = self._buffer(("x", b), (b, self._c_pad, h, w), channels_last=True)
+        out = self._buffer(("x" + tag, b), (b, self._c_pad, h, w), channels_last=True)
         if self._c_pad != c:
             out.zero_()
         out[:, :c].copy_(tmp)
@@ -195,21 +211,24 @@ class AtariCnnPolicy(object):
             gs = self._geoms[b] = (conv, dense)
         return gs
 
-    def _trunk(self, x):
+    def _trunk(self, x, w=None, tag=""):
         """Explicit conv/dense stack (no autograd) on NHWC memory.  Returns (conv activations
-        [B,Ho,Wo,K], hidden activations [B,units]); every activation is post bias+relu."""
+        [B,Ho,Wo,K], hidden activations [B,units]); every activation is post bias+relu.
+        `w`: the layers' (W, b) views to use (default: the trainable ones); `tag` keeps the scratch
+        activations of a second forward (e.g. a target network) apart."""
         b = x.shape[0]
+        w = self._w if w is None else w
         conv_g, dense_g = self._layer_geoms(b)
         acts, a = [], x
         for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
-            z = self._buffer(("act", i, b), (b, ho, wo, nf))
-            _lib.conv2d_fwd(a, self._w[2 * i], self._w[2 * i + 1], z, conv_g[i], True, self._conv_ws)
+            z = self._buffer(("act" + tag, i, b), (b, ho, wo, nf))
+            _lib.conv2d_fwd(a, w[2 * i], w[2 * i + 1], z, conv_g[i], True, self._conv_ws)
             acts.append(z)
             a = z
         hids, k = [], 2 * self._n_conv
         for j, (hs, fan_in) in enumerate(self._hid_geom):
-            hcur = self._buffer(("hid", j, b), (b, hs))
-            _lib.conv2d_fwd(a, self._w[k], self._w[k + 1], hcur, dense_g[j], True, self._conv_ws)
+            hcur = self._buffer(("hid" + tag, j, b), (b, hs))
+            _lib.conv2d_fwd(a, w[k], w[k + 1], hcur, dense_g[j], True, self._conv_ws)
             hids.append(hcur)
             a = hcur
             k += 2
@@ -264,31 +283,38 @@ class AtariCnnPolicy(object):
                               mb["advantages"], mb["returns"], mb.get("old_prob"), mb.get("valids"),
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
                               ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws)
-            conv_g, dense_g = self._layer_geoms(b)
-            w, ws = self._w, self._conv_ws
-            # ---- dense layers, last to first
-            d_cur = dh
-            for j in range(self._n_hid - 1, -1, -1):
-                k = 2 * (self._n_conv + j)
-                hs, fan_in = self._hid_geom[j]
-                _lib.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._relu_ws)
-                inp = hids[j - 1] if j > 0 else acts[-1]
-                _lib.conv2d_bwd_weight(d_cur, inp, self._g[k], dense_g[j], ws)
-                d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
-                _lib.conv2d_bwd_data(d_cur, w[k], None, d_prev, dense_g[j])
-                d_cur = d_prev
-            # ---- conv layers, last to first (d_cur is already the NHWC gradient of the last conv output)
-            d_act = d_cur
-            for i in range(self._n_conv - 1, -1, -1):
-                nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
-                _lib.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._relu_ws)
-                inp = acts[i - 1] if i > 0 else x
-                _lib.conv2d_bwd_weight(d_act, inp, self._g[2 * i], conv_g[i], ws)
-                if i > 0:
-                    d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape))
-                    _lib.conv2d_bwd_data(d_act, w[2 * i], None, d_in, conv_g[i])
-                    d_act = d_in
+            self._backward_trunk(x, acts, hids, dh)
             return loss4
+
+    def _backward_trunk(self, x, acts, hids, dh):
+        """Gradients of every trunk layer into flat_grads, given dh = d loss / d (last hidden
+        activation, before its relu mask).  x, acts, hids as returned by _scaled / _trunk."""
+        b = x.shape[0]
+        g = self.grads
+        conv_g, dense_g = self._layer_geoms(b)
+        w, ws = self._w, self._conv_ws
+        # ---- dense layers, last to first
+        d_cur = dh
+        for j in range(self._n_hid - 1, -1, -1):
+            k = 2 * (self._n_conv + j)
+            hs, fan_in = self._hid_geom[j]
+            _lib.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._relu_ws)
+            inp = hids[j - 1] if j > 0 else acts[-1]
+            _lib.conv2d_bwd_weight(d_cur, inp, self._g[k], dense_g[j], ws)
+            d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
+            _lib.conv2d_bwd_data(d_cur, w[k], None, d_prev, dense_g[j])
+            d_cur = d_prev
+        # ---- conv layers, last to first (d_cur is already the NHWC gradient of the last conv output)
+        d_act = d_cur
+        for i in range(self._n_conv - 1, -1, -1):
+            nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
+            _lib.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._relu_ws)
+            inp = acts[i - 1] if i > 0 else x
+            _lib.conv2d_bwd_weight(d_act, inp, self._g[2 * i], conv_g[i], ws)
+            if i > 0:
+                d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape))
+                _lib.conv2d_bwd_data(d_act, w[2 * i], None, d_in, conv_g[i])
+                d_act = d_in
 
     def dist_info_value_sym(self, obs_u8, idx=None):
         """Training-time forward through autograd (explicit=False path)."""
@@ -358,8 +384,7 @@ class AtariCnnPolicy(object):
                 w = w.T
             out += [w, arr[k + 1]]
             k += 2
-        wh, bh, a = arr[k], arr[k + 1], self.n_act
-        out += [wh[:a].T, bh[:a], wh[a:].T, bh[a:]]
+        out += self._head_to_reference(arr[k], arr[k + 1])
         return np.concatenate([np.ascontiguousarray(x).reshape(-1) for x in out]).astype(np.float32)
 
     def _set_from_reference_arrays(self, ref):
@@ -380,8 +405,7 @@ class AtariCnnPolicy(object):
                 w = w.T
             internal += [w, ref[k + 1]]
             k += 2
-        internal += [np.concatenate([ref[k].T, ref[k + 2].T], axis=0),
-                     np.concatenate([ref[k + 1], ref[k + 3]])]
+        internal += self._head_to_internal(ref[k:])
         for o, s, a in zip(self._offsets, self._shapes, internal):
             assert tuple(a.shape) == tuple(s), (a.shape, s)
             host[o:o + a.size] = np.ascontiguousarray(a).reshape(-1)

@@ -183,8 +183,10 @@ class GpuVecSampler(BaseMbSampler):
     def obtain_samples(self, itr):
         """reference: sampler.py:97-104 (+ serve_actions :120-151)"""
         n, t = self._total_n_envs, self.horizon
-        # one np.random.rand(B) per (step, group) in the reference == one flat draw here
-        self._uniforms_host.copy_(torch.from_numpy(np.random.rand(t * n)))
+        # one np.random.rand(B) per (step, group) in the reference == one flat draw here; a policy
+        # with its own action randomness (epsilon-greedy) makes the reference's draws itself
+        draws = self.policy.host_draws(t, n) if hasattr(self.policy, "host_draws") else np.random.rand(t * n)
+        self._uniforms_host.copy_(torch.from_numpy(draws))
         with torch.cuda.device(self.device):
             if self.use_graph:
                 if self._graph is None:
@@ -225,6 +227,8 @@ class GpuVecSampler(BaseMbSampler):
         obs = buf.observations.view(n, t, *buf.observations.shape[1:])
         obs[:, 0].copy_(self.step_obs)                         # worker.py:30-32
         for s in range(t):
+            if hasattr(self.policy, "set_step"):
+                self.policy.set_step(s)
             prob, value = self.policy.prob_value(self.step_obs)
             _lib.env_act_step(self._game, self._state, ro, prob, value, self._uniforms[s], s,
                               self.mid_batch_reset, self._kernel_max_path_length(), self.discount)

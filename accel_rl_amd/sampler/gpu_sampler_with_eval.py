@@ -80,7 +80,8 @@ class GpuVecEvalSampler(GpuVecSampler):
         """sampler_with_eval.py:20-54 + collect_eval (worker_with_eval.py:148-176)."""
         ne, te, est, env = self._total_n_eval_envs, self.eval_horizon, self._eval_st, self.env
         # one np.random.rand(B) per (step, group) in the reference == one flat draw here
-        self._eval_uniforms_host.copy_(torch.from_numpy(np.random.rand(te * ne)))
+        draws = self.policy.host_draws(te, ne) if hasattr(self.policy, "host_draws") else np.random.rand(te * ne)
+        self._eval_uniforms_host.copy_(torch.from_numpy(draws))
         with torch.cuda.device(self.device):
             self._eval_uniforms.view(-1).copy_(self._eval_uniforms_host, non_blocking=True)
             for k in ("traj_len", "traj_nonzero", "traj_ret", "traj_raw", "traj_disc", "done_count"):
@@ -88,6 +89,8 @@ class GpuVecEvalSampler(GpuVecSampler):
             est.traj_curdisc.fill_(1.)
             _lib.env_reset(self._game, self._eval_state, self._eval_rollout, None, env.max_start_noops)
             for s in range(te):
+                if hasattr(self.policy, "set_step"):
+                    self.policy.set_step(s)
                 prob, value = self.policy.prob_value(self.eval_step_obs)
                 _lib.env_act_step(self._game, self._eval_state, self._eval_rollout, prob, value,
                                   self._eval_uniforms[s], 0, True, self._kernel_max_path_length(), self.discount)

@@ -373,6 +373,34 @@ int arl_sumtree_add(double* tree, int32_t levels, const int32_t* tree_idxs, cons
 int arl_sumtree_gather(const double* tree, const int32_t* tree_idxs, int64_t n, double scale,
                        double* out, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Categorical DQN output stage
+ * ------------------------------------------------------------------------- */
+
+/* Action serving: per-action softmax over atoms, Q_a = sum_i p_ai z_i, greedy action = first
+ * maximum; where override[b] >= 0 that action is taken instead (the epsilon-greedy draw, made
+ * on the host RNG as the reference does).  The chosen action is written as a one-hot row so the
+ * sampler's categorical kernel selects exactly it.  Replaces AtariCatDqnPolicy.get_actions /
+ * actions_sym, accel_rl/policies/dqn/atari_cat_dqn_policy.py:84-126 (+ catdqn_cnn.py:94-99).
+ *   logits f32[batch][n_actions][atom_stride], atom_stride % 4 == 0 >= n_atoms <= 64;
+ *   z f32[n_atoms]; onehot f32[batch][n_actions]; greedy u8[batch] or NULL            */
+int arl_catdqn_act(const float* logits, const float* z, const int32_t* override_or_null, int64_t batch,
+                   int32_t n_actions, int32_t n_atoms, int32_t atom_stride, float* onehot,
+                   uint8_t* greedy_or_null, void* stream);
+
+/* Loss of CategoricalDQN.build_loss, accel_rl/algos/dqn/cat_dqn.py:40-109: next action greedy
+ * under the target net (or the policy net: double DQN), its atom probabilities under the target
+ * net projected from the support shifted by the n-step return (clipped to [v_min, v_max], zeroed
+ * gamma^n z where terminal) onto the base support; cross-entropy against clip(pred, 1e-6, 1),
+ * importance-weighted mean; priorities = clip(KL, 1e-6, 1e6).
+ *   out: dlogits f32[batch][n_actions][atom_stride] (d mean-loss / d pred_logits),
+ *        loss_rows f32[batch] (their sum is the loss), kl f32[batch]                       */
+int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_logits, const float* pol_next_logits_or_null,
+                    const float* z, const uint8_t* actions, const float* returns, const uint8_t* terminals,
+                    const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t n_atoms,
+                    int32_t atom_stride, float v_min, float v_max, float gamma_n, float* dlogits,
+                    float* loss_rows, float* kl, void* stream);
+
 /* Optimiser state for ONE flat fp32 parameter bucket (all trainable params in
  * get_params order, accel_rl/optimizers/util.py:35-39). */
 typedef struct arl_opt_state {
