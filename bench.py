@@ -284,6 +284,56 @@ def cpu_baseline(device, policy, smp, seconds=10.0):
                        (batches, dt, 2 * n_par, n_par, half // n_par, b1, logical))
 
 
+def catdqn_main(args):
+    """BASELINE config 5 (not the headline metric): Categorical DQN "seaquest", 1M-transition device replay
+    (prioritized), 256 envs x horizon 4, spec-1 trunk, reward horizon 3, training intensity 8."""
+    from accel_rl_amd.algos.dqn.cat_dqn import CategoricalDQN
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+    from accel_rl_amd.policies.dqn.atari_cat_dqn_policy import AtariCatDqnPolicy
+    from accel_rl_amd.runners.accel_rl import AccelRLEval
+    from accel_rl_amd.sampler.gpu_sampler_with_eval import GpuVecEvalSampler
+    from accel_rl_amd.util import logger
+    import __graft_entry__
+    __graft_entry__.build()
+    logger.set_quiet(True)
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(device)
+    n_env, horizon = 256, 4
+    sampler = GpuVecEvalSampler(eval_steps=12800, eval_envs_per=1, EnvCls=SynthAtariEnv, env_args=dict(game="seaquest"),
+                                horizon=horizon, n_parallel=16, envs_per=n_env // 32, max_path_length=int(27e3),
+                                max_decorrelation_steps=0, device=device)
+    algo = CategoricalDQN(batch_size=args.dqn_batch, min_steps_learn=40 * n_env * horizon, replay_size=int(1e6), training_intensity=8,
+                          reward_horizon=3, prioritized_replay=True, double_dqn=True)
+    policy = AtariCatDqnPolicy(**cnn_specs[1])
+    runner = AccelRLEval(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=0, eval_interval_steps=1e8)
+    runner.startup()
+    itr = 0
+    for _ in range(40 + args.warmup):               # 40 sampling-only steps fill the replay, then the warm-up
+        samples, _ = sampler.obtain_samples(itr)
+        algo.optimize_policy(itr, samples)
+        itr += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        samples, _ = sampler.obtain_samples(itr)
+        algo.optimize_policy(itr, samples)
+        itr += 1
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    line = {"metric": "env-steps/sec (whole node), Categorical-DQN Seaquest, 1M-transition replay (BASELINE config 5, "
+                      "not the headline metric)",
+            "value": round(args.steps * n_env * horizon / el, 1), "unit": "env-steps/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Cat-DQN seaquest, %d envs x horizon %d, spec-1 trunk, 51 atoms, prioritized replay "
+                                   "of %d transitions (frames %.1f GB in HBM), n-step 3, double DQN, minibatch %d x %d "
+                                   "updates per step (training intensity 8), adam" %
+                                   (n_env, horizon, algo.replay_buffer.env_replay_size * n_env,
+                                    algo.replay_buffer.frames.numel() / 1e9, args.dqn_batch, algo._updates_per_optimize)}}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,7 +346,8 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the GAE-scan roofline leg (used for the rocprofv3 --pmc passes)")
     ap.add_argument("--suite", action="store_true", help="BASELINE config 4: one game per rank")
-    ap.add_argument("--workload", choices=["ppo256", "a2c1024"], default="ppo256",
+    ap.add_argument("--dqn-batch", type=int, default=512, help="catdqn workload: replay minibatch size")
+    ap.add_argument("--workload", choices=["ppo256", "a2c1024", "catdqn"], default="ppo256",
                     help="ppo256 = BASELINE config 2 (the metric's config, default); a2c1024 = config 3 "
                          "(A2C, 1024 envs, 5-step returns, spec-0 CNN, one rmsprop step per batch)")
     args = ap.parse_args()
@@ -305,6 +356,8 @@ def main():
     if args.workload == "a2c1024":
         N_ENVS, CNN_SPEC = 1024, 0
         args.no_cpu_baseline = args.no_roofline = True
+    if args.workload == "catdqn":
+        return catdqn_main(args)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
