@@ -91,6 +91,7 @@ _SIGNATURES = {
     "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32] + [_vp] * 7),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv_trace_buffer": (None, [_vp]),
+    "arl_conv_force_generic": (None, [_i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),

@@ -70,7 +70,6 @@ struct GemmArgs {
     int M, N, K;
     int k_per_split;        // multiple of BK; gridDim.z splits
     int64_t split_stride;   // elements between split outputs (dense M*N)
-    int debug;              // tuning aid: bit 0 = no global loads (all offsets out of range), bit 1 = no barriers
     unsigned long long* trace;  // tuning aid: per-workgroup timestamps (arl_conv_trace_buffer), or null
     // stride-s data gradient: the s*s input-pixel parity classes are independent implicit GEMMs that
     // differ only in the fields below; one launch runs them all, blockIdx.z = class (igemm_kernel only)
@@ -178,7 +177,7 @@ __global__ __launch_bounds__(256) void rowgather_gemm_kernel(const GemmArgs a) {
             const int ty = tap / a.g.taps_x, tx = tap - ty * a.g.taps_x;
             const int dy = a.g.step * ty, dx = a.g.step * tx;
             const int delta = (dy * a.g.Ws + dx) * a.g.Cs + ch;
-            const int kval = (r < kend) & !(a.debug & 1);
+            const int kval = r < kend;
 #pragma unroll
             for (int p = 0; p < RA; ++p) {
                 const int ok = kval & ((unsigned)(ry[p] + dy) < (unsigned)a.g.Hs) & ((unsigned)(rx[p] + dx) < (unsigned)a.g.Ws);
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void rowgather_gemm_kernel(const GemmArgs a) {
                 const int idx = tid + p * 256;
                 const int nl = idx / CH, chunk = idx - nl * CH;
                 const int n = n0 + nl, r = kb + chunk * 4;
-                const int ok = (NB4 % 256 == 0 || idx < NB4) & (n < a.N) & (r < kend) & !(a.debug & 1);
+                const int ok = (NB4 % 256 == 0 || idx < NB4) & (n < a.N) & (r < kend);
                 offB[p] = ok ? (unsigned)(n * a.b.ld + r) << 2 : OOB;
             }
         } else {
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(256) void rowgather_gemm_kernel(const GemmArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         store_tiles(buf ^ 1);
-        if (!(a.debug & 2)) __syncthreads();
+        __syncthreads();
     }
 
     // ---- epilogue: D[row][col], col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
@@ -1026,24 +1025,8 @@ int launch_fold(const float* part, int splits, int64_t total, const float* bias,
 constexpr int TARGET_WGS = 256;     // one workgroup per CU is already MFMA-bound (fp32 MFMA: 1 wave / SIMD)
 constexpr int BKT = 32;             // k-tile of the skinny configurations (host-side split granularity)
 
-int tuning_bk() {                   // ARL_CONV_BK=16|32 overrides the k-tile (tuning aid)
-    static int bk = [] { const char* e = getenv("ARL_CONV_BK"); return e ? atoi(e) : 0; }();
-    return bk;
-}
 unsigned long long* g_trace = nullptr;
-
-int tuning_debug() {
-    static int t = [] { const char* e = getenv("ARL_CONV_DEBUG"); return e ? atoi(e) : 0; }();
-    return t;
-}
-int tuning_wgs() {                  // ARL_CONV_WGS: workgroups targeted by the split planner
-    static int t = [] { const char* e = getenv("ARL_CONV_WGS"); return e ? atoi(e) : 0; }();
-    return t;
-}
-int tuning_tile() {                 // ARL_CONV_TILE=1: halve the row tile of the skinny configurations (tuning aid)
-    static int t = [] { const char* e = getenv("ARL_CONV_TILE"); return e ? atoi(e) : 0; }();
-    return t;
-}
+bool g_force_generic = false;       // arl_conv_force_generic: route every call to the generic kernels (tests)
 
 struct Geom {
     int64_t batch;
@@ -1078,8 +1061,7 @@ int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
 // split the reduction so that tiles * splits ~ TARGET_WGS, each split a multiple of BKT
 void plan_split(int tiles, int red, int* splits, int* per, int want = TARGET_WGS) {
-    const int target = tuning_wgs() > 0 ? tuning_wgs() : want;
-    int s = tiles >= target ? 1 : target / tiles;
+    int s = tiles >= want ? 1 : want / tiles;
     const int max_s = (red + 4 * BKT - 1) / (4 * BKT);          // at least 4 k-tiles per split
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
@@ -1092,6 +1074,8 @@ void plan_split(int tiles, int red, int* splits, int* per, int want = TARGET_WGS
 extern "C" int64_t arl_conv_workspace_bytes(void) { return (int64_t)64 << 20; }
 
 extern "C" void arl_conv_trace_buffer(void* device_u64_or_null) { g_trace = (unsigned long long*)device_u64_or_null; }
+
+extern "C" void arl_conv_force_generic(int32_t on) { g_force_generic = on != 0; }
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {
@@ -1108,7 +1092,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.kh * g.kw * g.C;
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.b.w = w; a.b.ld = a.K; a.b.w_bytes = (unsigned)((int64_t)a.N * a.K * 4);
-    a.o.dense = 1; a.debug = tuning_debug(); a.trace = g_trace;
+    a.o.dense = 1; a.trace = g_trace;
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
     if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 2 * TARGET_WGS);
@@ -1124,7 +1108,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     const bool single_tap = g.C % FBK == 0;
     const bool multi_tap = !single_tap && FBK % g.C == 0 && g.kw % (FBK / g.C) == 0;
     const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
-    const bool fast = tuning_debug() != 4 && a.K % FBK == 0 && per % FBK == 0 && (single_tap || multi_tap) &&
+    const bool fast = !g_force_generic && a.K % FBK == 0 && per % FBK == 0 && (single_tap || multi_tap) &&
                       (!has_pad || g.kh * g.kw <= 32);
     if (fast) {
         a.g.taps_y = g.kh; a.g.dmin = 0;
@@ -1139,10 +1123,9 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, true>(a, splits, multi_tap, has_pad, s);
     } else {
-        const bool bk16 = tuning_bk() == 16;
-        if (a.N <= 32) rc = bk16 ? launch_rowgather<4, 1, 2, 1, 16, true>(a, splits, s) : launch_rowgather<4, 1, 2, 1, 32, true>(a, splits, s);
-        else if (a.N <= 64) rc = bk16 ? launch_rowgather<2, 2, 2, 1, 16, true>(a, splits, s) : launch_rowgather<2, 2, 2, 1, 32, true>(a, splits, s);
-        else if (small) rc = bk16 ? launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s) : launch_rowgather<2, 2, 1, 1, 32, true>(a, splits, s);
+        if (a.N <= 32) rc = launch_rowgather<4, 1, 2, 1, 16, true>(a, splits, s);
+        else if (a.N <= 64) rc = launch_rowgather<2, 2, 2, 1, 16, true>(a, splits, s);
+        else if (small) rc = launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s);
         else rc = launch_rowgather<2, 2, 2, 2, 16, true>(a, splits, s);
     }
     if (rc || splits == 1) return rc;
@@ -1164,7 +1147,7 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
     constexpr int FBK = 32;
     const int taps_y = g.kh / st, taps_x = g.kw / st;
     const bool has_pad = !(g.kh == 1 && g.kw == 1 && g.pad_h == 0 && g.pad_w == 0);
-    const bool fast = tuning_debug() != 4 && g.K % FBK == 0 && taps_y * taps_x <= 32 && st * st <= 4;
+    const bool fast = !g_force_generic && g.K % FBK == 0 && taps_y * taps_x <= 32 && st * st <= 4;
     // One implicit GEMM per input-pixel parity class (ph, pw): pixels (h, w) = (st*oy + ph, st*ox + pw)
     // only see the taps i = i0 + st*ti, j = j0 + st*tj, which reach output row
     // (h + pad - i) / st = oy + (ph + pad - i0)/st - ti.
@@ -1184,7 +1167,7 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
         a.o.out_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
         a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
         a.k_per_split = round_up(a.K, BKT);
-        a.debug = tuning_debug(); a.trace = g_trace;
+        a.trace = g_trace;
         if (fast) {
             a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
             a.g.dmin = -((taps_y - 1) * g.Wo + (taps_x - 1)) * g.K;
@@ -1259,7 +1242,7 @@ extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw,
     }
     constexpr int FBK = 32;
     const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
-    const bool fast = tuning_debug() != 4 && a.Mred % FBK == 0 && per % FBK == 0 && (!has_pad || g.kh * g.kw <= 32);
+    const bool fast = !g_force_generic && a.Mred % FBK == 0 && per % FBK == 0 && (!has_pad || g.kh * g.kw <= 32);
     if (fast) {
         a.g.taps_y = g.kh; a.g.dmin = 0;
         a.g.rmin = (a.g.add_y * g.W + a.g.add_x) * g.C;

@@ -298,6 +298,10 @@ int64_t arl_conv_workspace_bytes(void);
  * NULL (the default) disables it.  Not thread-safe; not for production use.             */
 void arl_conv_trace_buffer(void* device_u64_or_null);
 
+/* Test hook: route every following call to the generic (any channel count / any K) kernels instead
+ * of the scalar-addressed fast path, so that both are covered by the parity tests.  Not thread-safe. */
+void arl_conv_force_generic(int32_t on);
+
 /* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
  * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,
  * policies/layers.py:22-41; the reference's flipped filters are stored pre-flipped).

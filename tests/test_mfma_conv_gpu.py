@@ -42,8 +42,44 @@ def _tol(want, k_red):
     return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
 
 
+@pytest.fixture(params=["fast", "generic"])
+def path(request):
+    """Both kernel families: the scalar-addressed fast path (taken whenever a k-tile of 32 stays inside
+    one filter row) and the generic fallback (any multiple-of-4 channel count, any K)."""
+    from accel_rl_amd import _lib
+    _lib.load().arl_conv_force_generic(1 if request.param == "generic" else 0)
+    yield request.param
+    _lib.load().arl_conv_force_generic(0)
+
+
+ODD_CASES = [(9, 20, 14, 12, 20, 3, 1, 1),      # channels 12 / 20: no power-of-two anywhere -> generic kernels
+             (7, 17, 13, 8, 24, 5, 1, 2),       # 5x5, pad 2
+             (11, 1, 1, 100, 36, 1, 1, 0)]      # dense with K = 100 (not a multiple of the k-tile)
+
+
+@pytest.mark.parametrize("case", ODD_CASES)
+def test_odd_shapes_take_the_generic_kernels(case):
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = case
+    x, wt, bias, geom, ws = _mk(case, seed=2)
+    ho, wo = _lib.conv_out_hw(geom)
+    y = torch.full((b, ho, wo, k), float("nan"), device=DEV)
+    _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+    want = F.relu(F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), bias, stride=st, padding=p)).permute(0, 2, 3, 1)
+    assert (y - want).abs().max().item() <= _tol(want, ks * ks * c)
+    dy = torch.randn(b, ho, wo, k, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    xr = x.permute(0, 3, 1, 2).detach().requires_grad_()
+    wr = wt.permute(0, 3, 1, 2).detach().requires_grad_()
+    gx, gw = torch.autograd.grad(F.conv2d(xr, wr, None, stride=st, padding=p), (xr, wr), dy.permute(0, 3, 1, 2))
+    dx, dw = torch.full_like(x, float("nan")), torch.full_like(wt, float("nan"))
+    _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
+    _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+    assert (dx - gx.permute(0, 2, 3, 1)).abs().max().item() <= _tol(gx, ks * ks * k)
+    assert (dw - gw.permute(0, 2, 3, 1)).abs().max().item() <= _tol(gw, b * ho * wo)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_forward_matches_torch(case):
+def test_forward_matches_torch(case, path):
     from accel_rl_amd import _lib
     b, h, w, c, k, ks, st, p = case
     x, wt, bias, geom, ws = _mk(case)
@@ -65,7 +101,7 @@ def test_forward_matches_torch(case):
 
 
 @pytest.mark.parametrize("case", CASES)
-def test_backward_matches_autograd(case):
+def test_backward_matches_autograd(case, path):
     from accel_rl_amd import _lib
     b, h, w, c, k, ks, st, p = case
     x, wt, bias, geom, ws = _mk(case, seed=1)
