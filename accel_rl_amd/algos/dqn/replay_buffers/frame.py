@@ -69,9 +69,13 @@ class FrameReplayBuffer(object):
         if self._idx_host is None or self._idx_host.shape[1] < b:
             self._idx_host = torch.zeros((2, b), dtype=torch.int32).pin_memory()
             self._idx_dev = torch.zeros((2, b), dtype=torch.int32, device=self.device)
+            self._idx_event = torch.cuda.Event()
+        else:
+            self._idx_event.synchronize()           # the previous upload has left the pinned buffer
         self._idx_host[0, :b].copy_(torch.from_numpy(np.asarray(env_idxs).astype(np.int32)))
         self._idx_host[1, :b].copy_(torch.from_numpy(np.asarray(step_idxs).astype(np.int32)))
         self._idx_dev[:, :b].copy_(self._idx_host[:, :b], non_blocking=True)
+        self._idx_event.record(torch.cuda.current_stream(self.device))
         return self._idx_dev[0, :b], self._idx_dev[1, :b]
 
     def extract_batch(self, env_idxs, step_idxs):

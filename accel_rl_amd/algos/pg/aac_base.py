@@ -67,6 +67,7 @@ class AdvActorCriticBase(RLAlgorithm):
         self._graph_out = None
         self._graph_samples = None
         self._warm_calls = 0
+        self._done_event = None
 
     def set_n_itr(self, n_itr):
         self.n_itr = n_itr
@@ -76,10 +77,22 @@ class AdvActorCriticBase(RLAlgorithm):
         schedule) are made first; the device work (bootstrap forward, scan, epochs x
         minibatches of forward/backward/update) is static-shape and, after two eager
         warm-up calls, is replayed from one hipGraph."""
+        # The pinned host buffers below (lr multiplier, minibatch indices) are read by copy nodes of the
+        # PREVIOUS call's device work, which may still be queued (the sampler no longer waits for the
+        # stream): wait for that call's own event -- not for the rollout already enqueued behind it.
+        if self._done_event is not None:
+            self._done_event.synchronize()
         if self.lr_schedule == "linear":                             # aac_base.py:165-168
             self._lr_mult_host.fill_(max((self.n_itr - itr) / self.n_itr, 0.))
         if hasattr(self.optimizer, "prepare_host"):
             self.optimizer.prepare_host(self._batch_size)
+        out = self._enqueue_optimize(itr, samples_data)
+        if self._done_event is None:
+            self._done_event = torch.cuda.Event()
+        self._done_event.record(torch.cuda.current_stream(self.policy.device))
+        return out
+
+    def _enqueue_optimize(self, itr, samples_data):
         graphable = self.use_graph and hasattr(self.optimizer, "device_updates") and \
             self.optimizer.parallelism_tag == "single"
         if not graphable:

@@ -37,6 +37,47 @@ from accel_rl_amd.util.misc import nbytes_unit, struct
 NOOP_RING = 4096
 
 
+class _LazyTrajInfos(list):
+    """The batch's completed TrajInfos, fetched on first use.  obtain_samples returns right after
+    enqueuing the rollout; a caller that first enqueues the learner (as the runners do) and only then
+    looks at the trajectory statistics waits for the ROLLOUT's event while the learner already runs."""
+
+    def __init__(self, sampler):
+        super().__init__()
+        self._sampler = sampler
+
+    def resolve(self):
+        smp, self._sampler = self._sampler, None
+        if smp is not None:
+            if smp._pending is self:
+                smp._pending = None
+            super().extend(smp._drain_traj_infos())
+        return self
+
+    def __len__(self):
+        self.resolve()
+        return super().__len__()
+
+    def __iter__(self):
+        self.resolve()
+        return super().__iter__()
+
+    def __getitem__(self, i):
+        self.resolve()
+        return super().__getitem__(i)
+
+    def __bool__(self):
+        return len(self) > 0
+
+    def __eq__(self, other):
+        self.resolve()
+        return super().__eq__(other)
+
+    def __repr__(self):
+        self.resolve()
+        return super().__repr__()
+
+
 class GpuVecSampler(BaseMbSampler):
 
     def __init__(self, n_parallel=1, envs_per=1, device=None, use_graph=True, **kwargs):
@@ -175,7 +216,17 @@ class GpuVecSampler(BaseMbSampler):
         self._rollout = self._make_rollout(self.samples_buf)
         self._uniforms_host = torch.empty(t * n, dtype=torch.float64).pin_memory()
         self._uniforms = torch.empty((t, n), dtype=torch.float64, device=dev)
-        self._done_host = torch.zeros(1 + 2 * 2 * self.n_parallel, dtype=torch.int64).pin_memory()
+        # pinned mirrors of the batch's small results (completed-episode records, no-op ring cursors):
+        # copied at the end of the batch ON the stream (inside the hipGraph), read by the host after
+        # waiting for the batch event only -- not for whatever was enqueued behind it (the learner)
+        st = self._st
+        self._host = struct(done_count=torch.zeros_like(st.done_count, device="cpu").pin_memory(),
+                            done_int=torch.zeros_like(st.done_int, device="cpu").pin_memory(),
+                            done_flt=torch.zeros_like(st.done_flt, device="cpu").pin_memory(),
+                            noop_cursor=torch.zeros_like(st.noop_cursor, device="cpu").pin_memory(),
+                            epoch=torch.zeros_like(st.epoch, device="cpu").pin_memory())
+        self._batch_event = torch.cuda.Event()
+        self._pending = None
         logger.log("GpuVecSampler -- total_n_envs: {}".format(self.total_n_envs))
         logger.log("GpuVecSampler -- batch buffer size: {:,.1f} {}".format(
             *nbytes_unit(count_buffer_size(self.samples_buf))))
@@ -183,6 +234,8 @@ class GpuVecSampler(BaseMbSampler):
     def obtain_samples(self, itr):
         """reference: sampler.py:97-104 (+ serve_actions :120-151)"""
         n, t = self._total_n_envs, self.horizon
+        if self._pending is not None:                    # the previous batch's records must be read out
+            self._pending.resolve()                      # before this batch overwrites the pinned mirrors
         # one np.random.rand(B) per (step, group) in the reference == one flat draw here; a policy
         # with its own action randomness (epsilon-greedy) makes the reference's draws itself
         draws = self.policy.host_draws(t, n) if hasattr(self.policy, "host_draws") else np.random.rand(t * n)
@@ -194,7 +247,9 @@ class GpuVecSampler(BaseMbSampler):
                 self._graph.replay()
             else:
                 self._enqueue_batch()
-        return self.samples_buf, self._drain_traj_infos()
+            self._batch_event.record()
+        self._pending = _LazyTrajInfos(self)
+        return self.samples_buf, self._pending
 
     def shutdown(self):
         self._graph = None
@@ -237,6 +292,8 @@ class GpuVecSampler(BaseMbSampler):
             buf.extra_observations.copy_(self.step_obs)        # sampler.py:147-151
         if not self.mid_batch_reset:                           # worker.py:108-113
             _lib.env_reset(self._game, self._state, ro, self._st.frozen, env.max_start_noops)
+        for k, host in self._host.items():
+            host.copy_(self._st[k], non_blocking=True)
 
     def _kernel_max_path_length(self):
         """The kernels end an episode when Length > limit (worker.py:42)."""
@@ -262,30 +319,31 @@ class GpuVecSampler(BaseMbSampler):
         torch.cuda.synchronize(self.device)
         self._graph = graph
 
-    def _drain_traj_infos(self, itr_check=False):
-        """Completed episodes of this batch (the reference's traj_infos_queue)."""
-        n_streams = 2 * self.n_parallel
-        torch.cuda.current_stream(self.device).synchronize()
-        count = int(self._st.done_count.item())
+    def _drain_traj_infos(self):
+        """Completed episodes of the batch whose event has passed (the reference's traj_infos_queue),
+        read from the pinned mirrors; tops the no-op ring up from the same snapshot."""
+        self._batch_event.synchronize()
+        h = self._host
+        count = min(int(h.done_count[0]), self._state.done_capacity)
         infos = []
         if count:
-            count = min(count, self._state.done_capacity)
-            ints = self._st.done_int[:count].cpu().numpy()
-            flts = self._st.done_flt[:count].cpu().numpy()
+            ints, flts = h.done_int[:count].numpy(), h.done_flt[:count].numpy()
             for (env_id, length, nonzero), (ret, raw, disc) in zip(ints, flts):
                 infos.append(TrajInfo(Length=int(length), Return=float(ret), RawReturn=float(raw),
                                       NonzeroRewards=int(nonzero), DiscountedReturn=float(disc),
                                       _env=int(env_id)))
-        if count or itr_check:
-            self._refill_noop_ring(n_streams)
+            self._refill_noop_ring(2 * self.n_parallel, int(h.epoch[0]), h.noop_cursor.numpy())
         return infos
 
-    def _refill_noop_ring(self, n_streams):
-        """Top the start-noop ring up with fresh draws from each worker stream."""
+    def _refill_noop_ring(self, n_streams, epoch=None, cursors=None):
+        """Top the start-noop ring up with fresh draws from each worker stream.  Without a snapshot
+        (start-up paths) the cursors are read from the device, which waits for the stream."""
         if self.env.max_start_noops <= 0:
             return
-        parity = int(self._st.epoch.item()) & 1
-        cursor = self._st.noop_cursor[parity].cpu().numpy()
+        if epoch is None:
+            epoch = int(self._st.epoch.item())
+            cursors = self._st.noop_cursor.cpu().numpy()
+        cursor = cursors[epoch & 1]
         dirty = False
         for w in range(n_streams):
             n_new = int(cursor[w] + NOOP_RING - self._ring_produced[w])
