@@ -102,6 +102,8 @@ _SIGNATURES = {
     "arl_sumtree_gather": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "arl_lstm_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "arl_lstm_cell_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -435,3 +437,29 @@ def catdqn_loss(pred_logits, tgt_next_logits, pol_next_logits, z, actions, retur
                                   ptr(actions), ptr(returns), ptr(terminals), ptr(is_weights), batch, n_actions,
                                   n_atoms, stride, float(v_min), float(v_max), float(gamma_n), ptr(dlogits),
                                   ptr(loss_rows), ptr(kl), stream_ptr(stream)), "arl_catdqn_loss")
+
+
+# ---------------------------------------------------------------------------
+# LSTM cell (csrc/lstm.hip).  Tensors may be row-strided views ([B, cols] with stride(1) == 1).
+# ---------------------------------------------------------------------------
+
+def _rows(t):
+    """(data_ptr, row stride in elements) of a 2-D tensor whose rows are contiguous."""
+    if t is None:
+        return None, 0
+    assert t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == torch.float32
+    return t.data_ptr(), t.stride(0)
+
+
+def lstm_cell_fwd(gx, gh, c_prev, h_out, c_out, gates=None, stream=None):
+    batch, hidden = c_prev.shape
+    (pgx, sgx), (pcp, scp), (ph, sh), (pc, sc), (pg, sg) = _rows(gx), _rows(c_prev), _rows(h_out), _rows(c_out), _rows(gates)
+    _check(load().arl_lstm_cell_fwd(pgx, sgx, ptr(gh), pcp, scp, batch, hidden, ph, sh, pc, sc, pg, sg,
+                                    stream_ptr(stream)), "arl_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dh, dh_rec, dc_next, gates, c_prev, c_out, dgates, dc_prev, stream=None):
+    batch, hidden = c_prev.shape
+    (pdh, sdh), (pg, sg), (pcp, scp), (pc, sc), (pdg, sdg) = _rows(dh), _rows(gates), _rows(c_prev), _rows(c_out), _rows(dgates)
+    _check(load().arl_lstm_cell_bwd(pdh, sdh, ptr(dh_rec), ptr(dc_next), pg, sg, pcp, scp, pc, sc, batch, hidden,
+                                    pdg, sdg, ptr(dc_prev), stream_ptr(stream)), "arl_lstm_cell_bwd")

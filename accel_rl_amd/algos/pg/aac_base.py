@@ -47,6 +47,13 @@ class AdvActorCriticBase(RLAlgorithm):
         self._dist_info_keys = policy.distribution.dist_info_keys
         input_names = ["observations", "actions", "advantages", "returns", "old_value"]
         input_names += ["old_%s" % k for k in self._dist_info_keys]
+        self._state_info_keys = list(policy.state_info_keys)             # aac_base.py:45-46
+        input_names += self._state_info_keys
+        if self._state_info_keys and hasattr(self.optimizer, "prepare_host") and \
+                getattr(self.optimizer, "_minibatch_size", None) is not None:
+            # the reference's PpoOptimizer slices rows, not trajectories (ppo_optimizer.py:67-75): recurrent
+            # policies are trained with the whole-batch optimizers only
+            raise NotImplementedError("recurrent policies need a whole-batch optimizer (A2C)")
         opt_examples = dict(advantages=np.float32(1), returns=np.float32(1))
         if self._use_valids:
             input_names.append("valids")
@@ -148,6 +155,9 @@ class AdvActorCriticBase(RLAlgorithm):
         values = (samples_data["observations"], samples_data["actions"], opt_data["advantages"],
                   opt_data["returns"], agent_infos["value"])
         values += tuple(agent_infos[k] for k in self._dist_info_keys)
+        # the stored previous hidden states; the policy reads only each segment's first row
+        # (s[::horizon], aac_base.py:157-161)
+        values += tuple(agent_infos[k] for k in self._state_info_keys)
         if self._use_valids:
             values += (opt_data["valids"],)
         return values
@@ -173,6 +183,8 @@ class AdvActorCriticBase(RLAlgorithm):
         if valids is not None:
             v = valids if mb.get("idx") is None else valids.index_select(0, mb["idx"].long())
             inv_count = (1. / v.sum(dtype=torch.float32)).reshape(1)
+        if self._state_info_keys:
+            mb = dict(mb, horizon=self._horizon)
         loss4 = self.policy.loss_and_grads(mb, self.loss_kind, getattr(self, "clip_param", 0.),
                                            self.v_loss_coeff, self.ent_loss_coeff, self._lr_mult,
                                            inv_count)

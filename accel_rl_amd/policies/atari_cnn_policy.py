@@ -97,27 +97,22 @@ class AtariCnnPolicy(object):
             c = nf
         self._conv_out = (c, h, w)
         fan = c * h * w
-        self._hid_geom = []
-        for hs in self.hidden_sizes:
-            if hs % 4:
-                raise NotImplementedError("hidden sizes must be multiples of 4 (got %d)" % hs)
-            ref += [_norm_c((fan, hs), 1.0), np.zeros(hs, np.float32)]
-            self._hid_geom.append((hs, fan))
-            fan = hs
+        hid_ref, hid_names, fan = self._hidden_reference_init(fan)
+        ref += hid_ref
+        self._n_hidden_tensors = len(hid_ref)
         head_ref, head_names = self._head_reference_init(fan, n_act)
         ref += head_ref
         self._ref_shapes = [a.shape for a in ref]
         self.param_short_names = (["Conv%d%s" % (i, s) for i in range(len(self._conv_geom)) for s in "Wb"] +
-                                  ["FC%d%s" % (i, s) for i in range(len(self._hid_geom)) for s in "Wb"] +
-                                  head_names)
+                                  hid_names + head_names)
         self.n_params = int(sum(a.size for a in ref))
         # ---- internal bucket: [conv W, b]... [hidden W, b]... W_head, b_head
         shapes = []
         for nf, ci, sz, st, pad, ho, wo in self._conv_geom:
             shapes += [(nf, sz, sz, ci), (nf,)]
-        for hs, fan_in in self._hid_geom:
-            shapes += [(hs, fan_in), (hs,)]
+        shapes += self._hidden_internal_shapes()
         shapes += self._head_internal_shapes(fan, n_act)
+        self._k_head = 2 * len(self._conv_geom) + self._n_hidden_tensors     # index of W_head in params / grads
         self._shapes = shapes
         sizes = [int(np.prod(s)) for s in shapes]
         self._offsets, off = [], 0
@@ -151,6 +146,47 @@ class AtariCnnPolicy(object):
         self._set_from_reference_arrays(ref)
         if self.initial_param_values is not None:
             self.set_param_values(self.initial_param_values)
+
+    # ---- hidden layers between the conv stack and the output layers: dense + relu
+    #      (pg_cnn.py:57-68); recurrent subclasses override these four
+    def _hidden_reference_init(self, fan):
+        ref, names, self._hid_geom = [], [], []
+        for i, hs in enumerate(self.hidden_sizes):
+            if hs % 4:
+                raise NotImplementedError("hidden sizes must be multiples of 4 (got %d)" % hs)
+            ref += [_norm_c((fan, hs), 1.0), np.zeros(hs, np.float32)]
+            names += ["FC%dW" % i, "FC%db" % i]
+            self._hid_geom.append((hs, fan))
+            fan = hs
+        return ref, names, fan
+
+    def _hidden_internal_shapes(self):
+        return [s for hs, fan_in in self._hid_geom for s in ((hs, fan_in), (hs,))]
+
+    def _conv_flat_to_internal(self, w_ref):
+        """(c*h*w, units) reference dense weight on the conv output -> (units, h*w*c) internal."""
+        co, ho, wo = self._conv_out
+        units = w_ref.shape[1]
+        return w_ref.reshape(co, ho, wo, units).transpose(3, 1, 2, 0).reshape(units, -1)
+
+    def _conv_flat_to_reference(self, w_int):
+        co, ho, wo = self._conv_out
+        units = w_int.shape[0]
+        return w_int.reshape(units, ho, wo, co).transpose(3, 1, 2, 0).reshape(-1, units)
+
+    def _hidden_to_reference(self, arrs):
+        out = []
+        for j in range(len(self._hid_geom)):
+            w = arrs[2 * j]
+            out += [self._conv_flat_to_reference(w) if j == 0 else w.T, arrs[2 * j + 1]]
+        return out
+
+    def _hidden_to_internal(self, refs):
+        out = []
+        for j in range(len(self._hid_geom)):
+            w = refs[2 * j]
+            out += [self._conv_flat_to_internal(w) if j == 0 else w.T, refs[2 * j + 1]]
+        return out
 
     # ---- output layers: policy + value heads fused in one matrix W_head[(A+1), hid]
     #      (pg_cnn.py:70-86); subclasses with other output layers override these four
@@ -274,7 +310,7 @@ class AtariCnnPolicy(object):
             x = self._scaled(mb["observations"], idx)
             b = x.shape[0]
             acts, hids = self._trunk(x)
-            g, k_head = self.grads, 2 * (self._n_conv + self._n_hid)
+            g, k_head = self.grads, self._k_head
             hid = self._hid_geom[-1][0]
             dout = self._buffer(("dout", b), (b, self.n_act + 1))
             dh = self._buffer(("dh", b), (b, hid))
@@ -304,8 +340,13 @@ class AtariCnnPolicy(object):
             d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
             _lib.conv2d_bwd_data(d_cur, w[k], None, d_prev, dense_g[j])
             d_cur = d_prev
-        # ---- conv layers, last to first (d_cur is already the NHWC gradient of the last conv output)
-        d_act = d_cur
+        self._backward_convs(x, acts, d_cur)
+
+    def _backward_convs(self, x, acts, d_act):
+        """Conv layers, last to first; d_act = NHWC gradient of the last conv output (before its relu mask)."""
+        b = x.shape[0]
+        g, w, ws = self.grads, self._w, self._conv_ws
+        conv_g, _ = self._layer_geoms(b)
         for i in range(self._n_conv - 1, -1, -1):
             nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
             _lib.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._relu_ws)
@@ -375,15 +416,8 @@ class AtariCnnPolicy(object):
             w = arr[k][..., :self._c_in] if i == 0 else arr[k]             # drop the zero padding channels
             out += [w.transpose(0, 3, 1, 2)[:, :, ::-1, ::-1], arr[k + 1]]
             k += 2
-        co, ho, wo = self._conv_out
-        for j, (hs, fan_in) in enumerate(self._hid_geom):
-            w = arr[k]
-            if j == 0:      # (hs, h*w*c) -> (c*h*w, hs)
-                w = w.reshape(hs, ho, wo, co).transpose(3, 1, 2, 0).reshape(fan_in, hs)
-            else:
-                w = w.T
-            out += [w, arr[k + 1]]
-            k += 2
+        out += self._hidden_to_reference(arr[k:k + self._n_hidden_tensors])
+        k += self._n_hidden_tensors
         out += self._head_to_reference(arr[k], arr[k + 1])
         return np.concatenate([np.ascontiguousarray(x).reshape(-1) for x in out]).astype(np.float32)
 
@@ -396,15 +430,8 @@ class AtariCnnPolicy(object):
                 w = np.concatenate([w, np.zeros(w.shape[:3] + (self._c_pad - self._c_in,), np.float32)], axis=3)
             internal += [w, ref[k + 1]]
             k += 2
-        co, ho, wo = self._conv_out
-        for j, (hs, fan_in) in enumerate(self._hid_geom):
-            w = ref[k]
-            if j == 0:      # (c*h*w, hs) -> (hs, h*w*c)
-                w = w.reshape(co, ho, wo, hs).transpose(3, 1, 2, 0).reshape(hs, fan_in)
-            else:
-                w = w.T
-            internal += [w, ref[k + 1]]
-            k += 2
+        internal += self._hidden_to_internal(ref[k:k + self._n_hidden_tensors])
+        k += self._n_hidden_tensors
         internal += self._head_to_internal(ref[k:])
         for o, s, a in zip(self._offsets, self._shapes, internal):
             assert tuple(a.shape) == tuple(s), (a.shape, s)

@@ -76,7 +76,7 @@ class AtariCatDqnPolicy(AtariCnnPolicy):
         w = self._w if w is None else w
         b = x.shape[0]
         acts, hids = self._trunk(x, w=w, tag=tag)
-        k = 2 * (self._n_conv + self._n_hid)
+        k = self._k_head
         out = self._buffer(("logits" + tag, b), (b, self.n_act * self._atom_stride))
         geom = self._head_geom(b)
         _lib.conv2d_fwd(hids[-1], w[k], w[k + 1], out, geom, False, self._conv_ws)
@@ -181,7 +181,7 @@ class AtariCatDqnPolicy(AtariCnnPolicy):
             kl = self._buffer(("kl", b), (b,))
             _lib.catdqn_loss(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
                              self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl)
-            k = 2 * (self._n_conv + self._n_hid)
+            k = self._k_head
             geom = self._head_geom(b)
             hid = self._hid_geom[-1][0]
             # output layer: db = column sums (the relu-backward kernel with an all-ones "activation"),

@@ -207,12 +207,19 @@ class GpuVecSampler(BaseMbSampler):
         policy.reset(n_batch=1)
         example_obs = self.env_spec.observation_space.sample()
         policy.get_action(torch.from_numpy(example_obs).to(dev))
-        examples = dict(actions=np.zeros((), self.env_spec.action_space.dtype),
-                        agent_infos=dict(prob=np.zeros(n_act, np.float32), value=np.float32(0)))
+        agent_infos = dict(prob=np.zeros(n_act, np.float32), value=np.float32(0))
+        self._recurrent = bool(getattr(policy, "recurrent", False))
+        if self._recurrent:                               # previous hidden state of every step (base.py:86-93)
+            if not hasattr(policy, "act_step"):
+                raise NotImplementedError("recurrent policies must provide act_step / reset_rows")
+            for key, state in zip(policy.state_info_keys, policy.get_prev_hiddens()):
+                agent_infos[key] = np.zeros(state.shape[1], np.float32)
+            self._prev_frozen = torch.zeros(n, dtype=torch.uint8, device=dev)
+        examples = dict(actions=np.zeros((), self.env_spec.action_space.dtype), agent_infos=agent_infos)
         policy_buf = buffer_with_segs_view(examples, n * t, t, dev)
         self.samples_buf = combine_distinct_buffers(self.envs_buf, policy_buf)
         assert buffer_length(self.samples_buf) == self.sample_size
-        policy.reset(n_batch=self.n_parallel * self.envs_per)
+        policy.reset(n_batch=n if self._recurrent else self.n_parallel * self.envs_per)
         self._rollout = self._make_rollout(self.samples_buf)
         self._uniforms_host = torch.empty(t * n, dtype=torch.float64).pin_memory()
         self._uniforms = torch.empty((t, n), dtype=torch.float64, device=dev)
@@ -284,10 +291,22 @@ class GpuVecSampler(BaseMbSampler):
         for s in range(t):
             if hasattr(self.policy, "set_step"):
                 self.policy.set_step(s)
-            prob, value = self.policy.prob_value(self.step_obs)
+            if self._recurrent:
+                prob, value, *prev = self.policy.act_step(self.step_obs)
+                for key, state in zip(self.policy.state_info_keys, prev):      # stored at (env, step)
+                    buf.agent_infos[key].view(n, t, -1)[:, s].copy_(state)
+                if not self.mid_batch_reset:
+                    self._prev_frozen.copy_(self._st.frozen)
+            else:
+                prob, value = self.policy.prob_value(self.step_obs)
             _lib.env_act_step(self._game, self._state, ro, prob, value, self._uniforms[s], s,
                               self.mid_batch_reset, self._kernel_max_path_length(), self.discount)
             _lib.env_frame_step(self._game, self._state, ro, s, env.max_start_noops)
+            if self._recurrent:
+                # step_buf.reset -> policy.reset_one before the next serve (worker.py:46,88; sampler.py:135-138)
+                hit = self._st.reset_flag if self.mid_batch_reset else \
+                    self._st.frozen * (1 - self._prev_frozen)
+                self.policy.reset_rows(hit)
         if self.need_extra_obs:
             buf.extra_observations.copy_(self.step_obs)        # sampler.py:147-151
         if not self.mid_batch_reset:                           # worker.py:108-113

@@ -405,6 +405,27 @@ int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_logits, cons
                     int32_t atom_stride, float v_min, float v_max, float gamma_n, float* dlogits,
                     float* loss_rows, float* kl, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * LSTM cell of the recurrent policies
+ * ------------------------------------------------------------------------- */
+
+/* Elementwise part of FastLstmLayer.step, accel_rl/policies/layers.py:331-346: gate order
+ * f, i, c~, o; f, i, o = sigmoid, c~ = tanh; c = f c_prev + i c~; h = o tanh(c).  gx = x W_x + b and
+ * gh = h_prev W_h are the callers' dense products (gh may be NULL = zero).  Every *_stride is the
+ * element distance between consecutive rows, so a time slice of a [trajectory][time] batch can be
+ * addressed in place.  gates (optional) receives the activated gates for the backward pass. */
+int arl_lstm_cell_fwd(const float* gx, int64_t gx_stride, const float* gh_or_null, const float* c_prev,
+                      int64_t cprev_stride, int64_t batch, int32_t hidden, float* h_out, int64_t h_stride,
+                      float* c_out, int64_t c_stride, float* gates_or_null, int64_t gates_stride, void* stream);
+
+/* Backward of the above for one time step: dh (from the layers above, strided) + dh_rec (from step
+ * t+1, contiguous) and dc_next -> pre-activation gate gradients dgates[B][4H] and dc_prev. */
+int arl_lstm_cell_bwd(const float* dh_or_null, int64_t dh_stride, const float* dh_rec_or_null,
+                      const float* dc_next_or_null, const float* gates, int64_t gates_stride,
+                      const float* c_prev, int64_t cprev_stride, const float* c_out, int64_t c_stride,
+                      int64_t batch, int32_t hidden, float* dgates, int64_t dgates_stride, float* dc_prev,
+                      void* stream);
+
 /* Optimiser state for ONE flat fp32 parameter bucket (all trainable params in
  * get_params order, accel_rl/optimizers/util.py:35-39). */
 typedef struct arl_opt_state {
