@@ -322,6 +322,7 @@ class GpuVecSampler(BaseMbSampler):
         """Warm up on a side stream, then capture one batch into a hipGraph."""
         snap = {k: v.clone() for k, v in self._st.items()}
         obs_snap = self.step_obs.clone()
+        hidden_snap = [h.clone() for h in self.policy.get_prev_hiddens()] if self._recurrent else []
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -335,6 +336,8 @@ class GpuVecSampler(BaseMbSampler):
         for k, v in snap.items():
             self._st[k].copy_(v)
         self.step_obs.copy_(obs_snap)
+        for h, v in zip(self.policy.get_prev_hiddens() if self._recurrent else [], hidden_snap):
+            h.copy_(v)
         torch.cuda.synchronize(self.device)
         self._graph = graph
 

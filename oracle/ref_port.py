@@ -414,6 +414,7 @@ class CpuSamplerPort(object):
                 self.step_obs[e] = self.envs[e].reset()
                 self.trajs.append(PortedTrajInfo(discount))
         self.frozen = [False] * n
+        self.reset_flags = np.zeros(n, bool)             # step_bufs[g].reset (act_server/buffers.py:24-30)
         return self.n_actions, n * t
 
     def obtain_samples(self, policy):
@@ -429,11 +430,18 @@ class CpuSamplerPort(object):
         for s in range(t):
             for j in (0, 1):
                 lo, hi = j * half, (j + 1) * half
+                if self.reset_flags[lo:hi].any():                   # sampler.py:135-138 (for recurrence)
+                    for i in np.where(self.reset_flags[lo:hi])[0]:
+                        if hasattr(policy, "reset_one"):            # BasePolicy.reset_one is a no-op
+                            policy.reset_one(idx=i)
+                    self.reset_flags[lo:hi] = False
                 acts, infos = policy.get_actions(self.step_obs[lo:hi])
                 idx = np.arange(lo, hi) * t + s                     # sampler.py:143-145
                 b["actions"][idx] = acts
-                b["prob"][idx] = infos["prob"]
-                b["value"][idx] = infos["value"]
+                for k, v in infos.items():                          # prob, value (+ previous hidden states)
+                    if k not in b:
+                        b[k] = np.zeros((n * t,) + np.asarray(v).shape[1:], np.asarray(v).dtype)
+                    b[k][idx] = v
                 for e in range(lo, hi):
                     if not self.mid_batch_reset and frozen[e]:      # worker.py:80
                         continue
@@ -445,6 +453,8 @@ class CpuSamplerPort(object):
                     hit = over_len or (d and info.get("need_reset", True))
                     if hit:                                         # worker.py:42-50
                         d = True
+                        if self.eval_envs_per is None:              # worker.py:46,88 (worker_with_eval.py omits it)
+                            self.reset_flags[e] = True
                         if over_len and "need_reset" in info:
                             info["need_reset"] = True
                         completed.append(traj)

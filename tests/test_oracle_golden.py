@@ -283,3 +283,58 @@ def test_minibatch_indices():
 def test_n_itr_table():
     for n_steps, sample_size, log_steps, n_itr, log_itrs in load_golden("g9_nitr")["table"]:
         assert P.n_itr_for(int(n_steps), int(sample_size), int(log_steps)) == (n_itr, log_itrs)
+
+
+# -- G14: recurrent policy through the sampler ------------------------------------
+
+class RecurrentTablePort(object):
+    """Host twin of the fixture's recurrent stand-in policy, with the reference's pair-of-states
+    handling for the alternating sampler (policies/base.py:32-93)."""
+    recurrent = True
+
+    def __init__(self, prob_table, value_table):
+        self.prob_table, self.value_table = prob_table, value_table
+        self._pair, self._j = None, 0
+
+    def reset(self, n_batch):
+        self._pair = [np.zeros((n_batch, 2), np.float32), np.zeros((n_batch, 2), np.float32)]
+        self._j = 0
+
+    def reset_one(self, idx):
+        self._pair[self._j][idx] = 0
+
+    def get_actions(self, obs):
+        h = self._pair[self._j]
+        key = obs.reshape(obs.shape[0], -1).astype(np.int64).sum(axis=1) % 64
+        idx = (key + np.floor(4 * h[:, 0]).astype(np.int64)) % 64
+        new_h = (np.float32(0.5) * h + np.stack([key.astype(np.float32) / np.float32(64),
+                                                 np.ones(len(key), np.float32)], axis=1)).astype(np.float32)
+        prob, value = self.prob_table[idx], self.value_table[idx]
+        acts = P.sample_actions(prob, np.random.rand(len(key)))
+        self._pair[self._j] = new_h
+        self._j ^= 1
+        return acts, dict(prob=prob, value=value, hprev_0=h)
+
+    def state(self):
+        return np.concatenate(self._pair)
+
+
+def test_recurrent_policy_plumbing_matches_reference_sampler():
+    """G14 (real multi-process sampler + a recurrent stand-in policy): which previous hidden state is
+    stored at which (env, step) and when reset_one is applied, mid_batch_reset False."""
+    g = load_golden("g14_recurrent_seaquest")
+    smp, _, n_batches = replay_rollout(g)
+    policy = RecurrentTablePort(g["prob_table"], g["value_table"])
+    policy.reset(smp.half)
+    t = smp.horizon
+    for b in range(n_batches):
+        buf, _ = smp.obtain_samples(policy)
+        valid = P.valid_mask(g["need_reset"][b].reshape(-1, t)).reshape(-1).astype(bool)
+        np.testing.assert_array_equal(buf["actions"], g["actions"][b], err_msg="b%d" % b)
+        np.testing.assert_array_equal(buf["prob"], g["prob"][b])
+        np.testing.assert_array_equal(buf["hprev_0"], g["hprev"][b], err_msg="b%d" % b)
+        np.testing.assert_array_equal(buf["rewards"][valid], g["rewards"][b][valid])
+        np.testing.assert_array_equal(_crc_rows(buf["observations"])[valid], g["obs_crc"][b][valid])
+        np.testing.assert_array_equal(_crc_rows(buf["extra_observations"]), g["extra_crc"][b])
+        np.testing.assert_array_equal(policy.state(), g["state_after"][b])
+    assert (g["hprev"][:, :, 0].reshape(n_batches, -1, t)[:, :, 1:] == 0).any()       # resets really happened mid-segment
