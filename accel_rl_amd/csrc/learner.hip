@@ -340,6 +340,20 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     }
 }
 
+// Fold the head weight-gradient partials straight into the gradient bucket: rows 0..K-1 of the staged
+// [(K+1)][hid] matrix -> dw_head, row K (first K columns) -> db_head; fixed summation order.
+__global__ __launch_bounds__(256) void head_fold_kernel(const float* __restrict__ part, int splits, int K, int hid,
+                                                        float* __restrict__ dw, float* __restrict__ db) {
+    const int width = (K + 1) * hid;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * hid + K) return;
+    const int src = i < K * hid ? i : K * hid + (i - K * hid);
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += part[(int64_t)z * width + src];
+    if (i < K * hid) dw[i] = s;
+    else db[i - K * hid] = s;
+}
+
 }  // namespace
 
 extern "C" int arl_gather_scale_obs_nhwc(const uint8_t* obs, const int32_t* idx_or_null,
@@ -448,20 +462,14 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
     // head weight / bias gradient: row-split partials, then one fold into a staging
     // matrix [(K+1)][hid]; rows 0..K-1 -> dw_head, row K (first K columns) -> db_head
     float* part = ws + 256 * 4;
-    float* staged = part + (size_t)WG_SPLITS * (K + 1) * hid;
     const int rows_per = ((int)batch + WG_SPLITS - 1) / WG_SPLITS;
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((hid + 63) / 64, WG_SPLITS), dim3(256),
                        (size_t)rows_per * K * 4, s, dout, h, (int)batch, (int)hid, K, part);
     rc = arl::check_launch("head_wgrad_kernel");
     if (rc) return rc;
-    const int width = (K + 1) * hid;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((width + 63) / 64), dim3(1024), 0, s,
-                       (const float*)part, WG_SPLITS, width, staged);
-    rc = arl::check_launch("fold_partials_kernel");
+    hipLaunchKernelGGL(head_fold_kernel, dim3((K * hid + K + 255) / 256), dim3(256), 0, s, (const float*)part,
+                       WG_SPLITS, K, (int)hid, dw_head, db_head);
+    rc = arl::check_launch("head_fold_kernel");
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(dw_head, staged, (size_t)K * hid * 4, hipMemcpyDeviceToDevice, s);
-    if (e == hipSuccess)
-        e = hipMemcpyAsync(db_head, staged + (size_t)K * hid, (size_t)K * 4, hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) { arl::set_error("head grads copy: %s", hipGetErrorString(e)); return (int)e; }
     return 0;
 }
