@@ -11,7 +11,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libaccel_rl_hip.so")
-SOURCES = ["batch_ops.hip", "scan.hip", "env.hip", "optim.hip", "learner.hip", "mfma_conv.hip", "replay.hip", "dqn.hip", "lstm.hip"]
+SOURCES = ["batch_ops.hip", "scan.hip", "env.hip", "optim.hip", "learner.hip", "mfma_conv.hip", "replay.hip", "dqn.hip", "lstm.hip", "gru.hip"]
 ARCH = "gfx950"
 
 

@@ -104,6 +104,10 @@ _SIGNATURES = {
     "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_lstm_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "arl_lstm_cell_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "arl_gru_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp]),
+    "arl_gru_cell_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "arl_rnn_cell_fwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "arl_rnn_cell_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
 }
 
@@ -463,3 +467,30 @@ def lstm_cell_bwd(dh, dh_rec, dc_next, gates, c_prev, c_out, dgates, dc_prev, st
     (pdh, sdh), (pg, sg), (pcp, scp), (pc, sc), (pdg, sdg) = _rows(dh), _rows(gates), _rows(c_prev), _rows(c_out), _rows(dgates)
     _check(load().arl_lstm_cell_bwd(pdh, sdh, ptr(dh_rec), ptr(dc_next), pg, sg, pcp, scp, pc, sc, batch, hidden,
                                     pdg, sdg, ptr(dc_prev), stream_ptr(stream)), "arl_lstm_cell_bwd")
+
+
+def gru_cell_fwd(gx, gh, h_prev, h_out, saved=None, stream=None):
+    batch, hidden = h_prev.shape
+    (pgx, sgx), (php, shp), (ph, sh), (ps, ss) = _rows(gx), _rows(h_prev), _rows(h_out), _rows(saved)
+    _check(load().arl_gru_cell_fwd(pgx, sgx, ptr(gh), php, shp, batch, hidden, ph, sh, ps, ss, stream_ptr(stream)),
+           "arl_gru_cell_fwd")
+
+
+def gru_cell_bwd(dh, dh_rec, dh_dir, saved, h_prev, dgx, dgh, dh_prev, stream=None):
+    batch, hidden = h_prev.shape
+    (pdh, sdh), (ps, ss), (php, shp), (pgx, sgx), (pgh, sgh) = _rows(dh), _rows(saved), _rows(h_prev), _rows(dgx), _rows(dgh)
+    _check(load().arl_gru_cell_bwd(pdh, sdh, ptr(dh_rec), ptr(dh_dir), ps, ss, php, shp, batch, hidden, pgx, sgx,
+                                   pgh, sgh, ptr(dh_prev), stream_ptr(stream)), "arl_gru_cell_bwd")
+
+
+def rnn_cell_fwd(gx, gh, h_out, stream=None):
+    batch, hidden = h_out.shape
+    (pgx, sgx), (ph, sh) = _rows(gx), _rows(h_out)
+    _check(load().arl_rnn_cell_fwd(pgx, sgx, ptr(gh), batch, hidden, ph, sh, stream_ptr(stream)), "arl_rnn_cell_fwd")
+
+
+def rnn_cell_bwd(dh, dh_rec, h_out, dpre, stream=None):
+    batch, hidden = h_out.shape
+    (pdh, sdh), (ph, sh), (pd, sd) = _rows(dh), _rows(h_out), _rows(dpre)
+    _check(load().arl_rnn_cell_bwd(pdh, sdh, ptr(dh_rec), ph, sh, batch, hidden, pd, sd, stream_ptr(stream)),
+           "arl_rnn_cell_bwd")

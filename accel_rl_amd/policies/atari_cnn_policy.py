@@ -110,9 +110,11 @@ class AtariCnnPolicy(object):
         shapes = []
         for nf, ci, sz, st, pad, ho, wo in self._conv_geom:
             shapes += [(nf, sz, sz, ci), (nf,)]
-        shapes += self._hidden_internal_shapes()
+        hid_shapes = self._hidden_internal_shapes()
+        self._n_hidden_internal = len(hid_shapes)       # may differ from the reference's count (GRU: 6 vs 12)
+        shapes += hid_shapes
         shapes += self._head_internal_shapes(fan, n_act)
-        self._k_head = 2 * len(self._conv_geom) + self._n_hidden_tensors     # index of W_head in params / grads
+        self._k_head = 2 * len(self._conv_geom) + self._n_hidden_internal    # index of W_head in params / grads
         self._shapes = shapes
         sizes = [int(np.prod(s)) for s in shapes]
         self._offsets, off = [], 0
@@ -416,8 +418,8 @@ class AtariCnnPolicy(object):
             w = arr[k][..., :self._c_in] if i == 0 else arr[k]             # drop the zero padding channels
             out += [w.transpose(0, 3, 1, 2)[:, :, ::-1, ::-1], arr[k + 1]]
             k += 2
-        out += self._hidden_to_reference(arr[k:k + self._n_hidden_tensors])
-        k += self._n_hidden_tensors
+        out += self._hidden_to_reference(arr[k:k + self._n_hidden_internal])
+        k += self._n_hidden_internal
         out += self._head_to_reference(arr[k], arr[k + 1])
         return np.concatenate([np.ascontiguousarray(x).reshape(-1) for x in out]).astype(np.float32)
 

@@ -426,6 +426,31 @@ int arl_lstm_cell_bwd(const float* dh_or_null, int64_t dh_stride, const float* d
                       int64_t batch, int32_t hidden, float* dgates, int64_t dgates_stride, float* dc_prev,
                       void* stream);
 
+/* GRU cell (GruLayer.step, accel_rl/policies/layers.py:163-168), gate order r, u, c in the 3H-wide
+ * arrays: r = s(gx_r + gh_r); u = s(gx_u + gh_u); c = tanh(gx_c + r gh_c); h = (1 - u) h_prev + u c.
+ * gx = x [W_xr W_xu W_xc] + b, gh = h_prev [W_hr W_hu W_hc] are the callers' dense products.
+ * saved (optional, [B][4H]) receives r, u, c, gh_c for the backward pass. */
+int arl_gru_cell_fwd(const float* gx, int64_t gx_stride, const float* gh, const float* h_prev,
+                     int64_t hprev_stride, int64_t batch, int32_t hidden, float* h_out, int64_t h_stride,
+                     float* saved_or_null, int64_t saved_stride, void* stream);
+
+/* Backward of one GRU step: dh (layers above, strided) + dh_rec + dh_dir (both contiguous, from
+ * step t+1) -> dgx[B][3H] (gradient wrt gx), dgh[B][3H] (wrt gh; its c block carries the factor r)
+ * and dh_prev[B][H] = the direct part dh (1 - u); the caller adds dgh W_h^T. */
+int arl_gru_cell_bwd(const float* dh_or_null, int64_t dh_stride, const float* dh_rec_or_null,
+                     const float* dh_dir_or_null, const float* saved, int64_t saved_stride,
+                     const float* h_prev, int64_t hprev_stride, int64_t batch, int32_t hidden,
+                     float* dgx, int64_t dgx_stride, float* dgh, int64_t dgh_stride, float* dh_prev,
+                     void* stream);
+
+/* Plain recurrent cell (RecurrentLayer.step, layers.py:80-82): h = tanh(gx + gh), and its backward
+ * dpre = (dh + dh_rec) (1 - h^2). */
+int arl_rnn_cell_fwd(const float* gx, int64_t gx_stride, const float* gh, int64_t batch, int32_t hidden,
+                     float* h_out, int64_t h_stride, void* stream);
+int arl_rnn_cell_bwd(const float* dh_or_null, int64_t dh_stride, const float* dh_rec_or_null,
+                     const float* h_out, int64_t h_stride, int64_t batch, int32_t hidden, float* dpre,
+                     int64_t dpre_stride, void* stream);
+
 /* Optimiser state for ONE flat fp32 parameter bucket (all trainable params in
  * get_params order, accel_rl/optimizers/util.py:35-39). */
 typedef struct arl_opt_state {

@@ -109,7 +109,7 @@ def test_rollout_step_state_and_reference_layout():
             policy.reset_rows(mask)
             h[[3, 7]] = 0
             c[[3, 7]] = 0
-    assert torch.allclose(policy._h, h, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(policy._state[0], h, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("masked", [False, True])
