@@ -71,6 +71,7 @@ struct GemmArgs {
     int k_per_split;        // multiple of BK; gridDim.z splits
     int64_t split_stride;   // elements between split outputs (dense M*N)
     unsigned long long* trace;  // tuning aid: per-workgroup timestamps (arl_conv_trace_buffer), or null
+    int debug;              // tuning aid (ARL_CONV_DEBUG): bit 0 = skip the epilogue's stores
     // stride-s data gradient: the s*s input-pixel parity classes are independent implicit GEMMs that
     // differ only in the fields below; one launch runs them all, blockIdx.z = class (igemm_kernel only)
     int n_par;
@@ -123,6 +124,45 @@ __device__ __forceinline__ void store_tiles_rowmajor(const f32x16 (&acc)[TM][TN]
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, voff, (unsigned)(rc * N) << 2, 0);
             }
     }
+}
+
+// Epilogue of the operand-swapped kernels (acc = W-tile x X-tile^T): D'[row][col] with col = lane & 31
+// the GEMM row m and row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) the output channel n, so a lane holds
+// four consecutive channels of ONE output row per register quad and stores them as one b128 -- four
+// store instructions per 32x32 tile instead of sixteen, and one row decode per lane instead of
+// sixteen.  row_off[i] = element offset of the lane's row in tile i (or < 0: row out of range);
+// bias_q[j][q] = the lane's four bias values of quad q of column tile j (zeros without a bias);
+// N % 4 == 0 (checked on the host).  mask: same layout as out, out = 0 where mask <= 0.
+template <int TM, int TN>
+__device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
+                                                  const long long (&row_off)[TM], int N, int col_base, int lane,
+                                                  const float4 (&bias_q)[TN][4], const float* mask, int relu) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = col_base + j * 32 + 8 * q + 4 * half;
+            const float4 bq = bias_q[j][q];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bool ok = row_off[i] >= 0 && n < N;
+                float4 val = make_float4(acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
+                                         acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w);
+                if (relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
+                const unsigned voff = ok ? (unsigned)((row_off[i] + n) << 2) : OOB;
+                if (mask) {
+                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (ok) mk = *reinterpret_cast<const float4*>(mask + row_off[i] + n);
+                    if (!(mk.x > 0.f)) val.x = 0.f;
+                    if (!(mk.y > 0.f)) val.y = 0.f;
+                    if (!(mk.z > 0.f)) val.z = 0.f;
+                    if (!(mk.w > 0.f)) val.w = 0.f;
+                }
+                u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff, 0, 0);
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -658,6 +698,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
+    float4 bias_q[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bias_q[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nk = (kend - kbeg) / BK;
     issue_loads(kbeg);
     store_tiles(0);
@@ -665,9 +710,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     if (a.trace) tr1 = __builtin_readcyclecounter();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) {                          // uniform branch: the last tile prefetches nothing
+        if (kt + 1 < nk) {                          // uniform branch
             next_tile();
             issue_loads(kbeg + (kt + 1) * BK);
+        } else if (a.o.bias) {                      // the last tile prefetches the epilogue's bias instead
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
+                    if (n < a.N) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
+                }
         }
         __builtin_amdgcn_sched_barrier(0);
         const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
@@ -697,57 +750,34 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1);
-        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tiles(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     if (a.trace) tr2 = __builtin_readcyclecounter();
     float* out = a.o.out + (a.n_par ? 0 : (int64_t)blockIdx.z * a.split_stride);
-    if (a.o.dense && !a.o.mask) {
-        store_tiles_rowmajor<TM, TN>(acc, out, M, a.N, m0 + wm * TM * 32, n0 + wn * TN * 32, lane, a.o.bias, a.o.relu);
-    } else {
-        // Strided (stride-parity data gradient) or masked output: rows map to scattered pixels.  Only the
-        // lane's first row is decoded with divisions; the other rows of the 32-row tile are at most 31 + 32*TM
-        // pixels further on, so their carries into (oy, b) are one multiply-shift each (exact for the
-        // small operands involved: x < 2^12, divisor < 2^10).
+    if (!(a.debug & 1)) {
+        // operands are swapped (acc = W-tile x X-tile^T): every lane owns ONE output row per 32-row tile
         const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out, a.o.out_bytes);
-        const unsigned inv_w = 65536u / (unsigned)g.out_w + 1u, inv_h = 65536u / (unsigned)g.out_h + 1u;
-        const int mb = m0 + wm * TM * 32 + 4 * half;
-        const int t0 = mb / g.out_w, ox0 = mb - t0 * g.out_w;
-        const int b0 = t0 / g.out_h, oy0 = t0 - b0 * g.out_h;
-        const bool small = g.out_w < 1024 && g.out_h < 1024;           // uniform
+        long long row_off[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int rc = i * 32 + (v & 3) + 8 * (v >> 2);
-                const int m = mb + rc;
-                int b, oy, ox;
-                if (small) {
-                    const unsigned x = (unsigned)(ox0 + rc), qx = (x * inv_w) >> 16;
-                    const unsigned y = (unsigned)oy0 + qx, qy = (y * inv_h) >> 16;
-                    ox = (int)(x - qx * (unsigned)g.out_w); oy = (int)(y - qy * (unsigned)g.out_h); b = b0 + (int)qy;
-                } else {
-                    const int t = m / g.out_w;
-                    ox = m - t * g.out_w; b = t / g.out_h; oy = t - b * g.out_h;
-                }
-                const int orow = a.o.dense ? m * a.N
-                                           : ((b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn * TN * 32 + j * 32 + l31;
-                    float val = acc[i][j][v];
-                    if (a.o.bias && n < a.N) val += a.o.bias[n];
-                    if (a.o.relu) val = fmaxf(val, 0.f);
-                    const bool ok = m < M && n < a.N;
-                    if (a.o.mask && ok && !(a.o.mask[orow + n] > 0.f)) val = 0.f;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rsO, ok ? (unsigned)(orow + n) << 2 : OOB, 0, 0);
-                }
+            const int m = m0 + (wm * TM + i) * 32 + l31;
+            if (a.o.dense) {
+                row_off[i] = m < M ? (long long)m * a.N : -1;
+            } else {                                    // stride-parity data gradient: rows map to scattered pixels
+                const int t = m / g.out_w, ox = m - t * g.out_w;
+                const int b = t / g.out_h, oy = t - b * g.out_h;
+                row_off[i] = m < M ? ((long long)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N
+                                   : -1;
             }
         }
+        store_tiles_quads<TM, TN>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu);
     }
     if (a.trace && tid == 0) {
         unsigned long long* t = a.trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
@@ -1026,6 +1056,11 @@ constexpr int TARGET_WGS = 256;     // one workgroup per CU is already MFMA-boun
 constexpr int BKT = 32;             // k-tile of the skinny configurations (host-side split granularity)
 
 unsigned long long* g_trace = nullptr;
+int g_debug = -1;
+int debug_flags() {
+    if (g_debug < 0) { const char* e = getenv("ARL_CONV_DEBUG"); g_debug = e ? atoi(e) : 0; }
+    return g_debug;
+}
 bool g_force_generic = false;       // arl_conv_force_generic: route every call to the generic kernels (tests)
 
 struct Geom {
@@ -1092,7 +1127,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.kh * g.kw * g.C;
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.b.w = w; a.b.ld = a.K; a.b.w_bytes = (unsigned)((int64_t)a.N * a.K * 4);
-    a.o.dense = 1; a.trace = g_trace;
+    a.o.dense = 1; a.trace = g_trace; a.debug = debug_flags();
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
     if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 2 * TARGET_WGS);
@@ -1109,8 +1144,9 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     const bool multi_tap = !single_tap && FBK % g.C == 0 && g.kw % (FBK / g.C) == 0;
     const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
     const bool fast = !g_force_generic && a.K % FBK == 0 && per % FBK == 0 && (single_tap || multi_tap) &&
-                      (!has_pad || g.kh * g.kw <= 32);
+                      (!has_pad || g.kh * g.kw <= 32) && a.N % 4 == 0;
     if (fast) {
+        a.o.out_bytes = (unsigned)((int64_t)a.M * a.N * 4);     // one split's output
         a.g.taps_y = g.kh; a.g.dmin = 0;
         a.g.rmin = (a.g.add_y * g.W + a.g.add_x) * g.C;
         a.g.origin = a.g.rmin + a.g.dmin;
@@ -1147,7 +1183,7 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
     constexpr int FBK = 32;
     const int taps_y = g.kh / st, taps_x = g.kw / st;
     const bool has_pad = !(g.kh == 1 && g.kw == 1 && g.pad_h == 0 && g.pad_w == 0);
-    const bool fast = !g_force_generic && g.K % FBK == 0 && taps_y * taps_x <= 32 && st * st <= 4;
+    const bool fast = !g_force_generic && g.K % FBK == 0 && taps_y * taps_x <= 32 && st * st <= 4 && g.C % 4 == 0;
     // One implicit GEMM per input-pixel parity class (ph, pw): pixels (h, w) = (st*oy + ph, st*ox + pw)
     // only see the taps i = i0 + st*ti, j = j0 + st*tj, which reach output row
     // (h + pad - i) / st = oy + (ph + pad - i0)/st - ti.
@@ -1167,7 +1203,7 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
         a.o.out_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
         a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
         a.k_per_split = round_up(a.K, BKT);
-        a.trace = g_trace;
+        a.trace = g_trace; a.debug = debug_flags();
         if (fast) {
             a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
             a.g.dmin = -((taps_y - 1) * g.Wo + (taps_x - 1)) * g.K;

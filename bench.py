@@ -368,13 +368,19 @@ def main():
         cpu_pool = start_cpu_pool()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    device = torch.device("cuda", local)
+    # ARL_BENCH_ONE_GPU=1 + ARL_BENCH_BACKEND=gloo: development check of the N>1 control flow with every
+    # rank on GPU 0 (RCCL refuses two ranks on one device); never a measurement.
+    device = torch.device("cuda", 0 if os.environ.get("ARL_BENCH_ONE_GPU") == "1" else local)
     torch.cuda.set_device(device)
     if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("NCCL_DEBUG", "WARN")        # no INFO/VERSION chatter on stdout
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        backend = os.environ.get("ARL_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import __graft_entry__
     __graft_entry__.build()

@@ -35,6 +35,11 @@ def main():
         lib.arl_conv_trace_buffer(None)
         t = tr.cpu().numpy().reshape(-1, 8)
         t = t[t[:, 0] != 0]
+        hw0, xcc0 = t[:, 6], t[:, 7] & 0xf
+        cu0 = ((hw0 >> 8) & 0xf) | (((hw0 >> 12) & 1) << 4) | (((hw0 >> 13) & 7) << 5) | (xcc0 << 8)
+        for x in np.unique(cu0):                                    # cycle counters are not global: align per CU
+            sel = cu0 == x
+            t[sel, 0:4] -= t[sel, 0].min() - 1
         n = len(t)
         t0 = t[:, 0].min()
         start, pro, loop, epi = t[:, 0] - t0, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
@@ -44,11 +49,19 @@ def main():
         hw, xcc = t[:, 6], t[:, 7] & 0xf
         cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
         per_cu = collections.Counter(cu.tolist())
+        # busy intervals per CU: how many workgroups are inside their main loop at a time
+        ev = sorted([(x, 1) for x in (t[:, 1] - t0)] + [(x, -1) for x in (t[:, 2] - t0)])
+        area, cur, last = 0, 0, 0
+        for x, d in ev:
+            area += cur * (x - last)
+            cur, last = cur + d, x
+        in_loop = area / float(end.max()) / len(per_cu)
         hist = collections.Counter(per_cu.values())
         print("%s fwd: %d WGs, wall %.1f us, counter/wall = %.2f ticks/ns; start skew p50/max %d/%d; prologue p50 %d, "
               "loop p50/max %d/%d, epilogue p50 %d, end max %d; CUs used %d, WGs/CU histogram %s" %
               (name, n, real, clk, np.median(start), start.max(), np.median(pro), np.median(loop), loop.max(),
                np.median(epi), end.max(), len(per_cu), dict(sorted(hist.items()))))
+        print("    mean workgroups per CU inside the main loop: %.2f; total/median WG lifetime %d" % (in_loop, np.median(t[:, 3] - t[:, 0])))
 
 
 if __name__ == "__main__":
