@@ -53,6 +53,13 @@ class ArlConvGeom(C.Structure):
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad_h", _i32), ("pad_w", _i32)]
 
 
+class ArlFoldItem(C.Structure):
+    _fields_ = [("part", _vp), ("out", _vp), ("total", _i64), ("splits", _i32), ("reserved", _i32)]
+
+
+FOLD_MAX_ITEMS = 24
+
+
 class ArlReplay(C.Structure):
     _fields_ = [("n_env", _i64), ("size", _i32), ("n_stack", _i32), ("frame_bytes", _i32),
                 ("reward_horizon", _i32), ("frames", _vp), ("n_blanks", _vp), ("acts", _vp),
@@ -95,6 +102,9 @@ _SIGNATURES = {
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
+    "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem), _vp]),
+    "arl_fold_many": (_i32, [C.POINTER(ArlFoldItem), _i32, _vp]),
+    "arl_relu_bwd_bias_parts": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_replay_append": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _vp, _vp, _i32, _i32, _f64, _i32, _vp]),
     "arl_replay_extract": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "arl_sumtree_find": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
@@ -375,6 +385,38 @@ def conv2d_bwd_weight(dy, x, dw, geom, workspace, stream=None):
     assert dw.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "dw size"
     _check(load().arl_conv2d_bwd_weight(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(geom),
                                         ptr(workspace), stream_ptr(stream)), "arl_conv2d_bwd_weight")
+
+
+class FoldList(object):
+    """Pending split folds of one backward pass (arl_fold_item): the *_parts calls append, run()
+    folds everything in one launch.  Every appended call needs its own workspace tensor."""
+
+    def __init__(self):
+        self._items = (ArlFoldItem * FOLD_MAX_ITEMS)()
+        self._n = 0
+
+    def _next(self):
+        assert self._n < FOLD_MAX_ITEMS, "too many pending folds"
+        self._n += 1
+        return C.byref(self._items[self._n - 1])
+
+    def conv2d_bwd_weight(self, dy, x, dw, geom, workspace, stream=None):
+        ho, wo = conv_out_hw(geom)
+        assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
+        assert x.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x size"
+        assert dw.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "dw size"
+        _check(load().arl_conv2d_bwd_weight_parts(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(geom),
+                                                  ptr(workspace), workspace.numel() * workspace.element_size(),
+                                                  self._next(), stream_ptr(stream)), "arl_conv2d_bwd_weight_parts")
+
+    def relu_bwd_bias_grad(self, dy, y, rows, channels, dbias, workspace, stream=None):
+        _check(load().arl_relu_bwd_bias_parts(dy.data_ptr(), y.data_ptr(), rows, channels, dbias.data_ptr(),
+                                              ptr(workspace), self._next(), stream_ptr(stream)),
+               "arl_relu_bwd_bias_parts")
+
+    def run(self, stream=None):
+        n, self._n = self._n, 0
+        _check(load().arl_fold_many(self._items, n, stream_ptr(stream)), "arl_fold_many")
 
 
 # ---------------------------------------------------------------------------

@@ -387,8 +387,8 @@ extern "C" int64_t arl_pg_head_workspace_bytes(void) {
     return (int64_t)(256 * 4 + WG_SPLITS * (K_MAX + 1) * HID_MAX + (K_MAX + 1) * HID_MAX) * sizeof(float);
 }
 
-extern "C" int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, int32_t channels,
-                                      float* dbias, void* workspace, void* stream) {
+static int relu_bwd_bias_launch(float* dy, const float* y, int64_t rows, int32_t channels, float* dbias,
+                                void* workspace, int* n_partials, void* stream) {
     ARL_REQUIRE(dy && y && dbias && workspace, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(rows > 0 && channels > 0 && (channels & 3) == 0 && channels <= HID_MAX, ARL_E_RANGE,
                 "channels must be a multiple of 4 and <= 1024");
@@ -399,11 +399,27 @@ extern "C" int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, i
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(relu_bwd_bias_kernel, dim3((unsigned)grid), dim3(256), 0, s, (float4*)dy,
                        (const float4*)y, rows, c4, (float4*)workspace);
-    int rc = arl::check_launch("relu_bwd_bias_kernel");
+    *n_partials = (int)grid;
+    return arl::check_launch("relu_bwd_bias_kernel");
+}
+
+extern "C" int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, int32_t channels,
+                                      float* dbias, void* workspace, void* stream) {
+    int grid = 0;
+    int rc = relu_bwd_bias_launch(dy, y, rows, channels, dbias, workspace, &grid, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3((channels + 63) / 64), dim3(1024), 0, s,
-                       (const float*)workspace, (int)grid, (int)channels, dbias);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3((channels + 63) / 64), dim3(1024), 0, (hipStream_t)stream,
+                       (const float*)workspace, grid, (int)channels, dbias);
     return arl::check_launch("fold_partials_kernel");
+}
+
+extern "C" int arl_relu_bwd_bias_parts(float* dy, const float* y, int64_t rows, int32_t channels, float* dbias,
+                                       void* workspace, arl_fold_item* item, void* stream) {
+    ARL_REQUIRE(item, ARL_E_ARG, "null pointer");
+    int grid = 0;
+    int rc = relu_bwd_bias_launch(dy, y, rows, channels, dbias, workspace, &grid, stream);
+    item->part = (const float*)workspace; item->out = dbias; item->total = channels; item->splits = grid;
+    return rc;
 }
 
 static int check_head(int64_t batch, int32_t hid, int32_t n_act) {

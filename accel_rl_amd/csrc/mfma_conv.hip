@@ -977,6 +977,42 @@ __global__ __launch_bounds__(256) void fold_splits_kernel(const float4* __restri
     }
 }
 
+// Several independent folds in one launch (arl_fold_many): block -> (item, 16 output float4s) through
+// a block-offset table in the kernel arguments; per item the same fixed summation order as above.
+struct FoldManyArgs {
+    arl_fold_item items[ARL_FOLD_MAX_ITEMS];
+    int block_start[ARL_FOLD_MAX_ITEMS + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void fold_many_kernel(const FoldManyArgs a) {
+    __shared__ float4 lds[16][16];
+    int it = 0;
+    while (it + 1 < a.n && (int)blockIdx.x >= a.block_start[it + 1]) ++it;      // uniform
+    const float4* part = reinterpret_cast<const float4*>(a.items[it].part);
+    float4* out = reinterpret_cast<float4*>(a.items[it].out);
+    const int64_t total4 = a.items[it].total >> 2;
+    const int splits = a.items[it].splits;
+    const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
+    const int64_t i = (int64_t)((int)blockIdx.x - a.block_start[it]) * 16 + o;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < total4)
+        for (int z = zg; z < splits; z += 16) {
+            const float4 v = part[(int64_t)z * total4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    lds[zg][o] = s;
+    __syncthreads();
+    if (zg == 0 && i < total4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float4 v = lds[k][o];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        out[i] = s;
+    }
+}
+
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool TAP_UNIFORM = false>
 int launch_rowgather(const GemmArgs& a, int splits, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
@@ -1245,8 +1281,10 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
     return 0;
 }
 
-extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
-                                     void* workspace, void* stream) {
+namespace {
+// weight gradient; with more than one row split the partials go to `workspace` and *splits_out > 1
+int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
+               int64_t workspace_bytes, int* splits_out, int64_t* total_out, void* stream) {
     ARL_REQUIRE(dy && x && dw && workspace, ARL_E_ARG, "null pointer");
     Geom g;
     int rc = check_geom(geom, &g);
@@ -1271,7 +1309,7 @@ extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw,
     a.m_per_split = per;
     const int64_t total = (int64_t)a.K_out * a.N;
     if (splits > 1) {
-        ARL_REQUIRE((int64_t)splits * total * 4 <= arl_conv_workspace_bytes(), ARL_E_RANGE, "workspace too small");
+        ARL_REQUIRE((int64_t)splits * total * 4 <= workspace_bytes, ARL_E_RANGE, "workspace too small");
         a.part = (float*)workspace;
     } else {
         a.part = dw;
@@ -1296,6 +1334,49 @@ extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw,
         else if (g.K <= 64) rc = launch_wgrad<2, 2, 1, 1, 16>(a, splits, s);
         else rc = launch_wgrad<2, 2, 2, 2, 16>(a, splits, s);
     }
+    *splits_out = splits;
+    *total_out = total;
+    return rc;
+}
+}  // namespace
+
+extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
+                                     void* workspace, void* stream) {
+    int splits = 1;
+    int64_t total = 0;
+    int rc = wgrad_impl(dy, x, dw, geom, workspace, arl_conv_workspace_bytes(), &splits, &total, stream);
     if (rc || splits == 1) return rc;
-    return launch_fold((const float*)workspace, splits, total, nullptr, 4, 0, dw, s);
+    return launch_fold((const float*)workspace, splits, total, nullptr, 4, 0, dw, (hipStream_t)stream);
+}
+
+extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
+                                           void* workspace, int64_t workspace_bytes, arl_fold_item* item,
+                                           void* stream) {
+    ARL_REQUIRE(item, ARL_E_ARG, "null pointer");
+    int splits = 1;
+    int64_t total = 0;
+    int rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total, stream);
+    item->part = (const float*)workspace; item->out = dw; item->total = total;
+    item->splits = splits > 1 ? splits : 0;             // 0: dw is already final
+    return rc;
+}
+
+extern "C" int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream) {
+    ARL_REQUIRE(items || n == 0, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(n >= 0 && n <= ARL_FOLD_MAX_ITEMS, ARL_E_RANGE, "too many fold items");
+    FoldManyArgs a = {};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (items[i].splits <= 0) continue;
+        ARL_REQUIRE(items[i].part && items[i].out && items[i].total > 0 && (items[i].total & 3) == 0, ARL_E_ARG,
+                    "fold item: null pointer or length not a multiple of 4");
+        ARL_REQUIRE(arl::aligned16(items[i].part) && arl::aligned16(items[i].out), ARL_E_ALIGN, "16-byte alignment");
+        a.items[a.n] = items[i];
+        a.block_start[a.n++] = blocks;
+        blocks += (int)(((items[i].total >> 2) + 15) / 16);
+    }
+    if (a.n == 0) return 0;
+    a.block_start[a.n] = blocks;
+    hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return arl::check_launch("fold_many_kernel");
 }

@@ -144,6 +144,7 @@ class AtariCnnPolicy(object):
         self._dist = Categorical(n_act)
         self._scale = float(np.float32(1. / self.pixel_scale))
         self._relu_ws = _lib.relu_bwd_workspace(self.device)
+        self._folds, self._fold_workspaces = _lib.FoldList(), {}
         self._loss_ws = _lib.pg_head_workspace(self.device)
         self._set_from_reference_arrays(ref)
         if self.initial_param_values is not None:
@@ -331,14 +332,15 @@ class AtariCnnPolicy(object):
         g = self.grads
         conv_g, dense_g = self._layer_geoms(b)
         w, ws = self._w, self._conv_ws
-        # ---- dense layers, last to first
+        # ---- dense layers, last to first; the split folds of the whole pass run once, at the end
         d_cur = dh
+        folds = self._folds
         for j in range(self._n_hid - 1, -1, -1):
             k = 2 * (self._n_conv + j)
             hs, fan_in = self._hid_geom[j]
-            _lib.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._relu_ws)
+            folds.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._fold_ws(("db", k)))
             inp = hids[j - 1] if j > 0 else acts[-1]
-            _lib.conv2d_bwd_weight(d_cur, inp, self._g[k], dense_g[j], ws)
+            folds.conv2d_bwd_weight(d_cur, inp, self._g[k], dense_g[j], self._fold_ws(("dw", k)))
             d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
             _lib.conv2d_bwd_data(d_cur, w[k], None, d_prev, dense_g[j])
             d_cur = d_prev
@@ -347,17 +349,27 @@ class AtariCnnPolicy(object):
     def _backward_convs(self, x, acts, d_act):
         """Conv layers, last to first; d_act = NHWC gradient of the last conv output (before its relu mask)."""
         b = x.shape[0]
-        g, w, ws = self.grads, self._w, self._conv_ws
+        g, w = self.grads, self._w
         conv_g, _ = self._layer_geoms(b)
+        folds = self._folds
         for i in range(self._n_conv - 1, -1, -1):
             nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
-            _lib.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._relu_ws)
+            folds.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._fold_ws(("db", 2 * i)))
             inp = acts[i - 1] if i > 0 else x
-            _lib.conv2d_bwd_weight(d_act, inp, self._g[2 * i], conv_g[i], ws)
+            folds.conv2d_bwd_weight(d_act, inp, self._g[2 * i], conv_g[i], self._fold_ws(("dw", 2 * i)))
             if i > 0:
                 d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape))
                 _lib.conv2d_bwd_data(d_act, w[2 * i], None, d_in, conv_g[i])
                 d_act = d_in
+        folds.run()
+
+    def _fold_ws(self, key):
+        """One workspace per pending fold (the partials stay live until folds.run())."""
+        ws = self._fold_workspaces.get(key)
+        if ws is None:
+            ws = self._fold_workspaces[key] = (_lib.relu_bwd_workspace(self.device) if key[0] == "db"
+                                               else _lib.conv_workspace(self.device))
+        return ws
 
     def dist_info_value_sym(self, obs_u8, idx=None):
         """Training-time forward through autograd (explicit=False path)."""

@@ -243,6 +243,23 @@ int arl_bias_relu(float* x, const float* bias, int64_t rows, int32_t channels, v
 int64_t arl_relu_bwd_workspace_bytes(void);
 int arl_relu_bwd_bias_grad(float* dy, const float* y, int64_t rows, int32_t channels,
                            float* dbias, void* workspace, void* stream);
+/* Deferred folds.  The weight-gradient and bias-gradient kernels write per-split partial sums; the
+ * *_parts entry points stop there and describe the pending fold in *item (splits == 0: `out` is already
+ * final), so that a whole backward pass ends in ONE arl_fold_many launch instead of one small fold
+ * kernel per tensor.  Each item needs its own workspace region, live until arl_fold_many has run;
+ * out[i] = sum_z part[z*total + i] in a fixed order (bit-reproducible). */
+typedef struct arl_fold_item {
+    const float* part;      /* f32[splits][total] */
+    float*       out;       /* f32[total], 16-byte aligned */
+    int64_t      total;     /* multiple of 4 */
+    int32_t      splits;
+    int32_t      reserved;
+} arl_fold_item;
+#define ARL_FOLD_MAX_ITEMS 24
+
+/* Same, leaving the column-sum fold to arl_fold_many (see arl_fold_item). */
+int arl_relu_bwd_bias_parts(float* dy, const float* y, int64_t rows, int32_t channels, float* dbias,
+                            void* workspace, arl_fold_item* item, void* stream);
 
 /* Policy / value heads + softmax for action serving: prob = softmax(h W_pi^T + b),
  * value = h w_v + b_v.  Replaces the output layers of _f_prob_value,
@@ -321,6 +338,11 @@ int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_nu
  * folded in a fixed order (no atomics).                                           */
 int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
                           void* workspace, void* stream);
+
+/* Deferred-fold variant (arl_fold_item above). */
+int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
+                                void* workspace, int64_t workspace_bytes, arl_fold_item* item, void* stream);
+int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Replay memory of the DQN family
