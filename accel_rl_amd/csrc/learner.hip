@@ -163,7 +163,22 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
     extern __shared__ __attribute__((aligned(16))) float s_w[];     // [K][hid]
     __shared__ float s_loss[4][4];
     const int A = a.n_act, K = A + 1, hid = a.hid, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < K * hid; i += blockDim.x) s_w[i] = a.w_head[i];
+    if (((K * hid) & 3) || (reinterpret_cast<uintptr_t>(a.w_head) & 15)) {
+        for (int i = threadIdx.x; i < K * hid; i += blockDim.x) s_w[i] = a.w_head[i];
+    } else {    // stage W: independent b128 loads, four in flight per thread
+        const int n4 = (K * hid) >> 2;
+        const float4* src = reinterpret_cast<const float4*>(a.w_head);
+        float4* dst = reinterpret_cast<float4*>(s_w);
+        for (int i0 = threadIdx.x; i0 < n4; i0 += 4 * 256) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < n4) v[u] = src[i0 + u * 256];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u * 256 < n4) dst[i0 + u * 256] = v[u];
+        }
+    }
     __syncthreads();
     const float TINY = 1e-8f;                                        // categorical.py:6
     const float inv_n = TRAIN ? (a.inv_count ? a.inv_count[0] : 1.f / (float)a.batch) : 0.f;
@@ -187,48 +202,40 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
                 out[k] = wave_sum_f(sdot) + a.b_head[k];
             }
         }
-        float v = 0.f, mx = -3.0e38f;
+        // Lane k owns action k (lane A the value): the transcendental work is done once per action, not
+        // once per lane; sums over actions stay sequential in k (readlane), i.e. in a fixed order.
+        float v = 0.f, mx = -3.0e38f, mine = 0.f;
 #pragma unroll
         for (int k = 0; k < K_MAX; ++k) {
             if (k < A) mx = fmaxf(mx, out[k]);
             if (k == A) v = out[k];
+            if (k < K) mine = (lane == k) ? out[k] : mine;
         }
-        float p[ARL_MAX_ACTIONS], z = 0.f;
+        const bool is_act = lane < A;
+        const float ex = is_act ? expf(mine - mx) : 0.f;
+        float z = 0.f;
 #pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) {
-            p[k] = (k < A) ? expf(out[k] - mx) : 0.f;
-            z += p[k];
-        }
-#pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) p[k] = p[k] / z;
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
+            if (k < A) z += __shfl(ex, k, 64);
+        const float pk = ex / z;
         if (!TRAIN) {
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
-                    if (k < A) prob_out[(int64_t)b * A + k] = p[k];
-                value_out[b] = v;
-            }
+            if (is_act) prob_out[(int64_t)b * A + lane] = pk;
+            if (lane == 0) value_out[b] = v;
             continue;
         }
         const int64_t row = a.idx ? (int64_t)a.idx[b] : b;
         const float w = (a.valids ? (a.valids[row] != 0 ? 1.f : 0.f) : 1.f) * inv_n;   // valids_mean
         const int act = a.actions[row];
         const float adv = a.adv[row], ret = a.ret[row];
-        float pa = 0.f;
-#pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) pa = (k == act) ? p[k] : pa;
+        const float pa = __shfl(pk, act, 64);
         // ---- d loss / d p_k : entropy term for every action (categorical.py:76-78)
-        float g[ARL_MAX_ACTIONS];
+        const float lg = is_act ? logf(pk + TINY) : 0.f;
+        const float ent_k = pk * lg;
+        float gk = is_act ? a.ent_coeff * w * (lg + pk / (pk + TINY)) : 0.f;     // d(-c_e * ent)/dp_k
         float ent = 0.f;
 #pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) {
-            g[k] = 0.f;
-            if (k < A) {
-                const float lg = logf(p[k] + TINY);
-                ent -= p[k] * lg;
-                g[k] = a.ent_coeff * w * (lg + p[k] / (p[k] + TINY));    // d(-c_e * ent)/dp_k
-            }
-        }
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
+            if (k < A) ent -= __shfl(ent_k, k, 64);
         float pi_term, g_act;
         if (a.kind == 1) {                                               // PPO, ppo.py:42-51
             const float old_pa = a.old_prob[row * A + act];
@@ -245,23 +252,18 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
             g_act = -w * adv / (pa + TINY);
         }
         const float dv = 2.f * a.v_coeff * w * (v - ret);                // aac_base.py:60-61
+        gk += (lane == act) ? g_act : 0.f;
+        const float gp = gk * pk;
         float dot = 0.f;
 #pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k) {
-            g[k] += (k == act) ? g_act : 0.f;
-            dot += g[k] * p[k];
-        }
-        float dl[K_MAX];                                                 // softmax backward
+        for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
+            if (k < A) dot += __shfl(gp, k, 64);
+        const float dlk = is_act ? pk * (gk - dot) : (lane == A ? dv : 0.f);      // softmax backward | value
+        if (lane < K) a.dout[(int64_t)b * K + lane] = dlk;
+        float dl[K_MAX];
 #pragma unroll
-        for (int k = 0; k < K_MAX; ++k) {
-            dl[k] = 0.f;
-            if (k < ARL_MAX_ACTIONS && k < A) dl[k] = p[k < ARL_MAX_ACTIONS ? k : 0] * (g[k < ARL_MAX_ACTIONS ? k : 0] - dot);
-            if (k == A) dl[k] = dv;
-        }
+        for (int k = 0; k < K_MAX; ++k) dl[k] = (k < K) ? __shfl(dlk, k, 64) : 0.f;
         if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < K_MAX; ++k)
-                if (k < K) a.dout[(int64_t)b * K + k] = dl[k];
             l_pi += -w * pi_term;
             l_v += a.v_coeff * w * (v - ret) * (v - ret);
             l_ent += -a.ent_coeff * w * ent;
@@ -342,8 +344,29 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
 
 // Fold the head weight-gradient partials straight into the gradient bucket: rows 0..K-1 of the staged
 // [(K+1)][hid] matrix -> dw_head, row K (first K columns) -> db_head; fixed summation order.
+// The last block instead folds the per-workgroup loss partials [n_loss][4] into loss4 (16 interleaved
+// chains per component, then a fixed-order sum).
 __global__ __launch_bounds__(256) void head_fold_kernel(const float* __restrict__ part, int splits, int K, int hid,
-                                                        float* __restrict__ dw, float* __restrict__ db) {
+                                                        float* __restrict__ dw, float* __restrict__ db,
+                                                        const float* __restrict__ loss_part, int n_loss,
+                                                        float* __restrict__ loss4) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ float l[16][4];
+        const int c = threadIdx.x & 3, lanes = threadIdx.x >> 2;
+        if (lanes < 16) {
+            float s = 0.f;
+            for (int g = lanes; g < n_loss; g += 16) s += loss_part[g * 4 + c];
+            l[lanes][c] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += l[w][threadIdx.x];
+            loss4[threadIdx.x] = s;
+        }
+        return;
+    }
     const int width = (K + 1) * hid;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K * hid + K) return;
@@ -472,9 +495,6 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
     rc = arl::check_launch("head_kernel<train>");
     if (rc) return rc;
     float* ws = (float*)workspace;
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(1024), 0, s, (const float*)ws, grid, 4, loss4);
-    rc = arl::check_launch("fold_partials_kernel");
-    if (rc) return rc;
     // head weight / bias gradient: row-split partials, then one fold into a staging
     // matrix [(K+1)][hid]; rows 0..K-1 -> dw_head, row K (first K columns) -> db_head
     float* part = ws + 256 * 4;
@@ -483,8 +503,8 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
                        (size_t)rows_per * K * 4, s, dout, h, (int)batch, (int)hid, K, part);
     rc = arl::check_launch("head_wgrad_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(head_fold_kernel, dim3((K * hid + K + 255) / 256), dim3(256), 0, s, (const float*)part,
-                       WG_SPLITS, K, (int)hid, dw_head, db_head);
+    hipLaunchKernelGGL(head_fold_kernel, dim3((K * hid + K + 255) / 256 + 1), dim3(256), 0, s, (const float*)part,
+                       WG_SPLITS, K, (int)hid, dw_head, db_head, (const float*)ws, grid, loss4);
     rc = arl::check_launch("head_fold_kernel");
     if (rc) return rc;
     return 0;
