@@ -104,6 +104,8 @@ _SIGNATURES = {
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
     "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem), _vp]),
     "arl_fold_many": (_i32, [C.POINTER(ArlFoldItem), _i32, _vp]),
+    "arl_conv2d_bwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
+                                   C.POINTER(ArlFoldItem), _vp]),
     "arl_relu_bwd_bias_parts": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_replay_append": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _vp, _vp, _i32, _i32, _f64, _i32, _vp]),
     "arl_replay_extract": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -408,6 +410,17 @@ class FoldList(object):
         _check(load().arl_conv2d_bwd_weight_parts(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(geom),
                                                   ptr(workspace), workspace.numel() * workspace.element_size(),
                                                   self._next(), stream_ptr(stream)), "arl_conv2d_bwd_weight_parts")
+
+    def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, stream=None):
+        """dx and (deferred) dw of one layer in a single launch."""
+        ho, wo = conv_out_hw(geom)
+        assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
+        assert x.numel() == dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x / dx size"
+        assert dw.numel() == w.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w / dw size"
+        _check(load().arl_conv2d_bwd_pair(dy.data_ptr(), w.data_ptr(), ptr(mask), dx.data_ptr(), x.data_ptr(),
+                                          dw.data_ptr(), C.byref(geom), ptr(workspace),
+                                          workspace.numel() * workspace.element_size(), self._next(),
+                                          stream_ptr(stream)), "arl_conv2d_bwd_pair")
 
     def relu_bwd_bias_grad(self, dy, y, rows, channels, dbias, workspace, stream=None):
         _check(load().arl_relu_bwd_bias_parts(dy.data_ptr(), y.data_ptr(), rows, channels, dbias.data_ptr(),

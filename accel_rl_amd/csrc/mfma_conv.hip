@@ -559,7 +559,7 @@ __device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned v
 }
 
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
+__device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* smem) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, CH = BK / 4;
     constexpr int LDA = BK + 4;
     constexpr int LDB = B_KC ? BK + 4 : BN;
@@ -569,24 +569,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
     constexpr int RB = (NB4 + 255) / 256;
     static_assert(WGM * WGN == 4 && BM % ROWS_PER_PASS == 0 && BK % 8 == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sA = smem;
     float* sB = smem + 2 * A_SZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = bx * BM, n0 = by * BN;
     GatherDesc g = a.g;
     int M = a.M, w_i0 = a.b.i0, w_j0 = a.b.j0, oadd_y = a.o.oadd_y, oadd_x = a.o.oadd_x;
     if (a.n_par) {                                  // uniform: this workgroup's parity class
-        const GemmArgs::Parity& q = a.par[blockIdx.z];
+        const GemmArgs::Parity& q = a.par[bz];
         M = q.M; g.out_h = q.out_h; g.out_w = q.out_w; g.add_y = q.add_y; g.add_x = q.add_x;
         g.rmin = q.rmin; g.dmin = q.dmin; g.origin = q.origin; g.src_bytes = q.src_bytes;
         w_i0 = q.i0; w_j0 = q.j0; oadd_y = q.oadd_y; oadd_x = q.oadd_x;
         if (m0 >= M) return;
     }
-    const int kbeg = a.n_par ? 0 : blockIdx.z * a.k_per_split;
+    const int kbeg = a.n_par ? 0 : bz * a.k_per_split;
     const int kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
     const int Cs = g.Cs, taps_x = g.taps_x, Ws = g.Ws, step = g.step;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
@@ -760,7 +759,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     }
 
     if (a.trace) tr2 = __builtin_readcyclecounter();
-    float* out = a.o.out + (a.n_par ? 0 : (int64_t)blockIdx.z * a.split_stride);
+    float* out = a.o.out + (a.n_par ? 0 : (int64_t)bz * a.split_stride);
     if (!(a.debug & 1)) {
         // operands are swapped (acc = W-tile x X-tile^T): every lane owns ONE output row per 32-row tile
         const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out, a.o.out_bytes);
@@ -780,12 +779,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
         store_tiles_quads<TM, TN>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu);
     }
     if (a.trace && tid == 0) {
-        unsigned long long* t = a.trace + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+        unsigned long long* t = a.trace + ((size_t)(bz * gridDim.y + by) * gridDim.x + bx) * 8;     // plain launches only
         t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_readcyclecounter();
         t[4] = rt0; t[5] = __builtin_amdgcn_s_memrealtime();
         t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
         t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
     }
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD>
+__global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // Weight gradient, scalar-addressed: dy advances by a uniform stride per tile (soffset); the
@@ -796,14 +801,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
 constexpr int WG_ROWS = 256;
 
 template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD>
-__global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
+__device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx, const int by, const int bz, float* smem) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
     constexpr int NA4 = BK * BM / 4, RA = (NA4 + 255) / 256, MC4 = BM / 4;
     constexpr int NC4 = BN / 4, KROWS = 256 / NC4, RB = BK / KROWS;
     constexpr int TILES_PER_GROUP = WG_ROWS / BK;
     static_assert(WGM * WGN == 4 && 256 % NC4 == 0 && BK % KROWS == 0 && BK % 8 == 0 && WG_ROWS % BK == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ uint2 s_row[2][WG_ROWS];     // per gathered row: byte offset of its tap origin, inverted tap mask
     float* sA = smem;
     float* sB = smem + 2 * A_SZ;
@@ -811,8 +815,8 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int n0 = blockIdx.x * BN, i0 = blockIdx.y * BM;
-    const int mbeg = blockIdx.z * a.m_per_split;
+    const int n0 = bx * BN, i0 = by * BM;
+    const int mbeg = bz * a.m_per_split;
     const int mend = (mbeg + a.m_per_split < a.Mred) ? mbeg + a.m_per_split : a.Mred;
     const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.dy, a.dy_bytes);
@@ -940,8 +944,32 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
         __syncthreads();
     }
 
-    float* out = a.part + (int64_t)blockIdx.z * a.K_out * a.N;
+    float* out = a.part + (int64_t)bz * a.K_out * a.N;
     store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD>
+__global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// One launch for a layer's data gradient AND weight gradient (independent of each other, both read dy):
+// workgroups [0, n_ig) run data-gradient tiles, the rest weight-gradient tiles.  One ramp-up and one
+// tail instead of two, and the dispatcher fills the CUs the first problem's last wave leaves idle.
+template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK, bool HAS_PAD>
+__global__ __launch_bounds__(256) void bwd_pair_kernel(const GemmArgs a, const WgradArgs w, const int dgx, const int dgy,
+                                                       const int n_ig, const int wgx, const int wgy) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int id = blockIdx.x;
+    if (id < n_ig) {
+        const int bx = id % dgx, t = id / dgx;
+        igemm_body<DWGM, DWGN, DTM, DTN, BK, false, false, HAS_PAD>(a, bx, t % dgy, t / dgy, smem);
+    } else {
+        id -= n_ig;
+        const int bx = id % wgx, t = id / wgx;
+        wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD>(w, bx, t % wgy, t / wgy, smem);
+    }
 }
 
 // out[i] = act(sum_z part[z][i] + bias[i % n_bias]), float4 lanes, fixed summation order:
@@ -1204,8 +1232,16 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, bias_or_null, a.N, relu, y, s);
 }
 
-extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
-                                   const arl_conv_geom* geom, void* stream) {
+namespace {
+// Fast-path launch descriptions, so that a layer's data and weight gradient can share one launch
+// (arl_conv2d_bwd_pair).  cfg: data gradient 0 = <4,1,1,1>, 1 = <2,2,2,1>, 2 = <2,2,2,2>;
+// weight gradient 0 = <1,4,1,1>, 1 = <2,2,1,1>, 2 = <2,2,2,2>.
+struct DgradPlan { GemmArgs a; bool fast, has_pad; int cfg; };
+struct WgradPlan { WgradArgs a; bool fast, has_pad; int cfg, splits; int64_t total; };
+
+// plan_only: describe the fast launch instead of issuing it (fast == false: nothing was done)
+int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float* dx, const arl_conv_geom* geom,
+               DgradPlan* plan_only, void* stream) {
     ARL_REQUIRE(dy && w && dx, ARL_E_ARG, "null pointer");
     Geom g;
     int rc = check_geom(geom, &g);
@@ -1263,11 +1299,17 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
                 }
             a.n_par = n; a.M = max_m;       // grid covers the largest class; smaller ones exit early
         }
+        if (plan_only) {
+            plan_only->a = a; plan_only->fast = true; plan_only->has_pad = has_pad;
+            plan_only->cfg = a.N <= 32 ? 0 : a.N <= 64 ? 1 : 2;
+            return 0;
+        }
         if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, false>(a, 1, false, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 2, 1, FBK, false>(a, 1, false, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
         return rc;
     }
+    if (plan_only) { plan_only->fast = false; return 0; }
     for (int ph = 0; ph < st && ph < g.H; ++ph) {
         for (int pw = 0; pw < st && pw < g.W; ++pw) {
             const GemmArgs a = describe(ph, pw);
@@ -1281,10 +1323,9 @@ extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float*
     return 0;
 }
 
-namespace {
 // weight gradient; with more than one row split the partials go to `workspace` and *splits_out > 1
 int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
-               int64_t workspace_bytes, int* splits_out, int64_t* total_out, void* stream) {
+               int64_t workspace_bytes, int* splits_out, int64_t* total_out, WgradPlan* plan_only, void* stream) {
     ARL_REQUIRE(dy && x && dw && workspace, ARL_E_ARG, "null pointer");
     Geom g;
     int rc = check_geom(geom, &g);
@@ -1326,10 +1367,17 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
         a.adv_b = WG_ROWS / img;
         a.adv_y = (WG_ROWS % img) / g.Wo;
         a.adv_x = (WG_ROWS % img) % g.Wo;
+        if (plan_only) {
+            plan_only->a = a; plan_only->fast = true; plan_only->has_pad = has_pad;
+            plan_only->cfg = g.K <= 32 ? 0 : g.K <= 64 ? 1 : 2;
+            plan_only->splits = splits; plan_only->total = total;
+            return 0;
+        }
         if (g.K <= 32) rc = launch_wgrad_fast<1, 4, 1, 1, FBK>(a, splits, has_pad, s);
         else if (g.K <= 64) rc = launch_wgrad_fast<2, 2, 1, 1, FBK>(a, splits, has_pad, s);
         else rc = launch_wgrad_fast<2, 2, 2, 2, FBK>(a, splits, has_pad, s);
     } else {
+        if (plan_only) { plan_only->fast = false; return 0; }
         if (g.K <= 32) rc = launch_wgrad<1, 4, 1, 1, 16>(a, splits, s);
         else if (g.K <= 64) rc = launch_wgrad<2, 2, 1, 1, 16>(a, splits, s);
         else rc = launch_wgrad<2, 2, 2, 2, 16>(a, splits, s);
@@ -1340,11 +1388,16 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
 }
 }  // namespace
 
+extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
+                                   const arl_conv_geom* geom, void* stream) {
+    return dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream);
+}
+
 extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
                                      void* workspace, void* stream) {
     int splits = 1;
     int64_t total = 0;
-    int rc = wgrad_impl(dy, x, dw, geom, workspace, arl_conv_workspace_bytes(), &splits, &total, stream);
+    int rc = wgrad_impl(dy, x, dw, geom, workspace, arl_conv_workspace_bytes(), &splits, &total, nullptr, stream);
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, total, nullptr, 4, 0, dw, (hipStream_t)stream);
 }
@@ -1355,9 +1408,65 @@ extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, floa
     ARL_REQUIRE(item, ARL_E_ARG, "null pointer");
     int splits = 1;
     int64_t total = 0;
-    int rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total, stream);
+    int rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total, nullptr, stream);
     item->part = (const float*)workspace; item->out = dw; item->total = total;
     item->splits = splits > 1 ? splits : 0;             // 0: dw is already final
+    return rc;
+}
+
+namespace {
+template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN>
+int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_t s) {
+    constexpr int BK = 32;
+    constexpr int DBM = DWGM * DTM * 32, DBN = DWGN * DTN * 32, WBM = WWGM * WTM * 32, WBN = WWGN * WTN * 32;
+    const size_t lds_d = (size_t)2 * (DBM * (BK + 4) + BK * DBN) * sizeof(float);
+    const size_t lds_w = (size_t)2 * BK * (WBM + WBN) * sizeof(float);
+    const size_t lds = lds_d > lds_w ? lds_d : lds_w;
+    const int dgx = (d.a.M + DBM - 1) / DBM, dgy = (d.a.N + DBN - 1) / DBN, dgz = d.a.n_par ? d.a.n_par : 1;
+    const int wgx = (w.a.N + WBN - 1) / WBN, wgy = (w.a.K_out + WBM - 1) / WBM, wgz = w.splits;
+    const int n_ig = dgx * dgy * dgz, n_wg = wgx * wgy * wgz;
+    int rc;
+    if (has_pad) {
+        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, true>;
+        rc = allow_big_lds(k, lds + 4096);
+        if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy);
+    } else {
+        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, false>;
+        rc = allow_big_lds(k, lds + 4096);
+        if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy);
+    }
+    return rc ? rc : arl::check_launch("bwd_pair_kernel");
+}
+
+}  // namespace
+
+extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
+                                   const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
+                                   int64_t workspace_bytes, arl_fold_item* item, void* stream) {
+    ARL_REQUIRE(item && geom, ARL_E_ARG, "null pointer");
+    DgradPlan dp = {};
+    WgradPlan wp = {};
+    int splits = 1;
+    int64_t total = 0;
+    int rc = dgrad_impl(dy, w, mask_or_null, dx, geom, &dp, stream);
+    if (rc) return rc;
+    rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total, &wp, stream);
+    if (rc) return rc;
+    const bool has_pad = dp.has_pad || wp.has_pad;
+    // Only the widest tile configuration pairs up: a shared launch runs every workgroup at the larger of the
+    // two LDS / register footprints, which costs the smaller-tile weight-gradient kernels their occupancy
+    // (measured: conv 2 / conv 3 pairs 9-18 us slower than apart, the dense pair 11 us faster).
+    const bool paired = dp.fast && wp.fast && dp.cfg == 2 && wp.cfg == 2 &&
+                        (!has_pad || geom->kh * geom->kw <= 32) && !g_trace;
+    if (!paired) {
+        rc = arl_conv2d_bwd_data(dy, w, mask_or_null, dx, geom, stream);
+        if (rc) return rc;
+        return arl_conv2d_bwd_weight_parts(dy, x, dw, geom, workspace, workspace_bytes, item, stream);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2>(dp, wp, has_pad, s);
+    item->part = (const float*)workspace; item->out = dw; item->total = wp.total;
+    item->splits = wp.splits > 1 ? wp.splits : 0;
     return rc;
 }
 

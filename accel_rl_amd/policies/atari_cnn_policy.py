@@ -340,9 +340,8 @@ class AtariCnnPolicy(object):
             hs, fan_in = self._hid_geom[j]
             folds.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._fold_ws(("db", k)))
             inp = hids[j - 1] if j > 0 else acts[-1]
-            folds.conv2d_bwd_weight(d_cur, inp, self._g[k], dense_g[j], self._fold_ws(("dw", k)))
             d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
-            _lib.conv2d_bwd_data(d_cur, w[k], None, d_prev, dense_g[j])
+            folds.conv2d_bwd_pair(d_cur, w[k], None, d_prev, inp, self._g[k], dense_g[j], self._fold_ws(("dw", k)))
             d_cur = d_prev
         self._backward_convs(x, acts, d_cur)
 
@@ -355,12 +354,13 @@ class AtariCnnPolicy(object):
         for i in range(self._n_conv - 1, -1, -1):
             nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
             folds.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._fold_ws(("db", 2 * i)))
-            inp = acts[i - 1] if i > 0 else x
-            folds.conv2d_bwd_weight(d_act, inp, self._g[2 * i], conv_g[i], self._fold_ws(("dw", 2 * i)))
-            if i > 0:
+            if i > 0:               # data + weight gradient of the layer share one launch
                 d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape))
-                _lib.conv2d_bwd_data(d_act, w[2 * i], None, d_in, conv_g[i])
+                folds.conv2d_bwd_pair(d_act, w[2 * i], None, d_in, acts[i - 1], self._g[2 * i], conv_g[i],
+                                      self._fold_ws(("dw", 2 * i)))
                 d_act = d_in
+            else:
+                folds.conv2d_bwd_weight(d_act, x, self._g[2 * i], conv_g[i], self._fold_ws(("dw", 2 * i)))
         folds.run()
 
     def _fold_ws(self, key):

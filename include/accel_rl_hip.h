@@ -344,6 +344,15 @@ int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, cons
                                 void* workspace, int64_t workspace_bytes, arl_fold_item* item, void* stream);
 int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream);
 
+/* A layer's data gradient and weight gradient (deferred fold) as ONE launch: the two are independent
+ * and both read dy, so their workgroups share a grid -- one ramp-up and one tail instead of two, and
+ * the second problem's workgroups fill the CUs the first one's last wave leaves idle.  Same results as
+ * arl_conv2d_bwd_data + arl_conv2d_bwd_weight_parts (which it falls back to when either side is not
+ * on the scalar-addressed fast path). */
+int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
+                        const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
+                        int64_t workspace_bytes, arl_fold_item* item, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Replay memory of the DQN family
  * ------------------------------------------------------------------------- */

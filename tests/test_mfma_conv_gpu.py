@@ -157,6 +157,28 @@ def test_adjoint_identities_at_full_size(case):
         assert abs(dot(x, dx) - ref) <= 1e-5 * scale, (case, ref, dot(x, dx))
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if c[5] % c[6] == 0] + ODD_CASES +
+                         [(20, 12, 9, 128, 96, 3, 1, 1)])      # wide conv: shares a launch like the dense layers
+@pytest.mark.parametrize("masked", [False, True])
+def test_paired_backward_is_the_two_separate_calls(case, masked):
+    """arl_conv2d_bwd_pair (one launch, deferred fold) == arl_conv2d_bwd_data + arl_conv2d_bwd_weight, bit for
+    bit: the same tiles in the same order, only co-scheduled (or the documented fallback for odd shapes)."""
+    from accel_rl_amd import _lib
+    x, wt, bias, geom, ws = _mk(case, seed=3)
+    ho, wo = _lib.conv_out_hw(geom)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    dy = torch.randn(case[0], ho, wo, case[4], device=DEV, generator=gen)
+    mask = torch.randn(x.shape, device=DEV, generator=gen) if masked else None
+    dx0, dw0 = torch.full_like(x, float("nan")), torch.full_like(wt, float("nan"))
+    _lib.conv2d_bwd_data(dy, wt, mask, dx0, geom)
+    _lib.conv2d_bwd_weight(dy, x, dw0, geom, ws)
+    dx1, dw1 = torch.full_like(x, float("nan")), torch.full_like(wt, float("nan"))
+    folds, ws2 = _lib.FoldList(), _lib.conv_workspace(DEV)
+    folds.conv2d_bwd_pair(dy, wt, mask, dx1, x, dw1, geom, ws2)
+    folds.run()
+    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+
+
 def test_argument_errors():
     from accel_rl_amd import _lib
     x, wt, bias, geom, ws = _mk((2, 12, 9, 64, 64, 3, 1, 1))
