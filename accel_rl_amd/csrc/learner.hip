@@ -40,12 +40,19 @@ __global__ __launch_bounds__(256) void gather_nhwc4_kernel(const uint8_t* __rest
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             w[c] = *reinterpret_cast<const uint32_t*>(obs + src + (int64_t)c * plane + (q << 2));
-        float4* o = reinterpret_cast<float4*>(out) + (b * plane + (q << 2));
+        // The 4 lanes of a quad hold 16 consecutive pixels (same image: plane % 16 == 0 keeps quads inside
+        // one row of groups).  Transposed inside the quad, store p of lane j writes pixel 4p + j, so every
+        // store instruction covers whole 64-byte runs instead of 16-byte pieces of four different ones.
+        const int j = threadIdx.x & 3;
+        float4* o = reinterpret_cast<float4*>(out) + (b * plane + ((q & ~3) << 2)) + j;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            const int sh = p * 8;
-            o[p] = make_float4((float)((w[0] >> sh) & 255u) * scale, (float)((w[1] >> sh) & 255u) * scale,
-                               (float)((w[2] >> sh) & 255u) * scale, (float)((w[3] >> sh) & 255u) * scale);
+            uint32_t v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                v[c] = (uint32_t)__shfl((int)w[c], (threadIdx.x & ~3) | p, 64) >> (8 * j);
+            o[4 * p] = make_float4((float)(v[0] & 255u) * scale, (float)(v[1] & 255u) * scale,
+                                   (float)(v[2] & 255u) * scale, (float)(v[3] & 255u) * scale);
         }
     }
 }
@@ -385,7 +392,7 @@ extern "C" int arl_gather_scale_obs_nhwc(const uint8_t* obs, const int32_t* idx_
     ARL_REQUIRE(obs && out, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(batch >= 0 && plane_bytes > 0, ARL_E_ARG, "bad batch/plane");
     ARL_REQUIRE(channels == 4, ARL_E_RANGE, "NHWC gather is specialised for 4 stacked frames");
-    ARL_REQUIRE((plane_bytes & 3) == 0, ARL_E_RANGE, "plane_bytes must be a multiple of 4");
+    ARL_REQUIRE((plane_bytes & 15) == 0, ARL_E_RANGE, "plane_bytes must be a multiple of 16");
     ARL_REQUIRE(arl::aligned4(obs) && arl::aligned16(out), ARL_E_ALIGN, "obs 4-byte, out 16-byte aligned");
     if (batch == 0) return 0;
     hipLaunchKernelGGL(gather_nhwc4_kernel, dim3(arl::stream_grid(batch * (plane_bytes >> 2), 256)),

@@ -228,7 +228,7 @@ int arl_gather_scale_obs(const uint8_t* obs, const int32_t* idx_or_null, int64_t
 
 /* Channels-last variant of arl_gather_scale_obs for the conv stack:
  * obs u8[n_rows][channels][plane_bytes] -> out f32[batch][plane_bytes][channels].
- * channels must be 4 (the 4-frame stack, atari_env.py:21).                      */
+ * channels must be 4 (the 4-frame stack, atari_env.py:21), plane_bytes % 16 == 0. */
 int arl_gather_scale_obs_nhwc(const uint8_t* obs, const int32_t* idx_or_null, int64_t batch,
                               int32_t channels, int32_t plane_bytes, float scale, float* out,
                               void* stream);
