@@ -1346,7 +1346,10 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
     else { bm = 128; bn = 128; }
     const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     int splits, per;
-    plan_split(tiles, a.Mred, &splits, &per);
+    // Row splits: the 128x128 configuration is MFMA-bound at one workgroup per CU (and its partials are
+    // large); the small-tile ones need two to three resident workgroups per CU to cover their barrier
+    // and load latencies (measured at the PPO minibatch: 256 -> 512 workgroups, 57 -> 50 us).
+    plan_split(tiles, a.Mred, &splits, &per, g.K <= 32 ? 2 * TARGET_WGS : g.K <= 64 ? 3 * TARGET_WGS : TARGET_WGS);
     a.m_per_split = per;
     const int64_t total = (int64_t)a.K_out * a.N;
     if (splits > 1) {
