@@ -1194,7 +1194,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     a.o.dense = 1; a.trace = g_trace; a.debug = debug_flags();
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
-    if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 2 * TARGET_WGS);
+    if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
     a.k_per_split = per;
     if (splits > 1) {
         ARL_REQUIRE((int64_t)splits * a.M * a.N * 4 <= arl_conv_workspace_bytes(), ARL_E_RANGE, "workspace too small");
