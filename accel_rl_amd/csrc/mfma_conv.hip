@@ -1218,7 +1218,10 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         // Small tiles keep the LDS footprint low enough for 3-4 workgroups per CU: with one wave per
         // SIMD the barrier, load and LDS latencies of each k-tile sit exposed between MFMA bursts
         // (64x64 instead of 128x64 tiles at N = 64: 46.8 -> 45.0 us, 50.6 -> 48.2 us at the PPO minibatch)
-        if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        // (the 128x32 tile at BK = 32 would allow only 3: a 16-wide k-tile, 5-6 resident, is 3-5 us faster)
+        if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
+            rc = launch_igemm<4, 1, 1, 1, 16, true>(a, splits, multi_tap, has_pad, s);
+        else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, true>(a, splits, multi_tap, has_pad, s);
@@ -1304,7 +1307,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             plan_only->cfg = a.N <= 32 ? 0 : a.N <= 64 ? 1 : 2;
             return 0;
         }
-        if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, false>(a, 1, false, has_pad, s);
+        if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, 1, false, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
         return rc;
