@@ -95,17 +95,18 @@ _SIGNATURES = {
     "arl_relu_bwd_bias_grad": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "arl_pg_head_workspace_bytes": (_i64, []),
     "arl_pg_head_infer": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32] + [_vp] * 7),
+    "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 7),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv_trace_buffer": (None, [_vp]),
     "arl_conv_force_generic": (None, [_i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
-    "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem), _vp]),
+    "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem),
+                                           _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_fold_many": (_i32, [C.POINTER(ArlFoldItem), _i32, _vp]),
     "arl_conv2d_bwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
-                                   C.POINTER(ArlFoldItem), _vp]),
+                                   C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_relu_bwd_bias_parts": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_replay_append": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _vp, _vp, _i32, _i32, _f64, _i32, _vp]),
     "arl_replay_extract": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -328,12 +329,13 @@ def pg_head_infer(h, w_head, b_head, prob, value, stream=None):
 
 def pg_head_loss(h, w_head, b_head, actions, advantages, returns, old_prob, valids, idx, lr_mult,
                  inv_count, n_actions, kind, clip_param, v_loss_coeff, ent_loss_coeff,
-                 dout, dh, dw_head, db_head, loss4, workspace, stream=None):
+                 dout, dh, dw_head, db_head, loss4, workspace, stream=None, relu_mask_dh=False):
+    """relu_mask_dh: h is a rectifier's output; return dh already multiplied by (h > 0)."""
     batch, hid = h.shape
     _check(load().arl_pg_head_loss(
         ptr(h), w_head.data_ptr(), b_head.data_ptr(), ptr(actions), ptr(advantages), ptr(returns),
         ptr(old_prob), ptr(valids), ptr(idx), ptr(lr_mult), ptr(inv_count), batch, hid, n_actions,
-        kind, float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), ptr(dout), ptr(dh),
+        kind, float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), int(bool(relu_mask_dh)), ptr(dout), ptr(dh),
         dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), stream_ptr(stream)),
         "arl_pg_head_loss")
 
@@ -402,25 +404,48 @@ class FoldList(object):
         self._n += 1
         return C.byref(self._items[self._n - 1])
 
-    def conv2d_bwd_weight(self, dy, x, dw, geom, workspace, stream=None):
+    def _bias_slot(self, dbias):
+        """(dbias pointer, item pointer) for the optional bias-gradient partials of a weight-gradient call."""
+        if dbias is None:
+            return None, None
+        return dbias.data_ptr(), self._next()
+
+    def _bias_done(self, dbias):
+        """False when the kernel could not produce the bias partials (generic path): drop the slot."""
+        if dbias is None:
+            return True
+        if self._items[self._n - 1].splits < 0:
+            self._n -= 1
+            return False
+        return True
+
+    def conv2d_bwd_weight(self, dy, x, dw, geom, workspace, dbias=None, stream=None):
+        """dw partials (and, with dbias, the column sums of dy) for the deferred fold.  Returns False when
+        dbias was asked for but not produced (the caller then uses relu_bwd_bias_grad)."""
         ho, wo = conv_out_hw(geom)
         assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
         assert x.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x size"
         assert dw.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "dw size"
+        item = self._next()
+        pb, ib = self._bias_slot(dbias)
         _check(load().arl_conv2d_bwd_weight_parts(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(geom),
                                                   ptr(workspace), workspace.numel() * workspace.element_size(),
-                                                  self._next(), stream_ptr(stream)), "arl_conv2d_bwd_weight_parts")
+                                                  item, pb, ib, stream_ptr(stream)), "arl_conv2d_bwd_weight_parts")
+        return self._bias_done(dbias)
 
-    def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, stream=None):
-        """dx and (deferred) dw of one layer in a single launch."""
+    def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, dbias=None, stream=None):
+        """dx (times mask > 0 if given) and (deferred) dw [+ dbias] of one layer in a single launch."""
         ho, wo = conv_out_hw(geom)
         assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
         assert x.numel() == dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x / dx size"
         assert dw.numel() == w.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w / dw size"
+        item = self._next()
+        pb, ib = self._bias_slot(dbias)
         _check(load().arl_conv2d_bwd_pair(dy.data_ptr(), w.data_ptr(), ptr(mask), dx.data_ptr(), x.data_ptr(),
                                           dw.data_ptr(), C.byref(geom), ptr(workspace),
-                                          workspace.numel() * workspace.element_size(), self._next(),
+                                          workspace.numel() * workspace.element_size(), item, pb, ib,
                                           stream_ptr(stream)), "arl_conv2d_bwd_pair")
+        return self._bias_done(dbias)
 
     def relu_bwd_bias_grad(self, dy, y, rows, channels, dbias, workspace, stream=None):
         _check(load().arl_relu_bwd_bias_parts(dy.data_ptr(), y.data_ptr(), rows, channels, dbias.data_ptr(),

@@ -157,6 +157,7 @@ struct HeadLossArgs {
     float* loss_partials;    // [gridDim][4] = pi, v, ent, their sum
     int batch, hid, n_act, kind;
     float clip_param, v_coeff, ent_coeff;
+    int mask_dh;             // dh *= (h > 0): h is a rectifier's output and the caller wants the gradient before it
 };
 
 // one wave per row (looping); lanes split the hidden dimension.  Every per-action
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
 #pragma unroll
                 for (int k = 0; k < K_MAX; ++k)
                     if (k < K) sdh += dl[k] * s_w[k * hid + c];
-                dhrow[c] = sdh;
+                dhrow[c] = (a.mask_dh && !(hv[j] > 0.f)) ? 0.f : sdh;
             }
         }
     }
@@ -480,8 +481,8 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
                                 const int32_t* idx_or_null, const float* lr_mult,
                                 const float* inv_count_or_null, int64_t batch, int32_t hid,
                                 int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
-                                float ent_loss_coeff, float* dout, float* dh, float* dw_head,
-                                float* db_head, float* loss4, void* workspace, void* stream) {
+                                float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
+                                float* dw_head, float* db_head, float* loss4, void* workspace, void* stream) {
     ARL_REQUIRE(h && w_head && b_head && actions && advantages && returns && lr_mult && dout && dh &&
                     dw_head && db_head && loss4 && workspace, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(kind == 0 || (kind == 1 && old_prob), ARL_E_ARG, "kind must be 0 (A2C) or 1 (PPO, needs old_prob)");
@@ -494,7 +495,7 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
     a.lr_mult = lr_mult; a.inv_count = inv_count_or_null; a.dout = dout; a.dh = dh;
     a.loss_partials = (float*)workspace;
     a.batch = (int)batch; a.hid = hid; a.n_act = n_actions; a.kind = kind;
-    a.clip_param = clip_param; a.v_coeff = v_loss_coeff; a.ent_coeff = ent_loss_coeff;
+    a.clip_param = clip_param; a.v_coeff = v_loss_coeff; a.ent_coeff = ent_loss_coeff; a.mask_dh = relu_mask_dh;
     const int grid = (int)((batch + 3) / 4 < 256 ? (batch + 3) / 4 : 256);
     const int K = n_actions + 1;
     hipLaunchKernelGGL((head_kernel<true>), dim3(grid), dim3(256), (size_t)K * hid * 4, s, a,

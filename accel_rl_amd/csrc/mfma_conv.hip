@@ -386,6 +386,7 @@ struct WgradArgs {
     int K_out, N, Mred;
     int m_per_split;        // multiple of BK
     int adv_b, adv_y, adv_x;    // fast path: 256 rows = adv_b images + adv_y output rows + adv_x pixels
+    float* bias_part;       // fast path: [splits][K_out] column sums of dy (the bias gradient's partials), or null
 };
 
 template <int WGM, int WGN, int TM, int TN, int BK>
@@ -867,6 +868,12 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         if (poy >= a.g.out_h) { poy -= a.g.out_h; ++pb; }
     };
 
+    // The workgroups of the first column tile also sum their dy rows per channel: the bias gradient's
+    // partials ride along (4 RA vector adds per k-tile in 1 / (N / BN) of the workgroups).
+    const bool do_bias = a.bias_part != nullptr && bx == 0;             // uniform
+    float4 bsum[RA];
+#pragma unroll
+    for (int p = 0; p < RA; ++p) bsum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[RA], vb[RB];
     auto issue_loads = [&](int tile) {              // tile index within the split
         const unsigned soffA = (unsigned)((mbeg + tile * BK) * a.K_out) << 2;
@@ -881,7 +888,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
             vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, bool fresh) {   // fresh: va holds a tile not stored before
         float* dA = sA + buf * A_SZ;
         float* dB = sB + buf * B_SZ;
 #pragma unroll
@@ -889,6 +896,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
             const int idx = tid + p * 256;
             if (NA4 % 256 != 0 && idx >= NA4) continue;
             *reinterpret_cast<float4*>(dA + idx * 4) = va[p];
+            if (do_bias && fresh) { bsum[p].x += va[p].x; bsum[p].y += va[p].y; bsum[p].z += va[p].z; bsum[p].w += va[p].w; }
         }
 #pragma unroll
         for (int p = 0; p < RB; ++p)
@@ -910,7 +918,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     produce_rows(1);
     __syncthreads();
     issue_loads(0);
-    store_tiles(0);
+    store_tiles(0, true);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
@@ -940,8 +948,26 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1);
+        store_tiles(buf ^ 1, kt + 1 < nk);
         __syncthreads();
+    }
+    if (do_bias) {                                  // [BK][MC4] float4 in the (now idle) A buffer, summed in row order
+        float4* red = reinterpret_cast<float4*>(sA);
+#pragma unroll
+        for (int p = 0; p < RA; ++p) {
+            const int idx = tid + p * 256;
+            if (NA4 % 256 == 0 || idx < NA4) red[idx] = bsum[p];
+        }
+        __syncthreads();
+        if (tid < MC4) {
+            float4 t = red[tid];
+            for (int kl = 1; kl < BK; ++kl) {
+                const float4 v = red[kl * MC4 + tid];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            const int ko = i0 + tid * 4;
+            if (ko < a.K_out) *reinterpret_cast<float4*>(a.bias_part + (int64_t)bz * a.K_out + ko) = t;
+        }
     }
 
     float* out = a.part + (int64_t)bz * a.K_out * a.N;
@@ -1327,8 +1353,11 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
 }
 
 // weight gradient; with more than one row split the partials go to `workspace` and *splits_out > 1
+// bias_part_out (optional): the fast kernels also leave [splits][K_out] column sums of dy behind the
+// weight partials in `workspace`; *bias_part_out = their address, or null when the generic kernels ran.
 int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
-               int64_t workspace_bytes, int* splits_out, int64_t* total_out, WgradPlan* plan_only, void* stream) {
+               int64_t workspace_bytes, int* splits_out, int64_t* total_out, float** bias_part_out,
+               WgradPlan* plan_only, void* stream) {
     ARL_REQUIRE(dy && x && dw && workspace, ARL_E_ARG, "null pointer");
     Geom g;
     int rc = check_geom(geom, &g);
@@ -1364,6 +1393,13 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
     constexpr int FBK = 32;
     const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
     const bool fast = !g_force_generic && a.Mred % FBK == 0 && per % FBK == 0 && (!has_pad || g.kh * g.kw <= 32);
+    if (bias_part_out) *bias_part_out = nullptr;
+    if (fast && bias_part_out) {
+        const int64_t used = splits > 1 ? (int64_t)splits * total : 0;
+        ARL_REQUIRE((used + (int64_t)splits * a.K_out) * 4 <= workspace_bytes, ARL_E_RANGE, "workspace too small");
+        a.bias_part = (float*)workspace + used;             // total % 4 == 0: stays 16-byte aligned
+        *bias_part_out = a.bias_part;
+    }
     if (fast) {
         a.g.taps_y = g.kh; a.g.dmin = 0;
         a.g.rmin = (a.g.add_y * g.W + a.g.add_x) * g.C;
@@ -1403,20 +1439,31 @@ extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw,
                                      void* workspace, void* stream) {
     int splits = 1;
     int64_t total = 0;
-    int rc = wgrad_impl(dy, x, dw, geom, workspace, arl_conv_workspace_bytes(), &splits, &total, nullptr, stream);
+    int rc = wgrad_impl(dy, x, dw, geom, workspace, arl_conv_workspace_bytes(), &splits, &total, nullptr, nullptr, stream);
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, total, nullptr, 4, 0, dw, (hipStream_t)stream);
 }
 
+namespace {
+void bias_item(arl_fold_item* item, const float* bias_part, float* dbias, int splits, int channels) {
+    item->part = bias_part; item->out = dbias; item->total = channels;
+    item->splits = bias_part ? splits : -1;             // -1: not produced (generic kernels ran)
+}
+}  // namespace
+
 extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
                                            void* workspace, int64_t workspace_bytes, arl_fold_item* item,
-                                           void* stream) {
-    ARL_REQUIRE(item, ARL_E_ARG, "null pointer");
+                                           float* dbias_or_null, arl_fold_item* bias_item_or_null, void* stream) {
+    ARL_REQUIRE(item && (!dbias_or_null || bias_item_or_null), ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(!dbias_or_null || arl::aligned16(dbias_or_null), ARL_E_ALIGN, "16-byte alignment");
     int splits = 1;
     int64_t total = 0;
-    int rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total, nullptr, stream);
+    float* bias_part = nullptr;
+    int rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total,
+                        dbias_or_null ? &bias_part : nullptr, nullptr, stream);
     item->part = (const float*)workspace; item->out = dw; item->total = total;
     item->splits = splits > 1 ? splits : 0;             // 0: dw is already final
+    if (dbias_or_null) bias_item(bias_item_or_null, bias_part, dbias_or_null, splits, geom->out_c);
     return rc;
 }
 
@@ -1448,15 +1495,19 @@ int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_
 
 extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
                                    const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
-                                   int64_t workspace_bytes, arl_fold_item* item, void* stream) {
-    ARL_REQUIRE(item && geom, ARL_E_ARG, "null pointer");
+                                   int64_t workspace_bytes, arl_fold_item* item, float* dbias_or_null,
+                                   arl_fold_item* bias_item_or_null, void* stream) {
+    ARL_REQUIRE(item && geom && (!dbias_or_null || bias_item_or_null), ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(!dbias_or_null || arl::aligned16(dbias_or_null), ARL_E_ALIGN, "16-byte alignment");
     DgradPlan dp = {};
     WgradPlan wp = {};
     int splits = 1;
     int64_t total = 0;
+    float* bias_part = nullptr;
     int rc = dgrad_impl(dy, w, mask_or_null, dx, geom, &dp, stream);
     if (rc) return rc;
-    rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total, &wp, stream);
+    rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total,
+                    dbias_or_null ? &bias_part : nullptr, &wp, stream);
     if (rc) return rc;
     const bool has_pad = dp.has_pad || wp.has_pad;
     // Only the widest tile configuration pairs up: a shared launch runs every workgroup at the larger of the
@@ -1467,12 +1518,14 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
     if (!paired) {
         rc = arl_conv2d_bwd_data(dy, w, mask_or_null, dx, geom, stream);
         if (rc) return rc;
-        return arl_conv2d_bwd_weight_parts(dy, x, dw, geom, workspace, workspace_bytes, item, stream);
+        return arl_conv2d_bwd_weight_parts(dy, x, dw, geom, workspace, workspace_bytes, item, dbias_or_null,
+                                           bias_item_or_null, stream);
     }
     hipStream_t s = (hipStream_t)stream;
     rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2>(dp, wp, has_pad, s);
     item->part = (const float*)workspace; item->out = dw; item->total = wp.total;
     item->splits = wp.splits > 1 ? wp.splits : 0;
+    if (dbias_or_null) bias_item(bias_item_or_null, bias_part, dbias_or_null, wp.splits, geom->out_c);
     return rc;
 }
 

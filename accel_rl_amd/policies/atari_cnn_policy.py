@@ -321,47 +321,56 @@ class AtariCnnPolicy(object):
             _lib.pg_head_loss(hids[-1], self.params[k_head], self.params[k_head + 1], mb["actions"],
                               mb["advantages"], mb["returns"], mb.get("old_prob"), mb.get("valids"),
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
-                              ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws)
-            self._backward_trunk(x, acts, hids, dh)
+                              ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws,
+                              relu_mask_dh=True)
+            self._backward_trunk(x, acts, hids, dh, masked=True)
             return loss4
 
-    def _backward_trunk(self, x, acts, hids, dh):
+    def _backward_trunk(self, x, acts, hids, dh, masked=False):
         """Gradients of every trunk layer into flat_grads, given dh = d loss / d (last hidden
-        activation, before its relu mask).  x, acts, hids as returned by _scaled / _trunk."""
+        activation); masked: dh is already multiplied by that activation's rectifier mask.
+        x, acts, hids as returned by _scaled / _trunk."""
         b = x.shape[0]
-        g = self.grads
         conv_g, dense_g = self._layer_geoms(b)
-        w, ws = self._w, self._conv_ws
         # ---- dense layers, last to first; the split folds of the whole pass run once, at the end
         d_cur = dh
-        folds = self._folds
         for j in range(self._n_hid - 1, -1, -1):
             k = 2 * (self._n_conv + j)
             hs, fan_in = self._hid_geom[j]
-            folds.relu_bwd_bias_grad(d_cur, hids[j], b, hs, g[k + 1], self._fold_ws(("db", k)))
             inp = hids[j - 1] if j > 0 else acts[-1]
             d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
-            folds.conv2d_bwd_pair(d_cur, w[k], None, d_prev, inp, self._g[k], dense_g[j], self._fold_ws(("dw", k)))
-            d_cur = d_prev
-        self._backward_convs(x, acts, d_cur)
+            self._layer_grads(d_cur, masked, hids[j], b, hs, k, dense_g[j], inp, d_prev)
+            d_cur, masked = d_prev, True
+        self._backward_convs(x, acts, d_cur, masked)
 
-    def _backward_convs(self, x, acts, d_act):
-        """Conv layers, last to first; d_act = NHWC gradient of the last conv output (before its relu mask)."""
+    def _backward_convs(self, x, acts, d_act, masked=False):
+        """Conv layers, last to first; d_act = NHWC gradient of the last conv output (masked: already
+        multiplied by its rectifier mask)."""
         b = x.shape[0]
-        g, w = self.grads, self._w
         conv_g, _ = self._layer_geoms(b)
-        folds = self._folds
         for i in range(self._n_conv - 1, -1, -1):
             nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
-            folds.relu_bwd_bias_grad(d_act, acts[i], b * ho * wo, nf, g[2 * i + 1], self._fold_ws(("db", 2 * i)))
-            if i > 0:               # data + weight gradient of the layer share one launch
-                d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape))
-                folds.conv2d_bwd_pair(d_act, w[2 * i], None, d_in, acts[i - 1], self._g[2 * i], conv_g[i],
-                                      self._fold_ws(("dw", 2 * i)))
-                d_act = d_in
-            else:
-                folds.conv2d_bwd_weight(d_act, x, self._g[2 * i], conv_g[i], self._fold_ws(("dw", 2 * i)))
-        folds.run()
+            d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape)) if i > 0 else None
+            self._layer_grads(d_act, masked, acts[i], b * ho * wo, nf, 2 * i, conv_g[i], acts[i - 1] if i > 0 else x, d_in)
+            d_act, masked = d_in, True
+        self._folds.run()
+
+    def _layer_grads(self, d, masked, y, rows, channels, k, geom, inp, d_in):
+        """One layer's backward: bias and weight gradient (deferred folds) and, with d_in, the data gradient
+        already multiplied by the rectifier mask of `inp` (the layer below's output), so that the layer below
+        gets its pre-activation gradient without another pass.  Not `masked`: d still needs this layer's own
+        mask, applied in place by the streaming kernel that also sums the bias gradient."""
+        folds, g = self._folds, self.grads
+        if not masked:
+            folds.relu_bwd_bias_grad(d, y, rows, channels, g[k + 1], self._fold_ws(("db", k)))
+        dbias = g[k + 1] if masked else None
+        if d_in is not None:        # data + weight gradient share one launch where that pays (dense layers)
+            done = folds.conv2d_bwd_pair(d, self._w[k], inp, d_in, inp, self._g[k], geom, self._fold_ws(("dw", k)),
+                                         dbias=dbias)
+        else:
+            done = folds.conv2d_bwd_weight(d, inp, self._g[k], geom, self._fold_ws(("dw", k)), dbias=dbias)
+        if not done:                # generic kernels leave the bias sums to the streaming kernel (its mask is idempotent)
+            folds.relu_bwd_bias_grad(d, y, rows, channels, g[k + 1], self._fold_ws(("db", k)))
 
     def _fold_ws(self, key):
         """One workspace per pending fold (the partials stay live until folds.run())."""

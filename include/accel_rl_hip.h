@@ -289,8 +289,8 @@ int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
                      const int32_t* idx_or_null, const float* lr_mult,
                      const float* inv_count_or_null, int64_t batch, int32_t hid, int32_t n_actions,
                      int32_t kind, float clip_param, float v_loss_coeff, float ent_loss_coeff,
-                     float* dout, float* dh, float* dw_head, float* db_head, float* loss4,
-                     void* workspace, void* stream);
+                     int32_t relu_mask_dh, float* dout, float* dh, float* dw_head, float* db_head,
+                     float* loss4, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * The policy network's dense contractions on the matrix cores (fp32 MFMA)
@@ -340,8 +340,13 @@ int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_
                           void* workspace, void* stream);
 
 /* Deferred-fold variant (arl_fold_item above). */
+/* dbias (optional): the kernel also leaves per-split column sums of dy (the bias gradient of a layer
+ * whose dy is already masked by its rectifier) behind the weight partials and describes their fold in
+ * *bias_item; bias_item->splits == -1 means "not produced" (the generic kernels ran): use
+ * arl_relu_bwd_bias_grad / _parts instead. */
 int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
-                                void* workspace, int64_t workspace_bytes, arl_fold_item* item, void* stream);
+                                void* workspace, int64_t workspace_bytes, arl_fold_item* item,
+                                float* dbias_or_null, arl_fold_item* bias_item_or_null, void* stream);
 int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream);
 
 /* A layer's data gradient and weight gradient (deferred fold) as ONE launch: the two are independent
@@ -351,7 +356,8 @@ int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream);
  * on the scalar-addressed fast path). */
 int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
                         const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
-                        int64_t workspace_bytes, arl_fold_item* item, void* stream);
+                        int64_t workspace_bytes, arl_fold_item* item, float* dbias_or_null,
+                        arl_fold_item* bias_item_or_null, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Replay memory of the DQN family

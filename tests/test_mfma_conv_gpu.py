@@ -177,6 +177,23 @@ def test_paired_backward_is_the_two_separate_calls(case, masked):
     folds.conv2d_bwd_pair(dy, wt, mask, dx1, x, dw1, geom, ws2)
     folds.run()
     assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+    # ... and with the bias gradient's column sums riding along (fast kernels only; else "not produced")
+    want_db = dy.reshape(-1, case[4]).double().sum(0)
+    for paired in (True, False):
+        dx2, dw2 = torch.full_like(x, float("nan")), torch.full_like(wt, float("nan"))
+        db = torch.full((case[4],), float("nan"), device=DEV)
+        if paired:
+            done = folds.conv2d_bwd_pair(dy, wt, mask, dx2, x, dw2, geom, ws2, dbias=db)
+        else:
+            done = folds.conv2d_bwd_weight(dy, x, dw2, geom, ws2, dbias=db)
+        folds.run()
+        assert done == ((case[0] * ho * wo) % 32 == 0)       # the scalar-addressed kernels need whole 32-row k-tiles
+        assert torch.equal(dw0, dw2) and (not paired or torch.equal(dx0, dx2))
+        if done:
+            tol = 2e-5 * np.sqrt(dy.numel() / case[4]) * dy.abs().max().item()
+            assert (db.double() - want_db).abs().max().item() <= tol
+        else:
+            assert torch.isnan(db).all()
 
 
 def test_argument_errors():
