@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 kernel_trace.csv inside a time window given as fractions [lo, hi] of the
-whole trace: per-kernel totals, GPU busy vs idle.  usage: trace_summary.py kernel_trace.csv [lo hi [top]]"""
+whole trace (or, with lo, hi >= 1, between the lo-th and hi-th optimiser update): per-kernel totals, GPU busy
+vs idle.  usage: trace_summary.py kernel_trace.csv [lo hi [top]]"""
 import collections
 import csv
 import sys
@@ -15,6 +16,9 @@ with open(path) as f:
 rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 a, b = t0 + (t1 - t0) * lo, t0 + (t1 - t0) * hi
+if lo >= 1.0:       # lo, hi >= 1: window = from the lo-th to the hi-th optimiser update (update_kernel launches)
+    ups = [r[0] for r in rows if "update_kernel" in r[2]]
+    a, b = ups[int(lo)], ups[int(hi)]
 rows = [r for r in rows if r[0] >= a and r[1] <= b]
 span = rows[-1][1] - rows[0][0]
 busy, last_end = 0, rows[0][0]
