@@ -52,8 +52,9 @@ def test_struct_layouts_match_header(lib):
     import subprocess
     import tempfile
     from accel_rl_amd import _lib
-    src = ('#include <stdio.h>\n#include "accel_rl_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",'
-           'sizeof(arl_game),sizeof(arl_env_state),sizeof(arl_rollout),sizeof(arl_opt_state));return 0;}')
+    src = ('#include <stdio.h>\n#include "accel_rl_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+           'sizeof(arl_game),sizeof(arl_env_state),sizeof(arl_rollout),sizeof(arl_opt_state),'
+           'sizeof(arl_conv_geom),sizeof(arl_replay),sizeof(arl_fold_item));return 0;}')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -61,7 +62,8 @@ def test_struct_layouts_match_header(lib):
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(_lib.ArlGame), ctypes.sizeof(_lib.ArlEnvState),
-                     ctypes.sizeof(_lib.ArlRollout), ctypes.sizeof(_lib.ArlOptState)]
+                     ctypes.sizeof(_lib.ArlRollout), ctypes.sizeof(_lib.ArlOptState),
+                     ctypes.sizeof(_lib.ArlConvGeom), ctypes.sizeof(_lib.ArlReplay), ctypes.sizeof(_lib.ArlFoldItem)]
 
 
 def test_no_cpu_fallback():
