@@ -36,7 +36,9 @@ class CategoricalDQN(DQN):
             obs, next_obs, act, ret, term = minibatch[:5]
             isw = None
             if self.prioritized_replay:
-                isw = torch.as_tensor(np.asarray(minibatch[5], np.float32)).to(policy.device)
+                isw = minibatch[5]
+                if not isinstance(isw, torch.Tensor):
+                    isw = torch.as_tensor(np.asarray(isw, np.float32)).to(policy.device)
             term_u8 = term.view(torch.uint8) if term.dtype == torch.bool else term
             loss_rows, kl = policy.cat_loss_and_grads(obs, next_obs, act, ret, term_u8, isw, self.V_min, self.V_max,
                                                       gamma_n, double_dqn=self.double_dqn)

@@ -146,50 +146,48 @@ __global__ __launch_bounds__(256) void sumtree_gather_kernel(const double* __res
 }
 
 // np.add.at(tree, idxs >> level, diffs) for every level, several updates of one node applied in INPUT
-// order (that fixes the f64 rounding, sum_tree.py:54-57).  One workgroup, n <= 4096: per level the
-// (node, position) pairs are bitonic-sorted in LDS, which makes each node's updates a contiguous run in
-// input order; the first lane of a run adds it sequentially.
+// order (that fixes the f64 rounding, sum_tree.py:54-57).  The levels touch disjoint nodes, so each gets
+// its own workgroup (n <= 4096 items in LDS): the first item that names a node adds that node's whole run,
+// scanning the later items in order.  O(n^2 / 1024) LDS compares per thread, no sort, no atomics.
 constexpr int ADD_MAX = 4096;
 
-__global__ __launch_bounds__(1024) void sumtree_add_kernel(double* __restrict__ tree, int levels,
+__global__ __launch_bounds__(1024) void sumtree_add_kernel(double* __restrict__ tree,
                                                            const int32_t* __restrict__ idxs,
                                                            const double* __restrict__ diffs, int n) {
-    __shared__ unsigned long long keys[ADD_MAX];
+    __shared__ __attribute__((aligned(16))) unsigned s_node[ADD_MAX];
     __shared__ double s_diff[ADD_MAX];
-    const int tid = threadIdx.x;
-    int np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    for (int i = tid; i < n; i += 1024) s_diff[i] = diffs[i];
-    for (int l = 0; l < levels; ++l) {
-        for (int i = tid; i < np2; i += 1024) {
-            unsigned long long k = ~0ull;                        // padding sorts last
-            if (i < n) {
-                const unsigned node = (unsigned)((idxs[i] + 1) >> l) - 1u;      // parent = (i - 1) / 2, l times
-                k = ((unsigned long long)node << 32) | (unsigned)i;
-            }
-            keys[i] = k;
+    const int tid = threadIdx.x, l = blockIdx.x;                 // one workgroup per tree level
+    for (int i = tid; i < n; i += 1024) {
+        s_node[i] = (unsigned)((idxs[i] + 1) >> l) - 1u;         // parent = (i - 1) / 2, l times
+        s_diff[i] = diffs[i];
+    }
+    __syncthreads();
+    const uint4* node4 = reinterpret_cast<const uint4*>(s_node);
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned node = s_node[i];
+        bool first = true;
+        const int i4 = i >> 2;
+        for (int q = 0; q < i4 && first; ++q) {                  // four earlier items per LDS read
+            const uint4 v = node4[q];
+            first = !(v.x == node || v.y == node || v.z == node || v.w == node);
         }
-        __syncthreads();
-        for (int size = 2; size <= np2; size <<= 1)
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = tid; i < np2 / 2; i += 1024) {
-                    const int lo = 2 * i - (i & (stride - 1));
-                    const int hi = lo + stride;
-                    const bool up = (lo & size) == 0;
-                    const unsigned long long a = keys[lo], b = keys[hi];
-                    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
-                }
-                __syncthreads();
+        for (int j = i4 << 2; j < i && first; ++j) first = s_node[j] != node;
+        if (first) {                                             // this item opens its node's run: add the run in input order
+            double t = tree[node] + s_diff[i];
+            int j = i + 1;
+            for (; (j & 3) && j < n; ++j)
+                if (s_node[j] == node) t += s_diff[j];
+            for (; j + 3 < n; j += 4) {
+                const uint4 v = node4[j >> 2];
+                if (v.x == node) t += s_diff[j];
+                if (v.y == node) t += s_diff[j + 1];
+                if (v.z == node) t += s_diff[j + 2];
+                if (v.w == node) t += s_diff[j + 3];
             }
-        for (int i = tid; i < n; i += 1024) {
-            const unsigned node = (unsigned)(keys[i] >> 32);
-            if (i == 0 || (unsigned)(keys[i - 1] >> 32) != node) {
-                double t = tree[node];
-                for (int q = i; q < n && (unsigned)(keys[q] >> 32) == node; ++q) t += s_diff[(unsigned)keys[q]];
-                tree[node] = t;
-            }
+            for (; j < n; ++j)
+                if (s_node[j] == node) t += s_diff[j];
+            tree[node] = t;
         }
-        __syncthreads();
     }
 }
 
@@ -273,7 +271,7 @@ extern "C" int arl_sumtree_add(double* tree, int32_t levels, const int32_t* tree
     // consecutive chunks are exact: levels touch disjoint nodes and a node sees chunk A's updates before B's
     for (int64_t lo = 0; lo < n; lo += ADD_MAX) {
         const int m = (int)((n - lo < ADD_MAX) ? n - lo : ADD_MAX);
-        hipLaunchKernelGGL(sumtree_add_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree, levels,
+        hipLaunchKernelGGL(sumtree_add_kernel, dim3((unsigned)levels), dim3(1024), 0, (hipStream_t)stream, tree,
                            tree_idxs + lo, diffs + lo, m);
         int rc = arl::check_launch("sumtree_add_kernel");
         if (rc) return rc;

@@ -2,19 +2,28 @@
 step per call on a replay minibatch, optional global-norm clip, adam / rmsprop on the flat bucket
 (csrc/optim.hip).  `loss` is a callable(minibatch tuple) -> (priority f32[B], loss scalar) that leaves
 the gradient in the policy's flat bucket (the algorithm builds it)."""
+import numpy as np
+import torch
+
 from accel_rl_amd.optimizers.base import BaseOptimizer
 
 
 class DqnOptimizer(BaseOptimizer):
+    """use_graph: after two eager calls the whole update (three forward passes, loss, backward, optimiser
+    step: ~60 launches) is replayed from one hipGraph over static input buffers -- at the reference's
+    batch size of 32 the update is launch-bound, not compute-bound."""
 
     def __init__(self, learning_rate, update_method, update_method_args=None, grad_norm_clip=None,
-                 scale_conv_grads=False):
+                 scale_conv_grads=False, use_graph=True):
         if scale_conv_grads:
             raise NotImplementedError("scale_conv_grads belongs to the dueling architecture, which is not built")
         self._learning_rate = learning_rate
         self._update_method = update_method
         self._update_args = update_method.resolve(**(update_method_args or dict()))
         self._grad_norm_clip = grad_norm_clip
+        self._use_graph = use_graph
+        self._static = self._graph = self._graph_out = None
+        self._calls = 0
 
     def initialize(self, inputs, loss, target, priority_expr=None, givens=None, lr_mult=1):
         self._input_names = list(inputs)
@@ -23,9 +32,53 @@ class DqnOptimizer(BaseOptimizer):
         self._set_updates_per_call(1)
 
     def optimize(self, inputs):
+        if not self._use_graph:
+            return self._step(inputs)
+        static = self._stage(inputs)
+        self._calls += 1
+        if self._graph is None:
+            if self._calls <= 2:                                  # warm-up: buffers, kernel attributes
+                return self._step(static)
+            torch.cuda.synchronize(self._target.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._graph_out = self._step(static)
+            self._graph = graph
+        self._graph.replay()
+        priority, loss = self._graph_out          # graph-owned: valid until the next replay
+        return priority, loss.clone()
+
+    def _step(self, inputs):
         priority, loss = self._loss_fn(inputs)
         self._apply_update(1.0)
         return priority, loss
+
+    def _stage(self, inputs):
+        """Copy one minibatch into the static buffers the graph reads (host arrays -- the importance
+        weights -- through a pinned mirror guarded by an event)."""
+        dev = self._target.device
+        if self._static is None or any(tuple(s.shape) != tuple(np.shape(x)) for s, x in zip(self._static, inputs)):
+            assert self._graph is None, "the replay minibatch shape changed after graph capture"
+            self._static, self._pinned = [], []
+            for x in inputs:
+                if isinstance(x, torch.Tensor):
+                    self._static.append(torch.empty_like(x, device=dev))
+                    self._pinned.append(None)
+                else:
+                    x = np.asarray(x, np.float32)
+                    self._static.append(torch.empty(x.shape, dtype=torch.float32, device=dev))
+                    self._pinned.append(torch.empty(x.shape, dtype=torch.float32).pin_memory())
+            self._stage_event = torch.cuda.Event()
+        else:
+            self._stage_event.synchronize()                       # the previous upload has left the pinned mirrors
+        for s, p, x in zip(self._static, self._pinned, inputs):
+            if p is None:
+                s.copy_(x, non_blocking=True)
+            else:
+                p.copy_(torch.from_numpy(np.asarray(x, np.float32)))
+                s.copy_(p, non_blocking=True)
+        self._stage_event.record(torch.cuda.current_stream(dev))
+        return tuple(self._static)
 
     @property
     def parallelism_tag(self):
