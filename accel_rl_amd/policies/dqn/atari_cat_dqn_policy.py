@@ -37,6 +37,11 @@ class AtariCatDqnPolicy(AtariCnnPolicy):
 
     # ---- output layer: "action_atoms" dense, n_actions * n_atoms units (catdqn_cnn.py:69-76)
     def _head_reference_init(self, fan, n_act):
+        # atoms padded per action (zero weights, zero gradients) until the layer's width is a multiple of the
+        # MFMA k-tile: its data gradient then runs on the scalar-addressed kernels (18 x 52 = 936 fell back
+        # to the generic one: 94 us per update at batch 32)
+        while (n_act * self._atom_stride) % 32 and self._atom_stride < 64:
+            self._atom_stride += 4
         return [_norm_c((fan, n_act * self.n_atoms), 0.01), np.zeros(n_act * self.n_atoms, np.float32)], \
                ["OutputW", "Outputb"]
 
@@ -81,6 +86,12 @@ class AtariCatDqnPolicy(AtariCnnPolicy):
         geom = self._head_geom(b)
         _lib.conv2d_fwd(hids[-1], w[k], w[k + 1], out, geom, False, self._conv_ws)
         return out, acts, hids
+
+    def _ones_geom(self, b, width):
+        key = ("ones", b, width)
+        if key not in self._geoms:
+            self._geoms[key] = _lib.dense_geom(b, 4, width)
+        return self._geoms[key]
 
     def _head_geom(self, b):
         key = ("head", b)
@@ -184,15 +195,16 @@ class AtariCatDqnPolicy(AtariCnnPolicy):
             k = self._k_head
             geom = self._head_geom(b)
             hid = self._hid_geom[-1][0]
-            # output layer: db = column sums (the relu-backward kernel with an all-ones "activation"),
-            # dW = dlogits^T h, dh = dlogits W
-            ones = self._buffer(("ones", b), tuple(dlogits.shape))
-            if not getattr(ones, "_filled", False):
-                ones.fill_(1.)
-                ones._filled = True
-            _lib.relu_bwd_bias_grad(dlogits, ones, b, dlogits.shape[1], self.grads[k + 1], self._relu_ws)
-            _lib.conv2d_bwd_weight(dlogits, hids[-1], self._g[k], geom, self._conv_ws)
+            # output layer: dW = dlogits^T h, db = column sums of dlogits (riding along in the weight-gradient
+            # kernel), dh = (dlogits W) * (h > 0) -- one launch; the folds run at the end of the trunk's backward
             dh = self._buffer(("dh", b), (b, hid))
-            _lib.conv2d_bwd_data(dlogits, self._w[k], None, dh, geom)
-            self._backward_trunk(x, acts, hids, dh)
+            done = self._folds.conv2d_bwd_pair(dlogits, self._w[k], hids[-1], dh, hids[-1], self._g[k], geom,
+                                               self._fold_ws(("dw", k)), dbias=self.grads[k + 1])
+            if not done:        # ragged batch (generic kernels): column sums as the weight gradient of an all-ones input
+                ones = self._buffer(("ones4", b), (b, 4))
+                ones.fill_(1.)
+                db4 = self._buffer(("db4", b), (dlogits.shape[1], 4))
+                _lib.conv2d_bwd_weight(dlogits, ones, db4, self._ones_geom(b, dlogits.shape[1]), self._conv_ws)
+                self.grads[k + 1].copy_(db4[:, 0])
+            self._backward_trunk(x, acts, hids, dh, masked=True)
             return loss_rows, kl

@@ -123,8 +123,10 @@ def test_policy_forward_layout_and_epsilon_greedy_stream():
     obs = torch.from_numpy(rs.randint(0, 256, size=(24, 4, 104, 80), dtype=np.uint8)).to(DEV)
     logits, _, _ = policy._logits(policy._scaled(obs))
     want = _ref_logits(rp, spec, obs.float() * np.float32(1. / 255)).view(24, 6, 51)
-    got = logits.view(24, 6, 52)
-    assert torch.allclose(got[:, :, :51], want, rtol=1e-4, atol=1e-5) and not got[:, :, 51].any()
+    stride = policy._atom_stride                  # 51 atoms padded until 6 x stride is a multiple of the MFMA k-tile
+    assert stride == 64 and (6 * stride) % 32 == 0
+    got = logits.view(24, 6, stride)
+    assert torch.allclose(got[:, :, :51], want, rtol=1e-4, atol=1e-5) and not got[:, :, 51:].any()
     # epsilon-greedy: whole-rollout draws == the reference's per-(step, group) loop on the same seed
     greedy = policy.greedy_actions(obs).cpu().numpy()
     np.random.seed(77)
