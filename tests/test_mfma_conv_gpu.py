@@ -209,3 +209,39 @@ def test_argument_errors():
     assert rc == -2 and b"stride" in _lib.load().arl_last_error()
     with pytest.raises(RuntimeError):
         _lib.conv2d_fwd(x.cpu(), wt, None, y, geom, False, ws) if False else _lib.ptr(x.cpu())
+
+
+def test_fold_many_matches_separate_folds_and_checks_arguments():
+    """arl_fold_many: several independent split folds in one launch == the per-tensor fold (same fixed order);
+    items with splits <= 0 are skipped; bad items are refused."""
+    from accel_rl_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    items = (_lib.ArlFoldItem * 4)()
+    parts, outs, wants = [], [], []
+    for i, (splits, total) in enumerate([(7, 64), (33, 4), (1, 1028), (16, 20)]):
+        p = torch.randn(splits, total, device=DEV, generator=gen)
+        o = torch.full((total,), float("nan"), device=DEV)
+        # reference order of fold_splits_kernel: lane zg sums splits zg, zg + 16, ...; then the 16 lanes in order
+        lanes = [p[zg::16].double().float() for zg in range(16)]
+        acc = []
+        for l in lanes:
+            t = torch.zeros(total, device=DEV)
+            for row in l:
+                t = t + row
+            acc.append(t)
+        w = acc[0]
+        for t in acc[1:]:
+            w = w + t
+        parts.append(p); outs.append(o); wants.append(w)
+        items[i].part, items[i].out, items[i].total, items[i].splits = p.data_ptr(), o.data_ptr(), total, splits
+    items[3].splits = 0                                             # "already final": left alone
+    assert lib.arl_fold_many(items, 4, None) == 0
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs[i], wants[i]), i
+    assert torch.isnan(outs[3]).all()
+    items[3].splits, items[3].total = 16, 18                        # not a multiple of 4
+    assert lib.arl_fold_many(items, 4, None) < 0
+    assert lib.arl_fold_many(items, _lib.FOLD_MAX_ITEMS + 1, None) < 0
+    assert lib.arl_fold_many(None, 0, None) == 0
