@@ -60,18 +60,27 @@ __device__ __forceinline__ void lane_scan_lds(float* sr, float* sv, const uint8_
     } else {
         double carry = 0.0;                           // util.py:13
         float v_next = last_v;                        // util.py:9
+        // the step's operands are read one step ahead, so the LDS latency hides under the f64 chain
+        int idx = lane_env * T + T - 1, p = skewed(idx, skew_mask);
+        float rr_n = sr[p], vv_n = sv[p];
+        uint8_t dd_n = sd[idx];
         for (int t = T - 1; t >= 0; --t) {
-            const int idx = lane_env * T + t;
-            const int p = skewed(idx, skew_mask);
-            const float rr = sr[p], vv = sv[p];
-            const double nd = sd[idx] ? 0.0 : 1.0;    // util.py:8 (int64 -> f64)
+            const float rr = rr_n, vv = vv_n;
+            const uint8_t dd = dd_n;
+            const int pw = p;
+            if (t > 0) {
+                idx -= 1;
+                p = skewed(idx, skew_mask);
+                rr_n = sr[p]; vv_n = sv[p]; dd_n = sd[idx];
+            }
+            const double nd = dd ? 0.0 : 1.0;         // util.py:8 (int64 -> f64)
             const double gv = (PROMO == ARL_PROMO_NEP50) ? (double)(g32 * v_next)
                                                          : gamma * (double)v_next;
             const double delta = ((double)rr + gv * nd) - (double)vv;   // util.py:15
             carry = delta + (gl * nd) * carry;                          // util.py:16-17
             const float a = (float)carry;
-            sr[p] = a;
-            sv[p] = a + vv;                                             // util.py:21
+            sr[pw] = a;
+            sv[pw] = a + vv;                                            // util.py:21
             v_next = vv;
         }
     }
@@ -88,10 +97,11 @@ __device__ __forceinline__ void nt_store4(float4* p, float4 v) {
     __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(p));
 }
 
-// EPB envs per workgroup, EPB threads.  Requires 16-byte aligned r/v/out and
-// 4-byte aligned dones (checked by the host wrapper).
-template <bool NSTEP, int PROMO, int EPB>
-__global__ __launch_bounds__(EPB) void scan_lds_kernel(
+// EPB envs per workgroup, THREADS >= EPB threads (all of them stream the tile in and out, the first EPB
+// walk one segment each).  Requires 16-byte aligned r/v/out and 4-byte aligned dones (checked by the
+// host wrapper).
+template <bool NSTEP, int PROMO, int EPB, int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_lds_kernel(
     const float* __restrict__ r, const float* __restrict__ v, const uint8_t* __restrict__ d,
     const float* __restrict__ lv, double gamma, double gl, int64_t n_env, int T,
     int skew_mask, int cap, float* __restrict__ out0, float* __restrict__ out1) {
@@ -114,7 +124,7 @@ __global__ __launch_bounds__(EPB) void scan_lds_kernel(
         // prefetch this lane's bootstrap value while the tile streams in
         const float last_v = (tid < n_here) ? lv[e0 + tid] : 0.f;
 
-        for (int q = tid; q < nq; q += EPB) {
+        for (int q = tid; q < nq; q += THREADS) {
             const float4 a = nt_load4(gr4 + q);
             const float4 b = nt_load4(gv4 + q);
             const uint32_t dd = __builtin_nontemporal_load(gd4 + q);
@@ -123,7 +133,7 @@ __global__ __launch_bounds__(EPB) void scan_lds_kernel(
             sv[p] = b.x; sv[p + 1] = b.y; sv[p + 2] = b.z; sv[p + 3] = b.w;
             *reinterpret_cast<uint32_t*>(sd + (q << 2)) = dd;
         }
-        for (int i = (nq << 2) + tid; i < elems; i += EPB) {
+        for (int i = (nq << 2) + tid; i < elems; i += THREADS) {
             const int p = skewed(i, skew_mask);
             sr[p] = r[base + i];
             sv[p] = v[base + i];
@@ -137,12 +147,12 @@ __global__ __launch_bounds__(EPB) void scan_lds_kernel(
 
         float4* go0 = reinterpret_cast<float4*>(out0 + base);
         float4* go1 = reinterpret_cast<float4*>(out1 + base);
-        for (int q = tid; q < nq; q += EPB) {
+        for (int q = tid; q < nq; q += THREADS) {
             const int p = skewed(q << 2, skew_mask);
             nt_store4(go0 + q, make_float4(sr[p], sr[p + 1], sr[p + 2], sr[p + 3]));
             nt_store4(go1 + q, make_float4(sv[p], sv[p + 1], sv[p + 2], sv[p + 3]));
         }
-        for (int i = (nq << 2) + tid; i < elems; i += EPB) {
+        for (int i = (nq << 2) + tid; i < elems; i += THREADS) {
             const int p = skewed(i, skew_mask);
             out0[base + i] = sr[p];
             out1[base + i] = sv[p];
@@ -219,7 +229,7 @@ __global__ __launch_bounds__(256) void valids_kernel(
     }
 }
 
-template <bool NSTEP, int PROMO, int EPB>
+template <bool NSTEP, int PROMO, int EPB, int THREADS = EPB>
 int launch_lds(const float* r, const float* v, const uint8_t* d, const float* lv, double gamma,
                double gl, int64_t n_env, int T, float* o0, float* o1, hipStream_t s) {
     const int skew_mask = (T & 1) ? 0 : ~0;
@@ -230,7 +240,7 @@ int launch_lds(const float* r, const float* v, const uint8_t* d, const float* lv
     // one tile per workgroup (the loop in the kernel only matters beyond 2^30 tiles): a persistent grid
     // serialises load -> scan -> store inside each workgroup and ends ragged (5.6 vs 6.25 TB/s at 2^26 elements)
     const unsigned grid = (unsigned)(tiles < ((int64_t)1 << 30) ? tiles : ((int64_t)1 << 30));
-    hipLaunchKernelGGL((scan_lds_kernel<NSTEP, PROMO, EPB>), dim3(grid), dim3(EPB), lds, s, r, v,
+    hipLaunchKernelGGL((scan_lds_kernel<NSTEP, PROMO, EPB, THREADS>), dim3(grid), dim3(THREADS), lds, s, r, v,
                        d, lv, gamma, gl, n_env, T, skew_mask, cap, o0, o1);
     return arl::check_launch("scan_lds_kernel");
 }
@@ -243,13 +253,18 @@ int dispatch(const float* r, const float* v, const uint8_t* d, const float* lv, 
     // Tile = EPB envs.  LDS per tile ~ 9.3 * EPB * T bytes: cap it near 20 KB so 8
     // workgroups stay resident per CU; for small batches prefer narrower tiles so the
     // launch still spreads over many CUs (a 256-env batch = 4 x 64-env tiles).
-    if (vec_ok && T <= 34) {
-        int epb = (T <= 8) ? 256 : (T <= 17 ? 128 : 64);
+    // Longer horizons keep the ~40 KB budget with fewer envs per tile; the tile is still streamed by 256
+    // threads (a 64-thread workgroup left the load / store phases with one wave).
+    if (vec_ok && T <= 17) {
+        int epb = (T <= 8) ? 256 : 128;
         while (epb > 64 && (n_env + epb - 1) / epb < 512) epb >>= 1;
         if (epb == 256) return launch_lds<NSTEP, PROMO, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
         if (epb == 128) return launch_lds<NSTEP, PROMO, 128>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
         return launch_lds<NSTEP, PROMO, 64>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
     }
+    if (vec_ok && T <= 34) return launch_lds<NSTEP, PROMO, 64, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
+    if (vec_ok && T <= 136) return launch_lds<NSTEP, PROMO, 32, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
+    if (vec_ok && T <= 544) return launch_lds<NSTEP, PROMO, 8, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
     hipLaunchKernelGGL((scan_direct_kernel<NSTEP, PROMO>), dim3(arl::stream_grid(n_env, 256)),
                        dim3(256), 0, s, r, v, d, lv, gamma, gl, n_env, T, o0, o1);
     return arl::check_launch("scan_direct_kernel");

@@ -82,9 +82,10 @@ def test_nstep_golden_bit_exact(L):
 
 @pytest.mark.parametrize("n,t", [(256, 5), (1024, 5), (2048, 5), (1, 5), (257, 5), (1000, 1),
                                  (513, 2), (300, 8), (129, 9), (640, 16), (77, 17), (200, 32),
-                                 (65, 34), (50, 35), (40, 128), (3, 1000)])
+                                 (65, 34), (50, 35), (40, 128), (70, 136), (30, 137), (19, 544), (5, 545),
+                                 (3, 1000)])
 def test_scans_vs_oracle_shapes(L, n, t):
-    """Ragged tiles, every kernel variant (LDS 256/128/64-lane tiles, direct), both scans."""
+    """Ragged tiles, every kernel variant (LDS tiles of 256/128/64/32/8 envs, direct), both scans."""
     rs = np.random.RandomState(n * 1000 + t)
     r = rs.randn(n, t).astype(np.float32)
     v = (rs.randn(n, t) * 2).astype(np.float32)
