@@ -86,6 +86,49 @@ __device__ __forceinline__ void lane_scan_lds(float* sr, float* sv, const uint8_
     }
 }
 
+// The same walk over ONE chunk of a longer segment: `len` steps at LDS index lane_env * len + t, state
+// (carry / running return, next value) handed from chunk to chunk in registers.
+template <bool NSTEP, int PROMO>
+__device__ __forceinline__ void lane_scan_chunk(float* sr, float* sv, const uint8_t* sd, int lane_env, int len,
+                                                int skew_mask, double gamma, double gl, double& carry,
+                                                float& run32, float& v_next) {
+    const float g32 = (float)gamma;
+    int idx = lane_env * len + len - 1, p = skewed(idx, skew_mask);
+    float rr_n = sr[p], vv_n = sv[p];
+    uint8_t dd_n = sd[idx];
+    for (int t = len - 1; t >= 0; --t) {
+        const float rr = rr_n, vv = vv_n;
+        const uint8_t dd = dd_n;
+        const int pw = p;
+        if (t > 0) {
+            idx -= 1;
+            p = skewed(idx, skew_mask);
+            rr_n = sr[p]; vv_n = sv[p]; dd_n = sd[idx];
+        }
+        if (NSTEP) {
+            if (PROMO == ARL_PROMO_NEP50) {
+                run32 = dd ? rr : (run32 * g32) + rr;                   // util.py:31-35 (f32 *=, +=)
+                sr[pw] = run32;
+                sv[pw] = run32 - vv;                                    // aac_base.py:121
+            } else {
+                carry = dd ? (double)rr : (carry * gamma) + (double)rr;
+                const float ret = (float)carry;
+                sr[pw] = ret;
+                sv[pw] = ret - vv;
+            }
+        } else {
+            const double nd = dd ? 0.0 : 1.0;                           // util.py:8 (int64 -> f64)
+            const double gv = (PROMO == ARL_PROMO_NEP50) ? (double)(g32 * v_next) : gamma * (double)v_next;
+            const double delta = ((double)rr + gv * nd) - (double)vv;   // util.py:15
+            carry = delta + (gl * nd) * carry;                          // util.py:16-17
+            const float a = (float)carry;
+            sr[pw] = a;
+            sv[pw] = a + vv;                                            // util.py:21
+            v_next = vv;
+        }
+    }
+}
+
 // Streamed once: non-temporal loads / stores keep the tile traffic from displacing useful lines.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 nt_load4(const float4* p) {
@@ -158,6 +201,56 @@ __global__ __launch_bounds__(THREADS) void scan_lds_kernel(
             out1[base + i] = sv[p];
         }
         __syncthreads();   // tile reuse
+    }
+}
+
+// Long horizons (T % 4 == 0): the tile is EPB envs x TC steps, and a workgroup walks its envs' segments
+// backwards chunk by chunk, the scan state staying in the lanes' registers.  LDS per workgroup stays
+// ~20 KB whatever T is (whole segments of T = 128 fit only ~128 per CU, and the lane-sequential f64
+// chain then cannot hide its latency); every chunk row is one 4 TC-byte run, read and written with
+// 16-byte accesses.
+template <bool NSTEP, int PROMO, int EPB, int THREADS, int TC>
+__global__ __launch_bounds__(THREADS) void scan_lds_chunked_kernel(
+    const float* __restrict__ r, const float* __restrict__ v, const uint8_t* __restrict__ d,
+    const float* __restrict__ lv, double gamma, double gl, int64_t n_env, int T,
+    float* __restrict__ out0, float* __restrict__ out1) {
+    constexpr int RAW = EPB * TC, CAP = ((RAW + (RAW >> 5) + 4) + 3) & ~3, QPR = TC / 4;
+    __shared__ __attribute__((aligned(16))) float sr[CAP];
+    __shared__ __attribute__((aligned(16))) float sv[CAP];
+    __shared__ __attribute__((aligned(16))) uint8_t sd[RAW];
+    static_assert(TC % 4 == 0 && THREADS >= EPB, "tile shape");
+    const int tid = threadIdx.x;
+    const int skew_mask = ~0;                         // TC is even
+    const int64_t e0 = (int64_t)blockIdx.x * EPB;
+    const int n_here = (int)((n_env - e0) < EPB ? (n_env - e0) : EPB);
+    double carry = 0.0;
+    float run32 = (tid < n_here) ? lv[e0 + tid] : 0.f, v_next = run32;
+    if (NSTEP && PROMO != ARL_PROMO_NEP50) carry = (double)run32;
+    for (int hi = T; hi > 0; hi -= TC) {              // chunk = steps [lo, hi)
+        const int lo = hi - TC > 0 ? hi - TC : 0, len = hi - lo, qpr = len >> 2, nq = n_here * qpr;
+        for (int q = tid; q < nq; q += THREADS) {
+            const int env = q / qpr, j = q - env * qpr;
+            const int64_t g = (e0 + env) * T + lo + 4 * j;
+            const float4 a = nt_load4(reinterpret_cast<const float4*>(r + g));
+            const float4 b = nt_load4(reinterpret_cast<const float4*>(v + g));
+            const uint32_t dd = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(d + g));
+            const int i = env * len + 4 * j, p = skewed(i, skew_mask);
+            sr[p] = a.x; sr[p + 1] = a.y; sr[p + 2] = a.z; sr[p + 3] = a.w;
+            sv[p] = b.x; sv[p + 1] = b.y; sv[p + 2] = b.z; sv[p + 3] = b.w;
+            *reinterpret_cast<uint32_t*>(sd + i) = dd;
+        }
+        __syncthreads();
+        if (tid < n_here)
+            lane_scan_chunk<NSTEP, PROMO>(sr, sv, sd, tid, len, skew_mask, gamma, gl, carry, run32, v_next);
+        __syncthreads();
+        for (int q = tid; q < nq; q += THREADS) {
+            const int env = q / qpr, j = q - env * qpr;
+            const int64_t g = (e0 + env) * T + lo + 4 * j;
+            const int p = skewed(env * len + 4 * j, skew_mask);
+            nt_store4(reinterpret_cast<float4*>(out0 + g), make_float4(sr[p], sr[p + 1], sr[p + 2], sr[p + 3]));
+            nt_store4(reinterpret_cast<float4*>(out1 + g), make_float4(sv[p], sv[p + 1], sv[p + 2], sv[p + 3]));
+        }
+        __syncthreads();                              // the tile is reused by the next chunk
     }
 }
 
@@ -263,6 +356,13 @@ int dispatch(const float* r, const float* v, const uint8_t* d, const float* lv, 
         return launch_lds<NSTEP, PROMO, 64>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
     }
     if (vec_ok && T <= 34) return launch_lds<NSTEP, PROMO, 64, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
+    if (vec_ok && (T & 3) == 0) {                     // any longer horizon that is a multiple of 4
+        // 32 envs x 64-step chunks (measured at T = 128: 128x16 0.28, 64x32 0.58, 64x64 0.67, 32x64 0.73 of the HBM
+        // peak; whole segments, 32 x 128, 0.51): rows of 256 B keep the accesses wide, ~20 KB keeps 8 tiles resident
+        hipLaunchKernelGGL((scan_lds_chunked_kernel<NSTEP, PROMO, 32, 256, 64>), dim3((unsigned)((n_env + 31) / 32)),
+                           dim3(256), 0, s, r, v, d, lv, gamma, gl, n_env, T, o0, o1);
+        return arl::check_launch("scan_lds_chunked_kernel");
+    }
     if (vec_ok && T <= 136) return launch_lds<NSTEP, PROMO, 32, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
     if (vec_ok && T <= 544) return launch_lds<NSTEP, PROMO, 8, 256>(r, v, d, lv, gamma, gl, n_env, T, o0, o1, s);
     hipLaunchKernelGGL((scan_direct_kernel<NSTEP, PROMO>), dim3(arl::stream_grid(n_env, 256)),
