@@ -29,6 +29,19 @@ class _SyncMixin(object):
         if self._n_gpu > 1 or self._force_collective:
             dist.all_reduce(self._target.flat_grads, op=dist.ReduceOp.SUM, group=self._comm)
 
+    def _share_grad_async(self, tail):
+        """The same all-reduce, asynchronous, of the bucket's tail / head / whole (the split point is the
+        policy's `grad_split_offset`: everything behind it is final when the policy calls the split hook)."""
+        if not (self._n_gpu > 1 or self._force_collective):
+            return None
+        g = self._target.flat_grads
+        if tail is not None:
+            off = int(getattr(self._target, "grad_split_offset", 0))
+            g = g[off:] if tail else g[:off]
+            if g.numel() == 0:
+                return None
+        return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self._comm, async_op=True)
+
     def _avg_factor(self):
         return 1.0 / self._n_gpu
 

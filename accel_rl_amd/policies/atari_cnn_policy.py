@@ -122,6 +122,9 @@ class AtariCnnPolicy(object):
             self._offsets.append(off)
             off += (n + 3) // 4 * 4
         self._bucket_len = off
+        # everything from the first dense tensor on (dense layers, heads) is final once the dense layers'
+        # backward has run: the sync optimizers all-reduce that tail under the conv layers' backward
+        self.grad_split_offset = self._offsets[2 * len(self._conv_geom)]
         self.flat_params = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.flat_grads = torch.zeros(off, dtype=torch.float32, device=self.device)
 
@@ -323,10 +326,10 @@ class AtariCnnPolicy(object):
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
                               ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws,
                               relu_mask_dh=True)
-            self._backward_trunk(x, acts, hids, dh, masked=True)
+            self._backward_trunk(x, acts, hids, dh, masked=True, split_hook=mb.get("split_hook"))
             return loss4
 
-    def _backward_trunk(self, x, acts, hids, dh, masked=False):
+    def _backward_trunk(self, x, acts, hids, dh, masked=False, split_hook=None):
         """Gradients of every trunk layer into flat_grads, given dh = d loss / d (last hidden
         activation); masked: dh is already multiplied by that activation's rectifier mask.
         x, acts, hids as returned by _scaled / _trunk."""
@@ -341,6 +344,9 @@ class AtariCnnPolicy(object):
             d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
             self._layer_grads(d_cur, masked, hids[j], b, hs, k, dense_g[j], inp, d_prev)
             d_cur, masked = d_prev, True
+        if split_hook is not None and self._n_hid:      # dense + head gradients are final from here on
+            self._folds.run()
+            split_hook()
         self._backward_convs(x, acts, d_cur, masked)
 
     def _backward_convs(self, x, acts, d_act, masked=False):
