@@ -24,6 +24,7 @@
 #include "arl_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -698,29 +699,29 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
+    // The epilogue's bias: loaded here, consumed after the loop (no loop-carried copies, latency long gone).
     float4 bias_q[TN][4];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bias_q[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
+            bias_q[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.o.bias && n < a.N) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
+        }
     const int nk = (kend - kbeg) / BK;
     issue_loads(kbeg);
-    store_tiles(0);
+    store_tiles(nk & 1);                            // first tile's buffer chosen so that the loop ends on buffer 1
     __syncthreads();
     if (a.trace) tr1 = __builtin_readcyclecounter();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    // One k-tile with a COMPILE-TIME buffer index: every LDS address is then a per-thread constant plus an
+    // immediate (with `buf = kt & 1` the compiler re-derived four base addresses per tile with vector adds,
+    // and every vector instruction here is taken from the MFMAs' issue slots).
+    auto k_tile = [&](auto buf_c, int kt) {
+        constexpr int buf = decltype(buf_c)::value;
         if (kt + 1 < nk) {                          // uniform branch
             next_tile();
             issue_loads(kbeg + (kt + 1) * BK);
-        } else if (a.o.bias) {                      // the last tile prefetches the epilogue's bias instead
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
-                    if (n < a.N) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
-                }
         }
         __builtin_amdgcn_sched_barrier(0);
         const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
@@ -756,6 +757,14 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         if (kt + 1 < nk) {
             store_tiles(buf ^ 1);
             __syncthreads();
+        }
+    };
+    {   // an odd tile count peels its FIRST tile (from buffer 1); the rest is whole (buffer 0, buffer 1) pairs
+        int kt = 0;
+        if (nk & 1) { k_tile(std::integral_constant<int, 1>{}, 0); kt = 1; }
+        for (; kt < nk; kt += 2) {
+            k_tile(std::integral_constant<int, 0>{}, kt);
+            k_tile(std::integral_constant<int, 1>{}, kt + 1);
         }
     }
 

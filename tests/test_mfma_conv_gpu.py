@@ -20,7 +20,8 @@ CASES = [(37, 104, 80, 4, 32, 8, 4, 0),      # spec-1 conv 1 (ragged batch)
          (50, 12, 9, 64, 64, 3, 1, 1),       # spec-1 conv 3
          (1, 12, 9, 64, 64, 3, 1, 1),        # single image
          (512, 1, 1, 6912, 512, 1, 1, 0),    # spec-1 dense at the PPO minibatch (split-K forward)
-         (256, 1, 1, 6912, 512, 1, 1, 0),    # ... at the rollout batch
+         (256, 1, 1, 6912, 512, 1, 1, 0),    # ... at the rollout batch (9 k-tiles per split: odd)
+         (256, 1, 1, 3840, 512, 1, 1, 0),    # 5 k-tiles per split (the two-tile unrolled loop's odd tail)
          (80, 1, 1, 3456, 256, 1, 1, 0),     # spec-0 dense, ragged rows
          (5120, 1, 1, 512, 128, 1, 1, 0)]    # wide batch, no split
 
