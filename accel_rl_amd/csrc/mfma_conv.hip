@@ -927,10 +927,11 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     produce_rows(1);
     __syncthreads();
     issue_loads(0);
-    store_tiles(0, true);
+    store_tiles(nk & 1, true);                      // first tile's buffer chosen so that the loop ends on buffer 1
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
+    // one k-tile with a compile-time buffer index (as in igemm_body: no vector address math between MFMAs)
+    auto k_tile = [&](auto buf_c, int kt) {
+        constexpr int buf = decltype(buf_c)::value;
         if (kt + 1 < nk) issue_loads(kt + 1);
         // tile kt+1 was the last reader of group (kt+1)/T when it is that group's last tile; the
         // slot is rewritten (group + 2) one iteration later, after this iteration's barrier.
@@ -957,9 +958,20 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1, kt + 1 < nk);
-        __syncthreads();
+        if (kt + 1 < nk) {
+            store_tiles(buf ^ 1, true);
+            __syncthreads();
+        }
+    };
+    {   // an odd tile count peels its FIRST tile (from buffer 1); the rest is whole (buffer 0, buffer 1) pairs
+        int kt = 0;
+        if (nk & 1) { k_tile(std::integral_constant<int, 1>{}, 0); kt = 1; }
+        for (; kt < nk; kt += 2) {
+            k_tile(std::integral_constant<int, 0>{}, kt);
+            k_tile(std::integral_constant<int, 1>{}, kt + 1);
+        }
     }
+    if (do_bias) __syncthreads();                   // every wave is done with the tile buffers
     if (do_bias) {                                  // [BK][MC4] float4 in the (now idle) A buffer, summed in row order
         float4* red = reinterpret_cast<float4*>(sA);
 #pragma unroll
