@@ -44,6 +44,9 @@ struct GatherDesc {
     // dmin = smallest tap displacement; origin = rmin + dmin (descriptor base shift, <= 0);
     // src_bytes is then the descriptor size measured from src + origin
     int taps_y, rmin, dmin, origin;
+    // fast path only: ceil(2^32 / out_w), ceil(2^32 / out_h) when rows * divisor < 2^32 (then
+    // __umulhi(n, magic) == n / divisor exactly for every row index n), else 0 = divide
+    unsigned mg_w, mg_h;
 };
 
 // The weight operand.  B_KC:  element (n, r) at w[n*ld + r]                (r contiguous)
@@ -78,7 +81,7 @@ struct GemmArgs {
     int n_par;
     struct Parity {
         int M, out_h, out_w, add_y, add_x, rmin, dmin, origin, i0, j0, oadd_y, oadd_x;
-        unsigned src_bytes;
+        unsigned src_bytes, mg_w, mg_h;
     } par[4];
 };
 
@@ -555,6 +558,12 @@ __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t rsrc, unsigned
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+// n / d for a uniform runtime divisor: one v_mul_hi instead of the ~40-instruction division sequence
+// (vector instructions in these kernels are paid for in MFMA issue slots); magic == 0 -> plain division
+__device__ __forceinline__ int div_u(int n, int d, unsigned magic) {
+    if (magic) return (int)__umulhi((unsigned)n, magic);
+    return d == 1 ? n : n / d;                      // uniform branches
+}
 __device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned voff) {
     // imask bit set = tap invalid for this row -> force the offset out of range
     return ((unsigned)__builtin_amdgcn_sbfe(imask, bit, 1) & OOB) | voff;
@@ -583,6 +592,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     if (a.n_par) {                                  // uniform: this workgroup's parity class
         const GemmArgs::Parity& q = a.par[bz];
         M = q.M; g.out_h = q.out_h; g.out_w = q.out_w; g.add_y = q.add_y; g.add_x = q.add_x;
+        g.mg_w = q.mg_w; g.mg_h = q.mg_h;
         g.rmin = q.rmin; g.dmin = q.dmin; g.origin = q.origin; g.src_bytes = q.src_bytes;
         w_i0 = q.i0; w_j0 = q.j0; oadd_y = q.oadd_y; oadd_x = q.oadd_x;
         if (m0 >= M) return;
@@ -604,8 +614,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
 #pragma unroll
     for (int p = 0; p < RA; ++p) {
         const int m = m0 + a_row0 + p * ROWS_PER_PASS;
-        const int t = m / g.out_w, ox = m - t * g.out_w;
-        const int b = t / g.out_h, oy = t - b * g.out_h;
+        const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
+        const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
         const int ry = oy * g.mul + g.add_y, rx = ox * g.mul + g.add_x;
         const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
         voffA[p] = m < M ? (unsigned)(rbase - g.rmin + tpt * Cs + chl) << 2 : OOB;
@@ -780,8 +790,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             if (a.o.dense) {
                 row_off[i] = m < M ? (long long)m * a.N : -1;
             } else {                                    // stride-parity data gradient: rows map to scattered pixels
-                const int t = m / g.out_w, ox = m - t * g.out_w;
-                const int b = t / g.out_h, oy = t - b * g.out_h;
+                const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
+                const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
                 row_off[i] = m < M ? ((long long)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N
                                    : -1;
             }
@@ -1205,6 +1215,12 @@ int check_geom(const arl_conv_geom* g, Geom* o) {
 
 int round_up(int x, int q) { return (x + q - 1) / q * q; }
 
+// ceil(2^32 / d) if floor(n * that / 2^32) == n / d for every 0 <= n < rows (needs rows * d < 2^32), else 0
+unsigned div_magic(int64_t rows, int d) {
+    if (d <= 1 || rows * (int64_t)d >= ((int64_t)1 << 32)) return 0;
+    return (unsigned)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d);
+}
+
 // split the reduction so that tiles * splits ~ TARGET_WGS, each split a multiple of BKT
 void plan_split(int tiles, int red, int* splits, int* per, int want = TARGET_WGS) {
     int s = tiles >= want ? 1 : want / tiles;
@@ -1258,6 +1274,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
                       (!has_pad || g.kh * g.kw <= 32) && a.N % 4 == 0;
     if (fast) {
         a.o.out_bytes = (unsigned)((int64_t)a.M * a.N * 4);     // one split's output
+        a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
         a.g.taps_y = g.kh; a.g.dmin = 0;
         a.g.rmin = (a.g.add_y * g.W + a.g.add_x) * g.C;
         a.g.origin = a.g.rmin + a.g.dmin;
@@ -1331,6 +1348,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             a.g.dmin = -((taps_y - 1) * g.Wo + (taps_x - 1)) * g.K;
             a.g.origin = a.g.rmin + a.g.dmin;
             a.g.src_bytes = (unsigned)(g.batch * g.Ho * g.Wo * g.K * 4 - (int64_t)a.g.origin * 4);
+            a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
         }
         return a;
     };
@@ -1343,6 +1361,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
                     const GemmArgs q = describe(ph, pw);
                     GemmArgs::Parity& e = a.par[n++];
                     e.M = q.M; e.out_h = q.g.out_h; e.out_w = q.g.out_w; e.add_y = q.g.add_y; e.add_x = q.g.add_x;
+                    e.mg_w = q.g.mg_w; e.mg_h = q.g.mg_h;
                     e.rmin = q.g.rmin; e.dmin = q.g.dmin; e.origin = q.g.origin; e.src_bytes = q.g.src_bytes;
                     e.i0 = q.b.i0; e.j0 = q.b.j0; e.oadd_y = q.o.oadd_y; e.oadd_x = q.o.oadd_x;
                     if (q.M > max_m) max_m = q.M;
