@@ -163,14 +163,32 @@ struct HeadLossArgs {
 // one wave per row (looping); lanes split the hidden dimension.  Every per-action
 // array is indexed with compile-time indices only (fully unrolled loops with
 // `k < n_act` guards) so that it lives in VGPRs, not scratch.
-constexpr int HV = HID_MAX / 64;
-
-template <bool TRAIN>
+// HVT = hid / 64 when the hidden width is a multiple of 64 (no per-lane guards: a guarded element costs an
+// exec-mask save / branch / restore, and the generic kernel is mostly those), 0 = any width.
+template <bool TRAIN, int HVT = 0>
 __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __restrict__ prob_out,
                                                    float* __restrict__ value_out) {
+    constexpr int HV = HVT ? HVT : HID_MAX / 64;
     extern __shared__ __attribute__((aligned(16))) float s_w[];     // [K][hid]
     __shared__ float s_loss[4][4];
     const int A = a.n_act, K = A + 1, hid = a.hid, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // A row's scalars hang off a three-deep chain of dependent loads (idx -> action -> old probability): they
+    // are fetched one row ahead -- the first row's before the weights are even staged -- so the chain's
+    // latency runs under the dot products instead of after them.
+    struct RowMeta { int64_t row; int act; float adv, ret, valid, old_pa; };
+    auto load_meta = [&](int b) {
+        RowMeta m = {b, 0, 0.f, 0.f, 1.f, 0.f};
+        if (TRAIN && b < a.batch) {
+            m.row = a.idx ? (int64_t)a.idx[b] : b;
+            m.act = a.actions[m.row];
+            m.adv = a.adv[m.row]; m.ret = a.ret[m.row];
+            m.valid = a.valids ? (a.valids[m.row] != 0 ? 1.f : 0.f) : 1.f;
+            if (a.kind == 1) m.old_pa = a.old_prob[m.row * A + m.act];
+        }
+        return m;
+    };
+    const int waves_total = (gridDim.x * blockDim.x) >> 6;
+    RowMeta meta = load_meta(blockIdx.x * (blockDim.x >> 6) + wave);
     if (((K * hid) & 3) || (reinterpret_cast<uintptr_t>(a.w_head) & 15)) {
         for (int i = threadIdx.x; i < K * hid; i += blockDim.x) s_w[i] = a.w_head[i];
     } else {    // stage W: independent b128 loads, four in flight per thread
@@ -192,12 +210,14 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
     const float inv_n = TRAIN ? (a.inv_count ? a.inv_count[0] : 1.f / (float)a.batch) : 0.f;
     const float clip = TRAIN ? a.clip_param * a.lr_mult[0] : 0.f;
     float l_pi = 0.f, l_v = 0.f, l_ent = 0.f;
-    const int waves = (gridDim.x * blockDim.x) >> 6;
+    const int waves = waves_total;
     for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < a.batch; b += waves) {
+        const RowMeta cur = meta;
+        meta = load_meta(b + waves);                                    // next row's chain starts now
         const float* hrow = a.h + (int64_t)b * hid;
         float hv[HV];
 #pragma unroll
-        for (int j = 0; j < HV; ++j) hv[j] = (lane + 64 * j < hid) ? hrow[lane + 64 * j] : 0.f;
+        for (int j = 0; j < HV; ++j) hv[j] = (HVT || lane + 64 * j < hid) ? hrow[lane + 64 * j] : 0.f;
         float out[K_MAX];
 #pragma unroll
         for (int k = 0; k < K_MAX; ++k) {
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
                 float sdot = 0.f;
 #pragma unroll
                 for (int j = 0; j < HV; ++j)
-                    if (lane + 64 * j < hid) sdot += hv[j] * s_w[k * hid + lane + 64 * j];
+                    if (HVT || lane + 64 * j < hid) sdot += hv[j] * s_w[k * hid + lane + 64 * j];
                 out[k] = wave_sum_f(sdot) + a.b_head[k];
             }
         }
@@ -231,10 +251,9 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
             if (lane == 0) value_out[b] = v;
             continue;
         }
-        const int64_t row = a.idx ? (int64_t)a.idx[b] : b;
-        const float w = (a.valids ? (a.valids[row] != 0 ? 1.f : 0.f) : 1.f) * inv_n;   // valids_mean
-        const int act = a.actions[row];
-        const float adv = a.adv[row], ret = a.ret[row];
+        const float w = cur.valid * inv_n;                              // valids_mean
+        const int act = cur.act;
+        const float adv = cur.adv, ret = cur.ret;
         const float pa = __shfl(pk, act, 64);
         // ---- d loss / d p_k : entropy term for every action (categorical.py:76-78)
         const float lg = is_act ? logf(pk + TINY) : 0.f;
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
             if (k < A) ent -= __shfl(ent_k, k, 64);
         float pi_term, g_act;
         if (a.kind == 1) {                                               // PPO, ppo.py:42-51
-            const float old_pa = a.old_prob[row * A + act];
+            const float old_pa = cur.old_pa;
             const float ratio = (pa + TINY) / (old_pa + TINY);           // categorical.py:66-70
             const float lo = 1.f - clip, hi = 1.f + clip;
             const float rc = fminf(fmaxf(ratio, lo), hi);
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
             const int c = lane + 64 * j;
-            if (c < hid) {
+            if (HVT || c < hid) {
                 float sdh = 0.f;
 #pragma unroll
                 for (int k = 0; k < K_MAX; ++k)
@@ -470,8 +489,14 @@ extern "C" int arl_pg_head_infer(const float* h, const float* w_head, const floa
     HeadLossArgs a = {};
     a.h = h; a.w_head = w_head; a.b_head = b_head; a.batch = (int)batch; a.hid = hid; a.n_act = n_actions;
     const int grid = (int)((batch + 3) / 4 < 1024 ? (batch + 3) / 4 : 1024);
-    hipLaunchKernelGGL((head_kernel<false>), dim3(grid), dim3(256), (size_t)(n_actions + 1) * hid * 4,
-                       (hipStream_t)stream, a, prob, value);
+    const size_t lds = (size_t)(n_actions + 1) * hid * 4;
+#define ARL_HEAD_INFER(HVT_) hipLaunchKernelGGL((head_kernel<false, HVT_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, prob, value)
+    if (hid == 512) ARL_HEAD_INFER(8);
+    else if (hid == 256) ARL_HEAD_INFER(4);
+    else if (hid == 1024) ARL_HEAD_INFER(16);
+    else if (hid == 64) ARL_HEAD_INFER(1);
+    else ARL_HEAD_INFER(0);
+#undef ARL_HEAD_INFER
     return arl::check_launch("head_kernel<infer>");
 }
 
@@ -498,8 +523,13 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
     a.clip_param = clip_param; a.v_coeff = v_loss_coeff; a.ent_coeff = ent_loss_coeff; a.mask_dh = relu_mask_dh;
     const int grid = (int)((batch + 3) / 4 < 256 ? (batch + 3) / 4 : 256);
     const int K = n_actions + 1;
-    hipLaunchKernelGGL((head_kernel<true>), dim3(grid), dim3(256), (size_t)K * hid * 4, s, a,
-                       (float*)nullptr, (float*)nullptr);
+#define ARL_HEAD_TRAIN(HVT_) hipLaunchKernelGGL((head_kernel<true, HVT_>), dim3(grid), dim3(256), (size_t)K * hid * 4, s, a, (float*)nullptr, (float*)nullptr)
+    if (hid == 512) ARL_HEAD_TRAIN(8);
+    else if (hid == 256) ARL_HEAD_TRAIN(4);
+    else if (hid == 1024) ARL_HEAD_TRAIN(16);
+    else if (hid == 64) ARL_HEAD_TRAIN(1);
+    else ARL_HEAD_TRAIN(0);
+#undef ARL_HEAD_TRAIN
     rc = arl::check_launch("head_kernel<train>");
     if (rc) return rc;
     float* ws = (float*)workspace;
