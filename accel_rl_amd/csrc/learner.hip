@@ -134,6 +134,9 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------- heads
+__device__ __forceinline__ float readlane_f(float x, int uniform_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), uniform_lane));
+}
 __device__ __forceinline__ float wave_sum_f(float x) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
@@ -218,33 +221,23 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
         float hv[HV];
 #pragma unroll
         for (int j = 0; j < HV; ++j) hv[j] = (HVT || lane + 64 * j < hid) ? hrow[lane + 64 * j] : 0.f;
-        float out[K_MAX];
-#pragma unroll
-        for (int k = 0; k < K_MAX; ++k) {
-            out[k] = 0.f;
-            if (k < K) {
-                float sdot = 0.f;
-#pragma unroll
-                for (int j = 0; j < HV; ++j)
-                    if (HVT || lane + 64 * j < hid) sdot += hv[j] * s_w[k * hid + lane + 64 * j];
-                out[k] = wave_sum_f(sdot) + a.b_head[k];
-            }
-        }
         // Lane k owns action k (lane A the value): the transcendental work is done once per action, not
-        // once per lane; sums over actions stay sequential in k (readlane), i.e. in a fixed order.
+        // once per lane; sums over actions stay sequential in k (readlane), i.e. in a fixed order.  The loops
+        // over k are real loops (K is uniform): unrolled to the 19-action maximum they were mostly branches.
         float v = 0.f, mx = -3.0e38f, mine = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float sdot = 0.f;
 #pragma unroll
-        for (int k = 0; k < K_MAX; ++k) {
-            if (k < A) mx = fmaxf(mx, out[k]);
-            if (k == A) v = out[k];
-            if (k < K) mine = (lane == k) ? out[k] : mine;
+            for (int j = 0; j < HV; ++j)
+                if (HVT || lane + 64 * j < hid) sdot += hv[j] * s_w[k * hid + lane + 64 * j];
+            const float o = wave_sum_f(sdot) + a.b_head[k];
+            if (k < A) mx = fmaxf(mx, o); else v = o;
+            mine = (lane == k) ? o : mine;
         }
         const bool is_act = lane < A;
         const float ex = is_act ? expf(mine - mx) : 0.f;
         float z = 0.f;
-#pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
-            if (k < A) z += __shfl(ex, k, 64);
+        for (int k = 0; k < A; ++k) z += readlane_f(ex, k);
         const float pk = ex / z;
         if (!TRAIN) {
             if (is_act) prob_out[(int64_t)b * A + lane] = pk;
@@ -260,9 +253,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
         const float ent_k = pk * lg;
         float gk = is_act ? a.ent_coeff * w * (lg + pk / (pk + TINY)) : 0.f;     // d(-c_e * ent)/dp_k
         float ent = 0.f;
-#pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
-            if (k < A) ent -= __shfl(ent_k, k, 64);
+        for (int k = 0; k < A; ++k) ent -= readlane_f(ent_k, k);
         float pi_term, g_act;
         if (a.kind == 1) {                                               // PPO, ppo.py:42-51
             const float old_pa = cur.old_pa;
@@ -282,31 +273,29 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
         gk += (lane == act) ? g_act : 0.f;
         const float gp = gk * pk;
         float dot = 0.f;
-#pragma unroll
-        for (int k = 0; k < ARL_MAX_ACTIONS; ++k)
-            if (k < A) dot += __shfl(gp, k, 64);
+        for (int k = 0; k < A; ++k) dot += readlane_f(gp, k);
         const float dlk = is_act ? pk * (gk - dot) : (lane == A ? dv : 0.f);      // softmax backward | value
         if (lane < K) a.dout[(int64_t)b * K + lane] = dlk;
-        float dl[K_MAX];
-#pragma unroll
-        for (int k = 0; k < K_MAX; ++k) dl[k] = (k < K) ? __shfl(dlk, k, 64) : 0.f;
         if (lane == 0) {
             l_pi += -w * pi_term;
             l_v += a.v_coeff * w * (v - ret) * (v - ret);
             l_ent += -a.ent_coeff * w * ent;
         }
-        // dh[b][c] = sum_k dl_k W[k][c]
+        // dh[b][c] = sum_k dl_k W[k][c], k in order
+        float sdh[HV];
+#pragma unroll
+        for (int j = 0; j < HV; ++j) sdh[j] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float dl_k = readlane_f(dlk, k);
+#pragma unroll
+            for (int j = 0; j < HV; ++j)
+                if (HVT || lane + 64 * j < hid) sdh[j] += dl_k * s_w[k * hid + lane + 64 * j];
+        }
         float* dhrow = a.dh + (int64_t)b * hid;
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
             const int c = lane + 64 * j;
-            if (HVT || c < hid) {
-                float sdh = 0.f;
-#pragma unroll
-                for (int k = 0; k < K_MAX; ++k)
-                    if (k < K) sdh += dl[k] * s_w[k * hid + c];
-                dhrow[c] = (a.mask_dh && !(hv[j] > 0.f)) ? 0.f : sdh;
-            }
+            if (HVT || c < hid) dhrow[c] = (a.mask_dh && !(hv[j] > 0.f)) ? 0.f : sdh[j];
         }
     }
     if (TRAIN) {
