@@ -75,7 +75,6 @@ struct GemmArgs {
     int k_per_split;        // multiple of BK; gridDim.z splits
     int64_t split_stride;   // elements between split outputs (dense M*N)
     unsigned long long* trace;  // tuning aid: per-workgroup timestamps (arl_conv_trace_buffer), or null
-    int debug;              // tuning aid (ARL_CONV_DEBUG): bit 0 = skip the epilogue's stores
     // stride-s data gradient: the s*s input-pixel parity classes are independent implicit GEMMs that
     // differ only in the fields below; one launch runs them all, blockIdx.z = class (igemm_kernel only)
     int n_par;
@@ -780,7 +779,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
 
     if (a.trace) tr2 = __builtin_readcyclecounter();
     float* out = a.o.out + (a.n_par ? 0 : (int64_t)bz * a.split_stride);
-    if (!(a.debug & 1)) {
+    {
         // operands are swapped (acc = W-tile x X-tile^T): every lane owns ONE output row per 32-row tile
         const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out, a.o.out_bytes);
         long long row_off[TM];
@@ -1177,11 +1176,6 @@ constexpr int TARGET_WGS = 256;     // one workgroup per CU is already MFMA-boun
 constexpr int BKT = 32;             // k-tile of the skinny configurations (host-side split granularity)
 
 unsigned long long* g_trace = nullptr;
-int g_debug = -1;
-int debug_flags() {
-    if (g_debug < 0) { const char* e = getenv("ARL_CONV_DEBUG"); g_debug = e ? atoi(e) : 0; }
-    return g_debug;
-}
 bool g_force_generic = false;       // arl_conv_force_generic: route every call to the generic kernels (tests)
 
 struct Geom {
@@ -1254,7 +1248,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.kh * g.kw * g.C;
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.b.w = w; a.b.ld = a.K; a.b.w_bytes = (unsigned)((int64_t)a.N * a.K * 4);
-    a.o.dense = 1; a.trace = g_trace; a.debug = debug_flags();
+    a.o.dense = 1; a.trace = g_trace;
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
     if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
@@ -1342,7 +1336,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         a.o.out_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
         a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
         a.k_per_split = round_up(a.K, BKT);
-        a.trace = g_trace; a.debug = debug_flags();
+        a.trace = g_trace;
         if (fast) {
             a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
             a.g.dmin = -((taps_y - 1) * g.Wo + (taps_x - 1)) * g.K;
