@@ -246,3 +246,62 @@ def test_fold_many_matches_separate_folds_and_checks_arguments():
     assert lib.arl_fold_many(items, 4, None) < 0
     assert lib.arl_fold_many(items, _lib.FOLD_MAX_ITEMS + 1, None) < 0
     assert lib.arl_fold_many(None, 0, None) == 0
+
+
+def _random_cases(n, seed):
+    """Random geometries inside the kernels' contract (channels / filters multiples of 4, kernel size a
+    multiple of the stride for the data gradient), biased towards the fast-path conditions (multiples of
+    32) but including ragged batches, odd images, odd k-tile counts and split reductions."""
+    rs = np.random.RandomState(seed)
+    out = []
+    while len(out) < n:
+        st = int(rs.choice([1, 1, 2, 4]))
+        ks = int(st * rs.choice([1, 2, 3]) if st > 1 else rs.choice([1, 3, 5]))
+        c = int(rs.choice([4, 8, 16, 32, 64, 96]))
+        k = int(rs.choice([4, 16, 32, 64, 128]))
+        h, w = int(rs.randint(ks, 30)), int(rs.randint(ks, 30))
+        p = int(rs.randint(0, 2)) if ks > 1 else 0
+        b = int(rs.choice([1, 7, 32, 64, 100]))
+        if ks == 1 and rs.rand() < 0.5:                      # dense layers: long reductions, split K
+            h = w = 1
+            c = int(rs.choice([256, 1152, 3840, 4000]))
+        out.append((b, h, w, c, k, ks, st, p))
+    return out
+
+
+@pytest.mark.parametrize("case", _random_cases(36, seed=20240930))
+def test_random_geometries_against_torch_and_the_generic_kernels(case):
+    """Forward, data gradient (masked) and weight gradient on random shapes: fp32 tolerance against
+    PyTorch (same bound as above) for whichever kernel family the dispatcher picks, and against the
+    generic kernels forced on the same inputs."""
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = case
+    x, wt, bias, geom, ws = _mk(case, seed=11)
+    ho, wo = _lib.conv_out_hw(geom)
+    gen = torch.Generator(device=DEV).manual_seed(13)
+    dy = torch.randn(b, ho, wo, k, device=DEV, generator=gen)
+    xr = x.permute(0, 3, 1, 2).detach().requires_grad_()
+    wr = wt.permute(0, 3, 1, 2).detach().requires_grad_()
+    out = F.conv2d(xr, wr, bias, stride=st, padding=p)
+    gx, gw = torch.autograd.grad(out, (xr, wr), dy.permute(0, 3, 1, 2))
+    want_y = F.relu(out.detach()).permute(0, 2, 3, 1)
+    gx, gw = gx.permute(0, 2, 3, 1), gw.permute(0, 2, 3, 1)
+    res = {}
+    for generic in (0, 1):
+        _lib.load().arl_conv_force_generic(generic)
+        try:
+            y = torch.full((b, ho, wo, k), float("nan"), device=DEV)
+            _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+            dx = torch.full((b, h, w, c), float("nan"), device=DEV)
+            _lib.conv2d_bwd_data(dy, wt, x, dx, geom)
+            dw = torch.full((k, ks, ks, c), float("nan"), device=DEV)
+            _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+        finally:
+            _lib.load().arl_conv_force_generic(0)
+        assert (y - want_y).abs().max().item() <= _tol(want_y, ks * ks * c), (case, generic)
+        want_dx = torch.where(x > 0, gx, torch.zeros_like(gx))
+        assert (dx - want_dx).abs().max().item() <= _tol(gx, (ks // st) ** 2 * k), (case, generic)
+        assert (dw - gw).abs().max().item() <= _tol(gw, b * ho * wo), (case, generic)
+        res[generic] = (y, dx, dw)
+    for a, g_ in zip(res[0], res[1]):                      # the two families agree to round-off too
+        assert torch.allclose(a, g_, rtol=1e-4, atol=1e-4 * max(g_.abs().max().item(), 1e-6))
