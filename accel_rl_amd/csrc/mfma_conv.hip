@@ -29,6 +29,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // GEMM rows gathered from an NHWC tensor: row m = (b, oy, ox); reduction index
 // r = (ty * taps_x + tx) * Cs + ch reads src[b][y0 + step*ty][x0 + step*tx][ch],
@@ -568,11 +569,17 @@ __device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned v
     return ((unsigned)__builtin_amdgcn_sbfe(imask, bit, 1) & OOB) | voff;
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD>
+// N16: layers with <= 16 output columns (spec 0's 16-filter conv 1, the data gradient into 16 channels) use
+// v_mfma_f32_16x16x4_f32 -- a 32-wide tile would spend half of every MFMA on columns that do not exist.
+// A wave then owns TM groups of 16 rows x 16 columns; lane (l & 15, l >> 4) holds row l & 15 and the four
+// channels 4 (l >> 4) .. + 3 of each group, again one b128 store per group.
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false>
 __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* smem) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, CH = BK / 4;
+    constexpr int MT = N16 ? 16 : 32;               // rows per MFMA tile
+    constexpr int BM = WGM * TM * MT, BN = N16 ? 16 : WGN * TN * 32, CH = BK / 4;
     constexpr int LDA = BK + 4;
-    constexpr int LDB = B_KC ? BK + 4 : BN;
+    constexpr int LDB = B_KC ? BK + 4 : (N16 ? 20 : BN);        // 20: the four k-quads of a 16-wide read hit distinct banks
+    static_assert(!N16 || (WGN == 1 && TN == 1 && BK % 16 == 0), "16-wide tiles: one column tile per wave");
     constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
     constexpr int ROWS_PER_PASS = 256 / CH;
     constexpr int RA = BM / ROWS_PER_PASS;
@@ -700,13 +707,18 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         }
     };
 
+    const int l15 = lane & 15, quad = lane >> 4;    // N16 lane coordinates
     f32x16 acc[TM][TN];
+    f32x4 acc16[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc16[i][v] = 0.f;
+    }
 
     // The epilogue's bias: loaded here, consumed after the loop (no loop-carried copies, latency long gone).
     float4 bias_q[TN][4];
@@ -714,9 +726,9 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
+            const int n = N16 ? n0 + 4 * quad : n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
             bias_q[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.o.bias && n < a.N) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
+            if (a.o.bias && n < a.N && (!N16 || q == 0)) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
         }
     const int nk = (kend - kbeg) / BK;
     issue_loads(kbeg);
@@ -733,6 +745,32 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             issue_loads(kbeg + (kt + 1) * BK);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (N16) {
+            const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
+            const float* cB = B_KC ? sB + buf * B_SZ + l15 * LDB + quad * 4
+                                   : sB + buf * B_SZ + (quad * 4) * LDB + l15;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                float fa[TM][4], fb[4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 16 * LDA + ks * 16);
+                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
+                }
+                if (B_KC) {
+                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 16);
+                    fb[0] = t.x; fb[1] = t.y; fb[2] = t.z; fb[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fb[q] = cB[(ks * 16 + q) * LDB];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[q], fa[i][q], acc16[i], 0, 0, 0);
+            }
+        } else {
         const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
         const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
                                : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
@@ -762,6 +800,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
         }
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) {
             store_tiles(buf ^ 1);
@@ -785,7 +824,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         long long row_off[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * 32 + l31;
+            const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
             if (a.o.dense) {
                 row_off[i] = m < M ? (long long)m * a.N : -1;
             } else {                                    // stride-parity data gradient: rows map to scattered pixels
@@ -795,7 +834,28 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                                    : -1;
             }
         }
-        store_tiles_quads<TM, TN>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu);
+        if constexpr (N16) {
+            const int n = n0 + 4 * quad;
+            const float4 bq = bias_q[0][0];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bool ok = row_off[i] >= 0 && n < a.N;
+                float4 val = make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
+                if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
+                if (a.o.mask) {
+                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (ok) mk = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
+                    if (!(mk.x > 0.f)) val.x = 0.f;
+                    if (!(mk.y > 0.f)) val.y = 0.f;
+                    if (!(mk.z > 0.f)) val.z = 0.f;
+                    if (!(mk.w > 0.f)) val.w = 0.f;
+                }
+                u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rsO, ok ? (unsigned)((row_off[i] + n) << 2) : OOB, 0, 0);
+            }
+        } else {
+            store_tiles_quads<TM, TN>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu);
+        }
     }
     if (a.trace && tid == 0) {
         unsigned long long* t = a.trace + ((size_t)(bz * gridDim.y + by) * gridDim.x + bx) * 8;     // plain launches only
@@ -806,10 +866,10 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD>
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // Weight gradient, scalar-addressed: dy advances by a uniform stride per tile (soffset); the
@@ -1125,16 +1185,16 @@ int allow_big_lds(K kernel, size_t lds) {           // > 64 KiB of dynamic LDS n
     return 0;
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC>
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16 = false>
 int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hipStream_t s) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * BN;
+    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? 16 : WGN * TN * 32;
+    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? 20 : BN);
     const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
     int rc = 0;
 #define ARL_IGEMM(MT, HP)                                                                                  \
     do {                                                                                                   \
-        auto k = igemm_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP>;                                         \
+        auto k = igemm_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16>;                                    \
         rc = allow_big_lds(k, lds);                                                                        \
         if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
     } while (0)
@@ -1277,7 +1337,9 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         // SIMD the barrier, load and LDS latencies of each k-tile sit exposed between MFMA bursts
         // (64x64 instead of 128x64 tiles at N = 64: 46.8 -> 45.0 us, 50.6 -> 48.2 us at the PPO minibatch)
         // (the 128x32 tile at BK = 32 would allow only 3: a 16-wide k-tile, 5-6 resident, is 3-5 us faster)
-        if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
+        if (a.N <= 16 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
+            rc = launch_igemm<4, 1, 2, 1, 16, true, true>(a, splits, multi_tap, has_pad, s);        // 16-wide MFMA tiles
+        else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 1, 1, 16, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
@@ -1367,7 +1429,8 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             plan_only->cfg = a.N <= 32 ? 0 : a.N <= 64 ? 1 : 2;
             return 0;
         }
-        if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
+        if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
+        else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, 1, false, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
         return rc;
