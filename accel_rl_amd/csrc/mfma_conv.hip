@@ -879,9 +879,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
 // Requirements: Mred % 256 == 0 is NOT needed, but Mred % BK == 0 and m_per_split % BK == 0.
 constexpr int WG_ROWS = 256;
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD>
+// M16: <= 16 output channels (spec 0's conv 1) -> v_mfma_f32_16x16x4_f32, 16 channel rows x 16-column groups
+// (a 32-row tile would spend half of every MFMA on channels that do not exist).
+template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false>
 __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx, const int by, const int bz, float* smem) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int BM = M16 ? 16 : WGM * TM * 32, BN = WGN * TN * 32;
+    static_assert(!M16 || (WGM == 1 && TM == 1 && BK % 16 == 0), "16-row tiles: one row tile");
     constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
     constexpr int NA4 = BK * BM / 4, RA = (NA4 + 255) / 256, MC4 = BM / 4;
     constexpr int NC4 = BN / 4, KROWS = 256 / NC4, RB = BK / KROWS;
@@ -988,6 +991,13 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    constexpr int G16 = TN * 2;                     // M16: 16-column groups per wave
+    const int l15 = lane & 15, quad = lane >> 4;
+    f32x4 acc16[G16];
+#pragma unroll
+    for (int gq = 0; gq < G16; ++gq)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc16[gq][v] = 0.f;
 
     // Row groups: group g (tiles g*T .. g*T+T-1) lives in slot g & 1.  Groups 0 and 1 are produced
     // up front; group g+2 is produced in the first iteration of group g+1's ... see loop.
@@ -1006,6 +1016,25 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         // slot is rewritten (group + 2) one iteration later, after this iteration's barrier.
         if (kt % TILES_PER_GROUP == 0 && kt >= TILES_PER_GROUP) produce_rows(((kt / TILES_PER_GROUP) + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (M16) {
+            const float* cA = sA + buf * A_SZ + (quad * 4) * BM + l15;
+            const float* cB = sB + buf * B_SZ + (quad * 4) * BN + wn * TN * 32 + l15;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                float fa[4], fb[G16][4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    fa[q] = cA[(ks * 16 + q) * BM];
+#pragma unroll
+                    for (int gq = 0; gq < G16; ++gq) fb[gq][q] = cB[(ks * 16 + q) * BN + gq * 16];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int gq = 0; gq < G16; ++gq)
+                        acc16[gq] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q], fb[gq][q], acc16[gq], 0, 0, 0);
+            }
+        } else {
         const float* cA = sA + buf * A_SZ + (half * 4) * BM + wm * TM * 32 + l31;
         const float* cB = sB + buf * B_SZ + (half * 4) * BN + wn * TN * 32 + l31;
 #pragma unroll
@@ -1025,6 +1054,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
+        }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) {
@@ -1061,13 +1091,25 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     }
 
     float* out = a.part + (int64_t)bz * a.K_out * a.N;
-    store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
+    if constexpr (M16) {                            // D[row = 4 quad + v][col = l15] per 16-column group
+#pragma unroll
+        for (int gq = 0; gq < G16; ++gq) {
+            const int col = n0 + wn * TN * 32 + gq * 16 + l15;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = i0 + 4 * quad + v;
+                if (row < a.K_out && col < a.N) out[(int64_t)row * a.N + col] = acc16[gq][v];
+            }
+        }
+    } else {
+        store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
+    }
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD>
+template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, M16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // One launch for a layer's data gradient AND weight gradient (independent of each other, both read dy):
@@ -1206,18 +1248,18 @@ int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hi
     return rc ? rc : arl::check_launch("igemm_kernel");
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK>
+template <int WGM, int WGN, int TM, int TN, int BK, bool M16 = false>
 int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t s) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    constexpr int BM = M16 ? 16 : WGM * TM * 32, BN = WGN * TN * 32;
     const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
     dim3 grid((a.N + BN - 1) / BN, (a.K_out + BM - 1) / BM, splits);
     int rc;
     if (has_pad) {
-        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, true>;
+        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, true, M16>;
         rc = allow_big_lds(k, lds + 4096);
         if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
     } else {
-        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, false>;
+        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, false, M16>;
         rc = allow_big_lds(k, lds + 4096);
         if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
     }
@@ -1470,7 +1512,8 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
     int bm, bn;
-    if (g.K <= 32) { bm = 32; bn = 128; }
+    if (g.K <= 16) { bm = 16; bn = 128; }
+    else if (g.K <= 32) { bm = 32; bn = 128; }
     else if (g.K <= 64) { bm = 64; bn = 64; }
     else { bm = 128; bn = 128; }
     const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
@@ -1512,7 +1555,8 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
             plan_only->splits = splits; plan_only->total = total;
             return 0;
         }
-        if (g.K <= 32) rc = launch_wgrad_fast<1, 4, 1, 1, FBK>(a, splits, has_pad, s);
+        if (g.K <= 16) rc = launch_wgrad_fast<1, 4, 1, 1, FBK, true>(a, splits, has_pad, s);       // 16-row MFMA tiles
+        else if (g.K <= 32) rc = launch_wgrad_fast<1, 4, 1, 1, FBK>(a, splits, has_pad, s);
         else if (g.K <= 64) rc = launch_wgrad_fast<2, 2, 1, 1, FBK>(a, splits, has_pad, s);
         else rc = launch_wgrad_fast<2, 2, 2, 2, FBK>(a, splits, has_pad, s);
     } else {
