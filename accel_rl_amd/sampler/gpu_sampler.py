@@ -37,6 +37,24 @@ from accel_rl_amd.util.misc import nbytes_unit, struct
 NOOP_RING = 4096
 
 
+def _packed_block(spec, device, pinned=False):
+    """One zeroed byte block holding every (name, shape, dtype) of `spec` at 16-byte-aligned offsets;
+    returns (block, {name: typed view})."""
+    offsets, total = [], 0
+    for _, shape, dtype in spec:
+        total = (total + 15) // 16 * 16
+        offsets.append(total)
+        total += int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    block = torch.zeros(total, dtype=torch.uint8, device=device)
+    if pinned:
+        block = block.pin_memory()
+    views = dict()
+    for (name, shape, dtype), off in zip(spec, offsets):
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        views[name] = block[off:off + nbytes].view(dtype).view(*shape)
+    return block, views
+
+
 class _LazyTrajInfos(list):
     """The batch's completed TrajInfos, fetched on first use.  obtain_samples returns right after
     enqueuing the rollout; a caller that first enqueues the learner (as the runners do) and only then
@@ -155,9 +173,14 @@ class GpuVecSampler(BaseMbSampler):
             traj_disc=f32(n), traj_curdisc=torch.ones(n, dtype=torch.float64, device=dev),
             frame_a=i32(n), frame_b=i32(n), frame_mode=u8(n), reset_flag=u8(n),
             noop_ring=u8(n_streams, NOOP_RING),
-            noop_cursor=torch.zeros((2, n_streams), dtype=torch.int64, device=dev),
-            epoch=i32(1), done_count=i32(1), done_int=i32(n * t, 3), done_flt=f32(n * t, 3),
         )
+        # the batch's small results live in ONE block so that one D2H copy mirrors them (see _host)
+        spec = (("noop_cursor", (2, n_streams), torch.int64), ("epoch", (1,), torch.int32),
+                ("done_count", (1,), torch.int32), ("done_int", (n * t, 3), torch.int32),
+                ("done_flt", (n * t, 3), torch.float32))
+        self._results_block, views = _packed_block(spec, dev)
+        self._st.update(views)
+        self._results_spec = spec
         self._worker_rngs = []
         self._eval_phases = np.zeros(n_streams * (eval_per or 0), np.int32)
         phases = np.zeros(n, np.int32)
@@ -226,12 +249,8 @@ class GpuVecSampler(BaseMbSampler):
         # pinned mirrors of the batch's small results (completed-episode records, no-op ring cursors):
         # copied at the end of the batch ON the stream (inside the hipGraph), read by the host after
         # waiting for the batch event only -- not for whatever was enqueued behind it (the learner)
-        st = self._st
-        self._host = struct(done_count=torch.zeros_like(st.done_count, device="cpu").pin_memory(),
-                            done_int=torch.zeros_like(st.done_int, device="cpu").pin_memory(),
-                            done_flt=torch.zeros_like(st.done_flt, device="cpu").pin_memory(),
-                            noop_cursor=torch.zeros_like(st.noop_cursor, device="cpu").pin_memory(),
-                            epoch=torch.zeros_like(st.epoch, device="cpu").pin_memory())
+        self._host_block, views = _packed_block(self._results_spec, "cpu", pinned=True)
+        self._host = struct(**views)
         self._batch_event = torch.cuda.Event()
         self._pending = None
         logger.log("GpuVecSampler -- total_n_envs: {}".format(self.total_n_envs))
@@ -311,8 +330,7 @@ class GpuVecSampler(BaseMbSampler):
             buf.extra_observations.copy_(self.step_obs)        # sampler.py:147-151
         if not self.mid_batch_reset:                           # worker.py:108-113
             _lib.env_reset(self._game, self._state, ro, self._st.frozen, env.max_start_noops)
-        for k, host in self._host.items():
-            host.copy_(self._st[k], non_blocking=True)
+        self._host_block.copy_(self._results_block, non_blocking=True)
 
     def _kernel_max_path_length(self):
         """The kernels end an episode when Length > limit (worker.py:42)."""

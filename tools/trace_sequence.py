@@ -1,6 +1,6 @@
 """One bench step as a timeline: every kernel between two consecutive GAE scans of a rocprofv3
 kernel_trace.csv, with start offset, duration and the idle gap before it.
-usage: trace_sequence.py kernel_trace.csv [marker-substring]"""
+usage: trace_sequence.py kernel_trace.csv [marker-substring [which-window, default -1 = last]]"""
 import csv
 import sys
 
@@ -12,7 +12,8 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 marks = [i for i, r in enumerate(rows) if marker in r[2]]
-a, b = marks[-2], marks[-1]
+which = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+a, b = marks[which - 1], marks[which]
 t0, last = rows[a][0], rows[a][0]
 busy = 0
 for s, e, n in rows[a:b]:
