@@ -25,6 +25,22 @@ def iterate_mb_idxs(batch_size, data_length, shuffle=False):
         yield order[lo:lo + batch_size] if shuffle else np.arange(lo, lo + batch_size)
 
 
+def iterate_traj_idxs(batch_size, data_length, horizon=1, shuffle=False):
+    """Minibatches of whole segments for recurrent policies: yields (row indices of the chosen segments in
+    time order, segment numbers); rows are segment-major (`horizon` consecutive rows per env), one host
+    permutation of the segments per call (reference: accel_rl/optimizers/util.py:21-32)."""
+    if data_length % horizon or batch_size % horizon or data_length % batch_size:
+        raise AssertionError("batch_size and data_length must be multiples of horizon, data_length of batch_size")
+    rows = np.arange(data_length).reshape(-1, horizon)
+    order = np.arange(data_length // horizon)
+    per = batch_size // horizon
+    if shuffle:
+        np.random.shuffle(order)
+    for lo in range(0, len(order), per):
+        chosen = order[lo:lo + per]
+        yield rows[chosen].reshape(-1), chosen
+
+
 class BaseOptimizer(object):
 
     def initialize(self, inputs, losses, constraints, target, givens=None, lr_mult=1):

@@ -36,6 +36,24 @@ def test_iterate_mb_idxs_matches_reference_stream():
             np.array([[m[0], m[-1] + 1] for m in ns], np.int64).reshape(-1, 2), g["c%d_noshuffle" % c])
 
 
+def test_iterate_traj_idxs_matches_reference_stream():
+    from accel_rl_amd.optimizers.base import iterate_traj_idxs
+    g = load_golden("g15_trajidx")
+    for c in range(int(g["n_cases"])):
+        bs, n, horizon, seed = [int(x) for x in g["c%d_cfg" % c]]
+        np.random.seed(seed)
+        for ep in range(2):
+            got = list(iterate_traj_idxs(bs, n, horizon=horizon, shuffle=True))
+            np.testing.assert_array_equal(np.stack([m[0] for m in got]), g["c%d_e%d_idx" % (c, ep)])
+            np.testing.assert_array_equal(np.stack([m[1] for m in got]), g["c%d_e%d_trajs" % (c, ep)])
+        got = list(iterate_traj_idxs(bs, n, horizon=horizon, shuffle=False))
+        np.testing.assert_array_equal(np.stack([m[0] for m in got]), g["c%d_plain_idx" % c])
+        np.testing.assert_array_equal(np.stack([m[1] for m in got]), g["c%d_plain_trajs" % c])
+        np.testing.assert_array_equal(np.random.randint(0, 2 ** 31 - 1, size=2), g["c%d_after" % c])   # same draws consumed
+    with pytest.raises(AssertionError):
+        list(iterate_traj_idxs(12, 20, horizon=5))
+
+
 def test_parallelism_mismatch_raises_type_error():
     from accel_rl_amd.runners.accel_rl import AccelRL
     from accel_rl_amd.algos.pg.ppo import mPPO, PPO
