@@ -115,6 +115,8 @@ _SIGNATURES = {
     "arl_sumtree_gather": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "arl_dqn_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "arl_dqn_loss": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_lstm_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "arl_lstm_cell_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "arl_gru_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp]),
@@ -521,6 +523,22 @@ def catdqn_loss(pred_logits, tgt_next_logits, pol_next_logits, z, actions, retur
                                   ptr(actions), ptr(returns), ptr(terminals), ptr(is_weights), batch, n_actions,
                                   n_atoms, stride, float(v_min), float(v_max), float(gamma_n), ptr(dlogits),
                                   ptr(loss_rows), ptr(kl), stream_ptr(stream)), "arl_catdqn_loss")
+
+
+def dqn_act(q, override, n_actions, onehot, greedy=None, stream=None):
+    batch = onehot.shape[0]
+    _check(load().arl_dqn_act(ptr(q), ptr(override), batch, n_actions, q.numel() // batch, ptr(onehot),
+                              ptr(greedy), stream_ptr(stream)), "arl_dqn_act")
+
+
+def dqn_loss(q, tgt_next_q, pol_next_q, actions, returns, terminals, is_weights, n_actions, gamma_n, delta_clip,
+             dq, loss_rows, td_abs, stream=None):
+    """delta_clip None: squared loss."""
+    batch = actions.numel()
+    _check(load().arl_dqn_loss(ptr(q), ptr(tgt_next_q), ptr(pol_next_q), ptr(actions), ptr(returns),
+                               ptr(terminals), ptr(is_weights), batch, n_actions, q.numel() // batch,
+                               float(gamma_n), 0.0 if delta_clip is None else float(delta_clip), ptr(dq),
+                               ptr(loss_rows), ptr(td_abs), stream_ptr(stream)), "arl_dqn_loss")
 
 
 # ---------------------------------------------------------------------------

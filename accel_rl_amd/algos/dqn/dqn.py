@@ -1,6 +1,9 @@
 """DQN family, host-side logic (reference: accel_rl/algos/dqn/dqn.py:12-221): replay memory,
-training intensity, epsilon / beta schedules, target-network period, evaluation hooks.  The loss
-itself belongs to the subclass (CategoricalDQN); plain Q-learning with the Huber loss is not built."""
+training intensity, epsilon / beta schedules, target-network period, evaluation hooks, and the
+(double) Q-learning loss with the Huber clip -- the reference's Theano graph is csrc/dqn.hip:arl_dqn_loss."""
+import numpy as np
+import torch
+
 from accel_rl_amd.algos.base import RLAlgorithm
 from accel_rl_amd.algos.dqn.replay_buffers.prioritized import PrioritizedReplayBuffer
 from accel_rl_amd.algos.dqn.replay_buffers.uniform import UniformReplayBuffer
@@ -68,7 +71,27 @@ class DQN(RLAlgorithm):
             self.replay_buffer = UniformReplayBuffer(**replay_args)
 
     def build_loss(self, env_spec, policy):
-        raise NotImplementedError("plain DQN (Huber Q-learning, dqn.py:137-172) is not built; use CategoricalDQN")
+        """dqn.py:137-172"""
+        if self.dueling_dqn:
+            raise NotImplementedError("the dueling architecture is not built")
+        gamma_n = float(np.float32(self.discount ** self.reward_horizon))
+        inputs = ["obs", "next_obs", "act", "disc_n_return", "terminal"]
+        if self.prioritized_replay:
+            inputs.append("importance_sample_weights")
+
+        def loss(minibatch):
+            obs, next_obs, act, ret, term = minibatch[:5]
+            isw = None
+            if self.prioritized_replay:
+                isw = minibatch[5]
+                if not isinstance(isw, torch.Tensor):
+                    isw = torch.as_tensor(np.asarray(isw, np.float32)).to(policy.device)
+            term_u8 = term.view(torch.uint8) if term.dtype == torch.bool else term
+            loss_rows, td_abs = policy.q_loss_and_grads(obs, next_obs, act, ret, term_u8, isw, gamma_n,
+                                                        self.delta_clip, double_dqn=self.double_dqn)
+            return td_abs, loss_rows.sum()
+
+        return inputs, loss
 
     def optimize_policy(self, itr, samples_data):
         """dqn.py:174-193"""

@@ -9,6 +9,11 @@
 //                     loss, KL priorities, and d loss / d logits in one pass
 //                     (algos/dqn/cat_dqn.py:40-109)
 //
+//   arl_dqn_act       plain Q-learning twin of arl_catdqn_act: greedy action = first maximum of the Q row
+//                     (policies/dqn/atari_dqn_policy.py:61-63,118-130)
+//   arl_dqn_loss      one-step / n-step Q-learning target (max or double-DQN selection), squared or
+//                     Huber loss, clipped |TD error| priorities, d loss / d Q (algos/dqn/dqn.py:137-172)
+//
 // Layout: logits f32[batch][n_actions][atom_stride], atom_stride = n_atoms rounded up to a
 // multiple of 4 (the dense layer producing them is an MFMA kernel with 16-byte rows); the padding
 // columns are ignored on input and receive zero gradient.  One wave per sample; lane i owns atom i
@@ -133,7 +138,106 @@ __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
     }
 }
 
+// ---- plain DQN: Q rows f32[batch][q_stride], the first n_actions columns valid; one lane per sample ----
+__device__ __forceinline__ int first_argmax(const float* row, int n) {
+    int best = 0;
+    float best_q = row[0];
+    for (int a = 1; a < n; ++a) {
+        const float q = row[a];
+        if (q > best_q) { best_q = q; best = a; }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void dqn_act_kernel(const float* __restrict__ q,
+                                                      const int32_t* __restrict__ override_or_null, int64_t batch,
+                                                      int n_actions, int stride, float* __restrict__ onehot,
+                                                      uint8_t* __restrict__ greedy) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int g = first_argmax(q + b * stride, n_actions);
+    int act = g;
+    if (override_or_null && override_or_null[b] >= 0) act = override_or_null[b];
+    for (int a = 0; a < n_actions; ++a) onehot[b * n_actions + a] = a == act ? 1.f : 0.f;
+    if (greedy) greedy[b] = (uint8_t)g;
+}
+
+struct DqnLossArgs {
+    const float* q;                 // policy net on obs              [B][S]
+    const float* tgt_next_q;        // target net on next_obs         [B][S]
+    const float* pol_next_q;        // policy net on next_obs (double DQN) or null
+    const uint8_t* actions;         // [B]
+    const float* returns;           // [B] n-step discounted return
+    const uint8_t* terminals;       // [B]
+    const float* is_weights;        // [B] or null
+    float* dq;                      // [B][S]
+    float* loss_rows;               // [B] per-sample (weighted) loss / B
+    float* td_abs;                  // [B] priorities: |TD error| clipped to delta_clip
+    int64_t batch;
+    int n_actions, stride;
+    float gamma_n, delta_clip;      // delta_clip <= 0: squared loss, unclipped priorities
+};
+
+__global__ __launch_bounds__(256) void dqn_loss_kernel(const DqnLossArgs a) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.batch) return;
+    const int A = a.n_actions, S = a.stride;
+    const float* tgt = a.tgt_next_q + b * S;
+    // dqn.py:146-150: double DQN picks the action with the policy net and values it with the target net
+    const float next_q = tgt[first_argmax(a.pol_next_q ? a.pol_next_q + b * S : tgt, A)];
+    const float keep = a.terminals[b] ? 0.f : 1.f;
+    const float y = a.returns[b] + keep * (a.gamma_n * next_q);            // :152-153
+    const int act = a.actions[b];
+    const float d = y - a.q[b * S + act];
+    const float ad = fabsf(d), c = a.delta_clip;
+    float loss = 0.5f * (d * d), slope = d;                                // d loss / d d
+    if (c > 0.f && ad > c) {                                               // Huber (:157-160)
+        loss = c * (ad - c / 2.f);
+        slope = d > 0.f ? c : -c;
+    }
+    const float w = (a.is_weights ? a.is_weights[b] : 1.f) / (float)a.batch;
+    float* dq = a.dq + b * S;
+    for (int k = 0; k < S; ++k) dq[k] = 0.f;
+    dq[act] = -(w * slope);                                                // d = y - q, y carries no gradient
+    a.loss_rows[b] = w * loss;
+    a.td_abs[b] = c > 0.f ? fminf(ad, c) : ad;                             // :165
+}
+
 }  // namespace
+
+static int check_q(int64_t batch, int n_actions, int stride) {
+    if (batch <= 0 || n_actions <= 0 || n_actions > 255 || stride < n_actions || (stride & 3)) {
+        arl::set_error("dqn: need batch > 0, 1 <= n_actions <= 255, q_stride >= n_actions and %% 4 == 0");
+        return ARL_E_RANGE;
+    }
+    return 0;
+}
+
+extern "C" int arl_dqn_act(const float* q, const int32_t* override_or_null, int64_t batch, int32_t n_actions,
+                           int32_t q_stride, float* onehot, uint8_t* greedy_or_null, void* stream) {
+    ARL_REQUIRE(q && onehot, ARL_E_ARG, "null pointer");
+    int rc = check_q(batch, n_actions, q_stride);
+    if (rc) return rc;
+    hipLaunchKernelGGL(dqn_act_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       q, override_or_null, batch, n_actions, q_stride, onehot, greedy_or_null);
+    return arl::check_launch("dqn_act_kernel");
+}
+
+extern "C" int arl_dqn_loss(const float* q, const float* tgt_next_q, const float* pol_next_q_or_null,
+                            const uint8_t* actions, const float* returns, const uint8_t* terminals,
+                            const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t q_stride,
+                            float gamma_n, float delta_clip, float* dq, float* loss_rows, float* td_abs, void* stream) {
+    ARL_REQUIRE(q && tgt_next_q && actions && returns && terminals && dq && loss_rows && td_abs, ARL_E_ARG,
+                "null pointer");
+    int rc = check_q(batch, n_actions, q_stride);
+    if (rc) return rc;
+    DqnLossArgs a = {};
+    a.q = q; a.tgt_next_q = tgt_next_q; a.pol_next_q = pol_next_q_or_null; a.actions = actions; a.returns = returns;
+    a.terminals = terminals; a.is_weights = is_weights_or_null; a.dq = dq; a.loss_rows = loss_rows; a.td_abs = td_abs;
+    a.batch = batch; a.n_actions = n_actions; a.stride = q_stride; a.gamma_n = gamma_n; a.delta_clip = delta_clip;
+    hipLaunchKernelGGL(dqn_loss_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return arl::check_launch("dqn_loss_kernel");
+}
 
 static int check_cat(int64_t batch, int n_actions, int n_atoms, int stride) {
     if (batch <= 0 || n_actions <= 0 || n_actions > 64 || n_atoms < 2 || n_atoms > 64 || stride < n_atoms || (stride & 3)) {

@@ -17,10 +17,11 @@ import numpy as np
 import torch
 
 from accel_rl_amd import _lib
-from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy, _norm_c
+from accel_rl_amd.policies.atari_cnn_policy import _norm_c
+from accel_rl_amd.policies.dqn.q_policy_base import QPolicyBase
 
 
-class AtariCatDqnPolicy(AtariCnnPolicy):
+class AtariCatDqnPolicy(QPolicyBase):
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=(),
                  pixel_scale=255., epsilon=1, n_atoms=51, dueling=False, initial_param_values=None):
@@ -61,117 +62,19 @@ class AtariCatDqnPolicy(AtariCnnPolicy):
         b[:, :n] = ref_tail[1].reshape(a, n)
         return [w.reshape(a * s, -1), b.reshape(-1)]
 
-    def initialize(self, env_spec, device=None, **kwargs):
-        super().initialize(env_spec, device=device, **kwargs)
-        self.flat_target = self.flat_params.clone()             # target network (:57-61)
-        sizes = [int(np.prod(s)) for s in self._shapes]
-        self._w_target = [self.flat_target[o:o + n] for o, n in zip(self._offsets, sizes)]
-        self._overrides = dict()          # n_envs -> (pinned host, device) i32[horizon][n_envs]
-        self._step = 0
-
     def incorporate_z(self, z):
         """Called by the algorithm while initialising (:69-78): the support of the value distribution."""
         z = np.asarray(z, np.float32)
         assert len(z) == self.n_atoms
         self.z = torch.from_numpy(z).to(self.device)
 
-    # ---- forward -----------------------------------------------------------
-    def _logits(self, x, w=None, tag=""):
-        """[B, n_actions * atom_stride] output-layer pre-activations (+ the trunk's activations)."""
-        w = self._w if w is None else w
-        b = x.shape[0]
-        acts, hids = self._trunk(x, w=w, tag=tag)
-        k = self._k_head
-        out = self._buffer(("logits" + tag, b), (b, self.n_act * self._atom_stride))
-        geom = self._head_geom(b)
-        _lib.conv2d_fwd(hids[-1], w[k], w[k + 1], out, geom, False, self._conv_ws)
-        return out, acts, hids
+    @property
+    def _head_width(self):
+        return self.n_act * self._atom_stride
 
-    def _ones_geom(self, b, width):
-        key = ("ones", b, width)
-        if key not in self._geoms:
-            self._geoms[key] = _lib.dense_geom(b, 4, width)
-        return self._geoms[key]
-
-    def _head_geom(self, b):
-        key = ("head", b)
-        if key not in self._geoms:
-            self._geoms[key] = _lib.dense_geom(b, self._hid_geom[-1][0], self.n_act * self._atom_stride)
-        return self._geoms[key]
-
-    def prob_value(self, observations):
-        """The sampler's serving call: a one-hot 'prob' row for the epsilon-greedy action of this
-        step (so that the categorical sampling kernel picks it) and a zero 'value'."""
+    def _serve(self, out, override, onehot, greedy=None):
         assert self.z is not None, "incorporate_z() first (the algorithm does)"
-        with torch.no_grad():
-            b = observations.shape[0]
-            logits, _, _ = self._logits(self._scaled(observations))
-            onehot = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
-            ov = None
-            if b in self._overrides and self._step < self._overrides[b][1].shape[0]:
-                ov = self._overrides[b][1][self._step]
-            _lib.catdqn_act(logits, self.z, ov, self.n_act, self.n_atoms, onehot)
-            if not hasattr(self, "_zero_value") or self._zero_value.numel() != b:
-                self._zero_value = torch.zeros(b, dtype=torch.float32, device=self.device)
-            return onehot, self._zero_value
-
-    def greedy_actions(self, observations):
-        with torch.no_grad():
-            b = observations.shape[0]
-            logits, _, _ = self._logits(self._scaled(observations))
-            onehot = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
-            greedy = torch.empty(b, dtype=torch.uint8, device=self.device)
-            _lib.catdqn_act(logits, self.z, None, self.n_act, self.n_atoms, onehot, greedy)
-            return greedy
-
-    # ---- epsilon-greedy draws (host RNG, reference order) ---------------------
-    def host_draws(self, horizon, n_envs, n_groups=2):
-        """All of one rollout's action randomness: for every (step, group) the reference's
-        get_actions draws rand(B) and then sample_n(#(rand < epsilon)).  Returns the uniforms the
-        sampler feeds its categorical kernel (0.5: with a one-hot row that selects the hot action)."""
-        ov = np.full((horizon, n_envs), -1, np.int32)
-        per = n_envs // n_groups
-        for s in range(horizon):
-            for j in range(n_groups):
-                u = np.random.rand(per)
-                idx = np.where(u < self._epsilon)[0]
-                ov[s, j * per + idx] = np.random.randint(low=0, high=self.n_act, size=len(idx), dtype=np.uint8)
-        # one table per env count (training / evaluation), allocated once: a captured rollout graph
-        # keeps reading the same device buffer
-        if n_envs not in self._overrides or self._overrides[n_envs][1].shape[0] != horizon:
-            self._overrides[n_envs] = (torch.zeros(ov.shape, dtype=torch.int32).pin_memory(),
-                                       torch.zeros(ov.shape, dtype=torch.int32, device=self.device))
-        host, dev = self._overrides[n_envs]
-        host.copy_(torch.from_numpy(ov))
-        dev.copy_(host, non_blocking=True)
-        return np.full(horizon * n_envs, 0.5)
-
-    def set_step(self, s):
-        self._step = s
-
-    def get_actions(self, observations, deterministic=False):
-        """Host-interface twin of the reference's get_actions (one group of one step)."""
-        acts = self.greedy_actions(observations).cpu().numpy()
-        if not deterministic:
-            idx = np.where(np.random.rand(len(acts)) < self._epsilon)[0]
-            acts[idx] = np.random.randint(low=0, high=self.n_act, size=len(idx), dtype=np.uint8)
-        return acts, dict()
-
-    def get_action(self, observation, deterministic=False):
-        if deterministic or (np.random.rand() > self._epsilon):
-            action = int(self.greedy_actions(observation[None])[0].item())
-        else:
-            action = self.action_space.sample()
-        return action, dict()
-
-    def get_epsilon(self):
-        return self._epsilon
-
-    def set_epsilon(self, value):
-        self._epsilon = value
-
-    def update_target(self):
-        self.flat_target.copy_(self.flat_params)
+        _lib.catdqn_act(out, self.z, override, self.n_act, self.n_atoms, onehot, greedy)
 
     # ---- training ------------------------------------------------------------
     def cat_loss_and_grads(self, obs, next_obs, actions, returns, terminals, is_weights, v_min, v_max, gamma_n,
@@ -192,19 +95,5 @@ class AtariCatDqnPolicy(AtariCnnPolicy):
             kl = self._buffer(("kl", b), (b,))
             _lib.catdqn_loss(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
                              self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl)
-            k = self._k_head
-            geom = self._head_geom(b)
-            hid = self._hid_geom[-1][0]
-            # output layer: dW = dlogits^T h, db = column sums of dlogits (riding along in the weight-gradient
-            # kernel), dh = (dlogits W) * (h > 0) -- one launch; the folds run at the end of the trunk's backward
-            dh = self._buffer(("dh", b), (b, hid))
-            done = self._folds.conv2d_bwd_pair(dlogits, self._w[k], hids[-1], dh, hids[-1], self._g[k], geom,
-                                               self._fold_ws(("dw", k)), dbias=self.grads[k + 1])
-            if not done:        # ragged batch (generic kernels): column sums as the weight gradient of an all-ones input
-                ones = self._buffer(("ones4", b), (b, 4))
-                ones.fill_(1.)
-                db4 = self._buffer(("db4", b), (dlogits.shape[1], 4))
-                _lib.conv2d_bwd_weight(dlogits, ones, db4, self._ones_geom(b, dlogits.shape[1]), self._conv_ws)
-                self.grads[k + 1].copy_(db4[:, 0])
-            self._backward_trunk(x, acts, hids, dh, masked=True)
+            self._head_backward(dlogits, x, acts, hids)
             return loss_rows, kl

@@ -1,0 +1,85 @@
+"""Plain DQN policy for Atari: conv stack -> dense -> one Q value per action; a target network;
+epsilon-greedy action serving.
+
+Mirror of the reference's AtariDqnPolicy / DqnCnn
+(accel_rl/policies/dqn/atari_dqn_policy.py:15-137, policies/dqn/networks/dqn_cnn.py:11-117).  Trunk,
+target network and action serving are QPolicyBase's; the output layer "output_q" is one dense MFMA
+call whose row is padded to 32 columns (zero weights, zero gradients) so that its data gradient
+runs on the scalar-addressed kernels, followed by csrc/dqn.hip (arl_dqn_act, arl_dqn_loss).
+Dueling heads and the shared scalar output bias are not implemented.
+"""
+import numpy as np
+import torch
+
+from accel_rl_amd import _lib
+from accel_rl_amd.policies.atari_cnn_policy import _norm_c
+from accel_rl_amd.policies.dqn.q_policy_base import QPolicyBase
+
+
+class AtariDqnPolicy(QPolicyBase):
+
+    def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=(),
+                 pixel_scale=255., epsilon=1, dueling=False, shared_last_bias=False, initial_param_values=None):
+        if dueling:
+            raise NotImplementedError("dueling heads (dqn_cnn.py:89-112) are not built")
+        if shared_last_bias:
+            raise NotImplementedError("shared_last_bias (dqn_cnn.py:73-88) is not built")
+        super().__init__(conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=hidden_sizes,
+                         pixel_scale=pixel_scale, initial_param_values=initial_param_values)
+        self._epsilon = epsilon
+
+    # ---- output layer: "output_q" dense, n_actions units (dqn_cnn.py:73-80)
+    def _head_reference_init(self, fan, n_act):
+        self._q_stride = (n_act + 31) // 32 * 32
+        return [_norm_c((fan, n_act), 0.01), np.zeros(n_act, np.float32)], ["OutputW", "Outputb"]
+
+    def _head_internal_shapes(self, fan, n_act):
+        return [(self._q_stride, fan), (self._q_stride,)]
+
+    def _head_to_reference(self, wh, bh):
+        return [wh[:self.n_act].T, bh[:self.n_act]]
+
+    def _head_to_internal(self, ref_tail):
+        w = np.zeros((self._q_stride, ref_tail[0].shape[0]), np.float32)
+        w[:self.n_act] = ref_tail[0].T
+        b = np.zeros(self._q_stride, np.float32)
+        b[:self.n_act] = ref_tail[1]
+        return [w, b]
+
+    @property
+    def _head_width(self):
+        return self._q_stride
+
+    def _serve(self, out, override, onehot, greedy=None):
+        _lib.dqn_act(out, override, self.n_act, onehot, greedy)
+
+    # ---- host-interface twins of q / target_q (:108-112) ------------------------
+    def q(self, observations):
+        with torch.no_grad():
+            return self._logits(self._scaled(observations))[0][:, :self.n_act].clone()
+
+    def target_q(self, observations):
+        with torch.no_grad():
+            return self._logits(self._scaled(observations), w=self._w_target, tag="t")[0][:, :self.n_act].clone()
+
+    # ---- training ------------------------------------------------------------
+    def q_loss_and_grads(self, obs, next_obs, actions, returns, terminals, is_weights, gamma_n, delta_clip,
+                         double_dqn=False):
+        """One minibatch of DQN.build_loss (dqn.py:137-172): forward of the policy net on obs, of the target
+        net (and, for double DQN, the policy net) on next_obs, the (Huber) TD loss, and the full backward
+        pass into flat_grads.  Returns (loss_rows f32[B] whose sum is the loss, td_abs f32[B])."""
+        with torch.no_grad():
+            b = obs.shape[0]
+            tgt_q, _, _ = self._logits(self._scaled(next_obs, tag="n"), w=self._w_target, tag="t")
+            pol_next = None
+            if double_dqn:
+                pol_next = self._logits(self._scaled(next_obs, tag="n"), tag="d")[0]
+            x = self._scaled(obs)
+            q, acts, hids = self._logits(x)
+            dq = self._buffer(("dlogits", b), tuple(q.shape))
+            loss_rows = self._buffer(("loss_rows", b), (b,))
+            td_abs = self._buffer(("td_abs", b), (b,))
+            _lib.dqn_loss(q, tgt_q, pol_next, actions, returns, terminals, is_weights, self.n_act, gamma_n,
+                          delta_clip, dq, loss_rows, td_abs)
+            self._head_backward(dq, x, acts, hids)
+            return loss_rows, td_abs

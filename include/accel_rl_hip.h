@@ -442,6 +442,24 @@ int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_logits, cons
                     int32_t atom_stride, float v_min, float v_max, float gamma_n, float* dlogits,
                     float* loss_rows, float* kl, void* stream);
 
+/* Plain DQN action serving: greedy action = first maximum of the Q row (T.argmax), override as
+ * above, one-hot row out.  Replaces AtariDqnPolicy.get_actions / actions_sym,
+ * accel_rl/policies/dqn/atari_dqn_policy.py:61-63,76-79,118-130.
+ *   q f32[batch][q_stride], q_stride % 4 == 0 >= n_actions (<= 255); onehot f32[batch][n_actions] */
+int arl_dqn_act(const float* q, const int32_t* override_or_null, int64_t batch, int32_t n_actions,
+                int32_t q_stride, float* onehot, uint8_t* greedy_or_null, void* stream);
+
+/* Loss of DQN.build_loss, accel_rl/algos/dqn/dqn.py:137-172: next_q = max_a target(next_obs) or
+ * (double DQN) target(next_obs)[argmax_a policy(next_obs)]; y = return + (1 - terminal) gamma^n
+ * next_q; d = y - q[action]; 0.5 d^2, or the Huber loss with threshold delta_clip (> 0);
+ * importance-weighted mean; priorities = clip(|d|, 0, delta_clip) (|d| when delta_clip <= 0).
+ *   out: dq f32[batch][q_stride] (d mean-loss / d q; zero outside the taken action),
+ *        loss_rows f32[batch] (their sum is the loss), td_abs f32[batch]                   */
+int arl_dqn_loss(const float* q, const float* tgt_next_q, const float* pol_next_q_or_null,
+                 const uint8_t* actions, const float* returns, const uint8_t* terminals,
+                 const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t q_stride,
+                 float gamma_n, float delta_clip, float* dq, float* loss_rows, float* td_abs, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * LSTM cell of the recurrent policies
  * ------------------------------------------------------------------------- */
