@@ -113,10 +113,10 @@ _SIGNATURES = {
     "arl_sumtree_find": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "arl_sumtree_add": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp]),
     "arl_sumtree_gather": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
-    "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
-    "arl_dqn_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "arl_dqn_loss": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "arl_dqn_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "arl_dqn_loss": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_lstm_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "arl_lstm_cell_bwd": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "arl_gru_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp]),
@@ -508,35 +508,35 @@ def sumtree_gather(tree, idxs, out, scale=1.0, stream=None):
 # categorical DQN output stage (csrc/dqn.hip)
 # ---------------------------------------------------------------------------
 
-def catdqn_act(logits, z, override, n_actions, n_atoms, onehot, greedy=None, stream=None):
+def catdqn_act(logits, z, override, n_actions, n_atoms, onehot, greedy=None, dueling=False, stream=None):
     batch = onehot.shape[0]
-    stride = logits.numel() // (batch * n_actions)
+    stride = logits.numel() // (batch * (n_actions + int(dueling)))
     _check(load().arl_catdqn_act(ptr(logits), ptr(z), ptr(override), batch, n_actions, n_atoms, stride,
-                                 ptr(onehot), ptr(greedy), stream_ptr(stream)), "arl_catdqn_act")
+                                 int(dueling), ptr(onehot), ptr(greedy), stream_ptr(stream)), "arl_catdqn_act")
 
 
 def catdqn_loss(pred_logits, tgt_next_logits, pol_next_logits, z, actions, returns, terminals, is_weights,
-                n_actions, n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl, stream=None):
+                n_actions, n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl, dueling=False, stream=None):
     batch = actions.numel()
-    stride = pred_logits.numel() // (batch * n_actions)
+    stride = pred_logits.numel() // (batch * (n_actions + int(dueling)))
     _check(load().arl_catdqn_loss(ptr(pred_logits), ptr(tgt_next_logits), ptr(pol_next_logits), ptr(z),
                                   ptr(actions), ptr(returns), ptr(terminals), ptr(is_weights), batch, n_actions,
-                                  n_atoms, stride, float(v_min), float(v_max), float(gamma_n), ptr(dlogits),
-                                  ptr(loss_rows), ptr(kl), stream_ptr(stream)), "arl_catdqn_loss")
+                                  n_atoms, stride, int(dueling), float(v_min), float(v_max), float(gamma_n),
+                                  ptr(dlogits), ptr(loss_rows), ptr(kl), stream_ptr(stream)), "arl_catdqn_loss")
 
 
-def dqn_act(q, override, n_actions, onehot, greedy=None, stream=None):
+def dqn_act(q, override, n_actions, onehot, greedy=None, dueling=False, stream=None):
     batch = onehot.shape[0]
-    _check(load().arl_dqn_act(ptr(q), ptr(override), batch, n_actions, q.numel() // batch, ptr(onehot),
-                              ptr(greedy), stream_ptr(stream)), "arl_dqn_act")
+    _check(load().arl_dqn_act(ptr(q), ptr(override), batch, n_actions, q.numel() // batch, int(dueling),
+                              ptr(onehot), ptr(greedy), stream_ptr(stream)), "arl_dqn_act")
 
 
 def dqn_loss(q, tgt_next_q, pol_next_q, actions, returns, terminals, is_weights, n_actions, gamma_n, delta_clip,
-             dq, loss_rows, td_abs, stream=None):
+             dq, loss_rows, td_abs, dueling=False, stream=None):
     """delta_clip None: squared loss."""
     batch = actions.numel()
     _check(load().arl_dqn_loss(ptr(q), ptr(tgt_next_q), ptr(pol_next_q), ptr(actions), ptr(returns),
-                               ptr(terminals), ptr(is_weights), batch, n_actions, q.numel() // batch,
+                               ptr(terminals), ptr(is_weights), batch, n_actions, q.numel() // batch, int(dueling),
                                float(gamma_n), 0.0 if delta_clip is None else float(delta_clip), ptr(dq),
                                ptr(loss_rows), ptr(td_abs), stream_ptr(stream)), "arl_dqn_loss")
 

@@ -25,6 +25,8 @@ class CategoricalDQN(DQN):
         return opt_args, eps_greedy_args, priority_args
 
     def build_loss(self, env_spec, policy):
+        assert bool(self.dueling_dqn) == bool(getattr(policy, "_dueling", False)), \
+            "dueling_dqn and the policy's `dueling` must agree (the reference's scripts pass both)"
         z = np.linspace(self.V_min, self.V_max, policy.n_atoms, dtype=np.float32)      # cat_dqn.py:49-52
         policy.incorporate_z(z)
         gamma_n = float(np.float32(self.discount ** self.reward_horizon))

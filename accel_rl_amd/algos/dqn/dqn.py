@@ -72,8 +72,8 @@ class DQN(RLAlgorithm):
 
     def build_loss(self, env_spec, policy):
         """dqn.py:137-172"""
-        if self.dueling_dqn:
-            raise NotImplementedError("the dueling architecture is not built")
+        assert bool(self.dueling_dqn) == bool(getattr(policy, "_dueling", False)), \
+            "dueling_dqn and the policy's `dueling` must agree (the reference's scripts pass both)"
         gamma_n = float(np.float32(self.discount ** self.reward_horizon))
         inputs = ["obs", "next_obs", "act", "disc_n_return", "terminal"]
         if self.prioritized_replay:

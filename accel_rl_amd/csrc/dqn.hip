@@ -14,7 +14,7 @@
 //   arl_dqn_loss      one-step / n-step Q-learning target (max or double-DQN selection), squared or
 //                     Huber loss, clipped |TD error| priorities, d loss / d Q (algos/dqn/dqn.py:137-172)
 //
-// Layout: logits f32[batch][n_actions][atom_stride], atom_stride = n_atoms rounded up to a
+// Layout: logits f32[batch][n_actions (+ 1 value row when dueling)][atom_stride], atom_stride = n_atoms rounded up to a
 // multiple of 4 (the dense layer producing them is an MFMA kernel with 16-byte rows); the padding
 // columns are ignored on input and receive zero gradient.  One wave per sample; lane i owns atom i
 // (n_atoms <= 64).  fp32, compiled with -ffp-contract=off.
@@ -34,21 +34,44 @@ __device__ __forceinline__ float wave_sum(float x) {
     return x;
 }
 
-// softmax over the atoms of one action; lane i returns p_i (0 for i >= n_atoms)
-__device__ __forceinline__ float atom_softmax(const float* row, int lane, int n_atoms) {
-    const float x = lane < n_atoms ? row[lane] : -3.0e38f;
+// softmax over the atoms of one action; lane i holds logit x (lanes >= n_atoms: anything) and returns p_i (0 there)
+__device__ __forceinline__ float atom_softmax(float x, int lane, int n_atoms) {
+    x = lane < n_atoms ? x : -3.0e38f;
     const float m = wave_max(x);
     const float e = lane < n_atoms ? expf(x - m) : 0.f;
     return e / wave_sum(e);
 }
 
-// greedy action of one sample under `logits`: argmax_a sum_i softmax(logits[a])_i z_i, first maximum
+// Dueling heads (policies/dqn/layers/dueling_merge_layer.py:32-35): the block holds n_actions advantage rows
+// followed by ONE value row; logit(a, i) = val_i + (adv_ai - mean_a adv_ai).  Per lane (= atom): the mean and
+// the value, read once per sample.
+struct Duel { float mean, val; bool on; };
+__device__ __forceinline__ Duel duel_terms(const float* logits, int lane, int n_actions, int n_atoms, int stride,
+                                           bool dueling) {
+    Duel d = {0.f, 0.f, dueling};
+    if (dueling && lane < n_atoms) {
+        float sum = 0.f;
+        for (int a = 0; a < n_actions; ++a) sum += logits[a * stride + lane];
+        d.mean = sum / (float)n_actions;
+        d.val = logits[n_actions * stride + lane];
+    }
+    return d;
+}
+__device__ __forceinline__ float atom_logit(const float* logits, int a, int lane, int n_atoms, int stride,
+                                            const Duel& d) {
+    if (lane >= n_atoms) return 0.f;
+    const float x = logits[a * stride + lane];
+    return d.on ? d.val + (x - d.mean) : x;
+}
+
+// greedy action of one sample under `logits`: argmax_a sum_i softmax(logit(a, .))_i z_i, first maximum
 __device__ __forceinline__ int greedy_action(const float* logits, int lane, int n_actions, int n_atoms,
-                                             int stride, float z_lane) {
+                                             int stride, float z_lane, bool dueling) {
+    const Duel d = duel_terms(logits, lane, n_actions, n_atoms, stride, dueling);
     int best = 0;
     float best_q = -3.0e38f;
     for (int a = 0; a < n_actions; ++a) {
-        const float q = wave_sum(atom_softmax(logits + a * stride, lane, n_atoms) * z_lane);
+        const float q = wave_sum(atom_softmax(atom_logit(logits, a, lane, n_atoms, stride, d), lane, n_atoms) * z_lane);
         if (q > best_q) { best_q = q; best = a; }
     }
     return best;
@@ -58,12 +81,14 @@ __global__ __launch_bounds__(256) void catdqn_act_kernel(const float* __restrict
                                                          const float* __restrict__ z,
                                                          const int32_t* __restrict__ override_or_null,
                                                          int64_t batch, int n_actions, int n_atoms, int stride,
-                                                         float* __restrict__ onehot, uint8_t* __restrict__ greedy) {
+                                                         int dueling, float* __restrict__ onehot,
+                                                         uint8_t* __restrict__ greedy) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= batch) return;
     const float z_lane = lane < n_atoms ? z[lane] : 0.f;
-    const int g = greedy_action(logits + b * n_actions * stride, lane, n_actions, n_atoms, stride, z_lane);
+    const int g = greedy_action(logits + b * (n_actions + dueling) * stride, lane, n_actions, n_atoms, stride, z_lane,
+                                dueling != 0);
     int act = g;
     if (override_or_null && override_or_null[b] >= 0) act = override_or_null[b];
     if (lane < n_actions) onehot[b * n_actions + lane] = lane == act ? 1.f : 0.f;
@@ -84,6 +109,7 @@ struct CatLossArgs {
     float* kl;                      // [B] priorities
     int64_t batch;
     int n_actions, n_atoms, stride;
+    int dueling;                    // 1: every [A][S] block above is [A + 1][S], the value row last
     float v_min, v_max, gamma_n;    // gamma_n = discount ** reward_horizon (rounded to f32 on the host)
 };
 
@@ -93,11 +119,13 @@ __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
     const int64_t b = (int64_t)blockIdx.x * 4 + wave;
     if (b >= a.batch) return;
     const int A = a.n_actions, n = a.n_atoms, S = a.stride;
+    const bool duel = a.dueling != 0;
+    const int64_t R = (int64_t)(A + a.dueling) * S;      // floats per sample
     const float z_lane = lane < n ? a.z[lane] : 0.f;
-    const float* tgt = a.tgt_next_logits + b * A * S;
+    const float* tgt = a.tgt_next_logits + b * R;
     // greedy next action: under the policy net (double DQN) or the target net (cat_dqn.py:77-81)
-    const int a_next = greedy_action(a.pol_next_logits ? a.pol_next_logits + b * A * S : tgt, lane, A, n, S, z_lane);
-    const float next_p = atom_softmax(tgt + a_next * S, lane, n);
+    const int a_next = greedy_action(a.pol_next_logits ? a.pol_next_logits + b * R : tgt, lane, A, n, S, z_lane, duel);
+    const float next_p = atom_softmax(atom_logit(tgt, a_next, lane, n, S, duel_terms(tgt, lane, A, n, S, duel)), lane, n);
     // shifted support, clipped to [v_min, v_max] (:56-62)
     const float keep = a.terminals[b] ? 0.f : 1.f;
     float zn = a.returns[b] + keep * (a.gamma_n * z_lane);
@@ -115,7 +143,8 @@ __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
         }
     // prediction, cross-entropy with NaN guard (:92-94)
     const int act = a.actions[b];
-    const float pred = atom_softmax(a.pred_logits + (b * A + act) * S, lane, n);
+    const float* prd = a.pred_logits + b * R;
+    const float pred = atom_softmax(atom_logit(prd, act, lane, n, S, duel_terms(prd, lane, A, n, S, duel)), lane, n);
     const float pc = fminf(fmaxf(pred, 1e-6f), 1.f);
     const float w = (a.is_weights ? a.is_weights[b] : 1.f) / (float)a.batch;
     const float ce = lane < n ? -(proj * logf(pc)) : 0.f;
@@ -126,12 +155,20 @@ __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
     // gradient: d loss / d pred_i = -w proj_i / pred_i inside the clip range, then softmax backward
     const float g = (lane < n && pred >= 1e-6f && pred <= 1.f) ? -w * proj / pred : 0.f;
     const float dot = wave_sum(g * pred);
-    float* dl = a.dlogits + b * A * S;
-    for (int q = lane; q < A * S; q += 64) {                           // every other action (and the padding) gets 0
-        const int qa = q / S, qi = q - qa * S;
-        if (qa != act || qi >= n) dl[q] = 0.f;
+    float* dl = a.dlogits + b * R;
+    const float d_lane = lane < n ? pred * (g - dot) : 0.f;            // d loss / d logit(act, lane)
+    if (!duel) {
+        for (int q = lane; q < A * S; q += 64) {                       // every other action (and the padding) gets 0
+            const int qa = q / S, qi = q - qa * S;
+            if (qa != act || qi >= n) dl[q] = 0.f;
+        }
+        if (lane < n) dl[act * S + lane] = d_lane;
+    } else {                                                           // through the merge: adv rows, then the value row
+        const float share = d_lane / (float)A;
+        for (int k = 0; k < A; ++k)
+            for (int i = lane; i < S; i += 64) dl[k * S + i] = i < n ? (k == act ? d_lane - share : -share) : 0.f;
+        for (int i = lane; i < S; i += 64) dl[A * S + i] = i < n ? d_lane : 0.f;
     }
-    if (lane < n) dl[act * S + lane] = pred * (g - dot);
     if (lane == 0) {
         a.loss_rows[b] = w * loss_b;
         a.kl[b] = fminf(fmaxf(kl_b, 1e-6f), 1e6f);
@@ -139,11 +176,21 @@ __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
 }
 
 // ---- plain DQN: Q rows f32[batch][q_stride], the first n_actions columns valid; one lane per sample ----
-__device__ __forceinline__ int first_argmax(const float* row, int n) {
+// dueling: the row holds n advantages followed by the value; q_a = val + (adv_a - mean adv)
+__device__ __forceinline__ float row_mean(const float* row, int n) {
+    float sum = 0.f;
+    for (int a = 0; a < n; ++a) sum += row[a];
+    return sum / (float)n;
+}
+__device__ __forceinline__ float q_at(const float* row, int a, int n, bool dueling, float mean) {
+    return dueling ? row[n] + (row[a] - mean) : row[a];
+}
+__device__ __forceinline__ int first_argmax(const float* row, int n, bool dueling) {
+    const float mean = dueling ? row_mean(row, n) : 0.f;
     int best = 0;
-    float best_q = row[0];
+    float best_q = q_at(row, 0, n, dueling, mean);
     for (int a = 1; a < n; ++a) {
-        const float q = row[a];
+        const float q = q_at(row, a, n, dueling, mean);
         if (q > best_q) { best_q = q; best = a; }
     }
     return best;
@@ -151,11 +198,11 @@ __device__ __forceinline__ int first_argmax(const float* row, int n) {
 
 __global__ __launch_bounds__(256) void dqn_act_kernel(const float* __restrict__ q,
                                                       const int32_t* __restrict__ override_or_null, int64_t batch,
-                                                      int n_actions, int stride, float* __restrict__ onehot,
-                                                      uint8_t* __restrict__ greedy) {
+                                                      int n_actions, int stride, int dueling,
+                                                      float* __restrict__ onehot, uint8_t* __restrict__ greedy) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
-    const int g = first_argmax(q + b * stride, n_actions);
+    const int g = first_argmax(q + b * stride, n_actions, dueling != 0);
     int act = g;
     if (override_or_null && override_or_null[b] >= 0) act = override_or_null[b];
     for (int a = 0; a < n_actions; ++a) onehot[b * n_actions + a] = a == act ? 1.f : 0.f;
@@ -175,6 +222,7 @@ struct DqnLossArgs {
     float* td_abs;                  // [B] priorities: |TD error| clipped to delta_clip
     int64_t batch;
     int n_actions, stride;
+    int dueling;                    // 1: column n_actions of every row is the value stream
     float gamma_n, delta_clip;      // delta_clip <= 0: squared loss, unclipped priorities
 };
 
@@ -184,11 +232,14 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(const DqnLossArgs a) {
     const int A = a.n_actions, S = a.stride;
     const float* tgt = a.tgt_next_q + b * S;
     // dqn.py:146-150: double DQN picks the action with the policy net and values it with the target net
-    const float next_q = tgt[first_argmax(a.pol_next_q ? a.pol_next_q + b * S : tgt, A)];
+    const bool duel = a.dueling != 0;
+    const int a_next = first_argmax(a.pol_next_q ? a.pol_next_q + b * S : tgt, A, duel);
+    const float next_q = q_at(tgt, a_next, A, duel, duel ? row_mean(tgt, A) : 0.f);
     const float keep = a.terminals[b] ? 0.f : 1.f;
     const float y = a.returns[b] + keep * (a.gamma_n * next_q);            // :152-153
     const int act = a.actions[b];
-    const float d = y - a.q[b * S + act];
+    const float* qrow = a.q + b * S;
+    const float d = y - q_at(qrow, act, A, duel, duel ? row_mean(qrow, A) : 0.f);
     const float ad = fabsf(d), c = a.delta_clip;
     float loss = 0.5f * (d * d), slope = d;                                // d loss / d d
     if (c > 0.f && ad > c) {                                               // Huber (:157-160)
@@ -197,44 +248,53 @@ __global__ __launch_bounds__(256) void dqn_loss_kernel(const DqnLossArgs a) {
     }
     const float w = (a.is_weights ? a.is_weights[b] : 1.f) / (float)a.batch;
     float* dq = a.dq + b * S;
+    const float gq = -(w * slope);                                         // d = y - q, y carries no gradient
     for (int k = 0; k < S; ++k) dq[k] = 0.f;
-    dq[act] = -(w * slope);                                                // d = y - q, y carries no gradient
+    if (!duel) {
+        dq[act] = gq;
+    } else {                                                               // through the merge
+        const float share = gq / (float)A;
+        for (int k = 0; k < A; ++k) dq[k] = k == act ? gq - share : -share;
+        dq[A] = gq;
+    }
     a.loss_rows[b] = w * loss;
     a.td_abs[b] = c > 0.f ? fminf(ad, c) : ad;                             // :165
 }
 
 }  // namespace
 
-static int check_q(int64_t batch, int n_actions, int stride) {
-    if (batch <= 0 || n_actions <= 0 || n_actions > 255 || stride < n_actions || (stride & 3)) {
-        arl::set_error("dqn: need batch > 0, 1 <= n_actions <= 255, q_stride >= n_actions and %% 4 == 0");
+static int check_q(int64_t batch, int n_actions, int stride, int dueling) {
+    if (batch <= 0 || n_actions <= 0 || n_actions > 255 || stride < n_actions + (dueling != 0) || (stride & 3)) {
+        arl::set_error("dqn: need batch > 0, 1 <= n_actions <= 255, q_stride >= n_actions (+ 1 if dueling) and %% 4 == 0");
         return ARL_E_RANGE;
     }
     return 0;
 }
 
 extern "C" int arl_dqn_act(const float* q, const int32_t* override_or_null, int64_t batch, int32_t n_actions,
-                           int32_t q_stride, float* onehot, uint8_t* greedy_or_null, void* stream) {
+                           int32_t q_stride, int32_t dueling, float* onehot, uint8_t* greedy_or_null, void* stream) {
     ARL_REQUIRE(q && onehot, ARL_E_ARG, "null pointer");
-    int rc = check_q(batch, n_actions, q_stride);
+    int rc = check_q(batch, n_actions, q_stride, dueling);
     if (rc) return rc;
     hipLaunchKernelGGL(dqn_act_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       q, override_or_null, batch, n_actions, q_stride, onehot, greedy_or_null);
+                       q, override_or_null, batch, n_actions, q_stride, dueling != 0, onehot, greedy_or_null);
     return arl::check_launch("dqn_act_kernel");
 }
 
 extern "C" int arl_dqn_loss(const float* q, const float* tgt_next_q, const float* pol_next_q_or_null,
                             const uint8_t* actions, const float* returns, const uint8_t* terminals,
                             const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t q_stride,
-                            float gamma_n, float delta_clip, float* dq, float* loss_rows, float* td_abs, void* stream) {
+                            int32_t dueling, float gamma_n, float delta_clip, float* dq, float* loss_rows,
+                            float* td_abs, void* stream) {
     ARL_REQUIRE(q && tgt_next_q && actions && returns && terminals && dq && loss_rows && td_abs, ARL_E_ARG,
                 "null pointer");
-    int rc = check_q(batch, n_actions, q_stride);
+    int rc = check_q(batch, n_actions, q_stride, dueling);
     if (rc) return rc;
     DqnLossArgs a = {};
     a.q = q; a.tgt_next_q = tgt_next_q; a.pol_next_q = pol_next_q_or_null; a.actions = actions; a.returns = returns;
     a.terminals = terminals; a.is_weights = is_weights_or_null; a.dq = dq; a.loss_rows = loss_rows; a.td_abs = td_abs;
-    a.batch = batch; a.n_actions = n_actions; a.stride = q_stride; a.gamma_n = gamma_n; a.delta_clip = delta_clip;
+    a.batch = batch; a.n_actions = n_actions; a.stride = q_stride; a.dueling = dueling != 0; a.gamma_n = gamma_n;
+    a.delta_clip = delta_clip;
     hipLaunchKernelGGL(dqn_loss_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return arl::check_launch("dqn_loss_kernel");
 }
@@ -248,21 +308,22 @@ static int check_cat(int64_t batch, int n_actions, int n_atoms, int stride) {
 }
 
 extern "C" int arl_catdqn_act(const float* logits, const float* z, const int32_t* override_or_null, int64_t batch,
-                              int32_t n_actions, int32_t n_atoms, int32_t atom_stride, float* onehot,
+                              int32_t n_actions, int32_t n_atoms, int32_t atom_stride, int32_t dueling, float* onehot,
                               uint8_t* greedy_or_null, void* stream) {
     ARL_REQUIRE(logits && z && onehot, ARL_E_ARG, "null pointer");
     int rc = check_cat(batch, n_actions, n_atoms, atom_stride);
     if (rc) return rc;
     hipLaunchKernelGGL(catdqn_act_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       logits, z, override_or_null, batch, n_actions, n_atoms, atom_stride, onehot, greedy_or_null);
+                       logits, z, override_or_null, batch, n_actions, n_atoms, atom_stride, dueling != 0, onehot,
+                       greedy_or_null);
     return arl::check_launch("catdqn_act_kernel");
 }
 
 extern "C" int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_logits, const float* pol_next_logits_or_null,
                                const float* z, const uint8_t* actions, const float* returns, const uint8_t* terminals,
                                const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t n_atoms,
-                               int32_t atom_stride, float v_min, float v_max, float gamma_n, float* dlogits,
-                               float* loss_rows, float* kl, void* stream) {
+                               int32_t atom_stride, int32_t dueling, float v_min, float v_max, float gamma_n,
+                               float* dlogits, float* loss_rows, float* kl, void* stream) {
     ARL_REQUIRE(pred_logits && tgt_next_logits && z && actions && returns && terminals && dlogits && loss_rows && kl,
                 ARL_E_ARG, "null pointer");
     int rc = check_cat(batch, n_actions, n_atoms, atom_stride);
@@ -272,7 +333,7 @@ extern "C" int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_l
     a.pred_logits = pred_logits; a.tgt_next_logits = tgt_next_logits; a.pol_next_logits = pol_next_logits_or_null;
     a.z = z; a.actions = actions; a.returns = returns; a.terminals = terminals; a.is_weights = is_weights_or_null;
     a.dlogits = dlogits; a.loss_rows = loss_rows; a.kl = kl; a.batch = batch;
-    a.n_actions = n_actions; a.n_atoms = n_atoms; a.stride = atom_stride;
+    a.n_actions = n_actions; a.n_atoms = n_atoms; a.stride = atom_stride; a.dueling = dueling != 0;
     a.v_min = v_min; a.v_max = v_max; a.gamma_n = gamma_n;
     hipLaunchKernelGGL(catdqn_loss_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     return arl::check_launch("catdqn_loss_kernel");

@@ -1,6 +1,6 @@
 """DQN-family optimizer (reference: accel_rl/optimizers/single/dqn_optimizer.py:11-54): one gradient
-step per call on a replay minibatch, optional global-norm clip, adam / rmsprop on the flat bucket
-(csrc/optim.hip).  `loss` is a callable(minibatch tuple) -> (priority f32[B], loss scalar) that leaves
+step per call on a replay minibatch, optional conv-gradient scaling and global-norm clip, adam / rmsprop
+on the flat bucket (csrc/optim.hip).  `loss` is a callable(minibatch tuple) -> (priority f32[B], loss scalar) that leaves
 the gradient in the policy's flat bucket (the algorithm builds it)."""
 import numpy as np
 import torch
@@ -15,8 +15,7 @@ class DqnOptimizer(BaseOptimizer):
 
     def __init__(self, learning_rate, update_method, update_method_args=None, grad_norm_clip=None,
                  scale_conv_grads=False, use_graph=True):
-        if scale_conv_grads:
-            raise NotImplementedError("scale_conv_grads belongs to the dueling architecture, which is not built")
+        self._scale_conv_grads = scale_conv_grads      # dueling networks: conv gradients x 2^-1/2 (:34-36)
         self._learning_rate = learning_rate
         self._update_method = update_method
         self._update_args = update_method.resolve(**(update_method_args or dict()))
@@ -50,6 +49,8 @@ class DqnOptimizer(BaseOptimizer):
 
     def _step(self, inputs):
         priority, loss = self._loss_fn(inputs)
+        if self._scale_conv_grads:                     # the conv tensors lead the bucket (optimizers/util.py:122-126)
+            self._target.flat_grads[:self._target.grad_split_offset].mul_(float(np.float32(2 ** -0.5)))
         self._apply_update(1.0)
         return priority, loss
 

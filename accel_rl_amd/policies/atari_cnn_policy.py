@@ -98,13 +98,12 @@ class AtariCnnPolicy(object):
         self._conv_out = (c, h, w)
         fan = c * h * w
         hid_ref, hid_names, fan = self._hidden_reference_init(fan)
-        ref += hid_ref
         self._n_hidden_tensors = len(hid_ref)
         head_ref, head_names = self._head_reference_init(fan, n_act)
-        ref += head_ref
+        ref += self._tail_to_flat(hid_ref + head_ref)
         self._ref_shapes = [a.shape for a in ref]
         self.param_short_names = (["Conv%d%s" % (i, s) for i in range(len(self._conv_geom)) for s in "Wb"] +
-                                  hid_names + head_names)
+                                  self._tail_to_flat(hid_names + head_names))
         self.n_params = int(sum(a.size for a in ref))
         # ---- internal bucket: [conv W, b]... [hidden W, b]... W_head, b_head
         shapes = []
@@ -192,6 +191,23 @@ class AtariCnnPolicy(object):
         for j in range(len(self._hid_geom)):
             w = refs[2 * j]
             out += [self._conv_flat_to_internal(w) if j == 0 else w.T, refs[2 * j + 1]]
+        return out
+
+    # The hooks above and below produce / consume the dense tensors in CONSTRUCTION order (hidden layers, then
+    # output layers).  Where the reference's flat parameter vector orders them differently (dueling networks:
+    # get_all_params walks the value branch first), `_tail_perm` lists, per flat position, the index into
+    # the construction-order list.
+    _tail_perm = None
+
+    def _tail_to_flat(self, tail):
+        return list(tail) if self._tail_perm is None else [tail[i] for i in self._tail_perm]
+
+    def _tail_from_flat(self, tail):
+        if self._tail_perm is None:
+            return list(tail)
+        out = [None] * len(tail)
+        for pos, i in enumerate(self._tail_perm):
+            out[i] = tail[pos]
         return out
 
     # ---- output layers: policy + value heads fused in one matrix W_head[(A+1), hid]
@@ -445,9 +461,9 @@ class AtariCnnPolicy(object):
             w = arr[k][..., :self._c_in] if i == 0 else arr[k]             # drop the zero padding channels
             out += [w.transpose(0, 3, 1, 2)[:, :, ::-1, ::-1], arr[k + 1]]
             k += 2
-        out += self._hidden_to_reference(arr[k:k + self._n_hidden_internal])
+        tail = self._hidden_to_reference(arr[k:k + self._n_hidden_internal])
         k += self._n_hidden_internal
-        out += self._head_to_reference(arr[k], arr[k + 1])
+        out += self._tail_to_flat(tail + self._head_to_reference(arr[k], arr[k + 1]))
         return np.concatenate([np.ascontiguousarray(x).reshape(-1) for x in out]).astype(np.float32)
 
     def _set_from_reference_arrays(self, ref):
@@ -459,9 +475,9 @@ class AtariCnnPolicy(object):
                 w = np.concatenate([w, np.zeros(w.shape[:3] + (self._c_pad - self._c_in,), np.float32)], axis=3)
             internal += [w, ref[k + 1]]
             k += 2
-        internal += self._hidden_to_internal(ref[k:k + self._n_hidden_tensors])
-        k += self._n_hidden_tensors
-        internal += self._head_to_internal(ref[k:])
+        tail = self._tail_from_flat(list(ref[k:]))
+        internal += self._hidden_to_internal(tail[:self._n_hidden_tensors])
+        internal += self._head_to_internal(tail[self._n_hidden_tensors:])
         for o, s, a in zip(self._offsets, self._shapes, internal):
             assert tuple(a.shape) == tuple(s), (a.shape, s)
             host[o:o + a.size] = np.ascontiguousarray(a).reshape(-1)

@@ -11,7 +11,8 @@ loss).  The target network is a second flat bucket; `update_target` is one devic
 Epsilon-greedy draws stay on the host RNG in the reference's order -- per (step, group):
 np.random.rand(B), then action_space.sample_n(#random) (atari_cat_dqn_policy.py:118-124) -- but are
 made for a whole rollout at once (`host_draws`) and shipped as an override table, so serving an
-action needs no host round trip.  Dueling heads are not implemented.
+action needs no host round trip.  Dueling (`dueling=True`): see QPolicyBase -- the stored block is
+n_actions advantage rows followed by one value row of atoms.
 """
 import numpy as np
 import torch
@@ -25,8 +26,6 @@ class AtariCatDqnPolicy(QPolicyBase):
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=(),
                  pixel_scale=255., epsilon=1, n_atoms=51, dueling=False, initial_param_values=None):
-        if dueling:
-            raise NotImplementedError("dueling C51 heads (catdqn_cnn.py:77-93) are not built")
         if not 2 <= n_atoms <= 64:
             raise NotImplementedError("n_atoms must be in [2, 64]")
         super().__init__(conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=hidden_sizes,
@@ -35,32 +34,57 @@ class AtariCatDqnPolicy(QPolicyBase):
         self._atom_stride = (n_atoms + 3) // 4 * 4
         self._epsilon = epsilon
         self.z = None
+        self._set_dueling(dueling)
+
+    def _out_units(self):
+        return self.n_act * self.n_atoms
+
+    def _val_units(self):
+        return self.n_atoms
+
+    def _duel_blocks(self):
+        s = self._atom_stride
+        return slice(0, self.n_act * s), slice(self.n_act * s, (self.n_act + 1) * s)
 
     # ---- output layer: "action_atoms" dense, n_actions * n_atoms units (catdqn_cnn.py:69-76)
     def _head_reference_init(self, fan, n_act):
         # atoms padded per action (zero weights, zero gradients) until the layer's width is a multiple of the
         # MFMA k-tile: its data gradient then runs on the scalar-addressed kernels (18 x 52 = 936 fell back
         # to the generic one: 94 us per update at batch 32)
-        while (n_act * self._atom_stride) % 32 and self._atom_stride < 64:
+        while (self._rows * self._atom_stride) % 32 and self._atom_stride < 64:
             self._atom_stride += 4
+        if self._dueling:
+            return self._duel_head_ref, ["OutputW", "Outputb", "ValW", "Valb"]
         return [_norm_c((fan, n_act * self.n_atoms), 0.01), np.zeros(n_act * self.n_atoms, np.float32)], \
                ["OutputW", "Outputb"]
 
+    @property
+    def _rows(self):
+        """Rows of atoms per sample in the stored output: the actions (+ the value row when dueling)."""
+        return self.n_act + int(self._dueling)
+
     def _head_internal_shapes(self, fan, n_act):
-        return [(n_act * self._atom_stride, fan), (n_act * self._atom_stride,)]
+        return [(self._rows * self._atom_stride, fan), (self._rows * self._atom_stride,)]
 
     def _head_to_reference(self, wh, bh):
         a, n, s = self.n_act, self.n_atoms, self._atom_stride
-        w = wh.reshape(a, s, -1)[:, :n].reshape(a * n, -1)
-        return [w.T, bh.reshape(a, s)[:, :n].reshape(-1)]
+        w3, b2 = wh.reshape(self._rows, s, -1), bh.reshape(self._rows, s)
+        if self._dueling:
+            hs = self.hidden_sizes[0]
+            return [w3[:a, :n, :hs].reshape(a * n, hs).T, b2[:a, :n].reshape(-1), w3[a, :n, hs:].T, b2[a, :n]]
+        return [w3[:, :n].reshape(a * n, -1).T, b2[:, :n].reshape(-1)]
 
     def _head_to_internal(self, ref_tail):
         a, n, s = self.n_act, self.n_atoms, self._atom_stride
-        w = np.zeros((a, s, ref_tail[0].shape[0]), np.float32)
-        w[:, :n] = ref_tail[0].T.reshape(a, n, -1)
-        b = np.zeros((a, s), np.float32)
-        b[:, :n] = ref_tail[1].reshape(a, n)
-        return [w.reshape(a * s, -1), b.reshape(-1)]
+        hs = ref_tail[0].shape[0]
+        w = np.zeros((self._rows, s, hs * (2 if self._dueling else 1)), np.float32)
+        b = np.zeros((self._rows, s), np.float32)
+        w[:a, :n, :hs] = ref_tail[0].T.reshape(a, n, hs)
+        b[:a, :n] = ref_tail[1].reshape(a, n)
+        if self._dueling:
+            w[a, :n, hs:] = ref_tail[2].T
+            b[a, :n] = ref_tail[3]
+        return [w.reshape(self._rows * s, -1), b.reshape(-1)]
 
     def incorporate_z(self, z):
         """Called by the algorithm while initialising (:69-78): the support of the value distribution."""
@@ -70,11 +94,11 @@ class AtariCatDqnPolicy(QPolicyBase):
 
     @property
     def _head_width(self):
-        return self.n_act * self._atom_stride
+        return self._rows * self._atom_stride
 
     def _serve(self, out, override, onehot, greedy=None):
         assert self.z is not None, "incorporate_z() first (the algorithm does)"
-        _lib.catdqn_act(out, self.z, override, self.n_act, self.n_atoms, onehot, greedy)
+        _lib.catdqn_act(out, self.z, override, self.n_act, self.n_atoms, onehot, greedy, dueling=self._dueling)
 
     # ---- training ------------------------------------------------------------
     def cat_loss_and_grads(self, obs, next_obs, actions, returns, terminals, is_weights, v_min, v_max, gamma_n,
@@ -94,6 +118,7 @@ class AtariCatDqnPolicy(QPolicyBase):
             loss_rows = self._buffer(("loss_rows", b), (b,))
             kl = self._buffer(("kl", b), (b,))
             _lib.catdqn_loss(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
-                             self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl)
+                             self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl,
+                             dueling=self._dueling)
             self._head_backward(dlogits, x, acts, hids)
             return loss_rows, kl

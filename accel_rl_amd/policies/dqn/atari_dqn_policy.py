@@ -6,7 +6,8 @@ Mirror of the reference's AtariDqnPolicy / DqnCnn
 target network and action serving are QPolicyBase's; the output layer "output_q" is one dense MFMA
 call whose row is padded to 32 columns (zero weights, zero gradients) so that its data gradient
 runs on the scalar-addressed kernels, followed by csrc/dqn.hip (arl_dqn_act, arl_dqn_loss).
-Dueling heads and the shared scalar output bias are not implemented.
+Dueling (`dueling=True`): see QPolicyBase -- the stored row is n_actions advantages followed by the value.
+The shared scalar output bias is not implemented.
 """
 import numpy as np
 import torch
@@ -20,30 +21,52 @@ class AtariDqnPolicy(QPolicyBase):
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=(),
                  pixel_scale=255., epsilon=1, dueling=False, shared_last_bias=False, initial_param_values=None):
-        if dueling:
-            raise NotImplementedError("dueling heads (dqn_cnn.py:89-112) are not built")
         if shared_last_bias:
             raise NotImplementedError("shared_last_bias (dqn_cnn.py:73-88) is not built")
         super().__init__(conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=hidden_sizes,
                          pixel_scale=pixel_scale, initial_param_values=initial_param_values)
         self._epsilon = epsilon
+        self._set_dueling(dueling)
 
-    # ---- output layer: "output_q" dense, n_actions units (dqn_cnn.py:73-80)
+    # ---- output layer: "output_q" dense, n_actions units (dqn_cnn.py:73-80) [+ "Val", 1 unit (:100-107)]
+    def _out_units(self):
+        return self.n_act
+
+    def _val_units(self):
+        return 1
+
+    def _duel_blocks(self):
+        return slice(0, self.n_act), slice(self.n_act, self.n_act + 1)
+
     def _head_reference_init(self, fan, n_act):
-        self._q_stride = (n_act + 31) // 32 * 32
+        self._q_stride = (n_act + int(self._dueling) + 31) // 32 * 32
+        if self._dueling:
+            return self._duel_head_ref, ["OutputW", "Outputb", "ValW", "Valb"]
         return [_norm_c((fan, n_act), 0.01), np.zeros(n_act, np.float32)], ["OutputW", "Outputb"]
 
     def _head_internal_shapes(self, fan, n_act):
         return [(self._q_stride, fan), (self._q_stride,)]
 
     def _head_to_reference(self, wh, bh):
-        return [wh[:self.n_act].T, bh[:self.n_act]]
+        a = self.n_act
+        if self._dueling:
+            hs = self.hidden_sizes[0]
+            return [wh[:a, :hs].T, bh[:a], wh[a:a + 1, hs:].T, bh[a:a + 1]]
+        return [wh[:a].T, bh[:a]]
 
     def _head_to_internal(self, ref_tail):
-        w = np.zeros((self._q_stride, ref_tail[0].shape[0]), np.float32)
-        w[:self.n_act] = ref_tail[0].T
+        a = self.n_act
+        fan = ref_tail[0].shape[0] * (2 if self._dueling else 1)
+        w = np.zeros((self._q_stride, fan), np.float32)
         b = np.zeros(self._q_stride, np.float32)
-        b[:self.n_act] = ref_tail[1]
+        b[:a] = ref_tail[1]
+        if self._dueling:
+            hs = self.hidden_sizes[0]
+            w[:a, :hs] = ref_tail[0].T
+            w[a, hs:] = ref_tail[2][:, 0]
+            b[a] = ref_tail[3][0]
+        else:
+            w[:a] = ref_tail[0].T
         return [w, b]
 
     @property
@@ -51,16 +74,22 @@ class AtariDqnPolicy(QPolicyBase):
         return self._q_stride
 
     def _serve(self, out, override, onehot, greedy=None):
-        _lib.dqn_act(out, override, self.n_act, onehot, greedy)
+        _lib.dqn_act(out, override, self.n_act, onehot, greedy, dueling=self._dueling)
 
     # ---- host-interface twins of q / target_q (:108-112) ------------------------
+    def _merged(self, out):
+        adv = out[:, :self.n_act]
+        if not self._dueling:
+            return adv.clone()
+        return out[:, self.n_act:self.n_act + 1] + (adv - adv.mean(dim=1, keepdim=True))
+
     def q(self, observations):
         with torch.no_grad():
-            return self._logits(self._scaled(observations))[0][:, :self.n_act].clone()
+            return self._merged(self._logits(self._scaled(observations))[0])
 
     def target_q(self, observations):
         with torch.no_grad():
-            return self._logits(self._scaled(observations), w=self._w_target, tag="t")[0][:, :self.n_act].clone()
+            return self._merged(self._logits(self._scaled(observations), w=self._w_target, tag="t")[0])
 
     # ---- training ------------------------------------------------------------
     def q_loss_and_grads(self, obs, next_obs, actions, returns, terminals, is_weights, gamma_n, delta_clip,
@@ -80,6 +109,6 @@ class AtariDqnPolicy(QPolicyBase):
             loss_rows = self._buffer(("loss_rows", b), (b,))
             td_abs = self._buffer(("td_abs", b), (b,))
             _lib.dqn_loss(q, tgt_q, pol_next, actions, returns, terminals, is_weights, self.n_act, gamma_n,
-                          delta_clip, dq, loss_rows, td_abs)
+                          delta_clip, dq, loss_rows, td_abs, dueling=self._dueling)
             self._head_backward(dq, x, acts, hids)
             return loss_rows, td_abs

@@ -8,12 +8,20 @@ np.random.rand(B), then action_space.sample_n(#random)
 (policies/dqn/atari_dqn_policy.py:125-130, atari_cat_dqn_policy.py:118-124) -- but are made for a
 whole rollout at once (`host_draws`) and shipped as an override table, so serving an action needs
 no host round trip.
+
+Dueling networks (dqn_cnn.py:89-112, catdqn_cnn.py:77-93; one hidden layer): the advantage stream's and
+the value stream's hidden layers are stacked into ONE dense layer of 2H units (rows 0..H-1 advantage,
+H..2H-1 value) and their output layers into ONE block-structured matrix over those 2H inputs
+(advantage rows read columns 0..H-1, value rows columns H..2H-1; the off-blocks are exactly zero
+and their gradients are masked to zero), so trunk and output layer stay one MFMA call each.  The
+merge val + (adv - mean adv) lives in the action / loss kernels.  The flat parameter vector keeps
+the reference's order (value branch first: hidden_Val, Val, hidden, output).
 """
 import numpy as np
 import torch
 
 from accel_rl_amd import _lib
-from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy, _norm_c
 
 
 class QPolicyBase(AtariCnnPolicy):
@@ -21,6 +29,54 @@ class QPolicyBase(AtariCnnPolicy):
     greedy)` (the action kernel) and the four `_head_*` layout hooks."""
 
     _epsilon = 1
+    _dueling = False
+
+    def _set_dueling(self, dueling):
+        self._dueling = bool(dueling)
+        if self._dueling:
+            if len(self.hidden_sizes) != 1:
+                raise NotImplementedError("dueling networks are built for one hidden layer")
+            # construction order [hid W, b, hid_Val W, b, out W, b, Val W, b] -> the reference's flat order
+            self._tail_perm = [2, 3, 6, 7, 0, 1, 4, 5]
+
+    # units of the advantage / value output layers (reference shapes)
+    def _out_units(self):
+        raise NotImplementedError
+
+    def _val_units(self):
+        raise NotImplementedError
+
+    def _hidden_reference_init(self, fan):
+        if not self._dueling:
+            return super()._hidden_reference_init(fan)
+        hs = self.hidden_sizes[0]
+        if hs % 4:
+            raise NotImplementedError("hidden sizes must be multiples of 4 (got %d)" % hs)
+        # draws in the reference's construction order: hidden, output, hidden_Val, Val
+        hid = [_norm_c((fan, hs), 1.0), np.zeros(hs, np.float32)]
+        out = [_norm_c((hs, self._out_units()), 0.01), np.zeros(self._out_units(), np.float32)]
+        hid_val = [_norm_c((fan, hs), 1.0), np.zeros(hs, np.float32)]
+        val = [_norm_c((hs, self._val_units()), 0.01), np.zeros(self._val_units(), np.float32)]
+        self._duel_head_ref = out + val
+        self._hid_geom = [(2 * hs, fan)]
+        return hid + hid_val, ["FC0W", "FC0b", "FCVal0W", "FCVal0b"], 2 * hs
+
+    def _hidden_to_reference(self, arrs):
+        if not self._dueling:
+            return super()._hidden_to_reference(arrs)
+        hs = self.hidden_sizes[0]
+        w, b = arrs
+        return [self._conv_flat_to_reference(w[:hs]), b[:hs], self._conv_flat_to_reference(w[hs:]), b[hs:]]
+
+    def _hidden_to_internal(self, refs):
+        if not self._dueling:
+            return super()._hidden_to_internal(refs)
+        return [np.concatenate([self._conv_flat_to_internal(refs[0]), self._conv_flat_to_internal(refs[2])], axis=0),
+                np.concatenate([refs[1], refs[3]])]
+
+    def _duel_blocks(self):
+        """(rows of the advantage block, rows of the value block) of the stored output matrix."""
+        raise NotImplementedError
 
     @property
     def _head_width(self):
@@ -36,6 +92,13 @@ class QPolicyBase(AtariCnnPolicy):
         self._w_target = [self.flat_target[o:o + n] for o, n in zip(self._offsets, sizes)]
         self._overrides = dict()          # n_envs -> (pinned host, device) i32[horizon][n_envs]
         self._step = 0
+        if self._dueling:                 # 1 on the two blocks of the output matrix that exist, 0 elsewhere
+            hs = self.hidden_sizes[0]
+            adv_rows, val_rows = self._duel_blocks()
+            mask = torch.zeros(self._shapes[self._k_head], dtype=torch.float32, device=self.device)
+            mask[adv_rows, :hs] = 1.
+            mask[val_rows, hs:] = 1.
+            self._duel_mask = mask
 
 
     # ---- forward -----------------------------------------------------------
@@ -153,3 +216,5 @@ class QPolicyBase(AtariCnnPolicy):
             _lib.conv2d_bwd_weight(dout, ones, db4, self._ones_geom(b, dout.shape[1]), self._conv_ws)
             self.grads[k + 1].copy_(db4[:, 0])
         self._backward_trunk(x, acts, hids, dh, masked=True)
+        if self._dueling:                 # the folds have run: keep the absent blocks' gradient at exactly zero
+            self.grads[k].mul_(self._duel_mask)

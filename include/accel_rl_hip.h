@@ -424,9 +424,12 @@ int arl_sumtree_gather(const double* tree, const int32_t* tree_idxs, int64_t n, 
  * sampler's categorical kernel selects exactly it.  Replaces AtariCatDqnPolicy.get_actions /
  * actions_sym, accel_rl/policies/dqn/atari_cat_dqn_policy.py:84-126 (+ catdqn_cnn.py:94-99).
  *   logits f32[batch][n_actions][atom_stride], atom_stride % 4 == 0 >= n_atoms <= 64;
- *   z f32[n_atoms]; onehot f32[batch][n_actions]; greedy u8[batch] or NULL            */
+ *   z f32[n_atoms]; onehot f32[batch][n_actions]; greedy u8[batch] or NULL
+ * dueling != 0 (DuelingMergeLayer, policies/dqn/layers/dueling_merge_layer.py:32-35, catdqn_cnn.py:77-93):
+ *   logits f32[batch][n_actions + 1][atom_stride], advantage rows then ONE value row;
+ *   logit(a, i) = val_i + (adv_ai - mean_a adv_ai) before the softmax.                    */
 int arl_catdqn_act(const float* logits, const float* z, const int32_t* override_or_null, int64_t batch,
-                   int32_t n_actions, int32_t n_atoms, int32_t atom_stride, float* onehot,
+                   int32_t n_actions, int32_t n_atoms, int32_t atom_stride, int32_t dueling, float* onehot,
                    uint8_t* greedy_or_null, void* stream);
 
 /* Loss of CategoricalDQN.build_loss, accel_rl/algos/dqn/cat_dqn.py:40-109: next action greedy
@@ -435,30 +438,36 @@ int arl_catdqn_act(const float* logits, const float* z, const int32_t* override_
  * gamma^n z where terminal) onto the base support; cross-entropy against clip(pred, 1e-6, 1),
  * importance-weighted mean; priorities = clip(KL, 1e-6, 1e6).
  *   out: dlogits f32[batch][n_actions][atom_stride] (d mean-loss / d pred_logits),
- *        loss_rows f32[batch] (their sum is the loss), kl f32[batch]                       */
+ *        loss_rows f32[batch] (their sum is the loss), kl f32[batch]
+ * dueling != 0: all three logit blocks and dlogits are [n_actions + 1][atom_stride] as above;
+ *   dlogits is the gradient w.r.t. the advantage rows and the value row (through the merge). */
 int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_logits, const float* pol_next_logits_or_null,
                     const float* z, const uint8_t* actions, const float* returns, const uint8_t* terminals,
                     const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t n_atoms,
-                    int32_t atom_stride, float v_min, float v_max, float gamma_n, float* dlogits,
-                    float* loss_rows, float* kl, void* stream);
+                    int32_t atom_stride, int32_t dueling, float v_min, float v_max, float gamma_n,
+                    float* dlogits, float* loss_rows, float* kl, void* stream);
 
 /* Plain DQN action serving: greedy action = first maximum of the Q row (T.argmax), override as
  * above, one-hot row out.  Replaces AtariDqnPolicy.get_actions / actions_sym,
  * accel_rl/policies/dqn/atari_dqn_policy.py:61-63,76-79,118-130.
- *   q f32[batch][q_stride], q_stride % 4 == 0 >= n_actions (<= 255); onehot f32[batch][n_actions] */
+ *   q f32[batch][q_stride], q_stride % 4 == 0 >= n_actions (<= 255); onehot f32[batch][n_actions]
+ * dueling != 0 (dqn_cnn.py:89-112): columns 0..n_actions-1 are advantages, column n_actions the
+ *   value; q_a = val + (adv_a - mean adv).                                                  */
 int arl_dqn_act(const float* q, const int32_t* override_or_null, int64_t batch, int32_t n_actions,
-                int32_t q_stride, float* onehot, uint8_t* greedy_or_null, void* stream);
+                int32_t q_stride, int32_t dueling, float* onehot, uint8_t* greedy_or_null, void* stream);
 
 /* Loss of DQN.build_loss, accel_rl/algos/dqn/dqn.py:137-172: next_q = max_a target(next_obs) or
  * (double DQN) target(next_obs)[argmax_a policy(next_obs)]; y = return + (1 - terminal) gamma^n
  * next_q; d = y - q[action]; 0.5 d^2, or the Huber loss with threshold delta_clip (> 0);
  * importance-weighted mean; priorities = clip(|d|, 0, delta_clip) (|d| when delta_clip <= 0).
  *   out: dq f32[batch][q_stride] (d mean-loss / d q; zero outside the taken action),
- *        loss_rows f32[batch] (their sum is the loss), td_abs f32[batch]                   */
+ *        loss_rows f32[batch] (their sum is the loss), td_abs f32[batch]
+ * dueling != 0: rows as in arl_dqn_act; dq is the gradient w.r.t. advantages and value.        */
 int arl_dqn_loss(const float* q, const float* tgt_next_q, const float* pol_next_q_or_null,
                  const uint8_t* actions, const float* returns, const uint8_t* terminals,
                  const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t q_stride,
-                 float gamma_n, float delta_clip, float* dq, float* loss_rows, float* td_abs, void* stream);
+                 int32_t dueling, float gamma_n, float delta_clip, float* dq, float* loss_rows, float* td_abs,
+                 void* stream);
 
 /* ------------------------------------------------------------------------- *
  * LSTM cell of the recurrent policies

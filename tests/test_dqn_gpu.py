@@ -203,4 +203,4 @@ def test_dqn_trains_with_prioritized_replay_and_eval():
         finals.append(policy.get_param_values())
     np.testing.assert_array_equal(finals[0], finals[1])
     with pytest.raises(NotImplementedError):
-        AtariDqnPolicy(dueling=True, **cnn_specs[0])
+        AtariDqnPolicy(shared_last_bias=True, **cnn_specs[0])
