@@ -113,6 +113,9 @@ _SIGNATURES = {
     "arl_sumtree_find": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "arl_sumtree_add": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp]),
     "arl_sumtree_gather": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
+    "arl_sumtree_sample": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "arl_is_weights": (_i32, [_vp, _i64, _f64, _vp, _vp]),
+    "arl_priority_diffs": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_dqn_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -494,6 +497,27 @@ def sumtree_add(tree, levels, idxs, diffs, stream=None):
     _want(diffs, torch.float64, "diffs")
     _check(load().arl_sumtree_add(ptr(tree), levels, ptr(idxs), ptr(diffs), idxs.numel(), stream_ptr(stream)),
            "arl_sumtree_add")
+
+
+def sumtree_sample(tree, levels, uniforms, n, part_size, tree_idxs, env_idxs, step_idxs, probs, n_unique,
+                   stream=None):
+    _want(tree, torch.float64, "tree"), _want(uniforms, torch.float64, "uniforms")
+    _want(tree_idxs, torch.int32, "tree_idxs"), _want(probs, torch.float64, "probs")
+    _check(load().arl_sumtree_sample(ptr(tree), levels, ptr(uniforms), uniforms.numel(), n, part_size,
+                                     ptr(tree_idxs), ptr(env_idxs), ptr(step_idxs), ptr(probs), ptr(n_unique),
+                                     stream_ptr(stream)), "arl_sumtree_sample")
+
+
+def is_weights(probs, beta, out, stream=None):
+    _want(probs, torch.float64, "probs"), _want(out, torch.float32, "out")
+    _check(load().arl_is_weights(ptr(probs), probs.numel(), float(beta), ptr(out), stream_ptr(stream)),
+           "arl_is_weights")
+
+
+def priority_diffs(priorities, last_probs, alpha, diffs, stream=None):
+    _want(priorities, torch.float32, "priorities"), _want(last_probs, torch.float64, "last_probs")
+    _check(load().arl_priority_diffs(ptr(priorities), ptr(last_probs), priorities.numel(), float(alpha),
+                                     ptr(diffs), stream_ptr(stream)), "arl_priority_diffs")
 
 
 def sumtree_gather(tree, idxs, out, scale=1.0, stream=None):

@@ -100,7 +100,10 @@ class DQN(RLAlgorithm):
             return None, dict()
         priorities, losses = [], []
         for _ in range(self._updates_per_optimize):
-            opt_minibatch = self.replay_buffer.sample_batch(self.batch_size)
+            if self.prioritized_replay:
+                opt_minibatch = self.replay_buffer.sample_batch(self.batch_size, device_weights=True)
+            else:
+                opt_minibatch = self.replay_buffer.sample_batch(self.batch_size)
             priority, loss = self.optimizer.optimize(opt_minibatch)
             if self.prioritized_replay:
                 self.replay_buffer.update_batch_priorities(priority)

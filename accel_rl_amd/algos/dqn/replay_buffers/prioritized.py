@@ -1,5 +1,8 @@
 """Prioritized replay (reference: accel_rl/algos/dqn/replay_buffers/prioritized.py:5-38)."""
 import numpy as np
+import torch
+
+from accel_rl_amd import _lib
 
 from accel_rl_amd.algos.dqn.replay_buffers.frame import FrameReplayBuffer
 from accel_rl_amd.algos.dqn.replay_buffers.sum_tree import PartedSumTree
@@ -29,14 +32,31 @@ class PrioritizedReplayBuffer(FrameReplayBuffer):
         super().append_data(samples_data)
         self.priority_tree.advance()
 
-    def sample_batch(self, batch_size):
-        """-> extract_batch(...) + (importance weights f64[batch], host numpy)"""
-        env_idxs, step_idxs, probs = self.priority_tree.sample_n(batch_size)
+    def sample_batch(self, batch_size, device_weights=False):
+        """-> extract_batch(...) + (importance weights,): host f64 numpy as the reference returns them, or
+        (device_weights=True, what the DQN algorithms ask for) a device f32 tensor -- then leaf selection,
+        probabilities, batch extraction and weights never visit the host, which waits for one integer."""
+        dev = self.priority_tree.sample_n_device(batch_size) if device_weights else None
+        if dev is not None:
+            env_idxs, step_idxs, probs = dev
+            batch_data = self.extract_batch(env_idxs, step_idxs)
+            is_weights = torch.empty(batch_size, dtype=torch.float32, device=self.device)
+            _lib.is_weights(probs, self.beta, is_weights)
+            if self.priority_tree.confirm_unique():
+                return batch_data + (is_weights,)
+            env_idxs, step_idxs, probs = self.priority_tree.top_up()      # the reference would have drawn more
+        else:
+            env_idxs, step_idxs, probs = self.priority_tree.sample_n(batch_size)
         batch_data = self.extract_batch(env_idxs, step_idxs)
         is_weights = (1. / probs) ** self.beta          # (normalised by the max just below)
         is_weights /= max(is_weights)
+        if device_weights:
+            is_weights = torch.from_numpy(is_weights.astype(np.float32)).to(self.device)
         return batch_data + (is_weights,)
 
     def update_batch_priorities(self, priorities):
+        if isinstance(priorities, torch.Tensor) and priorities.is_cuda and priorities.dtype == torch.float32:
+            self.priority_tree.update_last_samples_pow(priorities, self.alpha)
+            return
         priorities = np.asarray(priorities.cpu() if hasattr(priorities, "cpu") else priorities)
         self.priority_tree.update_last_samples(priorities ** self.alpha)

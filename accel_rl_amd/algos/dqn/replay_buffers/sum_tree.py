@@ -2,9 +2,13 @@
 
 The f64 tree (16 MB for 1M leaves) lives in HBM; descent (`find`), leaf-to-root updates
 (`reconstruct`, in the reference's np.add.at order) and gathers are csrc/replay.hip kernels.
-What stays on the host is what must see the values to consume the host RNG exactly as the
-reference does: the np.random.rand draws and the sorted-unique / top-up loop of `sample_n`
-(a few dozen integers per call)."""
+What stays on the host is what must see values to consume the host RNG exactly as the reference
+does: the np.random.rand draws of `sample_n` and the decision to draw more when too few distinct
+leaves came back.  `sample_n` is the reference's interface (host arrays out);
+`sample_n_device` + `confirm_unique` is what the replay buffer uses: descent, sort, unique and
+the probabilities stay on the device (arl_sumtree_sample) and the host waits for ONE integer --
+the number of distinct leaves -- falling back to the host loop only when the reference would have
+topped up (rare at replay sizes)."""
 import numpy as np
 import torch
 
@@ -66,6 +70,50 @@ class PartedSumTree(object):
     def sample_n(self, n):
         """:77-86: n distinct leaves (sorted), their parts / steps / probabilities."""
         tree_idxs = np.unique(self.find(np.random.rand(int(1.05 * n))))
+        return self._finish_sample(tree_idxs, n)
+
+    # ---- sample_n without the host in the data path ------------------------------------------
+    _SAMPLE_MAX = 4096
+
+    def sample_n_device(self, n):
+        """Enqueue :77-86 for the common case (enough distinct leaves in the first 1.05 n draws); returns
+        device (env_idxs i32[n], step_idxs i32[n], probs f64[n]) -- valid only if `confirm_unique()` says so.
+        None when n is too large for the kernel (use sample_n)."""
+        m = int(1.05 * n)
+        if m > self._SAMPLE_MAX or m < n:
+            return None
+        st = getattr(self, "_dev_sample", None)
+        if st is None or st["n"] != n:
+            i32 = lambda k: torch.empty(k, dtype=torch.int32, device=self.device)      # noqa: E731
+            st = self._dev_sample = dict(
+                n=n, u_host=torch.empty(m, dtype=torch.float64).pin_memory(),
+                u=torch.empty(m, dtype=torch.float64, device=self.device), idx=i32(n), env=i32(n), step=i32(n),
+                probs=torch.empty(n, dtype=torch.float64, device=self.device), count=i32(1),
+                count_host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event())
+        st["u_host"].copy_(torch.from_numpy(np.random.rand(m)))        # the reference's first draw (:79)
+        st["u"].copy_(st["u_host"], non_blocking=True)
+        _lib.sumtree_sample(self.tree, self.tree_level, st["u"], n, self.part_size, st["idx"], st["env"],
+                            st["step"], st["probs"], st["count"])
+        st["count_host"].copy_(st["count"], non_blocking=True)
+        st["event"].record(torch.cuda.current_stream(self.device))
+        self.last_tree_idxs, self.last_probs = st["idx"], st["probs"]
+        return st["env"], st["step"], st["probs"]
+
+    def confirm_unique(self):
+        """Wait for the one integer of the last sample_n_device: were there n distinct leaves?"""
+        st = self._dev_sample
+        st["event"].synchronize()
+        return int(st["count_host"][0]) >= st["n"]
+
+    def top_up(self):
+        """The reference's while-loop (:80-86), continuing from the distinct leaves of the last
+        sample_n_device; returns what sample_n returns."""
+        st = self._dev_sample
+        n = st["n"]
+        tree_idxs = st["idx"][:int(st["count_host"][0])].cpu().numpy().astype(np.int64)
+        return self._finish_sample(tree_idxs, n)
+
+    def _finish_sample(self, tree_idxs, n):
         i = 0
         while len(tree_idxs) < n:
             i += 1
@@ -85,3 +133,9 @@ class PartedSumTree(object):
         """:74-75"""
         new = new_values if isinstance(new_values, torch.Tensor) else self._dev(new_values, torch.float64)
         self.reconstruct(self.last_tree_idxs, new.to(torch.float64) - self.last_probs)
+
+    def update_last_samples_pow(self, priorities, alpha):
+        """update_last_samples(priorities ** alpha) for device f32 priorities, without leaving the device."""
+        diffs = torch.empty(priorities.numel(), dtype=torch.float64, device=self.device)
+        _lib.priority_diffs(priorities, self.last_probs, alpha, diffs)
+        _lib.sumtree_add(self.tree, self.tree_level, self.last_tree_idxs, diffs)

@@ -1136,7 +1136,8 @@ __global__ __launch_bounds__(256) void bwd_pair_kernel(const GemmArgs a, const W
 // weight gradients (conv 1: 2048 float4 x 128 splits) without giving up determinism.
 __global__ __launch_bounds__(256) void fold_splits_kernel(const float4* __restrict__ part, int splits,
                                                           int64_t total4, const float4* __restrict__ bias,
-                                                          int bias4, int relu, float4* __restrict__ out) {
+                                                          int bias4, int relu, const float4* __restrict__ mask,
+                                                          float4* __restrict__ out) {
     __shared__ float4 lds[16][16];
     const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
     const int64_t i = (int64_t)blockIdx.x * 16 + o;
@@ -1159,6 +1160,13 @@ __global__ __launch_bounds__(256) void fold_splits_kernel(const float4* __restri
             s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
         }
         if (relu) { s.x = fmaxf(s.x, 0.f); s.y = fmaxf(s.y, 0.f); s.z = fmaxf(s.z, 0.f); s.w = fmaxf(s.w, 0.f); }
+        if (mask) {                                                  // relu backward: 0 where mask <= 0
+            const float4 m = mask[i];
+            if (!(m.x > 0.f)) s.x = 0.f;
+            if (!(m.y > 0.f)) s.y = 0.f;
+            if (!(m.z > 0.f)) s.z = 0.f;
+            if (!(m.w > 0.f)) s.w = 0.f;
+        }
         out[i] = s;
     }
 }
@@ -1267,10 +1275,11 @@ int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t 
 }
 
 int launch_fold(const float* part, int splits, int64_t total, const float* bias, int n_bias, int relu,
-                float* out, hipStream_t s) {
+                float* out, hipStream_t s, const float* mask = nullptr) {
     const int64_t total4 = total >> 2;
     hipLaunchKernelGGL(fold_splits_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, s,
-                       (const float4*)part, splits, total4, (const float4*)bias, n_bias >> 2, relu, (float4*)out);
+                       (const float4*)part, splits, total4, (const float4*)bias, n_bias >> 2, relu,
+                       (const float4*)mask, (float4*)out);
     return arl::check_launch("fold_splits_kernel");
 }
 
@@ -1405,8 +1414,9 @@ struct DgradPlan { GemmArgs a; bool fast, has_pad; int cfg; };
 struct WgradPlan { WgradArgs a; bool fast, has_pad; int cfg, splits; int64_t total; };
 
 // plan_only: describe the fast launch instead of issuing it (fast == false: nothing was done)
+// workspace (optional): lets a dense layer whose output tiles cannot fill the chip split its reduction
 int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float* dx, const arl_conv_geom* geom,
-               DgradPlan* plan_only, void* stream) {
+               DgradPlan* plan_only, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0) {
     ARL_REQUIRE(dy && w && dx, ARL_E_ARG, "null pointer");
     Geom g;
     int rc = check_geom(geom, &g);
@@ -1466,10 +1476,27 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
                 }
             a.n_par = n; a.M = max_m;       // grid covers the largest class; smaller ones exit early
         }
+        // Dense layers at small batch (the DQN updates: 32 rows; or a narrow input such as the C51 head's 256):
+        // a handful of 128x128 tiles walking the whole reduction is a latency chain (2 workgroups x 36 k-tiles:
+        // 83 us whatever the batch); 64x64 tiles with the reduction split as in the forward pass, rectifier
+        // mask applied by the fold.
+        const bool small = st == 1 && a.N > 64 && (int64_t)a.M * a.N <= ((int64_t)1 << 20) && a.N % 4 == 0;
         if (plan_only) {
             plan_only->a = a; plan_only->fast = true; plan_only->has_pad = has_pad;
-            plan_only->cfg = a.N <= 32 ? 0 : a.N <= 64 ? 1 : 2;
+            plan_only->cfg = a.N <= 32 ? 0 : a.N <= 64 ? 1 : small ? 3 : 2;
             return 0;
+        }
+        if (small) {
+            int splits = 1, per = a.k_per_split;
+            if (workspace) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
+            if ((int64_t)splits * a.M * a.N * 4 > workspace_bytes) { splits = 1; per = round_up(a.K, BKT); }
+            a.k_per_split = per;
+            if (splits > 1) {
+                a.o.out = (float*)workspace; a.o.mask = nullptr; a.split_stride = (int64_t)a.M * a.N;
+            }
+            rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, splits, false, has_pad, s);
+            if (rc || splits == 1) return rc;
+            return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, nullptr, 4, 0, dx, s, mask_or_null);
         }
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
@@ -1657,9 +1684,12 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
     const bool paired = dp.fast && wp.fast && dp.cfg == 2 && wp.cfg == 2 &&
                         (!has_pad || geom->kh * geom->kw <= 32) && !g_trace;
     if (!paired) {
-        rc = arl_conv2d_bwd_data(dy, w, mask_or_null, dx, geom, stream);
+        // the data gradient may split its reduction: it gets the upper half of the workspace (and is folded at
+        // once), the weight gradient's deferred partials the lower half
+        const int64_t half = (workspace_bytes / 2) & ~(int64_t)15;
+        rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, (char*)workspace + half, workspace_bytes - half);
         if (rc) return rc;
-        return arl_conv2d_bwd_weight_parts(dy, x, dw, geom, workspace, workspace_bytes, item, dbias_or_null,
+        return arl_conv2d_bwd_weight_parts(dy, x, dw, geom, workspace, half, item, dbias_or_null,
                                            bias_item_or_null, stream);
     }
     hipStream_t s = (hipStream_t)stream;

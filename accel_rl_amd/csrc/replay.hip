@@ -191,6 +191,114 @@ __global__ __launch_bounds__(1024) void sumtree_add_kernel(double* __restrict__ 
     }
 }
 
+// sample_n's device half (sum_tree.py:77-86): descend for every uniform, sort, drop duplicates, keep the n
+// smallest distinct leaves with their probabilities and (part, step) coordinates, and report how many distinct
+// leaves there were -- the host only needs that count to decide whether the reference would have drawn more.
+// One workgroup; the candidates (m <= 4096) are sorted in LDS by a bitonic network.
+constexpr int SAMPLE_MAX = 4096;
+
+__global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __restrict__ tree, int levels,
+                                                              const double* __restrict__ uniforms, int m, int n,
+                                                              int part_size, int32_t* __restrict__ tree_idxs,
+                                                              int32_t* __restrict__ env_idxs,
+                                                              int32_t* __restrict__ step_idxs,
+                                                              double* __restrict__ probs,
+                                                              int32_t* __restrict__ n_unique) {
+    __shared__ int s_key[SAMPLE_MAX];
+    __shared__ int s_pos[SAMPLE_MAX];
+    const int tid = threadIdx.x;
+    int P = 1;
+    while (P < m) P <<= 1;
+    const double root = tree[0];
+    for (int i = tid; i < P; i += 1024) {
+        int idx = 0x7fffffff;                                    // padding sorts behind every leaf
+        if (i < m) {
+            double v = uniforms[i] * root;
+            idx = 0;
+            for (int l = 0; l < levels - 1; ++l) {
+                idx = 2 * idx + 1;
+                const double left = tree[idx];
+                if (v > left) { v -= left; idx += 1; }
+            }
+        }
+        s_key[i] = idx;
+    }
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += 1024) {
+                const int partner = i ^ j;
+                if (partner > i) {
+                    const int a = s_key[i], b = s_key[partner];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_key[i] = b; s_key[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // distinct leaves: flag the first of every run, inclusive scan of the flags (Hillis-Steele in LDS)
+    for (int i = tid; i < P; i += 1024)
+        s_pos[i] = (s_key[i] != 0x7fffffff && (i == 0 || s_key[i] != s_key[i - 1])) ? 1 : 0;
+    __syncthreads();
+    for (int off = 1; off < P; off <<= 1) {
+        int add[SAMPLE_MAX / 1024];
+        for (int i = tid, q = 0; i < P; i += 1024, ++q) add[q] = i >= off ? s_pos[i - off] : 0;
+        __syncthreads();
+        for (int i = tid, q = 0; i < P; i += 1024, ++q) s_pos[i] += add[q];
+        __syncthreads();
+    }
+    const int shift = (1 << (levels - 1)) - 1;                   // tree index of leaf 0
+    for (int i = tid; i < P; i += 1024) {
+        const int key = s_key[i];
+        const bool first = key != 0x7fffffff && (i == 0 || key != s_key[i - 1]);
+        const int pos = s_pos[i] - 1;
+        if (first && pos < n) {
+            tree_idxs[pos] = key;
+            probs[pos] = tree[key];
+            const int leaf = key - shift;
+            env_idxs[pos] = leaf / part_size;
+            step_idxs[pos] = leaf - (leaf / part_size) * part_size;
+        }
+    }
+    // too few distinct leaves: the slots past them repeat the first one, so that work already queued behind this
+    // kernel (batch extraction) stays in bounds while the host learns from n_unique that it has to top up
+    const int total = s_pos[P - 1];
+    for (int pos = total + tid; pos < n; pos += 1024) {
+        const int key = s_key[0], leaf = key - shift;
+        tree_idxs[pos] = key;
+        probs[pos] = tree[key];
+        env_idxs[pos] = leaf / part_size;
+        step_idxs[pos] = leaf - (leaf / part_size) * part_size;
+    }
+    if (tid == 0) n_unique[0] = total;
+}
+
+// importance-sampling weights (prioritized.py:33-35): w = (1 / p) ** beta in f64, divided by their maximum,
+// rounded to f32 for the loss kernels.  One workgroup.
+__global__ __launch_bounds__(1024) void is_weights_kernel(const double* __restrict__ probs, int n, double beta,
+                                                          float* __restrict__ out) {
+    __shared__ double s_max[1024];
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) mx = fmax(mx, pow(1.0 / probs[i], beta));
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + off]);
+        __syncthreads();
+    }
+    mx = s_max[0];
+    for (int i = threadIdx.x; i < n; i += 1024) out[i] = (float)(pow(1.0 / probs[i], beta) / mx);
+}
+
+// update_batch_priorities' arithmetic (prioritized.py:37-38, sum_tree.py:74-75): the f32 priorities raised to
+// alpha in f32 (numpy keeps float32 ** python-float in float32), minus the probabilities sampled before, in f64
+__global__ __launch_bounds__(256) void priority_diffs_kernel(const float* __restrict__ priorities,
+                                                             const double* __restrict__ last_probs, int64_t n,
+                                                             double alpha, double* __restrict__ diffs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) diffs[i] = (double)(float)pow((double)priorities[i], (double)(float)alpha) - last_probs[i];
+}
+
 int check_replay(const arl_replay* rb) {
     if (!rb || !rb->frames || !rb->acts || !rb->n_blanks || !rb->terminals || !rb->rewards || !rb->returns) {
         arl::set_error("replay: null pointer");
@@ -253,6 +361,33 @@ extern "C" int arl_sumtree_find(const double* tree, int32_t levels, const double
     hipLaunchKernelGGL(sumtree_find_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        tree, levels, uniforms, n, tree_idxs);
     return arl::check_launch("sumtree_find_kernel");
+}
+
+extern "C" int arl_sumtree_sample(const double* tree, int32_t levels, const double* uniforms, int32_t m, int32_t n,
+                                  int32_t part_size, int32_t* tree_idxs, int32_t* env_idxs, int32_t* step_idxs,
+                                  double* probs, int32_t* n_unique, void* stream) {
+    ARL_REQUIRE(tree && uniforms && tree_idxs && env_idxs && step_idxs && probs && n_unique, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(levels >= 1 && levels <= 31 && m >= 1 && m <= SAMPLE_MAX && n >= 1 && n <= m && part_size >= 1,
+                ARL_E_RANGE, "need 1 <= n <= m <= 4096 candidates");
+    hipLaunchKernelGGL(sumtree_sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree, levels, uniforms,
+                       m, n, part_size, tree_idxs, env_idxs, step_idxs, probs, n_unique);
+    return arl::check_launch("sumtree_sample_kernel");
+}
+
+extern "C" int arl_is_weights(const double* probs, int64_t n, double beta, float* out, void* stream) {
+    ARL_REQUIRE(probs && out, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(n >= 1 && n < ((int64_t)1 << 31), ARL_E_RANGE, "bad n");
+    hipLaunchKernelGGL(is_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, probs, (int)n, beta, out);
+    return arl::check_launch("is_weights_kernel");
+}
+
+extern "C" int arl_priority_diffs(const float* priorities, const double* last_probs, int64_t n, double alpha,
+                                  double* diffs, void* stream) {
+    ARL_REQUIRE(priorities && last_probs && diffs, ARL_E_ARG, "null pointer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(priority_diffs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       priorities, last_probs, n, alpha, diffs);
+    return arl::check_launch("priority_diffs_kernel");
 }
 
 extern "C" int arl_sumtree_gather(const double* tree, const int32_t* tree_idxs, int64_t n, double scale,

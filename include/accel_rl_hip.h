@@ -414,6 +414,24 @@ int arl_sumtree_add(double* tree, int32_t levels, const int32_t* tree_idxs, cons
 int arl_sumtree_gather(const double* tree, const int32_t* tree_idxs, int64_t n, double scale,
                        double* out, void* stream);
 
+/* The device half of PartedSumTree.sample_n (sum_tree.py:77-86): find() for m uniforms, sorted distinct
+ * leaves, the n smallest kept with their probabilities and (part, step) = divmod(leaf, part_size);
+ * n_unique[0] = number of distinct leaves found (< n: the reference would draw more -- the caller tops
+ * up through arl_sumtree_find as before; output slots past the distinct leaves repeat the first one, so
+ * consumers already queued stay in bounds).  1 <= n <= m <= 4096.                                 */
+int arl_sumtree_sample(const double* tree, int32_t levels, const double* uniforms, int32_t m, int32_t n,
+                       int32_t part_size, int32_t* tree_idxs, int32_t* env_idxs, int32_t* step_idxs,
+                       double* probs, int32_t* n_unique, void* stream);
+
+/* Importance-sampling weights of PrioritizedReplayBuffer.sample_batch (prioritized.py:33-35):
+ * out[i] = f32( (1 / probs[i]) ** beta / max_j (1 / probs[j]) ** beta ), arithmetic in f64.        */
+int arl_is_weights(const double* probs, int64_t n, double beta, float* out, void* stream);
+
+/* diffs[i] = f64( f32(priorities[i] ** alpha) ) - last_probs[i]: the argument update_last_samples hands to
+ * reconstruct (prioritized.py:37-38, sum_tree.py:74-75); follow with arl_sumtree_add.                */
+int arl_priority_diffs(const float* priorities, const double* last_probs, int64_t n, double alpha,
+                       double* diffs, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Categorical DQN output stage
  * ------------------------------------------------------------------------- */

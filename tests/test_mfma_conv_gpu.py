@@ -23,7 +23,8 @@ CASES = [(37, 104, 80, 4, 32, 8, 4, 0),      # spec-1 conv 1 (ragged batch)
          (256, 1, 1, 6912, 512, 1, 1, 0),    # ... at the rollout batch (9 k-tiles per split: odd)
          (256, 1, 1, 3840, 512, 1, 1, 0),    # 5 k-tiles per split (the two-tile unrolled loop's odd tail)
          (80, 1, 1, 3456, 256, 1, 1, 0),     # spec-0 dense, ragged rows
-         (5120, 1, 1, 512, 128, 1, 1, 0)]    # wide batch, no split
+         (5120, 1, 1, 512, 128, 1, 1, 0),    # wide batch, no split
+         (32, 1, 1, 256, 1152, 1, 1, 0)]     # C51 head at the DQN batch: 4 output tiles, data gradient splits its reduction
 
 
 def _mk(case, seed=0):
@@ -163,7 +164,8 @@ def test_adjoint_identities_at_full_size(case):
 @pytest.mark.parametrize("masked", [False, True])
 def test_paired_backward_is_the_two_separate_calls(case, masked):
     """arl_conv2d_bwd_pair (one launch, deferred fold) == arl_conv2d_bwd_data + arl_conv2d_bwd_weight, bit for
-    bit: the same tiles in the same order, only co-scheduled (or the documented fallback for odd shapes)."""
+    bit: the same tiles in the same order, only co-scheduled (or the documented fallbacks: separate launches for
+    odd shapes; a split reduction for thin dense data gradients)."""
     from accel_rl_amd import _lib
     x, wt, bias, geom, ws = _mk(case, seed=3)
     ho, wo = _lib.conv_out_hw(geom)
@@ -177,7 +179,16 @@ def test_paired_backward_is_the_two_separate_calls(case, masked):
     folds, ws2 = _lib.FoldList(), _lib.conv_workspace(DEV)
     folds.conv2d_bwd_pair(dy, wt, mask, dx1, x, dw1, geom, ws2)
     folds.run()
-    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+    assert torch.equal(dw0, dw1)
+    # the data gradient too -- except for a stride-1 layer with few output tiles (dense layers at small batch),
+    # whose reduction the paired call splits across workgroups (it has a workspace, the bare call has not)
+    split_ok = case[6] == 1 and case[3] > 64 and x.numel() <= 1 << 20
+
+    def same_dx(a, b):
+        if torch.equal(a, b):
+            return True
+        return split_ok and (a - b).abs().max().item() <= 2e-6 * np.sqrt(dy.numel() / case[0]) * a.abs().max().item()
+    assert same_dx(dx0, dx1)
     # ... and with the bias gradient's column sums riding along (fast kernels only; else "not produced")
     want_db = dy.reshape(-1, case[4]).double().sum(0)
     for paired in (True, False):
@@ -189,7 +200,7 @@ def test_paired_backward_is_the_two_separate_calls(case, masked):
             done = folds.conv2d_bwd_weight(dy, x, dw2, geom, ws2, dbias=db)
         folds.run()
         assert done == ((case[0] * ho * wo) % 32 == 0)       # the scalar-addressed kernels need whole 32-row k-tiles
-        assert torch.equal(dw0, dw2) and (not paired or torch.equal(dx0, dx2))
+        assert torch.equal(dw0, dw2) and (not paired or same_dx(dx0, dx2))
         if done:
             tol = 2e-5 * np.sqrt(dy.numel() / case[4]) * dy.abs().max().item()
             assert (db.double() - want_db).abs().max().item() <= tol

@@ -167,3 +167,83 @@ def test_config5_shapes_against_oracle(promo):
     np.testing.assert_array_equal(tree.tree.cpu().numpy(), ref.tree)
     u = rs.rand(1000)
     np.testing.assert_array_equal(tree.find(u), ref.find(u))
+
+
+@pytest.mark.parametrize("levels,m,n", [(5, 9, 8), (8, 33, 32), (12, 537, 512), (21, 33, 32), (10, 4096, 3900),
+                                        (4, 40, 3)])
+def test_sumtree_sample_kernel_matches_host_unique(levels, m, n):
+    """arl_sumtree_sample = find + np.unique + [:n] + gather + divmod of sum_tree.py:77-86, and the count of
+    distinct leaves -- including trees so small that most draws collide."""
+    from accel_rl_amd import _lib
+    rs = np.random.RandomState(levels * 1000 + m)
+    n_leaves = 2 ** (levels - 1)
+    leaves = rs.rand(n_leaves) * (rs.rand(n_leaves) < 0.7)             # zero-priority leaves are never found
+    tree = np.zeros(2 ** levels - 1)
+    tree[n_leaves - 1:] = leaves
+    for i in range(n_leaves - 2, -1, -1):
+        tree[i] = tree[2 * i + 1] + tree[2 * i + 2]
+    t = torch.from_numpy(tree).to(DEV)
+    u = rs.rand(m)
+    found = torch.empty(m, dtype=torch.int32, device=DEV)
+    _lib.sumtree_find(t, levels, torch.from_numpy(u).to(DEV), found)
+    uniq = np.unique(found.cpu().numpy())
+    part = 7 if levels > 4 else 3
+    i32 = lambda: torch.full((n,), -7, dtype=torch.int32, device=DEV)      # noqa: E731
+    idx, env, step = i32(), i32(), i32()
+    probs = torch.full((n,), -1., dtype=torch.float64, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    _lib.sumtree_sample(t, levels, torch.from_numpy(u).to(DEV), n, part, idx, env, step, probs, count)
+    c = int(count.item())
+    assert c == len(uniq)
+    k = min(c, n)
+    np.testing.assert_array_equal(idx.cpu().numpy()[:k], uniq[:k])
+    np.testing.assert_array_equal(probs.cpu().numpy()[:k], tree[uniq[:k]])
+    e, s = np.divmod(uniq[:k] - (n_leaves - 1), part)
+    np.testing.assert_array_equal(env.cpu().numpy()[:k], e)
+    np.testing.assert_array_equal(step.cpu().numpy()[:k], s)
+    assert (idx.cpu().numpy()[k:] == uniq[0]).all()                  # the slots past the distinct leaves repeat the first
+
+
+def test_prioritized_device_path_tracks_the_reference_path():
+    """sample_batch(device_weights=True) + update_batch_priorities(device f32) -- the path the DQN algorithms
+    take -- against the host path (itself pinned bit for bit to the reference, above) on the same seeds:
+    identical leaves and batches (integer work: exact), weights to f32 rounding, tree to 1e-7 (f32 pow).
+    The golden tree is small, so the top-up fallback is exercised as well."""
+    from accel_rl_amd.algos.dqn.replay_buffers.prioritized import PrioritizedReplayBuffer
+    obs = _pad(G12["pri_in_obs"])
+    acts, rews, dones = (G12["pri_in_%s" % k] for k in ("acts", "rews", "dones"))
+    mk = lambda: PrioritizedReplayBuffer(alpha=0.6, beta_initial=0.4, default_priority=1., env_spec=_Spec((4, 6, 8)),   # noqa: E731
+                                         size=60, reward_horizon=3, sampling_horizon=5, n_environments=3,
+                                         discount=0.99, device=DEV)
+    host, dev = mk(), mk()
+    fast = slow = 0
+    rs = np.random.RandomState(0)
+    for b in range(9):
+        for buf in (host, dev):
+            buf.append_data(_samples(obs, acts, rews, dones, b))
+        if b >= 1:
+            for batch in (6, 3, 6):
+                seed = 3000 + 10 * b + batch
+                np.random.seed(seed)
+                want = host.sample_batch(batch)
+                after = np.random.randint(0, 2 ** 31 - 1)
+                np.random.seed(seed)
+                got = dev.sample_batch(batch, device_weights=True)
+                assert np.random.randint(0, 2 ** 31 - 1) == after           # same host RNG consumption
+                st = dev.priority_tree._dev_sample
+                if int(st["count_host"][0]) >= batch:
+                    fast += 1
+                else:
+                    slow += 1
+                for w, g in zip(want[:5], got[:5]):
+                    assert torch.equal(w, g)
+                assert got[5].dtype == torch.float32 and got[5].is_cuda
+                np.testing.assert_allclose(got[5].cpu().numpy(), want[5].astype(np.float32), rtol=3e-7, atol=0)
+                np.testing.assert_array_equal(dev.priority_tree.last_tree_idxs.cpu().numpy(),
+                                              host.priority_tree.last_tree_idxs.cpu().numpy())
+                pri = (rs.rand(batch) * 2 + 0.01).astype(np.float32)
+                host.update_batch_priorities(pri)
+                dev.update_batch_priorities(torch.from_numpy(pri).to(DEV))
+                np.testing.assert_allclose(dev.priority_tree.tree.cpu().numpy(), host.priority_tree.tree.cpu().numpy(),
+                                           rtol=2e-7, atol=1e-12)
+    assert fast > 0 and slow > 0, (fast, slow)
