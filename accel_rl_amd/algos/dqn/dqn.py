@@ -69,6 +69,7 @@ class DQN(RLAlgorithm):
             self.replay_buffer = PrioritizedReplayBuffer(**replay_args)
         else:
             self.replay_buffer = UniformReplayBuffer(**replay_args)
+        self.replay_buffer.reuse_outputs = True       # minibatches are consumed before the next one is drawn
 
     def build_loss(self, env_spec, policy):
         """dqn.py:137-172"""

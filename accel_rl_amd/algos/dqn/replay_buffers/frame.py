@@ -83,14 +83,31 @@ class FrameReplayBuffer(object):
         if not isinstance(env_idxs, torch.Tensor):
             env_idxs, step_idxs = self._upload_idxs(env_idxs, step_idxs)
         b = env_idxs.numel()
+        obs, nxt, acts, rets, terms, terms_bool = self._batch_outputs(b)
+        _lib.replay_extract(self._rb, env_idxs, step_idxs, obs, nxt, acts, rets, terms)
+        return obs, nxt, acts, rets, terms_bool
+
+    # `reuse_outputs` (set by the DQN algorithms): every batch of one size lands in the SAME device tensors,
+    # marked `_arl_static`, so a hipGraph-replayed update reads them in place instead of copies -- the
+    # previous batch is overwritten, which the reference's fresh arrays would not be.
+    reuse_outputs = False
+
+    def _batch_outputs(self, b):
+        cache = self.__dict__.setdefault("_out_cache", dict())
+        if self.reuse_outputs and b in cache:
+            return cache[b]
         shape = (b, self.num_img_obs) + self.frame_shape
         obs = torch.empty(shape, dtype=torch.uint8, device=self.device)
         nxt = torch.empty(shape, dtype=torch.uint8, device=self.device)
         acts = torch.empty(b, dtype=torch.uint8, device=self.device)
         rets = torch.empty(b, dtype=torch.float32, device=self.device)
         terms = torch.empty(b, dtype=torch.uint8, device=self.device)
-        _lib.replay_extract(self._rb, env_idxs, step_idxs, obs, nxt, acts, rets, terms)
-        return obs, nxt, acts, rets, terms.view(torch.bool)
+        out = (obs, nxt, acts, rets, terms, terms.view(torch.bool))
+        if self.reuse_outputs:
+            for t in out:
+                t._arl_static = True
+            cache[b] = out
+        return out
 
     def extract_observations(self, env_idxs, step_idxs):
         return self.extract_batch(env_idxs, step_idxs)[0]

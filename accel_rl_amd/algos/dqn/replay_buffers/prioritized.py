@@ -40,7 +40,7 @@ class PrioritizedReplayBuffer(FrameReplayBuffer):
         if dev is not None:
             env_idxs, step_idxs, probs = dev
             batch_data = self.extract_batch(env_idxs, step_idxs)
-            is_weights = torch.empty(batch_size, dtype=torch.float32, device=self.device)
+            is_weights = self._weights_out(batch_size)
             _lib.is_weights(probs, self.beta, is_weights)
             if self.priority_tree.confirm_unique():
                 return batch_data + (is_weights,)
@@ -51,8 +51,20 @@ class PrioritizedReplayBuffer(FrameReplayBuffer):
         is_weights = (1. / probs) ** self.beta          # (normalised by the max just below)
         is_weights /= max(is_weights)
         if device_weights:
-            is_weights = torch.from_numpy(is_weights.astype(np.float32)).to(self.device)
+            out = self._weights_out(batch_size)
+            out.copy_(torch.from_numpy(is_weights.astype(np.float32)))
+            is_weights = out
         return batch_data + (is_weights,)
+
+    def _weights_out(self, b):
+        cache = self.__dict__.setdefault("_isw_cache", dict())
+        if self.reuse_outputs and b in cache:
+            return cache[b]
+        out = torch.empty(b, dtype=torch.float32, device=self.device)
+        if self.reuse_outputs:
+            out._arl_static = True
+            cache[b] = out
+        return out
 
     def update_batch_priorities(self, priorities):
         if isinstance(priorities, torch.Tensor) and priorities.is_cuda and priorities.dtype == torch.float32:

@@ -58,11 +58,16 @@ class DqnOptimizer(BaseOptimizer):
         """Copy one minibatch into the static buffers the graph reads (host arrays -- the importance
         weights -- through a pinned mirror guarded by an event)."""
         dev = self._target.device
-        if self._static is None or any(tuple(s.shape) != tuple(np.shape(x)) for s, x in zip(self._static, inputs)):
-            assert self._graph is None, "the replay minibatch shape changed after graph capture"
+        in_place = [isinstance(x, torch.Tensor) and getattr(x, "_arl_static", False) for x in inputs]
+        if self._static is None or any(tuple(s.shape) != tuple(np.shape(x)) or (keep and s is not x)
+                                       for s, x, keep in zip(self._static, inputs, in_place)):
+            assert self._graph is None, "the replay minibatch changed shape or buffers after graph capture"
             self._static, self._pinned = [], []
-            for x in inputs:
-                if isinstance(x, torch.Tensor):
+            for x, keep in zip(inputs, in_place):
+                if keep:                                          # the replay buffer's own static outputs
+                    self._static.append(x)
+                    self._pinned.append(None)
+                elif isinstance(x, torch.Tensor):
                     self._static.append(torch.empty_like(x, device=dev))
                     self._pinned.append(None)
                 else:
@@ -72,13 +77,18 @@ class DqnOptimizer(BaseOptimizer):
             self._stage_event = torch.cuda.Event()
         else:
             self._stage_event.synchronize()                       # the previous upload has left the pinned mirrors
+        copied = False
         for s, p, x in zip(self._static, self._pinned, inputs):
+            if s is x:
+                continue
+            copied = True
             if p is None:
                 s.copy_(x, non_blocking=True)
             else:
                 p.copy_(torch.from_numpy(np.asarray(x, np.float32)))
                 s.copy_(p, non_blocking=True)
-        self._stage_event.record(torch.cuda.current_stream(dev))
+        if copied:
+            self._stage_event.record(torch.cuda.current_stream(dev))
         return tuple(self._static)
 
     @property

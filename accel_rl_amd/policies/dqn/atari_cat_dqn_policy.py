@@ -108,12 +108,7 @@ class AtariCatDqnPolicy(QPolicyBase):
         full backward pass into flat_grads.  Returns (loss_rows f32[B] whose sum is the loss, kl f32[B])."""
         with torch.no_grad():
             b = obs.shape[0]
-            tgt_logits, _, _ = self._logits(self._scaled(next_obs, tag="n"), w=self._w_target, tag="t")
-            pol_next = None
-            if double_dqn:
-                pol_next = self._logits(self._scaled(next_obs, tag="n"), tag="d")[0]
-            x = self._scaled(obs)
-            logits, acts, hids = self._logits(x)
+            x, logits, acts, hids, tgt_logits, pol_next = self._forward_for_loss(obs, next_obs, double_dqn)
             dlogits = self._buffer(("dlogits", b), tuple(logits.shape))
             loss_rows = self._buffer(("loss_rows", b), (b,))
             kl = self._buffer(("kl", b), (b,))

@@ -99,12 +99,7 @@ class AtariDqnPolicy(QPolicyBase):
         pass into flat_grads.  Returns (loss_rows f32[B] whose sum is the loss, td_abs f32[B])."""
         with torch.no_grad():
             b = obs.shape[0]
-            tgt_q, _, _ = self._logits(self._scaled(next_obs, tag="n"), w=self._w_target, tag="t")
-            pol_next = None
-            if double_dqn:
-                pol_next = self._logits(self._scaled(next_obs, tag="n"), tag="d")[0]
-            x = self._scaled(obs)
-            q, acts, hids = self._logits(x)
+            x, q, acts, hids, tgt_q, pol_next = self._forward_for_loss(obs, next_obs, double_dqn)
             dq = self._buffer(("dlogits", b), tuple(q.shape))
             loss_rows = self._buffer(("loss_rows", b), (b,))
             td_abs = self._buffer(("td_abs", b), (b,))

@@ -113,6 +113,27 @@ class QPolicyBase(AtariCnnPolicy):
         _lib.conv2d_fwd(hids[-1], w[k], w[k + 1], out, geom, False, self._conv_ws)
         return out, acts, hids
 
+    def _forward_for_loss(self, obs, next_obs, double_dqn):
+        """The three forward passes of a DQN-family loss: online net on obs (activations kept for the backward
+        pass), target net on next_obs and -- double DQN -- online net on next_obs.  The two online passes run as
+        ONE pass over 2B rows (at the DQN batch of 32 every layer is latency-bound, so the second half is nearly
+        free), whose first-half slices feed the backward pass; the target pass reads the same scaled next_obs.
+        Returns (x, out, acts, hids, target_out, online_next_out or None)."""
+        b = obs.shape[0]
+        c, h, w = self._obs_shape
+        if not double_dqn or c != 4:
+            tgt, _, _ = self._logits(self._scaled(next_obs, tag="n"), w=self._w_target, tag="t")
+            pol_next = self._logits(self._scaled(next_obs, tag="n"), tag="d")[0] if double_dqn else None
+            x = self._scaled(obs)
+            out, acts, hids = self._logits(x)
+            return x, out, acts, hids, tgt, pol_next
+        x2 = self._buffer(("x2", 2 * b), (2 * b, c, h, w), channels_last=True)
+        _lib.gather_scale_obs_nhwc(obs, None, x2[:b], self._scale)
+        _lib.gather_scale_obs_nhwc(next_obs, None, x2[b:], self._scale)
+        tgt, _, _ = self._logits(x2[b:], w=self._w_target, tag="t")
+        out2, acts2, hids2 = self._logits(x2, tag="2")
+        return x2[:b], out2[:b], [a[:b] for a in acts2], [hd[:b] for hd in hids2], tgt, out2[b:]
+
     def _ones_geom(self, b, width):
         key = ("ones", b, width)
         if key not in self._geoms:
