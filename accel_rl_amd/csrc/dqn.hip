@@ -16,8 +16,8 @@
 //
 // Layout: logits f32[batch][n_actions (+ 1 value row when dueling)][atom_stride], atom_stride = n_atoms rounded up to a
 // multiple of 4 (the dense layer producing them is an MFMA kernel with 16-byte rows); the padding
-// columns are ignored on input and receive zero gradient.  One wave per sample; lane i owns atom i
-// (n_atoms <= 64).  fp32, compiled with -ffp-contract=off.
+// columns are ignored on input and receive zero gradient.  Lane i owns atom i; one wave per sample (action
+// kernel) / one workgroup per sample (loss kernel); n_atoms <= 64.  fp32, compiled with -ffp-contract=off.
 
 #include "arl_common.h"
 
@@ -113,33 +113,50 @@ struct CatLossArgs {
     float v_min, v_max, gamma_n;    // gamma_n = discount ** reward_horizon (rounded to f32 on the host)
 };
 
+// One workgroup per sample.  The greedy next action needs a softmax expectation per action -- a serial chain
+// of wave reductions -- so the actions are dealt to the four waves; wave 0 then carries the sample through
+// projection, loss and gradient (lane i = atom i).
 __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
-    __shared__ float s_next[4][64], s_znext[4][64];
+    __shared__ float s_next[64], s_znext[64], s_q[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-    if (b >= a.batch) return;
+    const int64_t b = blockIdx.x;
     const int A = a.n_actions, n = a.n_atoms, S = a.stride;
     const bool duel = a.dueling != 0;
     const int64_t R = (int64_t)(A + a.dueling) * S;      // floats per sample
     const float z_lane = lane < n ? a.z[lane] : 0.f;
     const float* tgt = a.tgt_next_logits + b * R;
-    // greedy next action: under the policy net (double DQN) or the target net (cat_dqn.py:77-81)
-    const int a_next = greedy_action(a.pol_next_logits ? a.pol_next_logits + b * R : tgt, lane, A, n, S, z_lane, duel);
+    // greedy next action: under the policy net (double DQN) or the target net (cat_dqn.py:77-81), first maximum
+    {
+        const float* sel = a.pol_next_logits ? a.pol_next_logits + b * R : tgt;
+        const Duel d = duel_terms(sel, lane, A, n, S, duel);
+        for (int k = wave; k < A; k += 4) {
+            const float q = wave_sum(atom_softmax(atom_logit(sel, k, lane, n, S, d), lane, n) * z_lane);
+            if (lane == 0) s_q[k] = q;
+        }
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    int a_next = 0;
+    float best_q = s_q[0];
+    for (int k = 1; k < A; ++k) {
+        const float q = s_q[k];
+        if (q > best_q) { best_q = q; a_next = k; }
+    }
     const float next_p = atom_softmax(atom_logit(tgt, a_next, lane, n, S, duel_terms(tgt, lane, A, n, S, duel)), lane, n);
     // shifted support, clipped to [v_min, v_max] (:56-62)
     const float keep = a.terminals[b] ? 0.f : 1.f;
     float zn = a.returns[b] + keep * (a.gamma_n * z_lane);
     zn = fminf(fmaxf(zn, a.v_min), a.v_max);
-    s_next[wave][lane] = next_p;        // wave-private LDS rows: in-order LDS access of one wave needs no barrier
-    s_znext[wave][lane] = zn;
+    s_next[lane] = next_p;              // only wave 0 is left: in-order LDS access of one wave needs no barrier
+    s_znext[lane] = zn;
     __builtin_amdgcn_wave_barrier();
     // projection on the base support (:63-70,88-90): proj_i = sum_j next_p_j clip(1 - |zn_j - z_i| / dz, 0, 1)
     const float dz = (a.v_max - a.v_min) / (float)(n - 1);
     float proj = 0.f;
     if (lane < n)
         for (int j = 0; j < n; ++j) {
-            const float c = 1.f - fabsf(s_znext[wave][j] - z_lane) / dz;
-            proj += s_next[wave][j] * fminf(fmaxf(c, 0.f), 1.f);
+            const float c = 1.f - fabsf(s_znext[j] - z_lane) / dz;
+            proj += s_next[j] * fminf(fmaxf(c, 0.f), 1.f);
         }
     // prediction, cross-entropy with NaN guard (:92-94)
     const int act = a.actions[b];
@@ -335,6 +352,6 @@ extern "C" int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_l
     a.dlogits = dlogits; a.loss_rows = loss_rows; a.kl = kl; a.batch = batch;
     a.n_actions = n_actions; a.n_atoms = n_atoms; a.stride = atom_stride; a.dueling = dueling != 0;
     a.v_min = v_min; a.v_max = v_max; a.gamma_n = gamma_n;
-    hipLaunchKernelGGL(catdqn_loss_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(catdqn_loss_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
     return arl::check_launch("catdqn_loss_kernel");
 }

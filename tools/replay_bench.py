@@ -70,6 +70,15 @@ def main():
         out = torch.empty(b, dtype=torch.int32, device=DEV)
         us = ev(lambda: _lib.sumtree_find(tree.tree, tree.tree_level, u, out))
         print("tree find    %4d: %7.1f us" % (b, us))
+        if int(1.05 * b) <= 4096:
+            m = int(1.05 * b)
+            um = torch.rand(m, dtype=torch.float64, device=DEV, generator=gen)
+            i32 = lambda: torch.empty(b, dtype=torch.int32, device=DEV)      # noqa: E731
+            ti, te, ts, cnt = i32(), i32(), i32(), torch.zeros(1, dtype=torch.int32, device=DEV)
+            pr = torch.empty(b, dtype=torch.float64, device=DEV)
+            us = ev(lambda: _lib.sumtree_sample(tree.tree, tree.tree_level, um, b, tree.part_size, ti, te, ts, pr, cnt))
+            print("tree sample  %4d: %7.1f us  (find + sort + unique + probabilities of %d draws; %d distinct)"
+                  % (b, us, m, int(cnt.item())))
         d = torch.randn(b, dtype=torch.float64, device=DEV, generator=gen)
         us = ev(lambda: _lib.sumtree_add(tree.tree, tree.tree_level, out, d))
         print("tree update  %4d: %7.1f us" % (b, us))
