@@ -94,8 +94,8 @@ class PpoOptimizer(BaseOptimizer):
         if not self._n_minibatches:
             return [], []
         self._idx_dev.copy_(self._idx_host, non_blocking=True)
-        if self._explicit_grads and self._graph_minibatch:
-            return self._graphed_minibatches(data)
+        if self._explicit_grads and self._overlap_allreduce:
+            return self._overlapped_minibatches(data)
         losses = []
         for k in range(self._n_minibatches):
             losses.append(self._backward(self._losses, self._minibatch(data, self._idx_dev[k])))
@@ -113,74 +113,25 @@ class PpoOptimizer(BaseOptimizer):
                 mb[name] = tensor.index_select(0, idx64)
         return mb
 
-    # Multi-GPU: the collective stays an ordinary eager call between replays of per-minibatch hipGraphs, so
-    # RCCL never has to be captured.  Each minibatch is captured as TWO graphs split where the policy reports
-    # that the tail of the gradient bucket (dense layers + heads: 98 % of the bytes for spec 1) is final: its
-    # all-reduce then runs on RCCL's stream underneath the second graph (the conv layers' backward, ~60 % of
-    # the minibatch).
-    _graph_minibatch = False
-    _mb_graphs = None
+    # Multi-GPU (`_overlap_allreduce`, set by the sync optimizers): minibatches are enqueued eagerly -- at ~550 us
+    # of device work per minibatch the host stays far ahead, and a hipGraph per minibatch only added its launch
+    # latency at every hand-over to RCCL's stream (measured at world size 1: 232 k -> 237 k env-steps/s without
+    # the graphs).  The policy reports, through `split_hook`, the point of its backward pass from which the tail
+    # of the gradient bucket (dense layers + heads: 98 % of the bytes for spec 1) is final: that tail's
+    # all-reduce is issued there and runs on RCCL's stream underneath the conv layers' backward (~60 % of the
+    # minibatch); the small head of the bucket follows, and the optimiser step waits for both.
+    _overlap_allreduce = False
 
-    def _capture_minibatches(self, data):
-        """One (or two, if the policy calls the split hook) hipGraph per minibatch slot k, reading
-        `_idx_dev[k]` in place; from the second slot on the graph opens with the optimiser step of the
-        minibatch before it, so the only eager device work between replays is the collectives."""
-        dev = self._target.device
-        torch.cuda.synchronize(dev)
-        graphs, pool = [], torch.cuda.graph_pool_handle()
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for k in range(self._n_minibatches):
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                state = dict(split=False)
-
-                def split():                                   # called by the policy between the two halves
-                    g1.capture_end()
-                    g2.capture_begin(pool=pool, capture_error_mode="thread_local")
-                    state["split"] = True
-
-                # thread_local: the process group's watchdog thread polls events of earlier collectives
-                g1.capture_begin(pool=pool, capture_error_mode="thread_local")
-                if k:
-                    self._apply_update(self._avg_factor())
-                mb = self._minibatch(data, self._idx_dev[k])
-                mb["split_hook"] = split
-                loss = self._backward(self._losses, mb)
-                (g2 if state["split"] else g1).capture_end()
-                graphs.append((g1, g2 if state["split"] else None, loss))
-        torch.cuda.current_stream(dev).wait_stream(side)
-        self._mb_graphs, self._mb_data = graphs, data
-
-    def _graphed_minibatches(self, data):
-        if self._mb_graphs is None:
-            self._mb_warm = getattr(self, "_mb_warm", 0) + 1
-            if self._mb_warm > 2:
-                self._capture_minibatches(data)
+    def _overlapped_minibatches(self, data):
         losses = []
-        if self._mb_graphs is None:                             # eager warm-up calls: same protocol
-            for k in range(self._n_minibatches):
-                pending = []
-                mb = self._minibatch(data, self._idx_dev[k])
-                mb["split_hook"] = lambda: pending.append(self._share_grad_async(tail=True))
-                losses.append(self._backward(self._losses, mb))
-                pending.append(self._share_grad_async(tail=False) if pending else self._share_grad_async(None))
-                self._wait_all(pending)
-                self._apply_update(self._avg_factor())
-            return losses, self._recent_grad_norms(self._n_minibatches)
-        assert all(data[n] is self._mb_data[n] for n in data), "static buffers expected"
-        assert len(self._mb_graphs) == self._n_minibatches, "static minibatch count expected"
-        for g1, g2, loss in self._mb_graphs:
-            g1.replay()
-            if g2 is not None:
-                pending = [self._share_grad_async(tail=True)]
-                g2.replay()
-                pending.append(self._share_grad_async(tail=False))
-            else:
-                pending = [self._share_grad_async(None)]
-            losses.append(loss)
+        for k in range(self._n_minibatches):
+            pending = []
+            mb = self._minibatch(data, self._idx_dev[k])
+            mb["split_hook"] = lambda: pending.append(self._share_grad_async(tail=True))
+            losses.append(self._backward(self._losses, mb))
+            pending.append(self._share_grad_async(tail=False) if pending else self._share_grad_async(None))
             self._wait_all(pending)
-        self._apply_update(self._avg_factor())                  # of the last minibatch
+            self._apply_update(self._avg_factor())
         return losses, self._recent_grad_norms(self._n_minibatches)
 
     @staticmethod

@@ -16,7 +16,7 @@ class _SyncMixin(object):
     _comm = None
     _n_gpu = 1
     _rank = 0
-    _graph_minibatch = True     # per-minibatch hipGraph around the eager all-reduce
+    _overlap_allreduce = True   # PpoOptimizer._overlapped_minibatches: bucket tail all-reduced under the conv backward
     _force_collective = False   # issue the all-reduce even with one rank (plumbing tests)
 
     def init_comm(self, gpu_comm, rank, n_gpu):
