@@ -1363,6 +1363,10 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
     if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
+    // ... and wider ones whose 128x128 tiles still leave CUs idle (spec-0 dense at the A2C batch: 5120 x 256 =
+    // 80 tiles walking 88 k-tiles each, 231 us)
+    const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (!small && a.N >= 128 && tiles128 * 4 <= TARGET_WGS * 3) plan_split(tiles128, a.K, &splits, &per, TARGET_WGS);
     a.k_per_split = per;
     if (splits > 1) {
         ARL_REQUIRE((int64_t)splits * a.M * a.N * 4 <= arl_conv_workspace_bytes(), ARL_E_RANGE, "workspace too small");

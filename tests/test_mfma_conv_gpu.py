@@ -23,7 +23,9 @@ CASES = [(37, 104, 80, 4, 32, 8, 4, 0),      # spec-1 conv 1 (ragged batch)
          (256, 1, 1, 6912, 512, 1, 1, 0),    # ... at the rollout batch (9 k-tiles per split: odd)
          (256, 1, 1, 3840, 512, 1, 1, 0),    # 5 k-tiles per split (the two-tile unrolled loop's odd tail)
          (80, 1, 1, 3456, 256, 1, 1, 0),     # spec-0 dense, ragged rows
-         (5120, 1, 1, 512, 128, 1, 1, 0),    # wide batch, no split
+         (5120, 1, 1, 512, 128, 1, 1, 0),    # wide batch: 40 tiles of 128x128, reduction split 4 ways
+         (1024, 1, 1, 2816, 256, 1, 1, 0),   # spec-0 dense at a mid-size batch: 128x128 tiles + split-K
+         (20000, 1, 1, 256, 128, 1, 1, 0),   # enough tiles: no split
          (32, 1, 1, 256, 1152, 1, 1, 0)]     # C51 head at the DQN batch: 4 output tiles, data gradient splits its reduction
 
 
