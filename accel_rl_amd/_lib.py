@@ -105,6 +105,9 @@ _SIGNATURES = {
     "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem),
                                            _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_fold_many": (_i32, [C.POINTER(ArlFoldItem), _i32, _vp]),
+    "arl_conv2d_u8_fwd": (_i32, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp]),
+    "arl_conv2d_u8_bwd_weight_parts": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
+                                              C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_conv2d_bwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
                                    C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_relu_bwd_bias_parts": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, C.POINTER(ArlFoldItem), _vp]),
@@ -378,6 +381,33 @@ def conv2d_fwd(x, w, bias, y, geom, relu, workspace, stream=None):
                                  stream_ptr(stream)), "arl_conv2d_fwd")
 
 
+def conv2d_u8_supported(in_h, in_w, out_c, kh, kw, stride, pad_h, pad_w):
+    """Geometries arl_conv2d_u8_fwd / _bwd_weight_parts accept (see include/accel_rl_hip.h)."""
+    return (pad_h == 0 and pad_w == 0 and stride % 4 == 0 and in_w % 4 == 0 and (in_h * in_w) % 4 == 0 and
+            kw in (4, 8, 16) and kh % (16 // kw) == 0 and out_c % 4 == 0 and out_c <= 32)
+
+
+def _u8_rows(obs, idx, geom):
+    _want(obs, torch.uint8, "obs")
+    assert obs.is_contiguous() and obs.numel() == obs.shape[0] * geom.in_c * geom.in_h * geom.in_w, "obs shape"
+    if idx is not None:
+        _want(idx, torch.int32, "idx")
+        assert idx.numel() == geom.batch, "idx length"
+    else:
+        assert obs.shape[0] == geom.batch, "obs rows"
+
+
+def conv2d_u8_fwd(obs, idx, scale, w, bias, y, geom, relu, stream=None):
+    """y[B,Ho,Wo,K] = act(conv(float(obs[idx]) * scale, w[K,C,kh,kw]) + bias), obs u8[n,C,H,W] read in place."""
+    _u8_rows(obs, idx, geom)
+    ho, wo = conv_out_hw(geom)
+    assert w.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w size"
+    assert y.numel() == geom.batch * ho * wo * geom.out_c, "y size"
+    _check(load().arl_conv2d_u8_fwd(obs.data_ptr(), obs.shape[0], ptr(idx), float(scale), w.data_ptr(), ptr(bias),
+                                    y.data_ptr(), C.byref(geom), int(bool(relu)), stream_ptr(stream)),
+           "arl_conv2d_u8_fwd")
+
+
 def conv2d_bwd_data(dy, w, mask, dx, geom, stream=None):
     ho, wo = conv_out_hw(geom)
     assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
@@ -436,6 +466,20 @@ class FoldList(object):
         _check(load().arl_conv2d_bwd_weight_parts(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), C.byref(geom),
                                                   ptr(workspace), workspace.numel() * workspace.element_size(),
                                                   item, pb, ib, stream_ptr(stream)), "arl_conv2d_bwd_weight_parts")
+        return self._bias_done(dbias)
+
+    def conv2d_u8_bwd_weight(self, dy, obs, idx, scale, dw, geom, workspace, dbias=None, stream=None):
+        """dw[K,C,kh,kw] partials (and, with dbias, the column sums of dy) of a convolution on u8 observations."""
+        _u8_rows(obs, idx, geom)
+        ho, wo = conv_out_hw(geom)
+        assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
+        assert dw.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "dw size"
+        item = self._next()
+        pb, ib = self._bias_slot(dbias)
+        _check(load().arl_conv2d_u8_bwd_weight_parts(dy.data_ptr(), obs.data_ptr(), obs.shape[0], ptr(idx),
+                                                     float(scale), dw.data_ptr(), C.byref(geom), ptr(workspace),
+                                                     workspace.numel() * workspace.element_size(), item, pb, ib,
+                                                     stream_ptr(stream)), "arl_conv2d_u8_bwd_weight_parts")
         return self._bias_done(dbias)
 
     def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, dbias=None, stream=None):

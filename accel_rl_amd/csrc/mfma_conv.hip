@@ -48,6 +48,14 @@ struct GatherDesc {
     // fast path only: ceil(2^32 / out_w), ceil(2^32 / out_h) when rows * divisor < 2^32 (then
     // __umulhi(n, magic) == n / divisor exactly for every row index n), else 0 = divide
     unsigned mg_w, mg_h;
+    // U8 kernels only (conv 1 straight from the sampler's observations, no f32 copy): planar u8 images,
+    // element (b, ch, y, x) = src8[row(b) * img_bytes + ch * plane + y * Ws + x], row(b) = idx ? idx[b] : b;
+    // reduction index r = (ch * kh8 + ty) * kw8 + tx (the weights are then (K, C, kh, kw));
+    // operand value = float(byte) * scale, converted between the global load and the LDS store
+    const unsigned char* src8;
+    const int* idx;
+    float scale;
+    int plane, img_bytes, kh8, kw8;
 };
 
 // The weight operand.  B_KC:  element (n, r) at w[n*ld + r]                (r contiguous)
@@ -558,6 +566,14 @@ __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t rsrc, unsigned
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ unsigned buf_ld1s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0);
+}
+// four packed bytes -> four scaled floats (v_cvt_f32_ubyte0..3 + multiplies; same values as arl_gather_scale_obs)
+__device__ __forceinline__ float4 bytes_to_f4(unsigned v, float sc) {
+    return make_float4((float)(v & 0xffu) * sc, (float)((v >> 8) & 0xffu) * sc, (float)((v >> 16) & 0xffu) * sc,
+                       (float)(v >> 24) * sc);
+}
 // n / d for a uniform runtime divisor: one v_mul_hi instead of the ~40-instruction division sequence
 // (vector instructions in these kernels are paid for in MFMA issue slots); magic == 0 -> plain division
 __device__ __forceinline__ int div_u(int n, int d, unsigned magic) {
@@ -573,7 +589,12 @@ __device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned v
 // v_mfma_f32_16x16x4_f32 -- a 32-wide tile would spend half of every MFMA on columns that do not exist.
 // A wave then owns TM groups of 16 rows x 16 columns; lane (l & 15, l >> 4) holds row l & 15 and the four
 // channels 4 (l >> 4) .. + 3 of each group, again one b128 store per group.
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false>
+// U8: the gathered operand is read from planar u8 images (GatherDesc::src8): a 4-wide k chunk is four
+// consecutive pixels of one filter row = one aligned dword (stride, width and plane size are multiples of 4,
+// no padding); a k-tile covers BK / kw8 whole filter rows of one plane, so the tile's address is again
+// per-thread constant + per-tile uniform.
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
+          bool U8 = false>
 __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* smem) {
     constexpr int MT = N16 ? 16 : 32;               // rows per MFMA tile
     constexpr int BM = WGM * TM * MT, BN = N16 ? 16 : WGN * TN * 32, CH = BK / 4;
@@ -609,11 +630,13 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
     if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     // descriptor origins: the smallest element offset a valid (row, tap) pair can produce
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.src + g.origin, g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsA = U8 ? make_rsrc(reinterpret_cast<const float*>(g.src8), g.src_bytes)
+                                          : make_rsrc(g.src + g.origin, g.src_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
 
     // ---- per-thread constants -------------------------------------------------------------
     const int a_chunk = tid % CH, a_row0 = tid / CH;
+    const int cpr8 = g.kw8 >> 2, rpt8 = U8 ? CH / cpr8 : 0;       // U8: chunks per filter row, filter rows per k-tile
     int tpt = 0, chl = a_chunk * 4;                 // tap within the tile / channel within the tap
     if (MULTI_TAP) { tpt = chl / Cs; chl -= tpt * Cs; }
     unsigned voffA[RA], imask[RA], voffB[RB];
@@ -625,6 +648,14 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         const int ry = oy * g.mul + g.add_y, rx = ox * g.mul + g.add_x;
         const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
         voffA[p] = m < M ? (unsigned)(rbase - g.rmin + tpt * Cs + chl) << 2 : OOB;
+        if constexpr (U8) {
+            const int tyl = a_chunk / cpr8, txq = a_chunk - tyl * cpr8;
+            voffA[p] = OOB;
+            if (m < M) {
+                const int row = g.idx ? g.idx[b] : b;
+                voffA[p] = (unsigned)(row * g.img_bytes + (ry + tyl) * Ws + rx + 4 * txq);
+            }
+        }
         imask[p] = 0;
         if (HAS_PAD) {                              // bit (ty*taps_x + tx) set <=> that tap is outside the image
             unsigned xbad = 0, im = 0;
@@ -661,8 +692,23 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         ty = tap / taps_x;
         tx = tap - ty * taps_x;
     }
+    if constexpr (U8) {                             // (plane ch0, first filter row ty of the tile); tx unused
+        const int khw = g.kh8 * g.kw8;
+        ch0 = kbeg / khw;
+        ty = (kbeg - ch0 * khw) / g.kw8;
+        tx = 0;
+    }
     float4 va[RA], vb[RB];
+    unsigned va8[RA];
     auto issue_loads = [&](int kk) {                // tile starting at reduction index kk, tap state (ty, tx, ch0)
+        if constexpr (U8) {
+            const unsigned soffA = (unsigned)(ch0 * g.plane + ty * Ws);
+#pragma unroll
+            for (int p = 0; p < RA; ++p) va8[p] = buf_ld1s(rsA, voffA[p], soffA);
+#pragma unroll
+            for (int p = 0; p < RB; ++p) vb[p] = buf_ld4s(rsB, voffB[p], (unsigned)kk << 2);
+            return;
+        }
         const unsigned soffA = (unsigned)(step * (ty * Ws + tx) * Cs + ch0 - g.dmin) << 2;
         unsigned soffB;
         if (B_KC) soffB = (unsigned)kk << 2;
@@ -675,6 +721,11 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         for (int p = 0; p < RB; ++p) vb[p] = buf_ld4s(rsB, voffB[p], soffB);
     };
     auto next_tile = [&]() {
+        if constexpr (U8) {
+            ty += rpt8;
+            if (ty >= g.kh8) { ty = 0; ++ch0; }
+            return;
+        }
         if (MULTI_TAP) {
             tx += BK / Cs;
             if (tx >= taps_x) { tx = 0; ++ty; }
@@ -691,7 +742,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         float* dB = sB + buf * B_SZ;
 #pragma unroll
         for (int p = 0; p < RA; ++p)
-            *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) = va[p];
+            *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) =
+                U8 ? bytes_to_f4(va8[p], g.scale) : va[p];
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             const int idx = tid + p * 256;
@@ -872,6 +924,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// forward convolution straight from planar u8 observations (see igemm_body, U8)
+template <int WGM, int WGN, int TM, int TN, int BK, bool N16>
+__global__ __launch_bounds__(256) void igemm_u8_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    igemm_body<WGM, WGN, TM, TN, BK, true, false, false, N16, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
 // Weight gradient, scalar-addressed: dy advances by a uniform stride per tile (soffset); the
 // gathered rows change every tile, so their element offsets and padding masks come from an LDS
 // table that all 256 threads refresh together, 256 rows (= 256 / BK tiles) at a time, each
@@ -881,7 +940,9 @@ constexpr int WG_ROWS = 256;
 
 // M16: <= 16 output channels (spec 0's conv 1) -> v_mfma_f32_16x16x4_f32, 16 channel rows x 16-column groups
 // (a 32-row tile would spend half of every MFMA on channels that do not exist).
-template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false>
+// U8: the gathered rows come from planar u8 images (GatherDesc::src8; column r = (ch * kh8 + ty) * kw8 + tx,
+// so dw is (K, C, kh, kw)); the row count needs no rounding (the last tile's missing rows read as zeros).
+template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false, bool U8 = false>
 __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx, const int by, const int bz, float* smem) {
     constexpr int BM = M16 ? 16 : WGM * TM * 32, BN = WGN * TN * 32;
     static_assert(!M16 || (WGM == 1 && TM == 1 && BK % 16 == 0), "16-row tiles: one row tile");
@@ -902,7 +963,8 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     const int mend = (mbeg + a.m_per_split < a.Mred) ? mbeg + a.m_per_split : a.Mred;
     const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.dy, a.dy_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = U8 ? make_rsrc(reinterpret_cast<const float*>(a.g.src8), a.g.src_bytes)
+                                          : make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
 
     // ---- per-thread constants: dy fragment offsets, gather column
     unsigned voffA[RA];
@@ -917,7 +979,13 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     const int r = n0 + b_c4 * 4;
     const int tap = r / Cs, ch = r - tap * Cs;
     const int cty = tap / taps_x, ctx = tap - cty * taps_x;
-    const unsigned cdelta = r < a.N ? (unsigned)(step * (cty * Ws + ctx) * Cs + ch - a.g.dmin) << 2 : OOB;
+    unsigned cdelta = r < a.N ? (unsigned)(step * (cty * Ws + ctx) * Cs + ch - a.g.dmin) << 2 : OOB;
+    if constexpr (U8) {
+        const int khw = a.g.kh8 * a.g.kw8;
+        const int pl = r / khw, rem = r - pl * khw;
+        const int fy = rem / a.g.kw8, fx = rem - fy * a.g.kw8;
+        cdelta = r < a.N ? (unsigned)(pl * a.g.plane + fy * Ws + fx) : OOB;
+    }
 
     // ---- row producer state: thread t owns row t of every 256-row group
     int pm = mbeg + tid, pb, poy, pox;
@@ -930,7 +998,11 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     auto produce_rows = [&](int slot) {
         const int ry = poy * a.g.mul + a.g.add_y, rx = pox * a.g.mul + a.g.add_x;
         unsigned off = OOB, im = ~0u;
-        if (pm < mend) {
+        if (U8 && pm < mend) {
+            const int row = a.g.idx ? a.g.idx[pb] : pb;
+            off = (unsigned)(row * a.g.img_bytes + ry * Ws + rx);
+            im = 0;
+        } else if (pm < mend) {
             off = (unsigned)(((pb * a.g.Hs + ry) * Ws + rx) * Cs - a.g.rmin) << 2;
             im = 0;
             if (HAS_PAD) {
@@ -956,17 +1028,24 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
 #pragma unroll
     for (int p = 0; p < RA; ++p) bsum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[RA], vb[RB];
+    unsigned vb8[RB];
     auto issue_loads = [&](int tile) {              // tile index within the split
         const unsigned soffA = (unsigned)((mbeg + tile * BK) * a.K_out) << 2;
         const int grp = tile / TILES_PER_GROUP, tin = tile - grp * TILES_PER_GROUP;
         const uint2* rows = &s_row[grp & 1][tin * BK + b_k0];
+        // (the buffer range check does not see soffset: U8's ragged last tile switches its missing dy rows off here)
+        const int rows_left = mend - (mbeg + tile * BK);
 #pragma unroll
-        for (int p = 0; p < RA; ++p) va[p] = buf_ld4s(rsA, voffA[p], soffA);
+        for (int p = 0; p < RA; ++p) {
+            const bool row_ok = !U8 || rows_left >= BK || (tid + p * 256) / MC4 < rows_left;
+            va[p] = buf_ld4s(rsA, row_ok ? voffA[p] : OOB, soffA);
+        }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             const uint2 e = rows[p * KROWS];
             const unsigned off = e.x + cdelta;      // either term may be the OOB marker (sum stays >= OOB, < 2^32)
-            vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
+            if constexpr (U8) vb8[p] = buf_ld1s(rsB, off, 0);
+            else vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
         }
     };
     auto store_tiles = [&](int buf, bool fresh) {   // fresh: va holds a tile not stored before
@@ -981,7 +1060,8 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         }
 #pragma unroll
         for (int p = 0; p < RB; ++p)
-            *reinterpret_cast<float4*>(dB + (b_k0 + p * KROWS) * BN + b_c4 * 4) = vb[p];
+            *reinterpret_cast<float4*>(dB + (b_k0 + p * KROWS) * BN + b_c4 * 4) =
+                U8 ? bytes_to_f4(vb8[p], a.g.scale) : vb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -1001,7 +1081,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
 
     // Row groups: group g (tiles g*T .. g*T+T-1) lives in slot g & 1.  Groups 0 and 1 are produced
     // up front; group g+2 is produced in the first iteration of group g+1's ... see loop.
-    const int nk = (mend - mbeg) / BK;
+    const int nk = U8 ? (mend - mbeg + BK - 1) / BK : (mend - mbeg) / BK;
     produce_rows(0);
     produce_rows(1);
     __syncthreads();
@@ -1110,6 +1190,13 @@ template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = fal
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, M16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// weight gradient of a convolution whose input is the planar u8 observations (see wgrad_fast_body, U8)
+template <int WGM, int WGN, int TM, int TN, int BK, bool M16>
+__global__ __launch_bounds__(256) void wgrad_u8_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    wgrad_fast_body<WGM, WGN, TM, TN, BK, false, M16, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // One launch for a layer's data gradient AND weight gradient (independent of each other, both read dy):
@@ -1637,6 +1724,109 @@ extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, floa
     item->splits = splits > 1 ? splits : 0;             // 0: dw is already final
     if (dbias_or_null) bias_item(bias_item_or_null, bias_part, dbias_or_null, splits, geom->out_c);
     return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// Convolution 1 straight from the sampler's observations: planar u8 [rows][C][H][W] read in place
+// (optionally through a row-index list), weights / weight gradient in (K, C, kh, kw) order.
+// ------------------------------------------------------------------------------------------
+namespace {
+struct U8Geom { int H, W, C, K, kh, kw, stride, Ho, Wo; int64_t batch; };
+
+int check_u8(const uint8_t* obs, int64_t obs_rows, const arl_conv_geom* g, U8Geom* o) {
+    ARL_REQUIRE(obs && g && obs_rows > 0, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(g->batch > 0 && g->in_h > 0 && g->in_w > 0 && g->in_c > 0 && g->out_c > 0 && g->kh > 0 && g->kw > 0 &&
+                    g->stride > 0, ARL_E_ARG, "conv: bad geometry");
+    const int cpr = g->kw / 4;
+    ARL_REQUIRE(g->pad_h == 0 && g->pad_w == 0 && g->stride % 4 == 0 && g->in_w % 4 == 0 &&
+                    (g->in_h * g->in_w) % 4 == 0 && (g->kw == 4 || g->kw == 8 || g->kw == 16) && g->kh % (4 / cpr) == 0 &&
+                    g->out_c % 4 == 0 && g->out_c <= 32 && ((uintptr_t)obs & 3) == 0,
+                ARL_E_RANGE, "u8 conv: needs pad 0, stride % 4 == 0, width % 4 == 0, kw in {4, 8, 16}, <= 32 filters");
+    o->H = g->in_h; o->W = g->in_w; o->C = g->in_c; o->K = g->out_c; o->kh = g->kh; o->kw = g->kw; o->stride = g->stride;
+    o->Ho = (g->in_h - g->kh) / g->stride + 1; o->Wo = (g->in_w - g->kw) / g->stride + 1; o->batch = g->batch;
+    const int64_t lim = (int64_t)OOB / 4;
+    ARL_REQUIRE(o->Ho > 0 && o->Wo > 0 && g->batch * (int64_t)o->Ho * o->Wo * g->out_c < lim &&
+                    obs_rows * (int64_t)g->in_c * g->in_h * g->in_w < (int64_t)OOB,
+                ARL_E_RANGE, "conv: tensor larger than the 32-bit buffer offsets address");
+    return 0;
+}
+
+void fill_u8(GatherDesc* d, const uint8_t* obs, int64_t obs_rows, const int32_t* idx, float scale, const U8Geom& g) {
+    d->src8 = obs; d->idx = idx; d->scale = scale;
+    d->plane = g.H * g.W; d->img_bytes = g.C * g.H * g.W; d->kh8 = g.kh; d->kw8 = g.kw;
+    d->src_bytes = (unsigned)(obs_rows * d->img_bytes);
+    d->Hs = g.H; d->Ws = g.W; d->Cs = 1; d->out_h = g.Ho; d->out_w = g.Wo;
+    d->mul = g.stride; d->add_y = 0; d->add_x = 0; d->taps_x = g.kw; d->taps_y = g.kh; d->step = 1;
+}
+}  // namespace
+
+extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int32_t* idx_or_null, float scale,
+                                 const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom,
+                                 int32_t relu, void* stream) {
+    ARL_REQUIRE(w && y, ARL_E_ARG, "null pointer");
+    U8Geom g;
+    int rc = check_u8(obs, obs_rows, geom, &g);
+    if (rc) return rc;
+    ARL_REQUIRE(arl::aligned16(w) && arl::aligned16(y) && (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN,
+                "16-byte alignment");
+    GemmArgs a = {};
+    fill_u8(&a.g, obs, obs_rows, idx_or_null, scale, g);
+    a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.C * g.kh * g.kw;
+    a.b.w = w; a.b.ld = a.K; a.b.w_bytes = (unsigned)((int64_t)a.N * a.K * 4);
+    a.o.dense = 1; a.o.out = y; a.o.bias = bias_or_null; a.o.relu = relu;
+    a.o.out_bytes = (unsigned)((int64_t)a.M * a.N * 4);
+    a.k_per_split = a.K;                            // K % 16 == 0 by check_u8 (whole filter rows per k-tile)
+    a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
+    a.trace = g_trace;
+    constexpr int BK = 16, BM = 128;
+    const dim3 grid((a.M + BM - 1) / BM, 1, 1);
+    if (a.N <= 16) {
+        const size_t lds = (size_t)2 * (BM * (BK + 4) + 16 * (BK + 4)) * sizeof(float);
+        hipLaunchKernelGGL((igemm_u8_kernel<4, 1, 2, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        const size_t lds = (size_t)2 * (BM * (BK + 4) + 32 * (BK + 4)) * sizeof(float);
+        hipLaunchKernelGGL((igemm_u8_kernel<4, 1, 1, 1, BK, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
+    return arl::check_launch("igemm_u8_kernel");
+}
+
+extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* obs, int64_t obs_rows,
+                                              const int32_t* idx_or_null, float scale, float* dw,
+                                              const arl_conv_geom* geom, void* workspace, int64_t workspace_bytes,
+                                              arl_fold_item* item, float* dbias_or_null,
+                                              arl_fold_item* bias_item_or_null, void* stream) {
+    ARL_REQUIRE(dy && dw && workspace && item && (!dbias_or_null || bias_item_or_null), ARL_E_ARG, "null pointer");
+    U8Geom g;
+    int rc = check_u8(obs, obs_rows, geom, &g);
+    if (rc) return rc;
+    ARL_REQUIRE(arl::aligned16(dy) && arl::aligned16(dw) && arl::aligned16(workspace) &&
+                    (!dbias_or_null || arl::aligned16(dbias_or_null)), ARL_E_ALIGN, "16-byte alignment");
+    WgradArgs a = {};
+    a.dy = dy;
+    fill_u8(&a.g, obs, obs_rows, idx_or_null, scale, g);
+    a.K_out = g.K; a.N = g.C * g.kh * g.kw; a.Mred = (int)(g.batch * g.Ho * g.Wo);
+    a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
+    const int bm = g.K <= 16 ? 16 : 32, bn = 128;
+    const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
+    int splits, per;
+    plan_split(tiles, a.Mred, &splits, &per, 2 * TARGET_WGS);
+    a.m_per_split = per;
+    const int64_t total = (int64_t)a.K_out * a.N;
+    const int64_t used = splits > 1 ? (int64_t)splits * total : 0;
+    ARL_REQUIRE((used + (int64_t)splits * a.K_out) * 4 <= workspace_bytes, ARL_E_RANGE, "workspace too small");
+    a.part = splits > 1 ? (float*)workspace : dw;
+    if (dbias_or_null) a.bias_part = (float*)workspace + used;
+    const int img = g.Ho * g.Wo;
+    a.adv_b = WG_ROWS / img; a.adv_y = (WG_ROWS % img) / g.Wo; a.adv_x = (WG_ROWS % img) % g.Wo;
+    constexpr int BK = 32;
+    const size_t lds = (size_t)2 * BK * (bm + bn) * sizeof(float);
+    const dim3 grid((a.N + bn - 1) / bn, (a.K_out + bm - 1) / bm, splits);
+    if (g.K <= 16) hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    item->part = (const float*)workspace; item->out = dw; item->total = total;
+    item->splits = splits > 1 ? splits : 0;
+    if (dbias_or_null) bias_item(bias_item_or_null, a.bias_part, dbias_or_null, splits, g.K);
+    return arl::check_launch("wgrad_u8_kernel");
 }
 
 namespace {

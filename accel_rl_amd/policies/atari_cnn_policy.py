@@ -7,7 +7,9 @@ policies/layers.py:11-41).  Every stage is hand-written HIP: the dense contracti
 csrc/mfma_conv.hip -- deterministic, no atomics, so seeded runs reproduce bit for bit
 -- and everything between them is csrc/learner.hip, all on channels-last activations:
 
-  forward :  gather+scale (u8 NCHW -> f32 NHWC)  ->  [conv + bias + relu] x n
+  forward :  conv 1 + bias + relu straight from the u8 observations (rows picked by the minibatch
+             indices and scaled by 1/255 inside the kernel's loader; other first layers:
+             gather+scale u8 NCHW -> f32 NHWC first)  ->  [conv + bias + relu] x (n - 1)
              -> dense + bias + relu -> heads+softmax (infer) | heads+losses+grads (train)
   backward:  head wgrad -> [relu-bwd+bias-grad -> dense dW / dx] -> [relu-bwd+bias-grad ->
              conv dW / dx] x n, every gradient written straight into ONE flat
@@ -18,7 +20,8 @@ autograd formulation of the same network through PyTorch's own conv2d / linear
 (`forward`) is kept as the A/B reference of the numerics tests only.
 
 Internal parameter layout (the bucket is ours to define): conv W as (K,kh,kw,C)
-= channels-last correlation kernels; first dense W with its input columns in
+= channels-last correlation kernels (conv 1 on the u8 path: (K,C,kh,kw), its input being
+planar); first dense W with its input columns in
 (h,w,c) order; both heads fused in one matrix W_head[(A+1), hid].
 get/set_param_values convert to/from the reference's flat vector: order conv_i.W,
 conv_i.b, hidden_i.W, hidden_i.b, output_pi.W, .b, output_v.W, .b
@@ -52,7 +55,21 @@ def _norm_c(shape, std):
     return out
 
 
+class ObsRows(object):
+    """Rows of a u8 observation array that the first convolution reads in place: obs[idx] (all rows
+    without idx), scaled inside the kernel.  Stands where the scaled f32 input tensor would."""
+    __slots__ = ("obs", "idx", "shape")
+
+    def __init__(self, obs, idx):
+        self.obs, self.idx = obs.contiguous(), idx
+        self.shape = (obs.shape[0] if idx is None else idx.shape[0],) + tuple(obs.shape[1:])
+
+
 class AtariCnnPolicy(object):
+
+    # conv 1 reads the u8 observations directly when its geometry allows (subclasses that build their
+    # own scaled inputs switch this off)
+    _u8_conv1 = True
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads,
                  hidden_sizes=(), pixel_scale=255., initial_param_values=None, explicit=True):
@@ -84,6 +101,9 @@ class AtariCnnPolicy(object):
         self._c_in, self._c_pad = c, (c + 3) // 4 * 4
         # ---- reference-layout initial values, drawn in the reference's order
         ref, self._conv_geom = [], []
+        nf0, sz0, st0, pad0 = self.conv_filters[0], self.conv_filter_sizes[0], self.conv_strides[0], self.conv_pads[0]
+        self._u8 = bool(self._u8_conv1 and self.explicit and
+                        _lib.conv2d_u8_supported(h, w, nf0, sz0, sz0, st0, pad0[0], pad0[1]))
         for nf, sz, st, pad in zip(self.conv_filters, self.conv_filter_sizes, self.conv_strides,
                                    self.conv_pads):
             ref += [_glorot_uniform((nf, c, sz, sz)), np.zeros(nf, np.float32)]
@@ -93,7 +113,9 @@ class AtariCnnPolicy(object):
                 raise NotImplementedError("conv filter counts must be multiples of 4 (got %d)" % nf)
             # the MFMA kernels want channel counts in multiples of 4: a 1-, 2- or 3-frame stack is
             # zero-padded to 4 input channels internally (the extra weights stay exactly zero)
-            self._conv_geom.append((nf, (c + 3) // 4 * 4, sz, st, tuple(pad), h, w))
+            # (the u8 path takes any plane count)
+            ci = c if (self._u8 and not self._conv_geom) else (c + 3) // 4 * 4
+            self._conv_geom.append((nf, ci, sz, st, tuple(pad), h, w))
             c = nf
         self._conv_out = (c, h, w)
         fan = c * h * w
@@ -107,8 +129,8 @@ class AtariCnnPolicy(object):
         self.n_params = int(sum(a.size for a in ref))
         # ---- internal bucket: [conv W, b]... [hidden W, b]... W_head, b_head
         shapes = []
-        for nf, ci, sz, st, pad, ho, wo in self._conv_geom:
-            shapes += [(nf, sz, sz, ci), (nf,)]
+        for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
+            shapes += [(nf, ci, sz, sz) if (i == 0 and self._u8) else (nf, sz, sz, ci), (nf,)]
         hid_shapes = self._hidden_internal_shapes()
         self._n_hidden_internal = len(hid_shapes)       # may differ from the reference's count (GRU: 6 vs 12)
         shapes += hid_shapes
@@ -129,13 +151,13 @@ class AtariCnnPolicy(object):
 
         def views(flat):
             out = []
-            for o, n, s in zip(self._offsets, sizes, shapes):
+            for k, (o, n, s) in enumerate(zip(self._offsets, sizes, shapes)):
                 v = flat[o:o + n].view(s)
-                out.append(v.permute(0, 3, 1, 2) if len(s) == 4 else v)   # logical (K,C,kh,kw)
+                out.append(v.permute(0, 3, 1, 2) if (len(s) == 4 and not (k == 0 and self._u8)) else v)   # logical (K,C,kh,kw)
             return out
         self.params = [torch.nn.Parameter(v) for v in views(self.flat_params)]
         self.grads = views(self.flat_grads)
-        # raw (memory-order) views for the HIP kernels: conv W is (K, kh, kw, C) in memory
+        # raw (memory-order) views for the HIP kernels: conv W is (K, kh, kw, C) in memory ((K, C, kh, kw): u8 conv 1)
         self._w = [self.flat_params[o:o + n] for o, n in zip(self._offsets, sizes)]
         self._g = [self.flat_grads[o:o + n] for o, n in zip(self._offsets, sizes)]
         self._conv_ws = _lib.conv_workspace(self.device)
@@ -240,6 +262,13 @@ class AtariCnnPolicy(object):
         return buf
 
     def _scaled(self, obs_u8, idx=None, tag=""):
+        """The network input for u8 [n,C,H,W] observations (rows optionally gathered by idx): on the u8
+        path just the (obs, idx) pair -- conv 1 scales while it loads --, else `_scaled_f32`."""
+        if self._u8:
+            return ObsRows(obs_u8, idx)
+        return self._scaled_f32(obs_u8, idx, tag)
+
+    def _scaled_f32(self, obs_u8, idx=None, tag=""):
         """u8 [n,C,H,W] (rows optionally gathered by idx) -> f32 * (1/pixel_scale),
         logical [B,C,H,W] in channels-last memory."""
         b = obs_u8.shape[0] if idx is None else idx.shape[0]
@@ -280,7 +309,10 @@ class AtariCnnPolicy(object):
         acts, a = [], x
         for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
             z = self._buffer(("act" + tag, i, b), (b, ho, wo, nf))
-            _lib.conv2d_fwd(a, w[2 * i], w[2 * i + 1], z, conv_g[i], True, self._conv_ws)
+            if isinstance(a, ObsRows):
+                _lib.conv2d_u8_fwd(a.obs, a.idx, self._scale, w[0], w[1], z, conv_g[0], True)
+            else:
+                _lib.conv2d_fwd(a, w[2 * i], w[2 * i + 1], z, conv_g[i], True, self._conv_ws)
             acts.append(z)
             a = z
         hids, k = [], 2 * self._n_conv
@@ -294,6 +326,8 @@ class AtariCnnPolicy(object):
 
     def forward(self, x):
         """Autograd formulation of the same network (A/B reference)."""
+        if isinstance(x, ObsRows):
+            x = self._scaled_f32(x.obs, x.idx)[:, :self._c_in]
         p = self.params
         for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
             x = F.relu(F.conv2d(x, p[2 * i], p[2 * i + 1], stride=st, padding=pad))
@@ -386,7 +420,10 @@ class AtariCnnPolicy(object):
         if not masked:
             folds.relu_bwd_bias_grad(d, y, rows, channels, g[k + 1], self._fold_ws(("db", k)))
         dbias = g[k + 1] if masked else None
-        if d_in is not None:        # data + weight gradient share one launch where that pays (dense layers)
+        if isinstance(inp, ObsRows):
+            done = folds.conv2d_u8_bwd_weight(d, inp.obs, inp.idx, self._scale, self._g[k], geom,
+                                              self._fold_ws(("dw", k)), dbias=dbias)
+        elif d_in is not None:      # data + weight gradient share one launch where that pays (dense layers)
             done = folds.conv2d_bwd_pair(d, self._w[k], inp, d_in, inp, self._g[k], geom, self._fold_ws(("dw", k)),
                                          dbias=dbias)
         else:
@@ -458,6 +495,10 @@ class AtariCnnPolicy(object):
         arr = self._internal_arrays(flat)
         out, k = [], 0
         for i in range(self._n_conv):
+            if i == 0 and self._u8:                                         # already (K, C, kh, kw)
+                out += [arr[k][:, :, ::-1, ::-1], arr[k + 1]]
+                k += 2
+                continue
             w = arr[k][..., :self._c_in] if i == 0 else arr[k]             # drop the zero padding channels
             out += [w.transpose(0, 3, 1, 2)[:, :, ::-1, ::-1], arr[k + 1]]
             k += 2
@@ -470,8 +511,10 @@ class AtariCnnPolicy(object):
         host = np.zeros(self._bucket_len, np.float32)
         internal, k = [], 0
         for i in range(self._n_conv):
-            w = ref[k][:, :, ::-1, ::-1].transpose(0, 2, 3, 1)
-            if i == 0 and self._c_pad != self._c_in:
+            w = ref[k][:, :, ::-1, ::-1]
+            if not (i == 0 and self._u8):
+                w = w.transpose(0, 2, 3, 1)
+            if i == 0 and not self._u8 and self._c_pad != self._c_in:
                 w = np.concatenate([w, np.zeros(w.shape[:3] + (self._c_pad - self._c_in,), np.float32)], axis=3)
             internal += [w, ref[k + 1]]
             k += 2

@@ -29,6 +29,7 @@ class QPolicyBase(AtariCnnPolicy):
     greedy)` (the action kernel) and the four `_head_*` layout hooks."""
 
     _epsilon = 1
+    _u8_conv1 = False       # _forward_for_loss packs obs and next_obs into one scaled f32 input of 2B rows
     _dueling = False
 
     def _set_dueling(self, dueling):

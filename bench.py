@@ -164,8 +164,9 @@ def kernel_table(device, sampler, algo, policy, reps=20):
     sampler.step_obs.copy_(obs_snap)
     idx = torch.randperm(n * t, device=device)[:512].to(torch.int32)
     out = torch.empty((512, 4, 104, 80), device=device).contiguous(memory_format=torch.channels_last)
+    # (conv 1 reads the u8 observations in place: the gather + scale pass is no longer on the step's path)
     add("gather_scale_obs_nhwc", lambda: _lib.gather_scale_obs_nhwc(buf.observations, idx, out, 1. / 255),
-        512 * 33280 * 5, 8)
+        512 * 33280 * 5, 0 if getattr(policy, "_u8", False) else 8)
     optim = algo.optimizer
     saved = [x.clone() for x in (policy.flat_params, optim._slot0, optim._slot1, optim._step_count)]
     policy.flat_grads.normal_()
@@ -194,6 +195,18 @@ def mfma_table(device, policy, batch=512, reps=20):
         flops = 2.0 * batch * ho * wo * g.out_c * g.kh * g.kw * g.in_c
         calls = [("fwd", lambda: _lib.conv2d_fwd(x, w, b, y, g, True, ws)),
                  ("wgrad", lambda: _lib.conv2d_bwd_weight(dy, x, dw, g, ws))]
+        if k == 0 and getattr(policy, "_u8", False):    # conv 1 as the step runs it: from 1280 u8 observations, rows by index
+            obs8 = torch.randint(0, 256, (N_ENVS * HORIZON, g.in_c, g.in_h, g.in_w), device=device,
+                                 dtype=torch.int32).to(torch.uint8)
+            idx8 = torch.randperm(N_ENVS * HORIZON, device=device)[:batch].to(torch.int32)
+            folds = _lib.FoldList()
+
+            def wgrad_u8():
+                folds.conv2d_u8_bwd_weight(dy, obs8, idx8, 1. / 255, dw, g, ws)
+                folds.run()
+            name = "conv1(u8 in place)"
+            calls = [("fwd", lambda: _lib.conv2d_u8_fwd(obs8, idx8, 1. / 255, w, b, y, g, True)),
+                     ("wgrad+fold", wgrad_u8)]
         if k > 0:                                   # the first layer's input needs no gradient
             calls.append(("dgrad", lambda: _lib.conv2d_bwd_data(dy, w, None, dx, g)))
         for tag, fn in calls:

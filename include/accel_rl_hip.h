@@ -359,6 +359,26 @@ int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_nu
                         int64_t workspace_bytes, arl_fold_item* item, float* dbias_or_null,
                         arl_fold_item* bias_item_or_null, void* stream);
 
+/* Convolution 1 read straight from the sampler's observations (no f32 copy of the input):
+ * obs u8[obs_rows][in_c][in_h][in_w] (the layout of samples_buf.observations,
+ * accel_rl/sampler/act_server/buffers.py:7-38), row b of the batch = obs[idx ? idx[b] : b]
+ * (the minibatch indices of optimizers/util.py:8-18), x = float(byte) * scale
+ * (atari_cnn_policy.py:88-91: the network input is obs * (1 / 255)).  Weights and their gradient are
+ * f32[out_c][in_c][kh][kw] (correlation kernels).  geom->batch = rows of the batch; in_c any count >= 1.
+ * Requires pad 0, stride % 4 == 0, in_w % 4 == 0, (in_h * in_w) % 4 == 0, kw in {4, 8, 16},
+ * kh % (16 / kw) == 0, out_c % 4 == 0 and <= 32 (else ARL_E_RANGE: use arl_gather_scale_obs_nhwc +
+ * arl_conv2d_fwd).  Same arithmetic as those two (the products are accumulated plane by plane instead
+ * of pixel by pixel).  */
+int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int32_t* idx_or_null, float scale,
+                      const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom,
+                      int32_t relu, void* stream);
+/* Its weight gradient (deferred fold, optional bias-gradient partials: as arl_conv2d_bwd_weight_parts). */
+int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* obs, int64_t obs_rows,
+                                   const int32_t* idx_or_null, float scale, float* dw,
+                                   const arl_conv_geom* geom, void* workspace, int64_t workspace_bytes,
+                                   arl_fold_item* item, float* dbias_or_null,
+                                   arl_fold_item* bias_item_or_null, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * Replay memory of the DQN family
  * ------------------------------------------------------------------------- */

@@ -1,0 +1,123 @@
+"""Convolution 1 read straight from the u8 observations (arl_conv2d_u8_fwd /
+arl_conv2d_u8_bwd_weight_parts, csrc/mfma_conv.hip) against plain PyTorch fp32 on
+float(obs[idx]) * scale, and against the two-kernel route it replaces
+(arl_gather_scale_obs_nhwc + arl_conv2d_fwd / arl_conv2d_bwd_weight).
+Floating point: |got - want| <= 2e-5 * sqrt(K_red) * max|want| (fp32 round-off of a
+reduction in another order); run to run the kernels must be bit-identical."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SCALE = float(np.float32(1. / 255.))
+
+#        rows  batch(idx)  C   H    W    K   kh  kw  stride
+CASES = [(700, 512, 4, 104, 80, 32, 8, 8, 4),      # spec-1 conv 1 at the PPO minibatch, gathered rows
+         (37, None, 4, 104, 80, 32, 8, 8, 4),      # ragged batch, rows in place
+         (64, None, 4, 104, 80, 16, 8, 8, 4),      # spec-0 conv 1 (16-wide MFMA tiles)
+         (90, 33, 1, 104, 80, 16, 8, 8, 4),        # one frame per observation (the A2C example), ragged
+         (21, 21, 3, 40, 36, 24, 4, 4, 4),         # 4-wide filter rows: four rows per k-tile
+         (19, 7, 2, 48, 64, 8, 3, 16, 8),          # 16-wide filter rows: one row per k-tile, stride 8
+         (3, 1, 4, 104, 80, 32, 8, 8, 4)]          # single image
+
+
+def _mk(case, seed=0):
+    from accel_rl_amd import _lib
+    rows, b, c, h, w, k, kh, kw, st = case
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    obs = torch.randint(0, 256, (rows, c, h, w), device=DEV, generator=gen, dtype=torch.int32).to(torch.uint8)
+    idx = None
+    if b is not None:
+        idx = torch.randint(0, rows, (b,), device=DEV, generator=gen, dtype=torch.int32)
+    wt = torch.randn(k, c, kh, kw, device=DEV, generator=gen) / np.sqrt(kh * kw * c)
+    bias = torch.randn(k, device=DEV, generator=gen)
+    geom = _lib.conv_geom(rows if b is None else b, h, w, c, k, kh, kw, st, 0, 0)
+    return obs, idx, wt, bias, geom
+
+
+def _x(obs, idx):
+    rows = obs if idx is None else obs[idx.long()]
+    return rows.float() * SCALE
+
+
+def _tol(want, k_red):
+    return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_forward(case, relu):
+    from accel_rl_amd import _lib
+    obs, idx, wt, bias, geom = _mk(case)
+    ho, wo = _lib.conv_out_hw(geom)
+    y = torch.full((geom.batch, ho, wo, geom.out_c), float("nan"), device=DEV)
+    _lib.conv2d_u8_fwd(obs, idx, SCALE, wt, bias, y, geom, relu)
+    want = F.conv2d(_x(obs, idx), wt, bias, stride=case[8])
+    if relu:
+        want = F.relu(want)
+    want = want.permute(0, 2, 3, 1)
+    assert torch.isfinite(y).all()
+    assert (y - want).abs().max().item() <= _tol(want, wt[0].numel())
+    y2 = torch.empty_like(y)
+    _lib.conv2d_u8_fwd(obs, idx, SCALE, wt, bias, y2, geom, relu)
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_weight_gradient(case):
+    from accel_rl_amd import _lib
+    obs, idx, wt, bias, geom = _mk(case, seed=1)
+    ho, wo = _lib.conv_out_hw(geom)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    dy = torch.randn(geom.batch, ho, wo, geom.out_c, device=DEV, generator=gen)
+    dy = torch.where(torch.rand(dy.shape, device=DEV, generator=gen) < 0.4, torch.zeros_like(dy), dy)
+    outs = []
+    for _ in range(2):
+        dw = torch.full_like(wt, float("nan"))
+        db = torch.full((geom.out_c,), float("nan"), device=DEV)
+        folds, ws = _lib.FoldList(), _lib.conv_workspace(DEV)
+        assert folds.conv2d_u8_bwd_weight(dy, obs, idx, SCALE, dw, geom, ws, dbias=db)
+        folds.run()
+        outs.append((dw, db))
+    dw, db = outs[0]
+    x = _x(obs, idx).requires_grad_(False)
+    w_ref = wt.clone().requires_grad_(True)
+    F.conv2d(x, w_ref, None, stride=case[8]).backward(dy.permute(0, 3, 1, 2))
+    want = w_ref.grad
+    k_red = geom.batch * ho * wo
+    assert torch.isfinite(dw).all()
+    assert (dw - want).abs().max().item() <= _tol(want, k_red)
+    want_b = dy.sum(dim=(0, 1, 2))
+    assert (db - want_b).abs().max().item() <= _tol(want_b, k_red)
+    assert torch.equal(dw, outs[1][0]) and torch.equal(db, outs[1][1])
+
+
+def test_matches_the_gather_route():
+    """Same operand values as gather+scale followed by the NHWC kernels: the results differ only by the
+    order of the reduction (plane by plane instead of pixel by pixel)."""
+    from accel_rl_amd import _lib
+    case = (300, 256, 4, 104, 80, 32, 8, 8, 4)
+    obs, idx, wt, bias, geom = _mk(case, seed=3)
+    ho, wo = _lib.conv_out_hw(geom)
+    y = torch.empty(geom.batch, ho, wo, geom.out_c, device=DEV)
+    _lib.conv2d_u8_fwd(obs, idx, SCALE, wt, bias, y, geom, True)
+    x = torch.empty((geom.batch, 4, 104, 80), device=DEV, memory_format=torch.channels_last)
+    _lib.gather_scale_obs_nhwc(obs, idx, x, SCALE)
+    assert torch.equal(x, _x(obs, idx))                     # the loader's conversion is this arithmetic
+    y2 = torch.empty_like(y)
+    w_hwc = wt.permute(0, 2, 3, 1).contiguous()
+    _lib.conv2d_fwd(x, w_hwc, bias, y2, geom, True, _lib.conv_workspace(DEV))
+    assert (y - y2).abs().max().item() <= _tol(y2, 256)
+
+
+def test_rejects_unsupported_geometry():
+    from accel_rl_amd import _lib
+    obs = torch.zeros(4, 4, 104, 80, dtype=torch.uint8, device=DEV)
+    y = torch.empty(4, 25, 19, 64, device=DEV)
+    wt = torch.empty(64, 4, 8, 8, device=DEV)
+    geom = _lib.conv_geom(4, 104, 80, 4, 64, 8, 8, 4, 0, 0)           # 64 filters: not on this path
+    assert not _lib.conv2d_u8_supported(104, 80, 64, 8, 8, 4, 0, 0)
+    with pytest.raises(RuntimeError):
+        _lib.conv2d_u8_fwd(obs, None, SCALE, wt, None, y, geom, True)

@@ -208,9 +208,10 @@ def test_param_vector_roundtrip_and_reference_layout():
     assert torch.allclose(prob, p1, rtol=1e-4, atol=1e-6) and torch.allclose(value, v1, rtol=1e-4, atol=1e-5)
 
 
-def test_single_frame_observations_are_zero_padded_to_four_channels():
-    """A2C example shape (num_img_obs=1, example_train_a2c.py:37): the internal conv-1 weight
-    carries 3 zero channels; the reference-layout vector and the outputs do not see them."""
+def test_single_frame_observations():
+    """A2C example shape (num_img_obs=1, example_train_a2c.py:37): conv 1 reads the single u8 plane in
+    place (weights (16,1,8,8)); on the NHWC route the internal conv-1 weight carries 3 zero channels that
+    the reference-layout vector and the outputs do not see."""
     policy, algo, buf, spec = make("a2c", 4, 5, False, n_frames=1)
     flat = policy.get_param_values()
     assert flat.size == policy.n_params == sum(int(np.prod(s)) for s in policy._ref_shapes)
@@ -225,8 +226,11 @@ def test_single_frame_observations_are_zero_padded_to_four_channels():
     fill(buf, policy, rs, 4, 5)
     for itr in range(2):
         algo.optimize_policy(itr, buf)
-    w0 = policy._w[0].view(16, 8, 8, 4)
-    assert torch.count_nonzero(w0[..., 1:]) == 0 and torch.count_nonzero(w0[..., 0]) > 0
+    if policy._u8:
+        assert policy._w[0].numel() == 16 * 64 and torch.count_nonzero(policy._w[0]) > 0
+    else:
+        w0 = policy._w[0].view(16, 8, 8, 4)
+        assert torch.count_nonzero(w0[..., 1:]) == 0 and torch.count_nonzero(w0[..., 0]) > 0
     policy.set_param_values(flat)
     np.testing.assert_array_equal(policy.get_param_values(), flat)
 
