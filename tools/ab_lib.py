@@ -1,0 +1,12 @@
+"""A/B aid: run a script of this repo against another build of the library.
+usage: python tools/ab_lib.py <path/to/lib.so> <script.py> [args...]"""
+import os
+import runpy
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from accel_rl_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+sys.argv = sys.argv[2:]
+runpy.run_path(sys.argv[0], run_name="__main__")

@@ -1,7 +1,10 @@
 """A2C with a recurrent policy at the example's scale: env-steps/s of rollout + BPTT update.
-usage: PYTHONPATH=. python tools/recurrent_bench.py [lstm|gru|rnn] [n_envs] [steps]"""
+usage: python tools/recurrent_bench.py [lstm|gru|rnn] [n_envs] [steps]"""
+import os
 import sys
 import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import torch
 
