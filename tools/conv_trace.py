@@ -61,6 +61,11 @@ def main():
               "loop p50/max %d/%d, epilogue p50 %d, end max %d; CUs used %d, WGs/CU histogram %s" %
               (name, n, real, clk, np.median(start), start.max(), np.median(pro), np.median(loop), loop.max(),
                np.median(epi), end.max(), len(per_cu), dict(sorted(hist.items()))))
+        rs, re = (t[:, 4] - t[:, 4].min()) / 100.0, (t[:, 5] - t[:, 4].min()) / 100.0      # us, the GPU-wide 100 MHz clock
+        wg_clk = np.median((t[:, 3] - t[:, 0]) / np.maximum(t[:, 5] - t[:, 4], 1) / 10.0)
+        print("    real time (100 MHz clock): workgroup starts p50/p90/max %.1f/%.1f/%.1f us, ends p10/p50/max %.1f/%.1f/%.1f us; "
+              "per-workgroup cycles / ns = %.3f GHz" % (np.median(rs), np.percentile(rs, 90), rs.max(),
+                                                        np.percentile(re, 10), np.median(re), re.max(), wg_clk))
         print("    mean workgroups per CU inside the main loop: %.2f; total/median WG lifetime %d" % (in_loop, np.median(t[:, 3] - t[:, 0])))
 
 
