@@ -97,8 +97,10 @@ class FrameReplayBuffer(object):
         if self.reuse_outputs and b in cache:
             return cache[b]
         shape = (b, self.num_img_obs) + self.frame_shape
-        obs = torch.empty(shape, dtype=torch.uint8, device=self.device)
-        nxt = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        # one allocation, obs directly followed by next_obs: the Q policies' online pass over both (double DQN)
+        # then reads the 2b rows in place (policies/dqn/q_policy_base.py: _pair_rows)
+        both = torch.empty((2 * b,) + shape[1:], dtype=torch.uint8, device=self.device)
+        obs, nxt = both[:b], both[b:]
         acts = torch.empty(b, dtype=torch.uint8, device=self.device)
         rets = torch.empty(b, dtype=torch.float32, device=self.device)
         terms = torch.empty(b, dtype=torch.uint8, device=self.device)

@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from accel_rl_amd import _lib
-from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy, _norm_c
+from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy, ObsRows, _norm_c
 
 
 class QPolicyBase(AtariCnnPolicy):
@@ -29,7 +29,6 @@ class QPolicyBase(AtariCnnPolicy):
     greedy)` (the action kernel) and the four `_head_*` layout hooks."""
 
     _epsilon = 1
-    _u8_conv1 = False       # _forward_for_loss packs obs and next_obs into one scaled f32 input of 2B rows
     _dueling = False
 
     def _set_dueling(self, dueling):
@@ -114,6 +113,24 @@ class QPolicyBase(AtariCnnPolicy):
         _lib.conv2d_fwd(hids[-1], w[k], w[k + 1], out, geom, False, self._conv_ws)
         return out, acts, hids
 
+    def _pair_rows(self, obs, next_obs):
+        """u8 [2B,C,H,W] = obs followed by next_obs: in place when the replay memory handed them out adjacent
+        (FrameReplayBuffer._batch_outputs), else through a scratch copy."""
+        b = obs.shape[0]
+        if (obs.is_contiguous() and next_obs.is_contiguous() and
+                obs.untyped_storage().data_ptr() == next_obs.untyped_storage().data_ptr() and
+                next_obs.data_ptr() == obs.data_ptr() + obs.numel()):
+            return torch.as_strided(obs, (2 * b,) + tuple(obs.shape[1:]), obs.stride())
+        key = ("obs_pair", b)
+        both = None if torch.cuda.is_current_stream_capturing() else self._scratch.get(key)
+        if both is None:
+            both = torch.empty((2 * b,) + tuple(obs.shape[1:]), dtype=torch.uint8, device=self.device)
+            if not torch.cuda.is_current_stream_capturing():
+                self._scratch[key] = both
+        both[:b].copy_(obs)
+        both[b:].copy_(next_obs)
+        return both
+
     def _forward_for_loss(self, obs, next_obs, double_dqn):
         """The three forward passes of a DQN-family loss: online net on obs (activations kept for the backward
         pass), target net on next_obs and -- double DQN -- online net on next_obs.  The two online passes run as
@@ -122,6 +139,12 @@ class QPolicyBase(AtariCnnPolicy):
         Returns (x, out, acts, hids, target_out, online_next_out or None)."""
         b = obs.shape[0]
         c, h, w = self._obs_shape
+        if double_dqn and self._u8:                     # conv 1 reads the u8 rows itself: no scaled copy at all
+            both = self._pair_rows(obs, next_obs)
+            tgt, _, _ = self._logits(ObsRows(both[b:], None), w=self._w_target, tag="t")
+            out2, acts2, hids2 = self._logits(ObsRows(both, None), tag="2")
+            return (ObsRows(both[:b], None), out2[:b], [a[:b] for a in acts2], [hd[:b] for hd in hids2], tgt,
+                    out2[b:])
         if not double_dqn or c != 4:
             tgt, _, _ = self._logits(self._scaled(next_obs, tag="n"), w=self._w_target, tag="t")
             pol_next = self._logits(self._scaled(next_obs, tag="n"), tag="d")[0] if double_dqn else None
