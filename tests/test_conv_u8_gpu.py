@@ -121,3 +121,49 @@ def test_rejects_unsupported_geometry():
     assert not _lib.conv2d_u8_supported(104, 80, 64, 8, 8, 4, 0, 0)
     with pytest.raises(RuntimeError):
         _lib.conv2d_u8_fwd(obs, None, SCALE, wt, None, y, geom, True)
+
+
+def _random_case(rs):
+    kw = int(rs.choice([4, 8, 16]))
+    kh = int(rs.choice([1, 2, 3, 4]) * (16 // kw))
+    st = int(rs.choice([4, 8]))
+    c = int(rs.randint(1, 6))
+    k = int(rs.randint(1, 9) * 4)
+    h = kh + st * int(rs.randint(0, 12)) + int(rs.randint(0, st))
+    w = (kw + st * int(rs.randint(0, 12)) + 4 * int(rs.randint(0, 3)) + 3) // 4 * 4
+    if (h * w) % 4:
+        h += 1 if (w % 4 == 0) else 0
+    rows = int(rs.randint(1, 70))
+    b = None if rs.rand() < 0.4 else int(rs.randint(1, 90))
+    return (rows, b, c, h, w, k, kh, kw, st)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("ARL_U8_RANDOM_CASES", "24"))))
+def test_random_geometries(seed):
+    """Random supported geometries (filter 1..4 k-tiles tall, 4 / 8 / 16 wide, stride 4 / 8, 1..5 planes,
+    4..32 filters, ragged rows, gathered or in place): forward and weight gradient against PyTorch."""
+    from accel_rl_amd import _lib
+    rs = np.random.RandomState(1000 + seed)
+    case = _random_case(rs)
+    rows, b, c, h, w, k, kh, kw, st = case
+    assert _lib.conv2d_u8_supported(h, w, k, kh, kw, st, 0, 0), case
+    obs, idx, wt, bias, geom = _mk(case, seed=seed)
+    ho, wo = _lib.conv_out_hw(geom)
+    x = _x(obs, idx)
+    y = torch.full((geom.batch, ho, wo, k), float("nan"), device=DEV)
+    _lib.conv2d_u8_fwd(obs, idx, SCALE, wt, bias, y, geom, False)
+    want = F.conv2d(x, wt, bias, stride=st).permute(0, 2, 3, 1)
+    assert (y - want).abs().max().item() <= _tol(want, wt[0].numel()), case
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    dy = torch.randn(geom.batch, ho, wo, k, device=DEV, generator=gen)
+    dw = torch.full_like(wt, float("nan"))
+    db = torch.full((k,), float("nan"), device=DEV)
+    folds = _lib.FoldList()
+    assert folds.conv2d_u8_bwd_weight(dy, obs, idx, SCALE, dw, geom, _lib.conv_workspace(DEV), dbias=db)
+    folds.run()
+    w_ref = wt.clone().requires_grad_(True)
+    F.conv2d(x, w_ref, None, stride=st).backward(dy.permute(0, 3, 1, 2))
+    k_red = geom.batch * ho * wo
+    assert (dw - w_ref.grad).abs().max().item() <= _tol(w_ref.grad, k_red), case
+    want_b = dy.sum(dim=(0, 1, 2))
+    assert (db - want_b).abs().max().item() <= _tol(want_b, k_red), case
