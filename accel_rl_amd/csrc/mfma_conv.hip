@@ -1809,7 +1809,9 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     const int bm = g.K <= 16 ? 16 : 32, bn = 128;
     const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     int splits, per;
-    plan_split(tiles, a.Mred, &splits, &per, 2 * TARGET_WGS);
+    // residency: the 16-row tiles (<= 16 filters) are small enough for 4 workgroups per CU (A2C-1024 batch:
+    // 300 -> 242 us; 6 or 8 per CU: 248-253); the 32-row ones stay at 2 (3: same, 4: slower)
+    plan_split(tiles, a.Mred, &splits, &per, (g.K <= 16 ? 4 : 2) * TARGET_WGS);
     a.m_per_split = per;
     const int64_t total = (int64_t)a.K_out * a.N;
     const int64_t used = splits > 1 ? (int64_t)splits * total : 0;
