@@ -5,7 +5,8 @@ Python double loop over envs and time calling numpy scalar code
 (algos/pg/util.py:6-63); here it is: one policy forward for the bootstrap values
 -> arl_gae_scan or arl_nstep_return -> (arl_valids_mask) -> (arl_standardize),
 all on the sampler's GPU, directly on the rollout buffer the sampler filled.
-The loss graph (aac_base.py:60-70) is torch autograd over the policy's forward.
+The loss graph (aac_base.py:60-70) is the policy's HIP forward / backward around the fused head kernel
+(csrc/learner.hip: both heads, softmax, pi / value / entropy losses and their gradients in one pass).
 """
 import torch
 
@@ -58,11 +59,11 @@ class AdvActorCriticBase(RLAlgorithm):
         if self._use_valids:
             input_names.append("valids")
             opt_examples["valids"] = np.int8(1)
-        self._explicit = bool(getattr(policy, "explicit", False))
-        self.optimizer.initialize(inputs=input_names,
-                                  losses=self._explicit_losses if self._explicit else self._losses,
-                                  constraints=None, target=policy,
-                                  givens=dict(explicit_grads=self._explicit), lr_mult=self._lr_mult)
+        if not hasattr(policy, "loss_and_grads"):
+            raise TypeError("the policy must provide loss_and_grads (HIP forward / backward into its flat "
+                            "gradient bucket); got {}".format(type(policy).__name__))
+        self.optimizer.initialize(inputs=input_names, losses=self._losses, constraints=None, target=policy,
+                                  lr_mult=self._lr_mult)
         self._opt_buf = buffer_with_segs_view(opt_examples, sample_size, horizon, dev)
         self._batch_size = sample_size
         self._mid_batch_reset = mid_batch_reset
@@ -115,7 +116,10 @@ class AdvActorCriticBase(RLAlgorithm):
             self._graph, self._graph_samples = graph, samples_data
         assert samples_data is self._graph_samples, "the sampler must hand over the same buffer"
         self._graph.replay()
-        return self._graph_out
+        # the graph owns its outputs and every replay overwrites them: callers that keep the diagnostics across
+        # iterations (AccelRL.store_diagnostics) get their own copy
+        opt_data, infos = self._graph_out
+        return opt_data, {k: v.clone() for k, v in infos.items()}
 
     def _device_optimize(self, itr, samples_data):
         self._lr_mult.copy_(self._lr_mult_host, non_blocking=True)
@@ -164,20 +168,9 @@ class AdvActorCriticBase(RLAlgorithm):
 
     # ---- loss graph (aac_base.py:60-70) ---------------------------------------
     def _losses(self, mb):
-        policy = self.policy
-        new_dist_info, new_value = policy.dist_info_value_sym(mb["observations"], mb.get("idx"))
-        valids = mb.get("valids")
-        old_dist_info = {k: mb["old_%s" % k] for k in self._dist_info_keys}
-        v_loss = self.v_loss_coeff * valids_mean((new_value - mb["returns"]) ** 2, valids)
-        ent = policy.distribution.entropy_sym(new_dist_info)
-        ent_loss = - self.ent_loss_coeff * valids_mean(ent, valids)
-        pi_loss = self.pi_loss(policy, mb["actions"], mb["advantages"], old_dist_info,
-                               new_dist_info, valids)
-        return pi_loss, v_loss, ent_loss
-
-    def _explicit_losses(self, mb):
-        """Same losses, fused: the policy's explicit forward + csrc/learner.hip head kernel
-        compute (pi_loss, v_loss, ent_loss) and write every gradient into flat_grads."""
+        """pi_loss + v_loss + ent_loss of one minibatch (aac_base.py:60-66, `pi_loss` of the subclass selected by
+        `loss_kind`) and their gradient: the policy's forward, the fused head kernel and the backward pass write
+        every gradient into flat_grads."""
         inv_count = None
         valids = mb.get("valids")
         if valids is not None:
@@ -193,6 +186,9 @@ class AdvActorCriticBase(RLAlgorithm):
     loss_kind = None        # 0 = A2C, 1 = PPO (selects the fused kernel's pi_loss)
 
     def pi_loss(self, policy, act, adv, old_dist_info, new_dist_info, valids):
+        """The subclass's policy loss as a formula on tensors (a2c.py:43-46 / ppo.py:42-51).  The learner does
+        not evaluate it -- `loss_kind` picks the same expression inside the fused head kernel; the numerics
+        tests differentiate it with autograd as the kernel's reference (tests/autograd_ref.py)."""
         raise NotImplementedError
 
     @property

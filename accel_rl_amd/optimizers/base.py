@@ -4,9 +4,10 @@ shared flat-bucket machinery.
 `initialize(inputs, losses, constraints, target, givens=None, lr_mult=1)` keeps
 the reference's argument names.  With Theano gone, `inputs` is the list of input
 NAMES (tuple order of prep_opt_inputs, aac_base.py:147-170) and `losses` is a
-callable `losses(minibatch: dict) -> (pi_loss, v_loss, ent_loss)` built by the
-algorithm from the policy's autograd forward; `target` is the policy;
-`lr_mult` a 1-element device tensor (the linear schedule writes it)."""
+callable `losses(minibatch: dict) -> loss4 = (pi_loss, v_loss, ent_loss, their sum)` that
+runs the policy's HIP forward / backward and OVERWRITES the target's flat gradient
+bucket; `target` is the policy; `lr_mult` a 1-element device tensor (the linear schedule
+writes it)."""
 import numpy as np
 import torch
 
@@ -56,7 +57,6 @@ class BaseOptimizer(object):
     # ---- shared: flat bucket + HIP update ------------------------------------
     def _setup_bucket(self, target, lr_mult, givens=None):
         self._target = target
-        self._explicit_grads = bool((givens or dict()).get("explicit_grads", False))
         dev = target.device
         n = target.flat_params.numel()
         self._slot0 = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -85,16 +85,8 @@ class BaseOptimizer(object):
             self._kernel_args = (a["rho"], 0.0, a["epsilon"])
 
     def _backward(self, losses, minibatch):
-        """Gradient of the summed loss into the flat gradient bucket.  With
-        `givens=dict(explicit_grads=True)` the loss callable runs the policy's explicit
-        forward/backward itself and OVERWRITES the bucket; otherwise autograd accumulates
-        into the (zeroed) bucket views."""
-        if self._explicit_grads:
-            return losses(minibatch)[3]          # the fused head kernel already summed the three terms
-        self._target.flat_grads.zero_()
-        loss = sum(losses(minibatch))
-        loss.backward()
-        return loss.detach()
+        """Gradient of the summed loss into the flat gradient bucket (overwritten); returns the summed loss."""
+        return losses(minibatch)[3]
 
     def _apply_update(self, avg_factor=1.0):
         """(avg) -> global norm (-> clip) -> adam/rmsprop: two HIP launches."""

@@ -27,7 +27,7 @@ class DqnOptimizer(BaseOptimizer):
     def initialize(self, inputs, loss, target, priority_expr=None, givens=None, lr_mult=1):
         self._input_names = list(inputs)
         self._loss_fn = loss
-        self._setup_bucket(target, lr_mult, dict(explicit_grads=True))
+        self._setup_bucket(target, lr_mult)
         self._set_updates_per_call(1)
 
     def optimize(self, inputs):

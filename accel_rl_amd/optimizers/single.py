@@ -94,7 +94,7 @@ class PpoOptimizer(BaseOptimizer):
         if not self._n_minibatches:
             return [], []
         self._idx_dev.copy_(self._idx_host, non_blocking=True)
-        if self._explicit_grads and self._overlap_allreduce:
+        if self._overlap_allreduce:
             return self._overlapped_minibatches(data)
         losses = []
         for k in range(self._n_minibatches):
@@ -104,14 +104,7 @@ class PpoOptimizer(BaseOptimizer):
         return losses, self._recent_grad_norms(self._n_minibatches)
 
     def _minibatch(self, data, idx):
-        if self._explicit_grads:                 # kernels gather rows by idx themselves
-            return dict(data, idx=idx)
-        mb = dict(idx=idx, observations=data["observations"])
-        idx64 = idx.long()
-        for name, tensor in data.items():
-            if name != "observations":
-                mb[name] = tensor.index_select(0, idx64)
-        return mb
+        return dict(data, idx=idx)               # the kernels gather the minibatch's rows by idx themselves
 
     # Multi-GPU (`_overlap_allreduce`, set by the sync optimizers): minibatches are enqueued eagerly -- at ~550 us
     # of device work per minibatch the host stays far ahead, and a hipGraph per minibatch only added its launch

@@ -15,9 +15,9 @@ csrc/mfma_conv.hip -- deterministic, no atomics, so seeded runs reproduce bit fo
              conv dW / dx] x n, every gradient written straight into ONE flat
              fp32 bucket (`flat_grads`) that the HIP optimiser / RCCL all-reduce consume.
 
-No autograd graph is built on the hot path (`explicit=True`, default).  The
-autograd formulation of the same network through PyTorch's own conv2d / linear
-(`forward`) is kept as the A/B reference of the numerics tests only.
+No autograd graph is ever built and no MIOpen / hipBLASLt kernel runs: the HIP kernels are the only
+backend (the autograd formulation of the same network used by the numerics tests lives in
+tests/autograd_ref.py).
 
 Internal parameter layout (the bucket is ours to define): conv W as (K,kh,kw,C)
 = channels-last correlation kernels (conv 1 on the u8 path: (K,C,kh,kw), its input being
@@ -30,7 +30,6 @@ dense W (in,out) with (c,h,w) input order.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from accel_rl_amd import _lib
 from accel_rl_amd.distributions import Categorical
@@ -72,7 +71,7 @@ class AtariCnnPolicy(object):
     _u8_conv1 = True
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads,
-                 hidden_sizes=(), pixel_scale=255., initial_param_values=None, explicit=True):
+                 hidden_sizes=(), pixel_scale=255., initial_param_values=None):
         self.conv_filters, self.conv_filter_sizes = list(conv_filters), list(conv_filter_sizes)
         self.conv_strides, self.conv_pads = list(conv_strides), list(conv_pads)
         self.hidden_sizes = list(hidden_sizes)
@@ -80,7 +79,6 @@ class AtariCnnPolicy(object):
             raise NotImplementedError("at least one hidden dense layer is required")
         self.pixel_scale = pixel_scale
         self.initial_param_values = initial_param_values
-        self.explicit = explicit
         self._scratch = dict()
 
     recurrent = property(lambda self: False)
@@ -102,7 +100,7 @@ class AtariCnnPolicy(object):
         # ---- reference-layout initial values, drawn in the reference's order
         ref, self._conv_geom = [], []
         nf0, sz0, st0, pad0 = self.conv_filters[0], self.conv_filter_sizes[0], self.conv_strides[0], self.conv_pads[0]
-        self._u8 = bool(self._u8_conv1 and self.explicit and
+        self._u8 = bool(self._u8_conv1 and
                         _lib.conv2d_u8_supported(h, w, nf0, sz0, sz0, st0, pad0[0], pad0[1]))
         for nf, sz, st, pad in zip(self.conv_filters, self.conv_filter_sizes, self.conv_strides,
                                    self.conv_pads):
@@ -324,28 +322,11 @@ class AtariCnnPolicy(object):
             k += 2
         return acts, hids
 
-    def forward(self, x):
-        """Autograd formulation of the same network (A/B reference)."""
-        if isinstance(x, ObsRows):
-            x = self._scaled_f32(x.obs, x.idx)[:, :self._c_in]
-        p = self.params
-        for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
-            x = F.relu(F.conv2d(x, p[2 * i], p[2 * i + 1], stride=st, padding=pad))
-        x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)
-        k = 2 * self._n_conv
-        for _ in self._hid_geom:
-            x = F.relu(F.linear(x, p[k], p[k + 1]))
-            k += 2
-        out = F.linear(x, p[k], p[k + 1])
-        return torch.softmax(out[:, :self.n_act], dim=1), out[:, self.n_act]
-
     def prob_value(self, observations):
         """Batched inference on device uint8 observations (the sampler's hot call;
         reference: _f_prob_value, atari_cnn_policy.py:67,109)."""
         with torch.no_grad():
             x = self._scaled(observations)
-            if not self.explicit:
-                return self.forward(x)
             b = x.shape[0]
             _, hids = self._trunk(x)
             prob = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
@@ -438,11 +419,6 @@ class AtariCnnPolicy(object):
             ws = self._fold_workspaces[key] = (_lib.relu_bwd_workspace(self.device) if key[0] == "db"
                                                else _lib.conv_workspace(self.device))
         return ws
-
-    def dist_info_value_sym(self, obs_u8, idx=None):
-        """Training-time forward through autograd (explicit=False path)."""
-        prob, value = self.forward(self._scaled(obs_u8, idx))
-        return dict(prob=prob), value
 
     def dist_info(self, observations, state_infos=None):
         return dict(prob=self.prob_value(observations)[0])

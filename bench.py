@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
-N_ENVS, HORIZON, GAME, CNN_SPEC = 256, 5, "breakout", 1
+N_ENVS, HORIZON, GAME, CNN_SPEC, MINIBATCH = 256, 5, "breakout", 1, 512
 GAMES_8 = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_rider", "enduro", "ms_pacman"]
 
 
@@ -59,9 +59,9 @@ def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind=
     if kind == "a2c":
         algo = (mA2C if multi else A2C)(discount=0.99, gae_lambda=1)
     elif multi:
-        algo = mPPO(discount=0.99, gae_lambda=0.95)
+        algo = mPPO(discount=0.99, gae_lambda=0.95, optimizer_args=dict(minibatch_size=MINIBATCH))
     else:
-        algo = PPO(discount=0.99, gae_lambda=0.95)
+        algo = PPO(discount=0.99, gae_lambda=0.95, optimizer_args=dict(minibatch_size=MINIBATCH))
     if multi:
         algo.optimizer._force_collective = True
         runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
@@ -267,18 +267,46 @@ def _served(device, policy):
     return Served()
 
 
-def _time_sampler(smp, served, device, policy, seconds):
-    from oracle import ref_port as P
-    smp.obtain_samples(served)                       # warm-up batch
-    t0 = time.time()
-    batches = 0
-    while time.time() - t0 < seconds or batches < 3:
-        buf, _ = smp.obtain_samples(served)
-        lv = policy.value(torch.from_numpy(buf["extra_observations"]).to(device)).cpu().numpy()
-        P.process_samples(buf["rewards"].reshape(N_ENVS, HORIZON), buf["dones"].reshape(N_ENVS, HORIZON),
-                          buf["value"].reshape(N_ENVS, HORIZON), lv, None, 0.99, 0.95)
-        batches += 1
-    return batches, time.time() - t0
+def _host_cpu():
+    """(model string, physical cores, logical cores) of this box from /proc/cpuinfo."""
+    model, cores = "unknown", set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "model name":
+                    model = val
+                elif key == "physical id":
+                    phys = val
+                elif key == "core id":
+                    core = val
+                elif not key and phys is not None:
+                    cores.add((phys, core))
+                    phys = core = None
+        if phys is not None:
+            cores.add((phys, core))
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return model, (len(cores) or max(1, logical // 2)), logical
+
+
+def _windows(one_batch, n_windows, seconds, min_batches=3):
+    """env-steps/s of `one_batch()` over n_windows back-to-back windows; returns (rates, batches, total time)."""
+    one_batch()                                      # warm-up batch
+    rates, total_b, total_t = [], 0, 0.0
+    for _ in range(n_windows):
+        t0, batches = time.time(), 0
+        while time.time() - t0 < seconds or batches < min_batches:
+            one_batch()
+            batches += 1
+        dt = time.time() - t0
+        rates.append(batches * N_ENVS * HORIZON / dt)
+        total_b += batches
+        total_t += dt
+    return rates, total_b, total_t
 
 
 def start_cpu_pool():
@@ -286,8 +314,7 @@ def start_cpu_pool():
     initialised HIP runtime is not safe; the reference forks its workers before Theano's first call too).
     They sit on a barrier, using no CPU, until cpu_baseline() runs."""
     from oracle.cpu_sampler_mp import CpuSamplerMP
-    logical = os.cpu_count() or 2
-    physical = max(1, logical // 2)
+    _, physical, _ = _host_cpu()
     half = N_ENVS // 2
     n_par = max(d for d in range(1, half + 1) if half % d == 0 and d <= max(1, physical - 1))
     smp = CpuSamplerMP(GAME, HORIZON, n_par, half // n_par, max_path_length=int(27e3), mid_batch_reset=True,
@@ -296,35 +323,66 @@ def start_cpu_pool():
     return smp
 
 
-def cpu_baseline(device, policy, smp, seconds=10.0):
+def cpu_baseline(device, policy, smp, sampler, algo, itr0, seconds=4.0, n_windows=3):
     """The reference's CPU sampler restated (oracle/, pinned to the real reference by the golden
-    fixtures) on this box's host cores, same workload's rollout + process_samples, no learner update:
-      * multi-process, as the reference runs it: master + 2*n_parallel workers in two alternating
-        groups (oracle/cpu_sampler_mp.py), n_parallel = the largest divisor of N/2 that fits the
-        physical cores minus one (scripts/launching/affinities.py:63-69) -> `value`, `cores`;
-      * the same arithmetic walked by ONE process (oracle/ref_port.CpuSamplerPort) -> `single_core`."""
+    fixtures) on this box's host cores, on the same workload; every figure is the MEDIAN of n_windows windows:
+      * `value`: multi-process, as the reference runs it -- master + 2*n_parallel workers in two alternating
+        groups (oracle/cpu_sampler_mp.py), n_parallel = the largest divisor of N/2 that fits the physical
+        cores minus one (scripts/launching/affinities.py:63-69) --, rollout + process_samples, no learner;
+      * `whole_loop`: the same sampler followed, serially as the reference's runner does it
+        (runners/accel_rl.py:28-37), by the SAME device learner the headline `value` runs (batch copied H2D,
+        algo.optimize_policy, wait) -- the like-for-like baseline of the headline number;
+      * `single_core`: the sampler's arithmetic walked by ONE process (oracle/ref_port.CpuSamplerPort)."""
     from oracle import ref_port as P
     served = _served(device, policy)
-    logical = os.cpu_count() or 2
+    model, physical, logical = _host_cpu()
     n_par, half = smp.n_parallel, N_ENVS // 2
+
+    def sample_and_process(s):
+        buf, _ = s.obtain_samples(served)
+        lv = policy.value(torch.from_numpy(buf["extra_observations"]).to(device)).cpu().numpy()
+        P.process_samples(buf["rewards"].reshape(N_ENVS, HORIZON), buf["dones"].reshape(N_ENVS, HORIZON),
+                          buf["value"].reshape(N_ENVS, HORIZON), lv, None, 0.99, 0.95)
+
+    dst = sampler.samples_buf
+    pairs = lambda buf: (                                            # noqa: E731
+        (dst.observations, buf["observations"]), (dst.rewards, buf["rewards"]), (dst.dones, buf["dones"]),
+        (dst.env_infos["raw_reward"], buf["raw_reward"]), (dst.env_infos["need_reset"], buf["need_reset"]),
+        (dst.actions, buf["actions"]), (dst.agent_infos["prob"], buf["prob"]),
+        (dst.agent_infos["value"], buf["value"]), (dst.extra_observations, buf["extra_observations"]))
+    itr = [itr0]
+
+    def whole_loop():
+        buf, _ = smp.obtain_samples(served)
+        for d, h in pairs(buf):
+            d.copy_(torch.from_numpy(np.ascontiguousarray(h)).view(d.dtype).reshape(d.shape))
+        algo.optimize_policy(itr[0], dst)
+        itr[0] += 1
+        torch.cuda.synchronize()
+
     np.random.seed(12345)
     try:
-        batches, dt = _time_sampler(smp, served, device, policy, seconds)
+        rates, batches, dt = _windows(lambda: sample_and_process(smp), n_windows, seconds)
+        loop_rates, loop_batches, loop_dt = _windows(whole_loop, n_windows, seconds * 0.75)
     finally:
         smp.shutdown()
-    multi = batches * N_ENVS * HORIZON / dt
     one = P.CpuSamplerPort(GAME, HORIZON, 16, N_ENVS // 32, max_path_length=int(27e3), mid_batch_reset=True)
     np.random.seed(12345)
     one.initialize(12346, discount=0.99)
-    b1, dt1 = _time_sampler(one, served, device, policy, seconds * 0.6)
-    return dict(value=round(multi, 1), unit="env-steps/s", cores=n_par + 1, kind="port",
-                single_core=round(b1 * N_ENVS * HORIZON / dt1, 1),
-                sample="%d batches (%.1f s) of the same workload's rollout + process_samples (256 envs x 5 steps): "
-                       "numpy restatement of the reference sampler / AtariEnv / GAE, master + %d worker "
-                       "processes (2 alternating groups x %d, %d envs each, pinned), actions served by the "
-                       "same policy on the GPU, no learner update; single_core = the same walked by one "
-                       "process (%d batches); host has %d logical cores" %
-                       (batches, dt, 2 * n_par, n_par, half // n_par, b1, logical))
+    one_rates, b1, dt1 = _windows(lambda: sample_and_process(one), n_windows, seconds * 0.4)
+    med = lambda x: float(np.median(x))                              # noqa: E731
+    return dict(value=round(med(rates), 1), unit="env-steps/s", cores=n_par + 1, kind="port",
+                windows=[round(r, 1) for r in rates], whole_loop=round(med(loop_rates), 1),
+                whole_loop_windows=[round(r, 1) for r in loop_rates],
+                single_core=round(med(one_rates), 1), cpu_model=model, physical_cores=physical,
+                logical_cores=logical,
+                sample="median of %d windows (%d batches, %.1f s in all) of the same workload's rollout + "
+                       "process_samples (256 envs x 5 steps): numpy restatement of the reference sampler / "
+                       "AtariEnv / GAE, master + %d worker processes (2 alternating groups x %d, %d envs each, "
+                       "pinned), actions served by the same policy on the GPU, no learner update; whole_loop = "
+                       "the same sampler + H2D of the batch + the device learner of `value`, serial "
+                       "(%d batches, %.1f s); single_core = the sampler walked by one process (%d batches)" %
+                       (n_windows, batches, dt, 2 * n_par, n_par, half // n_par, loop_batches, loop_dt, b1))
 
 
 def catdqn_main(args):
@@ -377,6 +435,21 @@ def catdqn_main(args):
     print(json.dumps(line), flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, as the
+    reference's runner forks its n-1 workers from one process (accel_rl/runners/multigpu_rl_base.py:20-45).
+    Re-executes this command line under torch.distributed.run (rendezvous on 127.0.0.1, a free port)."""
+    import socket
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,23 +462,38 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the GAE-scan roofline leg (used for the rocprofv3 --pmc passes)")
     ap.add_argument("--suite", action="store_true", help="BASELINE config 4: one game per rank")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 256 envs and minibatch 512 PER GPU (default); strong: --total-envs and a global "
+                         "minibatch of 4096 rows split over the GPUs (SURVEY 8d)")
+    ap.add_argument("--total-envs", type=int, default=2048, help="--scaling strong: environments of the whole job")
     ap.add_argument("--dqn-batch", type=int, default=512, help="catdqn workload: replay minibatch size")
     ap.add_argument("--workload", choices=["ppo256", "a2c1024", "catdqn"], default="ppo256",
                     help="ppo256 = BASELINE config 2 (the metric's config, default); a2c1024 = config 3 "
                          "(A2C, 1024 envs, 5-step returns, spec-0 CNN, one rmsprop step per batch)")
     args = ap.parse_args()
 
-    global N_ENVS, CNN_SPEC
+    global N_ENVS, CNN_SPEC, MINIBATCH
     if args.workload == "a2c1024":
         N_ENVS, CNN_SPEC = 1024, 0
         args.no_cpu_baseline = args.no_roofline = True
     if args.workload == "catdqn":
         return catdqn_main(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.scaling == "strong":
+        # the SAME job on 1, 2, 4, 8 GPUs (multigpu_rl_base.py:62-63 counts sample_size * n_runners per
+        # iteration): --total-envs environments and ONE global minibatch of 512 x 8 rows per update, both split
+        # evenly over the ranks -- every N takes the same number of optimiser steps on the same amount of data
+        if args.workload != "ppo256" or args.total_envs % (32 * world) or (512 * 8) % world:
+            raise SystemExit("--scaling strong: ppo256 workload, --total-envs a multiple of 32 x the rank count")
+        N_ENVS = args.total_envs // world
+        MINIBATCH = 512 * 8 // world
+        args.no_cpu_baseline = args.no_roofline = True
     cpu_pool = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.roofline_only:
         cpu_pool = start_cpu_pool()
@@ -415,6 +503,7 @@ def main():
     # rank on GPU 0 (RCCL refuses two ranks on one device); never a measurement.
     device = torch.device("cuda", 0 if os.environ.get("ARL_BENCH_ONE_GPU") == "1" else local)
     torch.cuda.set_device(device)
+    backend = None
     if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -465,14 +554,18 @@ def main():
         "unit": "env-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+        "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if backend else "none (single GPU)",
         "config": {"workload": ("A2C %s, %d envs/GPU, horizon %d (5-step returns), spec-%d CNN (fp32), one "
                                 "rmsprop step per batch; synthetic fixed-frame emulator; %s" if args.workload == "a2c1024"
-                                else "PPO %s, %d envs/GPU, horizon %d, spec-%d CNN (fp32), minibatch 512 x 4 epochs, "
+                                else "PPO %s, %d envs/GPU, horizon %d, spec-%d CNN (fp32), minibatch %d/GPU x 4 epochs, "
                                 "adam; synthetic fixed-frame emulator; %s") %
-                               ("8-game suite" if args.suite else GAME, N_ENVS, HORIZON, CNN_SPEC,
-                                "hipGraph rollout" if not args.no_graph else "eager"),
+                               (("8-game suite" if args.suite else GAME, N_ENVS, HORIZON, CNN_SPEC) +
+                                ((MINIBATCH,) if args.workload == "ppo256" else ()) +
+                                ("hipGraph rollout" if not args.no_graph else "eager",)),
+                   "total_envs": N_ENVS * world, "global_minibatch": MINIBATCH * world,
                    "env_steps_per_step_per_gpu": N_ENVS * HORIZON,
                    "parallelism": "dp%d sync all-reduce (RCCL)" % world if world > 1 else "single"},
     }
@@ -496,11 +589,13 @@ def main():
             line["kernels"] = kernel_table(device, sampler, algo, policy)
             line["mfma"] = mfma_table(device, policy)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(device, policy, cpu_pool)
+            line["cpu_baseline"] = cb = cpu_baseline(device, policy, cpu_pool, sampler, algo, itr + 2 * reps)
             line["gpu_over_cpu"] = {
-                "rollout_only": round(line["phases"]["rollout_only_env_steps_per_s"] / line["cpu_baseline"]["value"], 2),
-                "note": "like for like: GPU rollout (sampler only) vs CPU sampler port; `value` additionally "
-                        "contains the PPO learner, which the CPU baseline does not run"}
+                "rollout_only": round(line["phases"]["rollout_only_env_steps_per_s"] / cb["value"], 2),
+                "whole_loop": round(line["value"] / cb["whole_loop"], 2),
+                "note": "rollout_only: GPU rollout (sampler only) vs the CPU sampler port; whole_loop: `value` "
+                        "(rollout + PPO learner on the device) vs the CPU sampler port feeding the same device "
+                        "learner serially, as the reference's runner does"}
     runner.shutdown()
     if dist.is_initialized():
         dist.barrier()

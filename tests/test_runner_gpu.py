@@ -52,6 +52,17 @@ def test_train_loop_runs_and_logs(kind, mid_batch_reset, max_len):
         assert abs(algo._lr_mult.item() - (13 - 12) / 13) < 1e-6
 
 
+def test_grad_norm_stats_vary_over_a_log_interval_in_graph_mode():
+    """A2C = one update per iteration, 4 iterations per log interval, the last interval runs entirely from the
+    learner's hipGraph: the logged GradNorm entries must be the 4 iterations' own values (the graph-owned output
+    tensor is overwritten by every replay), i.e. Std > 0 and Min < Max."""
+    runner, sampler, algo, policy = _build("a2c", 160 * 12, max_path_length=40)
+    runner.train()
+    tab = runner.last_tabular
+    assert algo._graph is not None
+    assert tab["GradNormStd"] > 0 and tab["GradNormMin"] < tab["GradNormMax"]
+
+
 def test_seeded_runs_are_reproducible():
     out = []
     for _ in range(2):

@@ -169,6 +169,63 @@ def test_gpu_sampler_matches_oracle_at_baseline_sizes(n_parallel, envs_per, game
     smp.shutdown()
 
 
+SUITE_GAMES = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_rider", "enduro", "ms_pacman"]
+
+
+@pytest.mark.parametrize("game", SUITE_GAMES)
+def test_gpu_sampler_matches_oracle_on_every_suite_game(game):
+    """BASELINE config 4's workload: each of the 8 suite games at the per-GPU shard size (256 envs = 2 x 16 x 8,
+    horizon 5), every array of 14 batches bit-identical to the oracle's sampler port.  Covers the 6- and 9-action
+    sets and the 0 / 3 / 4 / 5 start-lives rules (envs/synthetic_atari.py GAMES); 70 steps with max_path_length 66
+    so that life losses (first at emulator tick 251 = step 55-62, depending on the start no-ops) and over-length
+    resets both occur (asserted)."""
+    from accel_rl_amd.envs.synthetic_atari import GAMES
+    seed, horizon, n_parallel, envs_per, n_batches, max_len = 23, 5, 16, 8, 14, 66
+    n_act = len(GAMES[game][1])
+    rs = np.random.RandomState(100 + GAMES[game][0])
+    logits = rs.randn(64, n_act) * 1.5
+    p = np.exp(logits - logits.max(1, keepdims=True))
+    tables = ((p / p.sum(1, keepdims=True)).astype(np.float32), (rs.randn(64) * 2).astype(np.float32))
+    kw = dict(max_start_noops=30)
+    smp = make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, True, max_len, kw, tables, 0.99, True)
+    assert smp.env_spec.action_space.n == n_act
+    ora = P.CpuSamplerPort(game, horizon, n_parallel, envs_per, max_path_length=max_len, mid_batch_reset=True, env_kwargs=kw)
+    np.random.seed(seed)
+    ora.initialize(seed + 1, discount=0.99)
+    shape = ora.step_obs.shape[1:]
+    for _ in range(2):                                   # the master's step-buffer examples (act_server/buffers.py:24-30)
+        np.random.randint(low=0, high=255, size=shape, dtype=np.uint8)
+        np.random.randint(n_act, dtype=np.uint8)
+    np.random.randint(low=0, high=255, size=shape, dtype=np.uint8)
+    np.random.rand()
+    host_policy = HostTablePolicy(*tables)
+    state = np.random.get_state()
+    n_completed, n_done, n_need = 0, 0, 0
+    for b in range(n_batches):
+        np.random.set_state(state)
+        buf, infos = smp.obtain_samples(b)
+        np.random.set_state(state)
+        want, completed = ora.obtain_samples(host_policy)
+        state = np.random.get_state()
+        for key, got in (("actions", buf.actions), ("rewards", buf.rewards), ("dones", buf.dones),
+                         ("raw_reward", buf.env_infos["raw_reward"]), ("need_reset", buf.env_infos["need_reset"]),
+                         ("prob", buf.agent_infos["prob"]), ("value", buf.agent_infos["value"])):
+            np.testing.assert_array_equal(got.cpu().numpy().astype(want[key].dtype), want[key],
+                                          err_msg="%s %s batch %d" % (game, key, b))
+        np.testing.assert_array_equal(buf.observations.cpu().numpy(), want["observations"])
+        np.testing.assert_array_equal(buf.extra_observations.cpu().numpy(), want["extra_observations"])
+        got_t = sorted((ti.Length, ti.Return, ti.RawReturn, ti.NonzeroRewards, ti.DiscountedReturn) for ti in infos)
+        assert got_t == sorted(ti.as_tuple() for ti in completed)
+        n_completed += len(got_t)
+        n_done += int(want["dones"].sum())
+        n_need += int(want["need_reset"].sum())
+        assert int(want["actions"].max()) == n_act - 1   # the whole action set is in play
+    assert n_completed >= 256 and n_need >= 256                   # every env ran over length once
+    if GAMES[game][2] > 0:
+        assert n_done > n_need                                    # life losses: done without need_reset
+    smp.shutdown()
+
+
 def test_decorrelation_runs_and_desynchronises():
     rs = np.random.RandomState(1)
     p = np.full((64, 4), 0.25, np.float32)
