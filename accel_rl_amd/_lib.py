@@ -39,7 +39,7 @@ class ArlEnvState(C.Structure):
                 ("noop_ring", _vp), ("noop_cursor", _vp), ("epoch", _vp),
                 ("noop_ring_len", _i32), ("envs_per_stream", _i32),
                 ("done_count", _vp), ("done_int", _vp), ("done_flt", _vp),
-                ("done_capacity", _i32)]
+                ("done_capacity", _i32), ("next_reset", _vp), ("launch_count", _vp)]
 
 
 class ArlRollout(C.Structure):
@@ -85,6 +85,8 @@ _SIGNATURES = {
                                 _vp, _vp, _vp, _vp, _i32, _i32, _f64, _f64, _vp]),
     "arl_env_frame_step": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                                   _i32, _i32, _vp]),
+    "arl_env_step": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
+                            _vp, _vp, _vp, _vp, _i32, _i32, _f64, _f64, _i32, _i32, _vp]),
     "arl_env_reset": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                              _vp, _i32, _vp]),
     "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -273,6 +275,15 @@ def env_act_step(game, state, rollout, prob, value, uniforms, step, mid_batch_re
                                    int(bool(mid_batch_reset)),
                                    float(max_path_length), float(discount), stream_ptr(stream)),
            "arl_env_act_step")
+
+
+def env_step(game, state, rollout, prob, value, uniforms, step, mid_batch_reset, max_path_length, discount,
+             max_start_noops, active=None, single_write=False, stream=None):
+    """act_step + frame_step (+ epoch bump) as ONE launch."""
+    _check(load().arl_env_step(C.byref(game), C.byref(state), C.byref(rollout), ptr(prob), ptr(value),
+                               ptr(uniforms), ptr(active), step, int(bool(mid_batch_reset)),
+                               float(max_path_length), float(discount), int(max_start_noops),
+                               int(bool(single_write)), stream_ptr(stream)), "arl_env_step")
 
 
 def env_frame_step(game, state, rollout, step, max_start_noops, stream=None):

@@ -67,54 +67,73 @@ __device__ __forceinline__ bool has_code(const arl_game& g, int code) {
     return f;
 }
 
-__global__ __launch_bounds__(256) void act_step_kernel(
-    const arl_game g, const arl_env_state st, const arl_rollout ro, const float* __restrict__ prob,
-    const float* __restrict__ value, const double* __restrict__ uniforms,
-    const uint8_t* __restrict__ active, int step, int mid_batch_reset, double max_path_length,
-    double discount) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= st.n_env) return;
-    if (active && !active[e]) {
-        st.reset_flag[e] = 0;
-        st.frame_mode[e] = MODE_SKIP;
-        return;
-    }
-    const int T = ro.horizon, A = g.n_actions;
-    const int64_t row = e * T + step;
+// One env's mutable state in registers.
+struct EnvRegs {
+    int tick, emu_lives, env_lives, phase, traj_len, traj_nz, over, frozen;
+    float traj_ret, traj_raw, traj_disc;
+    double curdisc;
+};
 
-    // ---- action: weighted_sample_n (special.py:22-27) + scatter (sampler.py:143-145)
-    const float* p = prob + e * A;
-    const double u = uniforms[e];
+__device__ __forceinline__ EnvRegs load_env(const arl_env_state& st, const int64_t e) {
+    EnvRegs s;
+    s.tick = st.tick[e]; s.emu_lives = st.emu_lives[e]; s.env_lives = st.env_lives[e]; s.phase = st.phase[e];
+    s.traj_len = st.traj_len[e]; s.traj_nz = st.traj_nonzero[e]; s.over = st.over[e]; s.frozen = st.frozen[e];
+    s.traj_ret = st.traj_ret[e]; s.traj_raw = st.traj_raw[e]; s.traj_disc = st.traj_disc[e];
+    s.curdisc = st.traj_curdisc[e];
+    return s;
+}
+
+// Everything one agent step of one env decides, as values: the scalar part of the step is load_env ->
+// step_compute (pure) -> step_commit (stores).  The fused step kernel runs the first two on EVERY lane of the
+// env's workgroup (same addresses: the loads broadcast), so all lanes know which frames to push without
+// waiting for the one lane that commits.
+struct StepOut {
+    int stepped, emulated;          // 0: env inactive this launch / env frozen for the rest of the batch
+    int a_idx;
+    float reward, raw;
+    int done, need_reset, hit, reset_flag, set_frozen;
+    int fa, fb, mode;
+    EnvRegs s;                      // state after the step (a flagged reset not yet applied)
+    int rec_len, rec_nz;            // completed-trajectory record (hit only)
+    float rec_ret, rec_raw, rec_disc;
+};
+
+__device__ __forceinline__ StepOut step_compute(const arl_game& g, const EnvRegs& in, const float* __restrict__ p,
+                                                const double u, const bool is_active, const int mid_batch_reset,
+                                                const double max_path_length, const double discount) {
+    StepOut o;
+    o.s = in;
+    o.stepped = is_active; o.emulated = 0; o.a_idx = 0; o.reward = 0.f; o.raw = 0.f;
+    o.done = 0; o.need_reset = 0; o.hit = 0; o.reset_flag = 0; o.set_frozen = 0;
+    o.fa = -1; o.fb = 0; o.mode = MODE_SKIP;
+    o.rec_len = 0; o.rec_nz = 0; o.rec_ret = 0.f; o.rec_raw = 0.f; o.rec_disc = 0.f;
+    if (!is_active) return o;
+    const int A = g.n_actions;
+
+    // ---- action: weighted_sample_n (special.py:22-27)
     float c = 0.f;
     int k = 0;
     for (int j = 0; j < A; ++j) {
-        const float pj = p[j];
-        ro.prob[row * A + j] = pj;
-        c += pj;
+        c += p[j];
         k += ((double)c < u) ? 1 : 0;
     }
     const int a_idx = k < A - 1 ? k : A - 1;
-    ro.actions[row] = (uint8_t)a_idx;
-    ro.value[row] = value[e];
-
-    st.reset_flag[e] = 0;
-    if (!mid_batch_reset && st.frozen[e]) {              // worker.py:80 (env sits out the batch)
-        st.frame_mode[e] = MODE_SKIP;
-        return;
-    }
+    o.a_idx = a_idx;
+    if (!mid_batch_reset && in.frozen) return o;         // worker.py:80 (env sits out the batch)
+    o.emulated = 1;
 
     // ---- AtariEnv.step (atari_env.py:65-78)
     const bool has_fire = has_code(g, 1), has_up = has_code(g, 2);
-    Emu emu = {st.tick[e], st.emu_lives[e], st.over[e] != 0};
-    int env_lives = st.env_lives[e];
-    const int phase = st.phase[e];
+    Emu emu = {in.tick, in.emu_lives, in.over != 0};
+    int env_lives = in.env_lives;
+    const int phase = in.phase;
     const int code = g.action_set[a_idx];
     float reward = 0.f;
     for (int i = 0; i < g.frame_skip - 1; ++i) reward += (float)emu_act(emu, code, g.start_lives, g.life_period);
     int fa = (phase + emu.tick) % g.n_frames;            // _get_screen(1)
     reward += (float)emu_act(emu, code, g.start_lives, g.life_period);
     int fb = (phase + emu.tick) % g.n_frames;            // _update_obs: _get_screen(2)
-    uint8_t mode = MODE_PUSH;
+    int mode = MODE_PUSH;
     const float raw = reward;
     if (g.clip_reward) reward = (reward > 0.f) ? 1.f : ((reward < 0.f) ? -1.f : 0.f);
 
@@ -135,12 +154,12 @@ __global__ __launch_bounds__(256) void act_step_kernel(
     }
 
     // ---- TrajInfo.step (sampler/util.py:92-101)
-    int t_len = st.traj_len[e] + 1;
-    float t_ret = st.traj_ret[e] + reward;
-    float t_raw = st.traj_raw[e] + (g.clip_reward ? raw : reward);
-    int t_nz = st.traj_nonzero[e] + (reward != 0.f ? 1 : 0);
-    double cur = st.traj_curdisc[e];
-    float t_disc = st.traj_disc[e] + (float)cur * reward;
+    int t_len = in.traj_len + 1;
+    float t_ret = in.traj_ret + reward;
+    float t_raw = in.traj_raw + (g.clip_reward ? raw : reward);
+    int t_nz = in.traj_nz + (reward != 0.f ? 1 : 0);
+    double cur = in.curdisc;
+    float t_disc = in.traj_disc + (float)cur * reward;
     cur *= discount;
 
     // ---- collector rules (worker.py:42-50 / :84-95)
@@ -150,34 +169,103 @@ __global__ __launch_bounds__(256) void act_step_kernel(
     if (hit) {
         done = true;
         if (over_len && g.episodic_lives) need_reset = true;
-        const int slot = atomicAdd(st.done_count, 1);
-        if (slot < st.done_capacity) {
-            st.done_int[slot * 3] = (int)e;
-            st.done_int[slot * 3 + 1] = t_len;
-            st.done_int[slot * 3 + 2] = t_nz;
-            st.done_flt[slot * 3] = t_ret;
-            st.done_flt[slot * 3 + 1] = t_raw;
-            st.done_flt[slot * 3 + 2] = t_disc;
-        }
+        o.rec_len = t_len; o.rec_nz = t_nz; o.rec_ret = t_ret; o.rec_raw = t_raw; o.rec_disc = t_disc;
         t_len = 0; t_ret = 0.f; t_raw = 0.f; t_nz = 0; t_disc = 0.f; cur = 1.0;
         if (mid_batch_reset) {
-            st.reset_flag[e] = 1;                        // env.reset() happens in frame_step
+            o.reset_flag = 1;                            // env.reset() follows (resolve_reset / reset_regs)
         } else {
-            st.frozen[e] = 1;                            // worker.py:89
+            o.set_frozen = 1;                            // worker.py:89
+            o.s.frozen = 1;
             mode = MODE_SKIP;                            // obs not written (worker.py:96-99)
         }
     }
+    o.reward = reward; o.raw = raw; o.done = done; o.need_reset = need_reset; o.hit = hit;
+    o.fa = fa; o.fb = fb; o.mode = mode;
+    o.s.tick = emu.tick; o.s.emu_lives = emu.lives; o.s.over = emu.over ? 1 : 0; o.s.env_lives = env_lives;
+    o.s.traj_len = t_len; o.s.traj_ret = t_ret; o.s.traj_raw = t_raw; o.s.traj_nz = t_nz; o.s.traj_disc = t_disc;
+    o.s.curdisc = cur;
+    return o;
+}
 
-    ro.rewards[row] = reward;
-    ro.dones[row] = done ? 1 : 0;
-    if (ro.raw_reward) ro.raw_reward[row] = raw;
-    if (ro.need_reset) ro.need_reset[row] = need_reset ? 1 : 0;
+// The stores of one step (one lane): scatter of the served action (sampler.py:143-145), rollout row, env state,
+// completed-trajectory record.  apply_frames: also the frame hand-off fields (after a resolved reset they
+// already hold the reset's frames).
+__device__ __forceinline__ void step_commit(const arl_game& g, const arl_env_state& st, const arl_rollout& ro,
+                                            const float* __restrict__ p, const float v, const StepOut& o,
+                                            const int64_t e, const int step) {
+    st.reset_flag[e] = (uint8_t)o.reset_flag;
+    if (!o.stepped) { st.frame_mode[e] = MODE_SKIP; return; }
+    const int A = g.n_actions;
+    const int64_t row = e * ro.horizon + step;
+    for (int j = 0; j < A; ++j) ro.prob[row * A + j] = p[j];
+    ro.actions[row] = (uint8_t)o.a_idx;
+    ro.value[row] = v;
+    if (!o.emulated) { st.frame_mode[e] = MODE_SKIP; return; }
+    if (o.hit) {
+        const int slot = atomicAdd(st.done_count, 1);
+        if (slot < st.done_capacity) {
+            st.done_int[slot * 3] = (int)e;
+            st.done_int[slot * 3 + 1] = o.rec_len;
+            st.done_int[slot * 3 + 2] = o.rec_nz;
+            st.done_flt[slot * 3] = o.rec_ret;
+            st.done_flt[slot * 3 + 1] = o.rec_raw;
+            st.done_flt[slot * 3 + 2] = o.rec_disc;
+        }
+        if (o.set_frozen) st.frozen[e] = 1;
+    }
+    ro.rewards[row] = o.reward;
+    ro.dones[row] = o.done ? 1 : 0;
+    if (ro.raw_reward) ro.raw_reward[row] = o.raw;
+    if (ro.need_reset) ro.need_reset[row] = o.need_reset ? 1 : 0;
+    st.tick[e] = o.s.tick; st.emu_lives[e] = o.s.emu_lives; st.over[e] = (uint8_t)o.s.over;
+    st.env_lives[e] = o.s.env_lives;
+    st.traj_len[e] = o.s.traj_len; st.traj_ret[e] = o.s.traj_ret; st.traj_raw[e] = o.s.traj_raw;
+    st.traj_nonzero[e] = o.s.traj_nz; st.traj_disc[e] = o.s.traj_disc; st.traj_curdisc[e] = o.s.curdisc;
+    st.frame_a[e] = o.fa; st.frame_b[e] = o.fb; st.frame_mode[e] = (uint8_t)o.mode;
+}
 
-    st.tick[e] = emu.tick; st.emu_lives[e] = emu.lives; st.over[e] = emu.over ? 1 : 0;
-    st.env_lives[e] = env_lives;
-    st.traj_len[e] = t_len; st.traj_ret[e] = t_ret; st.traj_raw[e] = t_raw;
-    st.traj_nonzero[e] = t_nz; st.traj_disc[e] = t_disc; st.traj_curdisc[e] = cur;
-    st.frame_a[e] = fa; st.frame_b[e] = fb; st.frame_mode[e] = mode;
+__global__ __launch_bounds__(256) void act_step_kernel(
+    const arl_game g, const arl_env_state st, const arl_rollout ro, const float* __restrict__ prob,
+    const float* __restrict__ value, const double* __restrict__ uniforms,
+    const uint8_t* __restrict__ active, int step, int mid_batch_reset, double max_path_length,
+    double discount) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= st.n_env) return;
+    const EnvRegs in = load_env(st, e);
+    const float* p = prob + e * g.n_actions;
+    const StepOut o = step_compute(g, in, p, uniforms[e], !active || active[e] != 0, mid_batch_reset,
+                                   max_path_length, discount);
+    step_commit(g, st, ro, p, value[e], o, e, step);
+}
+
+// AtariEnv.reset on registers (atari_env.py:93-100): reset_game, press start, `noops` no-op frames; the new
+// observation is a blank stack with one fresh frame on top.
+__device__ __forceinline__ void reset_regs(const arl_game& g, EnvRegs& s, const int noops, int& fa, int& fb, int& mode) {
+    Emu emu = {0, g.start_lives, false};                  // ale.reset_game(), atari_env.py:94
+    int env_lives = 0;
+    press_start(emu, g, has_code(g, 1), has_code(g, 2), env_lives);   // :96
+    for (int i = 0; i < noops; ++i) emu_act(emu, 0, g.start_lives, g.life_period);   // :97-98
+    s.tick = emu.tick; s.emu_lives = emu.lives; s.over = emu.over ? 1 : 0; s.env_lives = env_lives;
+    fa = -1;
+    fb = (s.phase + emu.tick) % g.n_frames;
+    mode = MODE_BLANK_PUSH;                               // _reset_obs + one _update_obs (:95,99)
+}
+
+// Will step_compute flag this env for a mid-batch reset in its NEXT step?  None of its rules depends on the
+// sampled action (the action only enters the reward): game over and life loss follow from the emulator's tick,
+// over-length from the trajectory length.  Every env's own workgroup evaluates this once its state is final
+// and leaves it in st.next_reset for the next launch (ping-pong by launch parity, like the cursors), where
+// the other workgroups of the worker stream read it: each then knows its env's rank among the stream's resets
+// (= which start no-op draw is its own) and the stream leader their number, without a second launch.
+__device__ __forceinline__ bool will_reset(const arl_game& g, const EnvRegs& s, const double max_path_length) {
+    Emu emu = {s.tick, s.emu_lives, s.over != 0};
+    for (int k = 0; k < g.frame_skip; ++k) emu_act(emu, 0, g.start_lives, g.life_period);
+    const bool need_reset = emu.over;
+    const bool lost = (emu.lives < s.env_lives) && (emu.lives > 0);
+    const bool done = g.episodic_lives ? (lost || need_reset) : emu.over;
+    const bool over_len = (double)(s.traj_len + 1) > max_path_length;
+    const bool reset_cond = g.episodic_lives ? need_reset : true;
+    return over_len || (done && reset_cond);
 }
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -213,11 +301,12 @@ __device__ __forceinline__ uint2 box8(uint4 a0, uint4 a1, uint4 b0, uint4 b1) {
 // start-noop draws inside a stream = env order among the envs that reset in
 // this launch (the reference worker loops over its envs, worker.py:38-50).
 __device__ void resolve_reset(const arl_game& g, const arl_env_state& st, int64_t e,
-                              const uint8_t* flags, int max_start_noops, int parity) {
+                              const uint8_t* flags, int max_start_noops, int parity, int known_rank = -1) {
     const int64_t per = st.envs_per_stream;
     const int64_t w = e / per, g0 = w * per;
-    int rank = 0;
-    for (int64_t i = g0; i < e; ++i) rank += (flags ? (flags[i] != 0) : 1);
+    int rank = known_rank < 0 ? 0 : known_rank;
+    if (known_rank < 0)
+        for (int64_t i = g0; i < e; ++i) rank += (flags ? (flags[i] != 0) : 1);
     const int64_t n_streams = (st.n_env + per - 1) / per;
     const int64_t cur = st.noop_cursor[parity * n_streams + w];
     int noops = 0;
@@ -232,6 +321,55 @@ __device__ void resolve_reset(const arl_game& g, const arl_env_state& st, int64_
     st.frame_a[e] = -1;
     st.frame_b[e] = (st.phase[e] + emu.tick) % g.n_frames;
     st.frame_mode[e] = MODE_BLANK_PUSH;                   // _reset_obs + one _update_obs (:95,99)
+}
+
+// The pixel part of one env step, one workgroup: new frame = rounded 2x2 box of the cropped max of bank
+// frames fa (< 0: none) and fb; new stack = the previous one (`prev`; zeros in MODE_BLANK_PUSH) shifted by one
+// with the new frame on top, written to out0 and (if given) out1.  prev may alias out0: a thread reads and
+// writes the same pixels of every plane, oldest plane first.
+// DYNAMIC: waves draw 64-unit chunks from an LDS counter instead of a fixed stride -- in the fused step kernel
+// wave 0 arrives late (its lane 0 commits the scalar results first) and the other waves take up its share.
+template <bool DYNAMIC = false>
+__device__ __forceinline__ void push_frame(const arl_game& g, const int fa_i, const int fb_i, const int mode,
+                                           const uint8_t* prev, uint8_t* out0, uint8_t* out1, const int tid,
+                                           int* next_unit = nullptr) {
+    const int F = g.n_stack;
+    const uint8_t* fb = g.bank + (int64_t)fb_i * RAW_FRAME;
+    const uint8_t* fa = (fa_i >= 0) ? g.bank + (int64_t)fa_i * RAW_FRAME : nullptr;
+    auto unit = [&](const int un) {
+        const int y = un / UNITS_PER_ROW, xb = un - y * UNITS_PER_ROW;
+        const int src = (2 * y) * ARL_RAW_W + xb * 16;
+        const uint4 b0 = *reinterpret_cast<const uint4*>(fb + src);
+        const uint4 b1 = *reinterpret_cast<const uint4*>(fb + src + ARL_RAW_W);
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
+        if (fa) {
+            a0 = *reinterpret_cast<const uint4*>(fa + src);
+            a1 = *reinterpret_cast<const uint4*>(fa + src + ARL_RAW_W);
+        }
+        const uint2 img = box8(a0, a1, b0, b1);
+        const int o = un * 8;
+        // stack: oldest -> newest (atari_env.py:156-157)
+        for (int f = 0; f < F - 1; ++f) {
+            uint2 pv = make_uint2(0, 0);
+            if (mode == MODE_PUSH) pv = *reinterpret_cast<const uint2*>(prev + (f + 1) * OBS_FRAME + o);
+            *reinterpret_cast<uint2*>(out0 + f * OBS_FRAME + o) = pv;
+            if (out1) *reinterpret_cast<uint2*>(out1 + f * OBS_FRAME + o) = pv;
+        }
+        *reinterpret_cast<uint2*>(out0 + (F - 1) * OBS_FRAME + o) = img;
+        if (out1) *reinterpret_cast<uint2*>(out1 + (F - 1) * OBS_FRAME + o) = img;
+    };
+    if constexpr (DYNAMIC) {
+        const int lane = tid & 63;
+        for (;;) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(next_unit, 64);
+            base = __shfl(base, 0, 64);
+            if (base >= UNITS) break;
+            if (base + lane < UNITS) unit(base + lane);
+        }
+    } else {
+        for (int un = tid; un < UNITS; un += 256) unit(un);
+    }
 }
 
 // RESET_ONLY: flags come from the caller (NULL = all), only step_obs is written.
@@ -261,45 +399,109 @@ __global__ __launch_bounds__(256) void frame_step_kernel(const arl_game g, const
             st.noop_cursor[(parity ^ 1) * n_streams + w] = st.noop_cursor[parity * n_streams + w] + total;
         }
         if (RESET_ONLY && flagged) st.frozen[e] = 0;
+        // arl_env_step's reset forecast (will_reset): a freshly reset env starts a trajectory (Length 0, so no
+        // over-length at the limits >= 1 that arl_env_step accepts); the others keep theirs
+        if (RESET_ONLY && st.next_reset) {
+            const int fpar = st.launch_count[0] & 1;
+            st.next_reset[(int64_t)(fpar ^ 1) * st.n_env + e] =
+                flagged ? (uint8_t)will_reset(g, load_env(st, e), 1e300) : st.next_reset[(int64_t)fpar * st.n_env + e];
+        }
     }
     __syncthreads();
-    const int mode = s_mode;
-    if (mode == MODE_SKIP) return;
-
-    const int F = g.n_stack;
-    const uint8_t* fb = g.bank + (int64_t)s_fb * RAW_FRAME;
-    const uint8_t* fa = (s_fa >= 0) ? g.bank + (int64_t)s_fa * RAW_FRAME : nullptr;
-    uint8_t* cur = ro.step_obs + e * (int64_t)F * OBS_FRAME;
+    if (s_mode == MODE_SKIP) return;
+    uint8_t* cur = ro.step_obs + e * (int64_t)g.n_stack * OBS_FRAME;
     uint8_t* dst = nullptr;
     if (!RESET_ONLY && step + 1 < ro.horizon)             // worker.py:52-53
-        dst = ro.observations + (e * ro.horizon + step + 1) * (int64_t)F * OBS_FRAME;
+        dst = ro.observations + (e * ro.horizon + step + 1) * (int64_t)g.n_stack * OBS_FRAME;
+    push_frame<false>(g, s_fa, s_fb, s_mode, cur, cur, dst, tid);
+}
 
-    for (int un = tid; un < UNITS; un += blockDim.x) {
-        const int y = un / UNITS_PER_ROW, xb = un - y * UNITS_PER_ROW;
-        const int src = (2 * y) * ARL_RAW_W + xb * 16;
-        const uint4 b0 = *reinterpret_cast<const uint4*>(fb + src);
-        const uint4 b1 = *reinterpret_cast<const uint4*>(fb + src + ARL_RAW_W);
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0;
-        if (fa) {
-            a0 = *reinterpret_cast<const uint4*>(fa + src);
-            a1 = *reinterpret_cast<const uint4*>(fa + src + ARL_RAW_W);
+// The whole env side of one agent step in ONE launch, one workgroup per env:
+//   (1) every lane evaluates will_reset for one env of this env's worker stream -> this env's rank among the
+//       stream's resets and (stream leader) their number, i.e. what frame_step used to read from the flags
+//       act_step had stored one launch earlier;
+//   (2) lane 0 runs act_one (sampling, scatter, emulator, rules, TrajInfo), resolves a pending reset and, as
+//       stream leader, publishes the stream's next no-op cursor;
+//   (3) the workgroup pushes the new frame (push_frame);
+//   (4) the last workgroup to arrive bumps the launch epoch (st.epoch[1] is the arrival ticket), so no
+//       epoch_kernel launch follows.
+// single_write (needs mid_batch_reset: no env sits a step out): the stacked observation is written ONCE -- to
+// observations[e][step + 1], or to step_obs after the batch's last step -- and the previous stack is read from
+// observations[e][step]; the policy then reads the current observations as rows e * horizon + step of the
+// rollout buffer instead of step_obs.  Otherwise step_obs is kept current at every step (second write).
+__global__ __launch_bounds__(256) void env_step_kernel(
+    const arl_game g, const arl_env_state st, const arl_rollout ro, const float* __restrict__ prob,
+    const float* __restrict__ value, const double* __restrict__ uniforms,
+    const uint8_t* __restrict__ active, int step, int mid_batch_reset, double max_path_length,
+    double discount, int max_start_noops, int single_write) {
+    const int64_t e = blockIdx.x;
+    const int tid = threadIdx.x;
+    __shared__ int s_next_unit;
+    const int parity = st.epoch[0] & 1;
+    const int fpar = st.launch_count[0] & 1;              // this state's own launch parity (the epoch is shared)
+    const int64_t per = st.envs_per_stream;
+    const int64_t w = e / per, g0 = w * per;
+    const int64_t hi = g0 + per < st.n_env ? g0 + per : st.n_env;
+    const int64_t n_streams = (st.n_env + per - 1) / per;
+    // ---- every lane: this env's state, served distribution and uniform (uniform addresses: broadcast loads)
+    const EnvRegs in = load_env(st, e);
+    const float* p = prob + e * g.n_actions;
+    const double u = uniforms[e];
+    const float v = value[e];
+    const bool is_active = !active || active[e] != 0;
+    const int64_t cursor = st.noop_cursor[parity * n_streams + w];
+    const uint8_t* flag_now = st.next_reset + (int64_t)fpar * st.n_env;         // written by the previous launch
+    int rank = 0, total = 0;
+    if (mid_batch_reset && max_start_noops > 0) {         // (no draws otherwise: nothing to rank)
+        for (int64_t base = g0; base < hi; base += 256) {
+            const int64_t i = base + tid;
+            const bool f = i < hi && flag_now[i] != 0 && (!active || active[i] != 0);
+            rank += __syncthreads_count(f && i < e);
+            total += __syncthreads_count(f);
         }
-        const uint2 img = box8(a0, a1, b0, b1);
-        const int o = un * 8;
-        // stack: oldest -> newest (atari_env.py:156-157)
-        for (int f = 0; f < F - 1; ++f) {
-            uint2 prev = make_uint2(0, 0);
-            if (mode == MODE_PUSH) prev = *reinterpret_cast<const uint2*>(cur + (f + 1) * OBS_FRAME + o);
-            *reinterpret_cast<uint2*>(cur + f * OBS_FRAME + o) = prev;
-            if (dst) *reinterpret_cast<uint2*>(dst + f * OBS_FRAME + o) = prev;
+    }
+    const uint8_t carried = flag_now[e];
+    if (tid == 0) s_next_unit = 0;
+    __syncthreads();                                      // every lane has its inputs: lane 0 may now overwrite them
+    StepOut o = step_compute(g, in, p, u, is_active, mid_batch_reset, max_path_length, discount);
+    if (o.reset_flag) {                                   // env.reset() (worker.py:47): start no-ops from the stream's ring
+        int noops = 0;
+        if (max_start_noops > 0)                          // randint(0, 1) draws nothing
+            noops = st.noop_ring[w * st.noop_ring_len + (cursor + rank) % st.noop_ring_len];
+        reset_regs(g, o.s, noops, o.fa, o.fb, o.mode);
+    }
+    if (tid == 0) {
+        step_commit(g, st, ro, p, v, o, e, step);
+        if (e == g0) st.noop_cursor[(parity ^ 1) * n_streams + w] = cursor + total;   // stream leader: next cursor
+        // this env's flag for the next launch: recomputed if it stepped, carried over if it sat this one out
+        st.next_reset[(int64_t)(fpar ^ 1) * st.n_env + e] = is_active ? (uint8_t)will_reset(g, o.s, max_path_length)
+                                                                     : carried;
+    }
+    if (o.mode != MODE_SKIP) {
+        const int64_t row_bytes = (int64_t)g.n_stack * OBS_FRAME;
+        uint8_t* cur = ro.step_obs + e * row_bytes;
+        uint8_t* next = step + 1 < ro.horizon ? ro.observations + (e * ro.horizon + step + 1) * row_bytes : nullptr;
+        if (single_write)
+            push_frame<true>(g, o.fa, o.fb, o.mode, ro.observations + (e * ro.horizon + step) * row_bytes,
+                             next ? next : cur, nullptr, tid, &s_next_unit);
+        else
+            push_frame<true>(g, o.fa, o.fb, o.mode, cur, cur, next, tid, &s_next_unit);   // worker.py:52-53
+    }
+    if (tid == 0) {
+        const int arrived = atomicAdd(st.epoch + 1, 1);
+        if (arrived == (int)st.n_env - 1) {               // everyone has read both counters before arriving
+            st.epoch[1] = 0;
+            st.epoch[0] += 1;
+            st.launch_count[0] += 1;
         }
-        *reinterpret_cast<uint2*>(cur + (F - 1) * OBS_FRAME + o) = img;
-        if (dst) *reinterpret_cast<uint2*>(dst + (F - 1) * OBS_FRAME + o) = img;
     }
 }
 
 // bump the launch epoch AFTER a frame_step launch (single lane)
-__global__ void epoch_kernel(int32_t* epoch) { epoch[0] += 1; }
+__global__ void epoch_kernel(int32_t* epoch, int32_t* launch_count) {
+    epoch[0] += 1;
+    if (launch_count) launch_count[0] += 1;
+}
 
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ a,
                                                          const uint8_t* __restrict__ b,
@@ -369,8 +571,29 @@ extern "C" int arl_env_frame_step(const arl_game* game, const arl_env_state* st,
                        *st, *ro, (const uint8_t*)nullptr, (int)step, (int)max_start_noops);
     rc = arl::check_launch("frame_step_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(epoch_kernel, dim3(1), dim3(1), 0, s, st->epoch);
+    hipLaunchKernelGGL(epoch_kernel, dim3(1), dim3(1), 0, s, st->epoch, (int32_t*)nullptr);
     return arl::check_launch("epoch_kernel");
+}
+
+extern "C" int arl_env_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                            const float* prob, const float* value, const double* uniforms,
+                            const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
+                            double max_path_length, double discount, int32_t max_start_noops,
+                            int32_t single_write, void* stream) {
+    int rc = check_env_args(game, st, ro);
+    if (rc) return rc;
+    ARL_REQUIRE(prob && value && uniforms, ARL_E_ARG, "null policy outputs");
+    ARL_REQUIRE(ro->rewards && ro->dones && ro->actions && ro->prob && ro->value && ro->observations, ARL_E_ARG,
+                "null rollout arrays");
+    ARL_REQUIRE(step >= 0 && step < ro->horizon, ARL_E_RANGE, "step outside horizon");
+    ARL_REQUIRE(!single_write || (mid_batch_reset && !active_or_null), ARL_E_ARG,
+                "single_write needs mid_batch_reset and every env stepping");
+    ARL_REQUIRE(st->next_reset && st->launch_count, ARL_E_ARG, "arl_env_step needs st->next_reset and st->launch_count");
+    ARL_REQUIRE(max_path_length >= 1.0, ARL_E_RANGE, "arl_env_step needs max_path_length >= 1");
+    hipLaunchKernelGGL(env_step_kernel, dim3((unsigned)st->n_env), dim3(256), 0, (hipStream_t)stream, *game, *st,
+                       *ro, prob, value, uniforms, active_or_null, (int)step, (int)mid_batch_reset,
+                       max_path_length, discount, (int)max_start_noops, (int)single_write);
+    return arl::check_launch("env_step_kernel");
 }
 
 extern "C" int arl_env_reset(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
@@ -382,7 +605,7 @@ extern "C" int arl_env_reset(const arl_game* game, const arl_env_state* st, cons
                        *st, *ro, flags_or_null, 0, (int)max_start_noops);
     rc = arl::check_launch("frame_step_kernel<reset>");
     if (rc) return rc;
-    hipLaunchKernelGGL(epoch_kernel, dim3(1), dim3(1), 0, s, st->epoch);
+    hipLaunchKernelGGL(epoch_kernel, dim3(1), dim3(1), 0, s, st->epoch, st->next_reset ? st->launch_count : (int32_t*)nullptr);
     return arl::check_launch("epoch_kernel");
 }
 

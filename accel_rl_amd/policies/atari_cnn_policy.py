@@ -69,6 +69,9 @@ class AtariCnnPolicy(object):
     # conv 1 reads the u8 observations directly when its geometry allows (subclasses that build their
     # own scaled inputs switch this off)
     _u8_conv1 = True
+    # prob_value(observations, rows) reads rows of a larger buffer in place (GpuVecSampler then keeps no second,
+    # contiguous copy of the current observations up to date); subclasses with their own prob_value say no
+    serves_rows = True
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads,
                  hidden_sizes=(), pixel_scale=255., initial_param_values=None):
@@ -322,11 +325,12 @@ class AtariCnnPolicy(object):
             k += 2
         return acts, hids
 
-    def prob_value(self, observations):
+    def prob_value(self, observations, rows=None):
         """Batched inference on device uint8 observations (the sampler's hot call;
-        reference: _f_prob_value, atari_cnn_policy.py:67,109)."""
+        reference: _f_prob_value, atari_cnn_policy.py:67,109).  rows (i32[B]): serve observations[rows]
+        without materialising them (the sampler's current observations are rows of its rollout buffer)."""
         with torch.no_grad():
-            x = self._scaled(observations)
+            x = self._scaled(observations, rows)
             b = x.shape[0]
             _, hids = self._trunk(x)
             prob = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)

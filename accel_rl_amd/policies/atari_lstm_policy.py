@@ -30,6 +30,7 @@ class RecurrentCnnPolicy(AtariCnnPolicy):
     set self._k_x = index of the internal [W_x^T, W_h^T, b] triple relative to the first hidden
     tensor), `_cell_fwd` and `_cell_bwd`."""
 
+    serves_rows = False         # own prob_value: the sampler keeps a contiguous copy of the current observations
     _gate_mult = 4
     _saved_mult = 4
     _separate_dgh = False       # gradient wrt h_prev W_h differs from the one wrt x W_x (GRU)

@@ -28,6 +28,7 @@ class QPolicyBase(AtariCnnPolicy):
     """Subclasses give `_head_width` (columns of the output layer as stored), `_serve(out, override, onehot,
     greedy)` (the action kernel) and the four `_head_*` layout hooks."""
 
+    serves_rows = False         # own prob_value: the sampler keeps a contiguous copy of the current observations
     _epsilon = 1
     _dueling = False
 

@@ -172,10 +172,10 @@ class GpuVecSampler(BaseMbSampler):
             frozen=u8(n), traj_len=i32(n), traj_nonzero=i32(n), traj_ret=f32(n), traj_raw=f32(n),
             traj_disc=f32(n), traj_curdisc=torch.ones(n, dtype=torch.float64, device=dev),
             frame_a=i32(n), frame_b=i32(n), frame_mode=u8(n), reset_flag=u8(n),
-            noop_ring=u8(n_streams, NOOP_RING),
+            noop_ring=u8(n_streams, NOOP_RING), next_reset=u8(2, n), launch_count=i32(1),
         )
         # the batch's small results live in ONE block so that one D2H copy mirrors them (see _host)
-        spec = (("noop_cursor", (2, n_streams), torch.int64), ("epoch", (1,), torch.int32),
+        spec = (("noop_cursor", (2, n_streams), torch.int64), ("epoch", (2,), torch.int32),
                 ("done_count", (1,), torch.int32), ("done_int", (n * t, 3), torch.int32),
                 ("done_flt", (n * t, 3), torch.float32))
         self._results_block, views = _packed_block(spec, dev)
@@ -206,7 +206,7 @@ class GpuVecSampler(BaseMbSampler):
         for k in ("tick", "emu_lives", "env_lives", "phase", "over", "frozen", "traj_len",
                   "traj_nonzero", "traj_ret", "traj_raw", "traj_disc", "traj_curdisc", "frame_a",
                   "frame_b", "frame_mode", "reset_flag", "noop_ring", "noop_cursor", "epoch",
-                  "done_count", "done_int", "done_flt"):
+                  "done_count", "done_int", "done_flt", "next_reset", "launch_count"):
             setattr(s, k, self._st[k].data_ptr())
         s.noop_ring_len, s.envs_per_stream, s.done_capacity = NOOP_RING, self.envs_per, n * t
         self._state = s
@@ -244,6 +244,13 @@ class GpuVecSampler(BaseMbSampler):
         assert buffer_length(self.samples_buf) == self.sample_size
         policy.reset(n_batch=n if self._recurrent else self.n_parallel * self.envs_per)
         self._rollout = self._make_rollout(self.samples_buf)
+        # The current observation of env e at step s is row e * t + s of the rollout buffer.  A policy that serves
+        # rows of a buffer in place lets the step kernel write each stacked observation once (no second,
+        # contiguous copy kept current in step_obs); needs every env to step at every step (mid_batch_reset).
+        self._single_write = bool(self.mid_batch_reset and not self._recurrent and
+                                  getattr(policy, "serves_rows", False) and self._kernel_max_path_length() >= 1)
+        self._step_rows = (torch.arange(n, dtype=torch.int32, device=dev)[None, :] * t +
+                           torch.arange(t, dtype=torch.int32, device=dev)[:, None]).contiguous()
         self._uniforms_host = torch.empty(t * n, dtype=torch.float64).pin_memory()
         self._uniforms = torch.empty((t, n), dtype=torch.float64, device=dev)
         # pinned mirrors of the batch's small results (completed-episode records, no-op ring cursors):
@@ -316,11 +323,12 @@ class GpuVecSampler(BaseMbSampler):
                     buf.agent_infos[key].view(n, t, -1)[:, s].copy_(state)
                 if not self.mid_batch_reset:
                     self._prev_frozen.copy_(self._st.frozen)
+            elif self._single_write:
+                prob, value = self.policy.prob_value(buf.observations, self._step_rows[s])
             else:
                 prob, value = self.policy.prob_value(self.step_obs)
-            _lib.env_act_step(self._game, self._state, ro, prob, value, self._uniforms[s], s,
-                              self.mid_batch_reset, self._kernel_max_path_length(), self.discount)
-            _lib.env_frame_step(self._game, self._state, ro, s, env.max_start_noops)
+            self._env_step(self._state, ro, prob, value, self._uniforms[s], s, self.mid_batch_reset,
+                           single_write=self._single_write)
             if self._recurrent:
                 # step_buf.reset -> policy.reset_one before the next serve (worker.py:46,88; sampler.py:135-138)
                 hit = self._st.reset_flag if self.mid_batch_reset else \
@@ -335,6 +343,18 @@ class GpuVecSampler(BaseMbSampler):
     def _kernel_max_path_length(self):
         """The kernels end an episode when Length > limit (worker.py:42)."""
         return self.max_path_length
+
+    def _env_step(self, state, ro, prob, value, uniforms, step, mid_batch_reset, active=None, single_write=False):
+        """The env side of one agent step: ONE launch (arl_env_step); the two-launch form only for a limit below
+        one step, which the fused kernel's reset forecast does not cover."""
+        limit = self._kernel_max_path_length()
+        if limit >= 1:
+            _lib.env_step(self._game, state, ro, prob, value, uniforms, step, mid_batch_reset, limit,
+                          self.discount, self.env.max_start_noops, active=active, single_write=single_write)
+        else:
+            _lib.env_act_step(self._game, state, ro, prob, value, uniforms, step, mid_batch_reset, limit,
+                              self.discount, active=active)
+            _lib.env_frame_step(self._game, state, ro, step, self.env.max_start_noops)
 
     def _capture(self):
         """Warm up on a side stream, then capture one batch into a hipGraph."""
@@ -381,7 +401,7 @@ class GpuVecSampler(BaseMbSampler):
         if self.env.max_start_noops <= 0:
             return
         if epoch is None:
-            epoch = int(self._st.epoch.item())
+            epoch = int(self._st.epoch[0].item())
             cursors = self._st.noop_cursor.cpu().numpy()
         cursor = cursors[epoch & 1]
         dirty = False
@@ -421,9 +441,7 @@ class GpuVecSampler(BaseMbSampler):
         for k in range(int(counts.max().item()) if n else 0):
             active = (counts > k).to(torch.uint8)
             u = torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
-            _lib.env_act_step(self._game, self._state, ro, prob, value, u, 0, True,
-                              self.max_path_length, self.discount, active=active)
-            _lib.env_frame_step(self._game, self._state, ro, 0, env.max_start_noops)
+            self._env_step(self._state, ro, prob, value, u, 0, True, active=active)
             if k % 256 == 255:
                 self._st.done_count.zero_()
                 self._refill_noop_ring(2 * self.n_parallel)

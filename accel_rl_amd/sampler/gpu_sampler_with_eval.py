@@ -48,12 +48,14 @@ class GpuVecEvalSampler(GpuVecSampler):
             frame_a=i32(ne), frame_b=i32(ne), frame_mode=u8(ne), reset_flag=u8(ne),
             # the worker's RNG stream is shared with its training envs: same ring, cursors, launch epoch
             noop_ring=st.noop_ring, noop_cursor=st.noop_cursor, epoch=st.epoch,
-            done_count=i32(1), done_int=i32(cap, 3), done_flt=f32(cap, 3))
+            done_count=i32(1), done_int=i32(cap, 3), done_flt=f32(cap, 3),
+            next_reset=u8(2, ne), launch_count=i32(1))
         s = _lib.ArlEnvState()
         s.n_env = ne
         for k in ("tick", "emu_lives", "env_lives", "phase", "over", "frozen", "traj_len", "traj_nonzero",
                   "traj_ret", "traj_raw", "traj_disc", "traj_curdisc", "frame_a", "frame_b", "frame_mode",
-                  "reset_flag", "noop_ring", "noop_cursor", "epoch", "done_count", "done_int", "done_flt"):
+                  "reset_flag", "noop_ring", "noop_cursor", "epoch", "done_count", "done_int", "done_flt",
+                  "next_reset", "launch_count"):
             setattr(s, k, self._eval_st[k].data_ptr())
         s.noop_ring_len, s.envs_per_stream, s.done_capacity = self._state.noop_ring_len, self.eval_envs_per, cap
         self._eval_state = s
@@ -92,9 +94,9 @@ class GpuVecEvalSampler(GpuVecSampler):
                 if hasattr(self.policy, "set_step"):
                     self.policy.set_step(s)
                 prob, value = self.policy.prob_value(self.eval_step_obs)
-                _lib.env_act_step(self._game, self._eval_state, self._eval_rollout, prob, value,
-                                  self._eval_uniforms[s], 0, True, self._kernel_max_path_length(), self.discount)
-                _lib.env_frame_step(self._game, self._eval_state, self._eval_rollout, 0, env.max_start_noops)
+                self._env_step(self._eval_state, self._eval_rollout, prob, value, self._eval_uniforms[s], 0, True)
+                if s % 256 == 255:          # many short episodes: keep the start no-op ring ahead of the device
+                    self._refill_noop_ring(2 * self.n_parallel)
             torch.cuda.current_stream(self.device).synchronize()
             count = min(int(est.done_count.item()), self._eval_state.done_capacity)
             infos = []

@@ -154,11 +154,13 @@ def kernel_table(device, sampler, algo, policy, reps=20):
     snap = {k: v.clone() for k, v in sampler._st.items()}
     obs_snap = sampler.step_obs.clone()
     ro, env = sampler._rollout, sampler.env
-    add("act_step", lambda: _lib.env_act_step(sampler._game, sampler._state, ro, prob, val, u, 0, True,
-                                              27e3, 0.99), n * (4 * a + 8 + 4 + 4 * a + 1 + 4 + 4 + 1 + 4 + 1), t)
-    # frame_step: 2 raw frames read + previous stack read + stacked obs written twice
-    add("frame_step(+epoch)", lambda: _lib.env_frame_step(sampler._game, sampler._state, ro, 0, env.max_start_noops),
-        n * (2 * 33600 + 3 * 8320 + 2 * 33280), t)
+    # the env side of a step is ONE launch; bytes = SURVEY 8d's algorithmic figure (2 raw frames in, 1 preprocessed
+    # frame out = 75 520 B per env-step) -- what the launch really moves is more: + the previous stack read
+    # (24 960 B) + the whole stacked observation written (33 280 B, once; twice for policies that do not serve
+    # rows of the rollout buffer)
+    add("env_step (act + frame + epoch bump, one launch)",
+        lambda: _lib.env_step(sampler._game, sampler._state, ro, prob, val, u, 0, True, 27e3, 0.99,
+                              env.max_start_noops, single_write=sampler._single_write), n * 75520, t)
     for k, v in snap.items():
         sampler._st[k].copy_(v)
     sampler.step_obs.copy_(obs_snap)

@@ -148,7 +148,7 @@ typedef struct arl_env_state {
      * (accel_rl/envs/atari_env.py:97 draws from the worker's numpy RNG)       */
     const uint8_t* noop_ring;   /* u8[n_streams][noop_ring_len] pre-drawn counts */
     int64_t* noop_cursor;       /* i64[2][n_streams], ping-pong by epoch parity  */
-    int32_t* epoch;             /* i32[1] number of frame_step launches so far   */
+    int32_t* epoch;             /* i32[2]: [0] number of env launches so far, [1] arrival ticket of arl_env_step */
     int32_t  noop_ring_len;
     int32_t  envs_per_stream;
     /* completed-trajectory records (the reference's traj_infos_queue,
@@ -157,6 +157,15 @@ typedef struct arl_env_state {
     int32_t* done_int;          /* i32[done_capacity][3] = env, Length, NonzeroRewards */
     float*   done_flt;          /* f32[done_capacity][3] = Return, RawReturn, DiscountedReturn */
     int32_t  done_capacity;
+    /* arl_env_step only (both may be NULL for the two-launch path).
+     * next_reset: u8[2][n_env], ping-pong by the parity of launch_count; [p][e] != 0 <=> env e will be flagged
+     * for a mid-batch reset by its next step.  Written by arl_env_step and arl_env_reset for the launch that
+     * follows; arl_env_act_step / arl_env_frame_step do not maintain it (after using them, reset every env with
+     * arl_env_reset before the next arl_env_step).
+     * launch_count: i32[1], arl_env_step / arl_env_reset launches on THIS state (the epoch above may be shared
+     * with another state that draws from the same no-op streams, e.g. a worker's evaluation envs).          */
+    uint8_t* next_reset;
+    int32_t* launch_count;
 } arl_env_state;
 
 /* Rollout batch buffer, env-major (accel_rl/sampler/act_server/buffers.py:7-38).
@@ -201,6 +210,21 @@ int arl_env_act_step(const arl_game* game, const arl_env_state* st, const arl_ro
  *   max_start_noops: atari_env.py:24                                          */
 int arl_env_frame_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
                        int32_t step, int32_t max_start_noops, void* stream);
+
+/* arl_env_act_step + arl_env_frame_step as ONE launch (one workgroup per env; lane 0 does the scalar rules,
+ * the workgroup the pixels, the last workgroup to finish advances the launch epoch): the env side of one agent
+ * step of serve_actions / ResetCollector.collect, overlap/sampler.py:129-145, overlap/worker.py:37-59,75-106,
+ * envs/atari_env.py:65-78,93-100,151-191.  Same arguments and results as the two calls in sequence.
+ * Needs st->next_reset and max_path_length >= 1.
+ *   single_write != 0 (needs mid_batch_reset != 0 and active_or_null == NULL): the new stacked observation is
+ *   written once -- to observations[env*horizon + step + 1], or to step_obs after the last step of the batch --
+ *   and the previous stack is read from observations[env*horizon + step] (which the caller has filled for
+ *   step 0, overlap/worker.py:30-32); step_obs is then only current after the last step.                      */
+int arl_env_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                 const float* prob, const float* value, const double* uniforms,
+                 const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
+                 double max_path_length, double discount, int32_t max_start_noops,
+                 int32_t single_write, void* stream);
 
 /* Reset every env whose flag is set (u8[n_env]; NULL = all): start_envs with
  * max_decorrelation_steps == 0 (sampler/util.py:26-33) and

@@ -28,9 +28,11 @@ class DeviceTablePolicy(object):
     """Device twin of the fixtures' table policy: key = pixel sum mod 64."""
     recurrent = False
 
-    def __init__(self, prob_table, value_table):
+    def __init__(self, prob_table, value_table, serves_rows=False):
         self.prob_table = torch.from_numpy(prob_table).to(DEV)
         self.value_table = torch.from_numpy(value_table).to(DEV)
+        self.serves_rows = serves_rows       # True: the sampler hands over (rollout buffer, rows) and writes each
+        self.row_calls = 0                   # stacked observation once (arl_env_step single_write)
 
     def _keys(self, obs):
         return obs.reshape(obs.shape[0], -1).sum(dim=1, dtype=torch.int64) % 64
@@ -38,7 +40,10 @@ class DeviceTablePolicy(object):
     def reset(self, n_batch):
         pass
 
-    def prob_value(self, obs):
+    def prob_value(self, obs, rows=None):
+        if rows is not None:
+            self.row_calls += 1
+            obs = obs[rows.long()]
         k = self._keys(obs)
         return self.prob_table[k].contiguous(), self.value_table[k].contiguous()
 
@@ -60,7 +65,7 @@ class HostTablePolicy(object):
 
 
 def make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, mid_batch_reset, max_path_length,
-                     env_kwargs, tables, discount, use_graph):
+                     env_kwargs, tables, discount, use_graph, serves_rows=False):
     from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
     from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
     from accel_rl_amd.util import logger
@@ -73,19 +78,23 @@ def make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, mid_batch_reset,
                         device=DEV, use_graph=use_graph)
     np.random.seed(seed)                                   # runner: set_seed(seed)
     smp.initialize(seed=seed + 1, affinities=dict(), discount=discount, need_extra_obs=True)
-    smp.policy_init(DeviceTablePolicy(*tables))
+    smp.policy_init(DeviceTablePolicy(*tables, serves_rows=serves_rows))
     return smp
 
 
+@pytest.mark.parametrize("serves_rows", [False, True])
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("tag", ["breakout", "pong_maxlen", "seaquest_nomid", "breakout_noop0"])
-def test_gpu_sampler_matches_reference_rollout(tag, use_graph):
+def test_gpu_sampler_matches_reference_rollout(tag, use_graph, serves_rows):
+    """serves_rows: the policy reads the current observations as rows of the rollout buffer and the step kernel
+    writes each stacked observation once (only with mid_batch_reset; 'seaquest_nomid' keeps step_obs current)."""
     g = load_golden("g7_rollout_" + tag)
     n_parallel, envs_per, horizon, n_batches, seed, mbr, maxlen = [int(x) for x in g["cfg"]]
     smp = make_gpu_sampler(str(g["game"]), horizon, n_parallel, envs_per, seed, bool(mbr),
                            np.inf if maxlen < 0 else maxlen,
                            dict(ast.literal_eval(str(g["env_args"]))),
-                           (g["prob_table"], g["value_table"]), float(g["discount"]), use_graph)
+                           (g["prob_table"], g["value_table"]), float(g["discount"]), use_graph, serves_rows)
+    assert smp._single_write == (serves_rows and bool(mbr))
     t = horizon
     traj = []
     for b in range(n_batches):
@@ -114,6 +123,7 @@ def test_gpu_sampler_matches_reference_rollout(tag, use_graph):
                          float(ti.NonzeroRewards), float(ti.DiscountedReturn)))
     want = sorted((int(b),) + tuple(float(x) for x in row) for b, row in zip(g["traj_batch"], g["traj"]))
     assert len(want) > 0 and sorted(traj) == want
+    assert (smp.policy.row_calls > 0) == smp._single_write
     smp.shutdown()
 
 
@@ -187,7 +197,8 @@ def test_gpu_sampler_matches_oracle_on_every_suite_game(game):
     p = np.exp(logits - logits.max(1, keepdims=True))
     tables = ((p / p.sum(1, keepdims=True)).astype(np.float32), (rs.randn(64) * 2).astype(np.float32))
     kw = dict(max_start_noops=30)
-    smp = make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, True, max_len, kw, tables, 0.99, True)
+    smp = make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, True, max_len, kw, tables, 0.99, True,
+                           serves_rows=GAMES[game][0] % 2 == 0)
     assert smp.env_spec.action_space.n == n_act
     ora = P.CpuSamplerPort(game, horizon, n_parallel, envs_per, max_path_length=max_len, mid_batch_reset=True, env_kwargs=kw)
     np.random.seed(seed)
