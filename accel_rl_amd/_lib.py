@@ -30,6 +30,9 @@ class ArlGame(C.Structure):
                 ("clip_reward", _i32), ("episodic_lives", _i32)]
 
 
+EPOCH_WORDS = 32 * 17         # ARL_EPOCH_WORDS: launch epoch + arl_env_step's arrival tickets
+
+
 class ArlEnvState(C.Structure):
     _fields_ = [("n_env", _i64), ("tick", _vp), ("emu_lives", _vp), ("env_lives", _vp),
                 ("phase", _vp), ("over", _vp), ("frozen", _vp),

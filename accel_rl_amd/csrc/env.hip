@@ -98,8 +98,19 @@ struct StepOut {
     float rec_ret, rec_raw, rec_disc;
 };
 
-__device__ __forceinline__ StepOut step_compute(const arl_game& g, const EnvRegs& in, const float* __restrict__ p,
-                                                const double u, const bool is_active, const int mid_batch_reset,
+// weighted_sample_n (special.py:22-27): k = #{j : cumsum_j(p) < u}, clamped; fp32 sequential cumsum, f64 compare
+__device__ __forceinline__ int sample_action(const float* __restrict__ p, const int A, const double u) {
+    float c = 0.f;
+    int k = 0;
+    for (int j = 0; j < A; ++j) {
+        c += p[j];
+        k += ((double)c < u) ? 1 : 0;
+    }
+    return k < A - 1 ? k : A - 1;
+}
+
+__device__ __forceinline__ StepOut step_compute(const arl_game& g, const EnvRegs& in, const int a_idx,
+                                                const bool is_active, const int mid_batch_reset,
                                                 const double max_path_length, const double discount) {
     StepOut o;
     o.s = in;
@@ -108,16 +119,6 @@ __device__ __forceinline__ StepOut step_compute(const arl_game& g, const EnvRegs
     o.fa = -1; o.fb = 0; o.mode = MODE_SKIP;
     o.rec_len = 0; o.rec_nz = 0; o.rec_ret = 0.f; o.rec_raw = 0.f; o.rec_disc = 0.f;
     if (!is_active) return o;
-    const int A = g.n_actions;
-
-    // ---- action: weighted_sample_n (special.py:22-27)
-    float c = 0.f;
-    int k = 0;
-    for (int j = 0; j < A; ++j) {
-        c += p[j];
-        k += ((double)c < u) ? 1 : 0;
-    }
-    const int a_idx = k < A - 1 ? k : A - 1;
     o.a_idx = a_idx;
     if (!mid_batch_reset && in.frozen) return o;         // worker.py:80 (env sits out the batch)
     o.emulated = 1;
@@ -190,6 +191,7 @@ __device__ __forceinline__ StepOut step_compute(const arl_game& g, const EnvRegs
 // The stores of one step (one lane): scatter of the served action (sampler.py:143-145), rollout row, env state,
 // completed-trajectory record.  apply_frames: also the frame hand-off fields (after a resolved reset they
 // already hold the reset's frames).
+template <bool COPY_PROB = true>
 __device__ __forceinline__ void step_commit(const arl_game& g, const arl_env_state& st, const arl_rollout& ro,
                                             const float* __restrict__ p, const float v, const StepOut& o,
                                             const int64_t e, const int step) {
@@ -197,7 +199,8 @@ __device__ __forceinline__ void step_commit(const arl_game& g, const arl_env_sta
     if (!o.stepped) { st.frame_mode[e] = MODE_SKIP; return; }
     const int A = g.n_actions;
     const int64_t row = e * ro.horizon + step;
-    for (int j = 0; j < A; ++j) ro.prob[row * A + j] = p[j];
+    if (COPY_PROB)
+        for (int j = 0; j < A; ++j) ro.prob[row * A + j] = p[j];
     ro.actions[row] = (uint8_t)o.a_idx;
     ro.value[row] = v;
     if (!o.emulated) { st.frame_mode[e] = MODE_SKIP; return; }
@@ -233,8 +236,8 @@ __global__ __launch_bounds__(256) void act_step_kernel(
     if (e >= st.n_env) return;
     const EnvRegs in = load_env(st, e);
     const float* p = prob + e * g.n_actions;
-    const StepOut o = step_compute(g, in, p, uniforms[e], !active || active[e] != 0, mid_batch_reset,
-                                   max_path_length, discount);
+    const StepOut o = step_compute(g, in, sample_action(p, g.n_actions, uniforms[e]), !active || active[e] != 0,
+                                   mid_batch_reset, max_path_length, discount);
     step_commit(g, st, ro, p, value[e], o, e, step);
 }
 
@@ -327,16 +330,77 @@ __device__ void resolve_reset(const arl_game& g, const arl_env_state& st, int64_
 // frames fa (< 0: none) and fb; new stack = the previous one (`prev`; zeros in MODE_BLANK_PUSH) shifted by one
 // with the new frame on top, written to out0 and (if given) out1.  prev may alias out0: a thread reads and
 // writes the same pixels of every plane, oldest plane first.
-// DYNAMIC: waves draw 64-unit chunks from an LDS counter instead of a fixed stride -- in the fused step kernel
-// wave 0 arrives late (its lane 0 commits the scalar results first) and the other waves take up its share.
-template <bool DYNAMIC = false>
+// The frame push in two halves, so that a caller can put other work under the loads' latency: FramePush::load
+// issues EVERY load of the thread's units (5 per thread, the last one for 16 threads only: 4 raw 16-byte rows +
+// the previous stack's 8-byte pieces each) before anything consumes one; FramePush::store boxes and writes.
+constexpr int PUSH_ITERS = (UNITS + 255) / 256;            // 5
+constexpr int MAX_STACK = 4;                              // previous planes kept in registers (n_stack <= 4 fast path)
+
+struct FramePush {
+    uint4 a0[PUSH_ITERS], a1[PUSH_ITERS], b0[PUSH_ITERS], b1[PUSH_ITERS];
+    uint2 pv[PUSH_ITERS][MAX_STACK - 1];
+
+    __device__ __forceinline__ void load(const arl_game& g, const int fa_i, const int fb_i, const int mode,
+                                         const uint8_t* prev, const int tid) {
+        const int F = g.n_stack;
+        const uint8_t* fb = g.bank + (int64_t)fb_i * RAW_FRAME;
+        const uint8_t* fa = (fa_i >= 0) ? g.bank + (int64_t)fa_i * RAW_FRAME : nullptr;
+#pragma unroll
+        for (int it = 0; it < PUSH_ITERS; ++it) {
+            const int un = tid + it * 256;
+            a0[it] = make_uint4(0, 0, 0, 0); a1[it] = a0[it]; b0[it] = a0[it]; b1[it] = a0[it];
+#pragma unroll
+            for (int f = 0; f < MAX_STACK - 1; ++f) pv[it][f] = make_uint2(0, 0);
+            if (un < UNITS) {
+                const int y = un / UNITS_PER_ROW, xb = un - y * UNITS_PER_ROW;
+                const int src = (2 * y) * ARL_RAW_W + xb * 16;
+                b0[it] = *reinterpret_cast<const uint4*>(fb + src);
+                b1[it] = *reinterpret_cast<const uint4*>(fb + src + ARL_RAW_W);
+                if (fa) {
+                    a0[it] = *reinterpret_cast<const uint4*>(fa + src);
+                    a1[it] = *reinterpret_cast<const uint4*>(fa + src + ARL_RAW_W);
+                }
+                if (mode == MODE_PUSH) {
+#pragma unroll
+                    for (int f = 0; f < MAX_STACK - 1; ++f)
+                        if (f < F - 1) pv[it][f] = *reinterpret_cast<const uint2*>(prev + (f + 1) * OBS_FRAME + un * 8);
+                }
+            }
+        }
+    }
+
+    // stack: oldest -> newest (atari_env.py:156-157)
+    __device__ __forceinline__ void store(const arl_game& g, uint8_t* out0, uint8_t* out1, const int tid) const {
+        const int F = g.n_stack;
+#pragma unroll
+        for (int it = 0; it < PUSH_ITERS; ++it) {
+            const int un = tid + it * 256;
+            if (un >= UNITS) continue;
+            const uint2 img = box8(a0[it], a1[it], b0[it], b1[it]);
+            const int o = un * 8;
+#pragma unroll
+            for (int f = 0; f < MAX_STACK - 1; ++f)
+                if (f < F - 1) {
+                    *reinterpret_cast<uint2*>(out0 + f * OBS_FRAME + o) = pv[it][f];
+                    if (out1) *reinterpret_cast<uint2*>(out1 + f * OBS_FRAME + o) = pv[it][f];
+                }
+            *reinterpret_cast<uint2*>(out0 + (F - 1) * OBS_FRAME + o) = img;
+            if (out1) *reinterpret_cast<uint2*>(out1 + (F - 1) * OBS_FRAME + o) = img;
+        }
+    }
+};
+
+// The pixel part of one env step, one workgroup: new frame = rounded 2x2 box of the cropped max of bank
+// frames fa (< 0: none) and fb; new stack = the previous one (`prev`; zeros in MODE_BLANK_PUSH) shifted by one
+// with the new frame on top, written to out0 and (if given) out1.  prev may alias out0: a thread reads and
+// writes the same pixels of every plane, oldest plane first.  (Any stack depth; the step kernel's fast path
+// is FramePush.)
 __device__ __forceinline__ void push_frame(const arl_game& g, const int fa_i, const int fb_i, const int mode,
-                                           const uint8_t* prev, uint8_t* out0, uint8_t* out1, const int tid,
-                                           int* next_unit = nullptr) {
+                                           const uint8_t* prev, uint8_t* out0, uint8_t* out1, const int tid) {
     const int F = g.n_stack;
     const uint8_t* fb = g.bank + (int64_t)fb_i * RAW_FRAME;
     const uint8_t* fa = (fa_i >= 0) ? g.bank + (int64_t)fa_i * RAW_FRAME : nullptr;
-    auto unit = [&](const int un) {
+    for (int un = tid; un < UNITS; un += 256) {
         const int y = un / UNITS_PER_ROW, xb = un - y * UNITS_PER_ROW;
         const int src = (2 * y) * ARL_RAW_W + xb * 16;
         const uint4 b0 = *reinterpret_cast<const uint4*>(fb + src);
@@ -348,7 +412,6 @@ __device__ __forceinline__ void push_frame(const arl_game& g, const int fa_i, co
         }
         const uint2 img = box8(a0, a1, b0, b1);
         const int o = un * 8;
-        // stack: oldest -> newest (atari_env.py:156-157)
         for (int f = 0; f < F - 1; ++f) {
             uint2 pv = make_uint2(0, 0);
             if (mode == MODE_PUSH) pv = *reinterpret_cast<const uint2*>(prev + (f + 1) * OBS_FRAME + o);
@@ -357,18 +420,6 @@ __device__ __forceinline__ void push_frame(const arl_game& g, const int fa_i, co
         }
         *reinterpret_cast<uint2*>(out0 + (F - 1) * OBS_FRAME + o) = img;
         if (out1) *reinterpret_cast<uint2*>(out1 + (F - 1) * OBS_FRAME + o) = img;
-    };
-    if constexpr (DYNAMIC) {
-        const int lane = tid & 63;
-        for (;;) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(next_unit, 64);
-            base = __shfl(base, 0, 64);
-            if (base >= UNITS) break;
-            if (base + lane < UNITS) unit(base + lane);
-        }
-    } else {
-        for (int un = tid; un < UNITS; un += 256) unit(un);
     }
 }
 
@@ -413,7 +464,7 @@ __global__ __launch_bounds__(256) void frame_step_kernel(const arl_game g, const
     uint8_t* dst = nullptr;
     if (!RESET_ONLY && step + 1 < ro.horizon)             // worker.py:52-53
         dst = ro.observations + (e * ro.horizon + step + 1) * (int64_t)g.n_stack * OBS_FRAME;
-    push_frame<false>(g, s_fa, s_fb, s_mode, cur, cur, dst, tid);
+    push_frame(g, s_fa, s_fb, s_mode, cur, cur, dst, tid);
 }
 
 // The whole env side of one agent step in ONE launch, one workgroup per env:
@@ -436,7 +487,6 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     double discount, int max_start_noops, int single_write) {
     const int64_t e = blockIdx.x;
     const int tid = threadIdx.x;
-    __shared__ int s_next_unit;
     const int parity = st.epoch[0] & 1;
     const int fpar = st.launch_count[0] & 1;              // this state's own launch parity (the epoch is shared)
     const int64_t per = st.envs_per_stream;
@@ -446,7 +496,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     // ---- every lane: this env's state, served distribution and uniform (uniform addresses: broadcast loads)
     const EnvRegs in = load_env(st, e);
     const float* p = prob + e * g.n_actions;
-    const double u = uniforms[e];
+    const int a_idx = sample_action(p, g.n_actions, uniforms[e]);
     const float v = value[e];
     const bool is_active = !active || active[e] != 0;
     const int64_t cursor = st.noop_cursor[parity * n_streams + w];
@@ -461,38 +511,53 @@ __global__ __launch_bounds__(256) void env_step_kernel(
         }
     }
     const uint8_t carried = flag_now[e];
-    if (tid == 0) s_next_unit = 0;
     __syncthreads();                                      // every lane has its inputs: lane 0 may now overwrite them
-    StepOut o = step_compute(g, in, p, u, is_active, mid_batch_reset, max_path_length, discount);
+    StepOut o = step_compute(g, in, a_idx, is_active, mid_batch_reset, max_path_length, discount);
     if (o.reset_flag) {                                   // env.reset() (worker.py:47): start no-ops from the stream's ring
         int noops = 0;
         if (max_start_noops > 0)                          // randint(0, 1) draws nothing
             noops = st.noop_ring[w * st.noop_ring_len + (cursor + rank) % st.noop_ring_len];
         reset_regs(g, o.s, noops, o.fa, o.fb, o.mode);
     }
+    const int64_t row_bytes = (int64_t)g.n_stack * OBS_FRAME;
+    uint8_t* cur = ro.step_obs + e * row_bytes;
+    uint8_t* next = step + 1 < ro.horizon ? ro.observations + (e * ro.horizon + step + 1) * row_bytes : nullptr;
+    const uint8_t* prev = single_write ? ro.observations + (e * ro.horizon + step) * row_bytes : cur;
+    uint8_t* out0 = single_write ? (next ? next : cur) : cur;
+    uint8_t* out1 = single_write ? nullptr : next;            // worker.py:52-53
+    const bool fast = g.n_stack <= MAX_STACK;
+    FramePush fp;
+    if (o.mode != MODE_SKIP && fast) fp.load(g, o.fa, o.fb, o.mode, prev, tid);
+    // the stores of the scalar part, under the frame loads' latency: lane 0 commits, lanes of wave 1 copy the
+    // served distribution (one element each instead of a load -> store chain per action on lane 0)
+    if (o.stepped && tid >= 64 && tid - 64 < g.n_actions)
+        ro.prob[(e * ro.horizon + step) * g.n_actions + (tid - 64)] = p[tid - 64];
     if (tid == 0) {
-        step_commit(g, st, ro, p, v, o, e, step);
+        step_commit<false>(g, st, ro, p, v, o, e, step);
         if (e == g0) st.noop_cursor[(parity ^ 1) * n_streams + w] = cursor + total;   // stream leader: next cursor
         // this env's flag for the next launch: recomputed if it stepped, carried over if it sat this one out
         st.next_reset[(int64_t)(fpar ^ 1) * st.n_env + e] = is_active ? (uint8_t)will_reset(g, o.s, max_path_length)
                                                                      : carried;
     }
     if (o.mode != MODE_SKIP) {
-        const int64_t row_bytes = (int64_t)g.n_stack * OBS_FRAME;
-        uint8_t* cur = ro.step_obs + e * row_bytes;
-        uint8_t* next = step + 1 < ro.horizon ? ro.observations + (e * ro.horizon + step + 1) * row_bytes : nullptr;
-        if (single_write)
-            push_frame<true>(g, o.fa, o.fb, o.mode, ro.observations + (e * ro.horizon + step) * row_bytes,
-                             next ? next : cur, nullptr, tid, &s_next_unit);
-        else
-            push_frame<true>(g, o.fa, o.fb, o.mode, cur, cur, next, tid, &s_next_unit);   // worker.py:52-53
+        if (fast) fp.store(g, out0, out1, tid);
+        else push_frame(g, o.fa, o.fb, o.mode, prev, out0, out1, tid);
     }
     if (tid == 0) {
-        const int arrived = atomicAdd(st.epoch + 1, 1);
-        if (arrived == (int)st.n_env - 1) {               // everyone has read both counters before arriving
-            st.epoch[1] = 0;
-            st.epoch[0] += 1;
-            st.launch_count[0] += 1;
+        // Arrival ticket, two levels (256 arrivals on ONE word cost ~3 us, ~12 ns each, serialised at its L2
+        // channel): env e arrives on shard e % 16 (own 128-byte line each); a shard's last arriver arrives on the
+        // top word; the last of those bumps the counters.  Everyone has read both counters before arriving.
+        const int n = (int)st.n_env, sh = (int)(e % ARL_TICKET_SHARDS);
+        const int expect = (n - sh + ARL_TICKET_SHARDS - 1) / ARL_TICKET_SHARDS;
+        int* shard = st.epoch + 32 * (sh + 1);
+        if (atomicAdd(shard, 1) == expect - 1) {
+            *shard = 0;
+            const int shards = n < ARL_TICKET_SHARDS ? n : ARL_TICKET_SHARDS;
+            if (atomicAdd(st.epoch + 1, 1) == shards - 1) {
+                st.epoch[1] = 0;
+                st.epoch[0] += 1;
+                st.launch_count[0] += 1;
+            }
         }
     }
 }

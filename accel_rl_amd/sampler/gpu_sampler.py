@@ -175,7 +175,7 @@ class GpuVecSampler(BaseMbSampler):
             noop_ring=u8(n_streams, NOOP_RING), next_reset=u8(2, n), launch_count=i32(1),
         )
         # the batch's small results live in ONE block so that one D2H copy mirrors them (see _host)
-        spec = (("noop_cursor", (2, n_streams), torch.int64), ("epoch", (2,), torch.int32),
+        spec = (("noop_cursor", (2, n_streams), torch.int64), ("epoch", (_lib.EPOCH_WORDS,), torch.int32),
                 ("done_count", (1,), torch.int32), ("done_int", (n * t, 3), torch.int32),
                 ("done_flt", (n * t, 3), torch.float32))
         self._results_block, views = _packed_block(spec, dev)

@@ -102,6 +102,8 @@ int arl_sample_categorical(const float* prob, const double* uniforms,
  * ------------------------------------------------------------------------- */
 
 #define ARL_MAX_ACTIONS 18
+#define ARL_TICKET_SHARDS 16
+#define ARL_EPOCH_WORDS (32 * (ARL_TICKET_SHARDS + 1))
 #define ARL_RAW_H 210
 #define ARL_RAW_W 160
 #define ARL_OBS_H 104     /* accel_rl/envs/atari_env.py:13 */
@@ -148,7 +150,8 @@ typedef struct arl_env_state {
      * (accel_rl/envs/atari_env.py:97 draws from the worker's numpy RNG)       */
     const uint8_t* noop_ring;   /* u8[n_streams][noop_ring_len] pre-drawn counts */
     int64_t* noop_cursor;       /* i64[2][n_streams], ping-pong by epoch parity  */
-    int32_t* epoch;             /* i32[2]: [0] number of env launches so far, [1] arrival ticket of arl_env_step */
+    int32_t* epoch;             /* i32[ARL_EPOCH_WORDS], zero-initialised: [0] number of env launches so far;
+                                 * the rest are arl_env_step's arrival tickets ([1] top, [32 (s + 1)] shard s) */
     int32_t  noop_ring_len;
     int32_t  envs_per_stream;
     /* completed-trajectory records (the reference's traj_infos_queue,
