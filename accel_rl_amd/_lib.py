@@ -135,6 +135,8 @@ _SIGNATURES = {
     "arl_rnn_cell_fwd": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "arl_rnn_cell_bwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp]),
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "arl_opt_step_noclip": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
+    "arl_opt_finish": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _vp, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -303,6 +305,20 @@ def opt_step(opt, method, learning_rate, avg_factor, clip, beta1_or_rho, beta2, 
     _check(load().arl_opt_step(C.byref(opt), method, learning_rate, avg_factor,
                                0.0 if clip is None else clip, beta1_or_rho, beta2, epsilon,
                                stream_ptr(stream)), "arl_opt_step")
+
+
+OPT_NORM_SLOTS, OPT_NORM_BLOCKS = 64, 2048
+
+
+def opt_step_noclip(opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k, step_pp, norm_parts,
+                    stream=None):
+    _check(load().arl_opt_step_noclip(C.byref(opt), method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon,
+                                      int(k), ptr(step_pp), ptr(norm_parts), stream_ptr(stream)), "arl_opt_step_noclip")
+
+
+def opt_finish(opt, n_updates, avg_factor, step_pp, norm_parts, stream=None):
+    _check(load().arl_opt_finish(C.byref(opt), int(n_updates), avg_factor, ptr(step_pp), ptr(norm_parts),
+                                 stream_ptr(stream)), "arl_opt_finish")
 
 
 # ---------------------------------------------------------------------------

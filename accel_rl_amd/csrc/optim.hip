@@ -135,7 +135,116 @@ __global__ __launch_bounds__(256) void update_kernel(arl_opt_state o, int n_part
     }
 }
 
+// ---- no norm clipping (PPO's default): nothing needs the global norm before the update, so the sum of squares
+// rides along in the update's own pass over the gradient (ONE launch per step, and the bucket is read once):
+// block b leaves its partial of update k at norm_parts[k][b]; arl_opt_finish turns the partials of a whole call
+// (k = 0 .. n - 1) into logged norms.  Lasagne's t: update k reads step_pp[k & 1] and block 0 writes t to
+// step_pp[(k + 1) & 1] (and to the public step_count) -- never the word the other blocks are reading.
+template <int METHOD>
+__global__ __launch_bounds__(256) void update_noclip_kernel(arl_opt_state o, int k, float lr_base, float avg,
+                                                            float b1, float b2, float eps, float* step_pp,
+                                                            double* __restrict__ norm_parts) {
+    __shared__ double lds[8];
+    const float t = step_pp[k & 1] + 1.0f;                          // update_methods_stats.py:66
+    const float lr = lr_base * o.lr_mult[0];
+    float a_t = 0.f;
+    if (METHOD == ARL_OPT_ADAM)
+        a_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));   // :67
+    const int64_t n = o.n_params, n4 = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    float4* p4 = reinterpret_cast<float4*>(o.params);
+    const float4* g4 = reinterpret_cast<const float4*>(o.grads);
+    float4* m4 = reinterpret_cast<float4*>(o.slot0);
+    float4* v4 = reinterpret_cast<float4*>(o.slot1);
+    double s = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 p = p4[i];
+        const float4 g = g4[i];
+        float4 m = m4[i];
+        float4 v = (METHOD == ARL_OPT_ADAM) ? v4[i] : make_float4(0, 0, 0, 0);
+        s += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
+        update_one<METHOD>(p.x, g.x, m.x, v.x, avg, 1.f, lr, a_t, b1, b2, eps);
+        update_one<METHOD>(p.y, g.y, m.y, v.y, avg, 1.f, lr, a_t, b1, b2, eps);
+        update_one<METHOD>(p.z, g.z, m.z, v.z, avg, 1.f, lr, a_t, b1, b2, eps);
+        update_one<METHOD>(p.w, g.w, m.w, v.w, avg, 1.f, lr, a_t, b1, b2, eps);
+        p4[i] = p;
+        m4[i] = m;
+        if (METHOD == ARL_OPT_ADAM) v4[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float g = o.grads[i];
+        float p = o.params[i], m = o.slot0[i], v = (METHOD == ARL_OPT_ADAM) ? o.slot1[i] : 0.f;
+        s += (double)g * g;
+        update_one<METHOD>(p, g, m, v, avg, 1.f, lr, a_t, b1, b2, eps);
+        o.params[i] = p;
+        o.slot0[i] = m;
+        if (METHOD == ARL_OPT_ADAM) o.slot1[i] = v;
+    }
+    s = block_sum_d(s, lds);
+    if (threadIdx.x == 0) {
+        norm_parts[(int64_t)k * ARL_OPT_NORM_BLOCKS + blockIdx.x] = s;
+        if (blockIdx.x == 0) { step_pp[(k + 1) & 1] = t; o.step_count[0] = t; }
+    }
+}
+
+// one block per update of the call: fold its partials in block order, log the norm; block 0 also levels the
+// two step words so that the next call's update 0 finds t whatever the parity of this call's length
+__global__ __launch_bounds__(256) void opt_finish_kernel(arl_opt_state o, int n_updates, int n_blocks, float avg,
+                                                         float* step_pp, const double* __restrict__ norm_parts) {
+    __shared__ double lds[8];
+    const int k = blockIdx.x;
+    double s = 0;
+    for (int i = threadIdx.x; i < n_blocks; i += blockDim.x) s += norm_parts[(int64_t)k * ARL_OPT_NORM_BLOCKS + i];
+    s = block_sum_d(s, lds);
+    if (threadIdx.x == 0) {
+        if (o.grad_norm_log) o.grad_norm_log[k % o.norm_log_len] = avg * (float)sqrt(s);
+        if (k == 0) { const float t = step_pp[n_updates & 1]; step_pp[0] = t; step_pp[1] = t; o.step_count[0] = t; }
+    }
+}
+
+int check_opt(const arl_opt_state* opt, int32_t method) {
+    ARL_REQUIRE(opt, ARL_E_ARG, "null state");
+    ARL_REQUIRE(opt->params && opt->grads && opt->slot0 && opt->step_count && opt->lr_mult, ARL_E_ARG,
+                "null pointer in state");
+    ARL_REQUIRE(method == ARL_OPT_ADAM || method == ARL_OPT_RMSPROP, ARL_E_ARG, "unknown method");
+    ARL_REQUIRE(method != ARL_OPT_ADAM || opt->slot1, ARL_E_ARG, "adam needs slot1");
+    ARL_REQUIRE(opt->n_params > 0, ARL_E_ARG, "n_params <= 0");
+    ARL_REQUIRE(!opt->grad_norm_log || opt->norm_log_len > 0, ARL_E_ARG, "norm_log_len <= 0");
+    ARL_REQUIRE(arl::aligned16(opt->params) && arl::aligned16(opt->grads) && arl::aligned16(opt->slot0) &&
+                    (!opt->slot1 || arl::aligned16(opt->slot1)), ARL_E_ALIGN, "flat buffers must be 16-byte aligned");
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int arl_opt_step_noclip(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
+                                   float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
+                                   double* norm_parts, void* stream) {
+    int rc = check_opt(opt, method);
+    if (rc) return rc;
+    ARL_REQUIRE(step_pp && norm_parts, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(k >= 0 && k < ARL_OPT_NORM_SLOTS, ARL_E_RANGE, "update index outside the call's slots");
+    const unsigned grid = arl::stream_grid(opt->n_params >> 2, 256);      // <= 2048 = ARL_OPT_NORM_BLOCKS
+    hipStream_t s = (hipStream_t)stream;
+    if (method == ARL_OPT_ADAM)
+        hipLaunchKernelGGL((update_noclip_kernel<ARL_OPT_ADAM>), dim3(grid), dim3(256), 0, s, *opt, (int)k,
+                           learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, step_pp, norm_parts);
+    else
+        hipLaunchKernelGGL((update_noclip_kernel<ARL_OPT_RMSPROP>), dim3(grid), dim3(256), 0, s, *opt, (int)k,
+                           learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, step_pp, norm_parts);
+    return arl::check_launch("update_noclip_kernel");
+}
+
+extern "C" int arl_opt_finish(const arl_opt_state* opt, int32_t n_updates, float avg_factor, float* step_pp,
+                              const double* norm_parts, void* stream) {
+    ARL_REQUIRE(opt && opt->step_count && step_pp && norm_parts, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(n_updates >= 1 && n_updates <= ARL_OPT_NORM_SLOTS, ARL_E_RANGE, "n_updates outside 1 .. ARL_OPT_NORM_SLOTS");
+    const unsigned grid = arl::stream_grid(opt->n_params >> 2, 256);
+    hipLaunchKernelGGL(opt_finish_kernel, dim3((unsigned)n_updates), dim3(256), 0, (hipStream_t)stream, *opt,
+                       (int)n_updates, (int)grid, avg_factor, step_pp, norm_parts);
+    return arl::check_launch("opt_finish_kernel");
+}
 
 extern "C" int arl_opt_step(const arl_opt_state* opt, int32_t method, float learning_rate,
                             float avg_factor, float clip, float beta1_or_rho, float beta2,

@@ -69,6 +69,7 @@ class BaseOptimizer(object):
         self._partials = torch.zeros(_lib.OPT_PARTIALS, dtype=torch.float64, device=dev)
         self._norm_log = torch.zeros(NORM_LOG_LEN, dtype=torch.float32, device=dev)
         self._n_updates = 0
+        self._step_pp = self._norm_parts = None      # the no-clip update's state (see _apply_update)
         st = _lib.ArlOptState()
         st.n_params = n
         st.params, st.grads = target.flat_params.data_ptr(), target.flat_grads.data_ptr()
@@ -89,10 +90,22 @@ class BaseOptimizer(object):
         return losses(minibatch)[3]
 
     def _apply_update(self, avg_factor=1.0):
-        """(avg) -> global norm (-> clip) -> adam/rmsprop: two HIP launches."""
+        """(avg) -> global norm (-> clip) -> adam/rmsprop.  With clipping: two HIP launches (the norm comes first).
+        Without (PPO's default): ONE launch -- the norm is only logged, its sum of squares rides along in the
+        update's pass over the gradient and `_recent_grad_norms` finishes the call's norms in one small launch."""
         b1, b2, eps = self._kernel_args
-        _lib.opt_step(self._opt_state, self._update_method.kernel_id, self._learning_rate,
-                      avg_factor, self._grad_norm_clip, b1, b2, eps)
+        if self._grad_norm_clip is None:
+            if self._step_pp is None:
+                dev = self._target.device
+                self._step_pp = self._step_count.repeat(2).contiguous()
+                self._norm_parts = torch.zeros(_lib.OPT_NORM_SLOTS * _lib.OPT_NORM_BLOCKS, dtype=torch.float64, device=dev)
+            k = self._n_updates % self._opt_state.norm_log_len      # position inside the call
+            _lib.opt_step_noclip(self._opt_state, self._update_method.kernel_id, self._learning_rate, avg_factor,
+                                 b1, b2, eps, k, self._step_pp, self._norm_parts)
+            self._pending_avg = avg_factor
+        else:
+            _lib.opt_step(self._opt_state, self._update_method.kernel_id, self._learning_rate,
+                          avg_factor, self._grad_norm_clip, b1, b2, eps)
         self._n_updates += 1
 
     def _set_updates_per_call(self, count):
@@ -107,4 +120,10 @@ class BaseOptimizer(object):
     def _recent_grad_norms(self, count):
         """Device tensor [count]: global grad norms of this call's updates (no host sync)."""
         assert 0 < count <= self._opt_state.norm_log_len
+        self._finish_updates(count)
         return self._norm_log[:count].clone()
+
+    def _finish_updates(self, count):
+        """Close a call of `count` no-clip updates (norm log, Lasagne's t); every call must end with this."""
+        if self._grad_norm_clip is None and self._step_pp is not None:
+            _lib.opt_finish(self._opt_state, count, self._pending_avg, self._step_pp, self._norm_parts)

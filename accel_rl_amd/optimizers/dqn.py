@@ -52,6 +52,7 @@ class DqnOptimizer(BaseOptimizer):
         if self._scale_conv_grads:                     # the conv tensors lead the bucket (optimizers/util.py:122-126)
             self._target.flat_grads[:self._target.grad_split_offset].mul_(float(np.float32(2 ** -0.5)))
         self._apply_update(1.0)
+        self._finish_updates(1)
         return priority, loss
 
     def _stage(self, inputs):

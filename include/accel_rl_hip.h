@@ -609,6 +609,20 @@ int arl_opt_step(const arl_opt_state* opt, int32_t method, float learning_rate,
                  float avg_factor, float clip, float beta1_or_rho, float beta2,
                  float epsilon, void* stream);
 
+/* The same update WITHOUT norm clipping (PPO's default, accel_rl/algos/pg/ppo.py:24: grad_norm_clip=None) as ONE
+ * launch: the sum of squares for the logged norm is taken in the update's own pass over the gradient.  A call of
+ * the optimizer (`optimize`, accel_rl/optimizers/single/ppo_optimizer.py:58-75) issues updates k = 0 .. n-1 and
+ * then arl_opt_finish(n), which writes grad_norm_log[k % norm_log_len] for all of them and settles step_count.
+ *   step_pp    f32[2] zero-initialised (Lasagne's t, ping-pong between consecutive updates)
+ *   norm_parts f64[ARL_OPT_NORM_SLOTS][ARL_OPT_NORM_BLOCKS] scratch                                            */
+#define ARL_OPT_NORM_SLOTS  64
+#define ARL_OPT_NORM_BLOCKS 2048
+int arl_opt_step_noclip(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
+                        float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
+                        double* norm_parts, void* stream);
+int arl_opt_finish(const arl_opt_state* opt, int32_t n_updates, float avg_factor, float* step_pp,
+                   const double* norm_parts, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -325,6 +325,45 @@ def test_adam_vs_oracle(L, n, clip):
     assert keep["t"].item() == 3.0
 
 
+@pytest.mark.parametrize("method", ["adam", "rmsprop"])
+@pytest.mark.parametrize("n", [3, 898613, 3620005])
+def test_noclip_single_launch_update_vs_oracle(L, n, method):
+    """arl_opt_step_noclip / arl_opt_finish: calls of 3, 2 and 5 updates (odd and even lengths: Lasagne's t ping-pongs
+    between two words) -- parameters after every update, the call's logged norms and t against the oracle."""
+    rs = np.random.RandomState(n % 997)
+    p0 = rs.randn(n).astype(np.float32)
+    p, g = dev(p0), torch.zeros(n, device=DEV)
+    adam = method == "adam"
+    st, keep = _opt_state(L, p, g, with_v=adam)
+    step_pp = torch.zeros(2, device=DEV)
+    parts = torch.zeros(L.OPT_NORM_SLOTS * L.OPT_NORM_BLOCKS, dtype=torch.float64, device=DEV)
+    m = np.zeros(n, np.float32); v = np.zeros(n, np.float32); t = np.float32(0); pw = p0.copy()
+    for call, n_upd in enumerate((3, 2, 5)):
+        norms = []
+        for k in range(n_upd):
+            gh = (rs.randn(n) * (0.01 if (call + k) else 3.0)).astype(np.float32)
+            g.copy_(dev(gh))
+            keep["lr"].fill_(1.0 - 0.1 * k)
+            lr = np.float32(1e-3 if adam else 7e-4) * np.float32(1.0 - 0.1 * k)
+            gavg = (gh * np.float32(0.5)).astype(np.float32)
+            _, norm = P.clip_by_total_norm(gavg, None)
+            norms.append(norm)
+            if adam:
+                L.opt_step_noclip(st, L.OPT_ADAM, 1e-3, 0.5, 0.9, 0.999, 1e-5, k, step_pp, parts)
+                pw, m, v, t = P.adam_step(pw, gavg, m, v, t, lr, eps=1e-5)
+            else:
+                L.opt_step_noclip(st, L.OPT_RMSPROP, 7e-4, 0.5, 0.9, 0.0, 1e-6, k, step_pp, parts)
+                pw, m = P.rmsprop_step(pw, gavg, m, lr)
+                t = np.float32(t + 1)
+            got = p.cpu().numpy()
+            assert np.allclose(got, pw, rtol=1e-5, atol=1e-6), (call, k, np.abs(got - pw).max())
+            assert keep["t"].item() == float(t)
+        L.opt_finish(st, n_upd, 0.5, step_pp, parts)
+        log = keep["log"].cpu().numpy()[:n_upd]
+        assert np.allclose(log, norms, rtol=1e-5), (call, log, norms)
+        assert keep["t"].item() == float(t) and step_pp.cpu().tolist() == [float(t)] * 2
+
+
 @pytest.mark.parametrize("clip", [None, 0.5])
 def test_rmsprop_vs_oracle(L, clip):
     n = 898613
