@@ -593,22 +593,29 @@ __device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned v
 // consecutive pixels of one filter row = one aligned dword (stride, width and plane size are multiples of 4,
 // no padding); a k-tile covers BK / kw8 whole filter rows of one plane, so the tile's address is again
 // per-thread constant + per-tile uniform.
+// PIPE3: three LDS stages and the k-tile's one barrier in the MIDDLE of its MFMAs.  A workgroup with one wave per
+// SIMD that stores tile t+1, waits at the barrier and only then reads its first fragments leaves the matrix pipe
+// idle once per k-tile (per-workgroup timestamps: two 112x64 workgroups on a CU keep the pipe 79 % busy, four 64x64
+// ones 90 %).  Here tile t+1 is stored and fenced halfway through tile t -- into the stage tile t-2 used, which every
+// wave has left since it passed the previous barrier --, so that nothing separates the last MFMA of a tile from the
+// first of the next; the loads of tile t+2 are issued right after the barrier (a full tile of latency cover).
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
-          bool U8 = false>
+          bool U8 = false, bool PIPE3 = false>
 __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* smem) {
     constexpr int MT = N16 ? 16 : 32;               // rows per MFMA tile
-    constexpr int BM = WGM * TM * MT, BN = N16 ? 16 : WGN * TN * 32, CH = BK / 4;
+    constexpr int BM = WGM * TM * MT, BN = N16 ? WGN * 16 : WGN * TN * 32, CH = BK / 4;
     constexpr int LDA = BK + 4;
-    constexpr int LDB = B_KC ? BK + 4 : (N16 ? 20 : BN);        // 20: the four k-quads of a 16-wide read hit distinct banks
-    static_assert(!N16 || (WGN == 1 && TN == 1 && BK % 16 == 0), "16-wide tiles: one column tile per wave");
-    constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
+    constexpr int LDB = B_KC ? BK + 4 : (N16 ? BN + 4 : BN);    // + 4: the four k-quads of a 16-wide read hit distinct banks
+    static_assert(!N16 || (TN == 1 && BK % 16 == 0), "16-wide tiles: one column tile per wave");
     constexpr int ROWS_PER_PASS = 256 / CH;
-    constexpr int RA = BM / ROWS_PER_PASS;
+    constexpr int RA = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;        // BM need not be a multiple of a loader pass:
+    constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;   // the last pass's surplus rows load and store nothing
+    constexpr int NST = PIPE3 ? 3 : 2;                                  // LDS stages
     constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
     constexpr int RB = (NB4 + 255) / 256;
-    static_assert(WGM * WGN == 4 && BM % ROWS_PER_PASS == 0 && BK % 8 == 0, "tile shape");
+    static_assert(WGM * WGN == 4 && BK % 8 == 0, "tile shape");
     float* sA = smem;
-    float* sB = smem + 2 * A_SZ;
+    float* sB = smem + NST * A_SZ;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -643,15 +650,16 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
 #pragma unroll
     for (int p = 0; p < RA; ++p) {
         const int m = m0 + a_row0 + p * ROWS_PER_PASS;
+        const bool row_ok = m < M && (BM % ROWS_PER_PASS == 0 || a_row0 + p * ROWS_PER_PASS < BM);
         const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
         const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
         const int ry = oy * g.mul + g.add_y, rx = ox * g.mul + g.add_x;
         const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
-        voffA[p] = m < M ? (unsigned)(rbase - g.rmin + tpt * Cs + chl) << 2 : OOB;
+        voffA[p] = row_ok ? (unsigned)(rbase - g.rmin + tpt * Cs + chl) << 2 : OOB;
         if constexpr (U8) {
             const int tyl = a_chunk / cpr8, txq = a_chunk - tyl * cpr8;
             voffA[p] = OOB;
-            if (m < M) {
+            if (row_ok) {
                 const int row = g.idx ? g.idx[b] : b;
                 voffA[p] = (unsigned)(row * g.img_bytes + (ry + tyl) * Ws + rx + 4 * txq);
             }
@@ -741,9 +749,11 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         float* dA = sA + buf * A_SZ;
         float* dB = sB + buf * B_SZ;
 #pragma unroll
-        for (int p = 0; p < RA; ++p)
+        for (int p = 0; p < RA; ++p) {
+            if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
             *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) =
                 U8 ? bytes_to_f4(va8[p], g.scale) : va[p];
+        }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
             const int idx = tid + p * 256;
@@ -778,31 +788,24 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int n = N16 ? n0 + 4 * quad : n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
+            const int n = N16 ? n0 + wn * 16 + 4 * quad : n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
             bias_q[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.o.bias && n < a.N && (!N16 || q == 0)) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
         }
     const int nk = (kend - kbeg) / BK;
-    issue_loads(kbeg);
-    store_tiles(nk & 1);                            // first tile's buffer chosen so that the loop ends on buffer 1
-    __syncthreads();
-    if (a.trace) tr1 = __builtin_readcyclecounter();
-    // One k-tile with a COMPILE-TIME buffer index: every LDS address is then a per-thread constant plus an
-    // immediate (with `buf = kt & 1` the compiler re-derived four base addresses per tile with vector adds,
-    // and every vector instruction here is taken from the MFMAs' issue slots).
-    auto k_tile = [&](auto buf_c, int kt) {
-        constexpr int buf = decltype(buf_c)::value;
-        if (kt + 1 < nk) {                          // uniform branch
-            next_tile();
-            issue_loads(kbeg + (kt + 1) * BK);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    // The MFMAs of sub-steps [LO, HI) of the k-tile in LDS stage BUF (16 k per sub-step with the 16-wide tiles, 8
+    // otherwise).  Compile-time stage: every LDS address is then a per-thread constant plus an immediate (with a
+    // run-time buffer index the compiler re-derived four base addresses per tile with vector adds, and every vector
+    // instruction here is taken from the MFMAs' issue slots).
+    constexpr int STEPS = N16 ? BK / 16 : BK / 8;
+    auto mfma_steps = [&](auto buf_c, auto lo_c, auto hi_c) {
+        constexpr int buf = decltype(buf_c)::value, LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
         if constexpr (N16) {
             const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
-            const float* cB = B_KC ? sB + buf * B_SZ + l15 * LDB + quad * 4
-                                   : sB + buf * B_SZ + (quad * 4) * LDB + l15;
+            const float* cB = B_KC ? sB + buf * B_SZ + (wn * 16 + l15) * LDB + quad * 4
+                                   : sB + buf * B_SZ + (quad * 4) * LDB + wn * 16 + l15;
 #pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
+            for (int ks = LO; ks < HI; ++ks) {
                 float fa[TM][4], fb[4];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
@@ -823,36 +826,147 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                         acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[q], fa[i][q], acc16[i], 0, 0, 0);
             }
         } else {
-        const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
-        const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
-                               : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
+            const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
+            const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
+                                   : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
 #pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float fa[TM][4], fb[TN][4];
+            for (int ks = LO; ks < HI; ++ks) {
+                float fa[TM][4], fb[TN][4];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
-                fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
+                for (int i = 0; i < TM; ++i) {
+                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
+                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (B_KC) {
+                        const float4 t = *reinterpret_cast<const float4*>(cB + j * 32 * LDB + ks * 8);
+                        fb[j][0] = t.x; fb[j][1] = t.y; fb[j][2] = t.z; fb[j][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) fb[j][q] = cB[(ks * 8 + q) * LDB + j * 32];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
             }
+        }
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using CH_ = std::integral_constant<int, STEPS / 2>;
+    using CS_ = std::integral_constant<int, STEPS>;
+    if constexpr (PIPE3) {
+        static_assert(STEPS == 2, "PIPE3: two sub-steps per k-tile (16-wide tiles with BK = 32, 32-wide with BK = 16)");
+        // Fragments are double-buffered in registers: the LDS reads of the NEXT sub-step (after the barrier: of the
+        // next tile's first sub-step) are issued before the MFMAs of the current one, so a wave that has its SIMD to
+        // itself does not wait for LDS between MFMA bursts either.
+        constexpr int NA = TM, NB = N16 ? 1 : TN;
+        struct Frags { float a[NA][4], b[NB][4]; };
+        auto read_frags = [&](auto buf_c, auto ks_c, Frags& f) {
+            constexpr int buf = decltype(buf_c)::value, ks = decltype(ks_c)::value;
+            if constexpr (N16) {
+                const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
+                const float* cB = B_KC ? sB + buf * B_SZ + (wn * 16 + l15) * LDB + quad * 4
+                                       : sB + buf * B_SZ + (quad * 4) * LDB + wn * 16 + l15;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
+                for (int i = 0; i < TM; ++i) {
+                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 16 * LDA + ks * 16);
+                    f.a[i][0] = t.x; f.a[i][1] = t.y; f.a[i][2] = t.z; f.a[i][3] = t.w;
+                }
                 if (B_KC) {
-                    const float4 t = *reinterpret_cast<const float4*>(cB + j * 32 * LDB + ks * 8);
-                    fb[j][0] = t.x; fb[j][1] = t.y; fb[j][2] = t.z; fb[j][3] = t.w;
+                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 16);
+                    f.b[0][0] = t.x; f.b[0][1] = t.y; f.b[0][2] = t.z; f.b[0][3] = t.w;
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) fb[j][q] = cB[(ks * 8 + q) * LDB + j * 32];
+                    for (int q = 0; q < 4; ++q) f.b[0][q] = cB[(ks * 16 + q) * LDB];
+                }
+            } else {
+                const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
+                const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
+                                       : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
+                    f.a[i][0] = t.x; f.a[i][1] = t.y; f.a[i][2] = t.z; f.a[i][3] = t.w;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (B_KC) {
+                        const float4 t = *reinterpret_cast<const float4*>(cB + j * 32 * LDB + ks * 8);
+                        f.b[j][0] = t.x; f.b[j][1] = t.y; f.b[j][2] = t.z; f.b[j][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) f.b[j][q] = cB[(ks * 8 + q) * LDB + j * 32];
+                    }
                 }
             }
+        };
+        auto run_mfmas = [&](const Frags& f) {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (N16) {
+                        acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[0][q], f.a[i][q], acc16[i], 0, 0, 0);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[j][q], f.a[i][q], acc[i][j], 0, 0, 0);
+                    }
+                }
+        };
+        const int r3 = nk % 3;                          // stage of tile kt = (kt + 3 - r3) % 3: the last tile ends on stage 2
+        issue_loads(kbeg);
+        store_tiles((3 - r3) % 3);
+        __syncthreads();
+        if (nk > 1) { next_tile(); issue_loads(kbeg + BK); }
+        if (a.trace) tr1 = __builtin_readcyclecounter();
+        Frags f0, f1;                                   // f0: a tile's first sub-step, f1: its second
+        if (r3 == 0) read_frags(C0{}, C0{}, f0);
+        else if (r3 == 1) read_frags(C2{}, C0{}, f0);
+        else read_frags(C1{}, C0{}, f0);
+        auto tile3 = [&](auto st_c, int kt) {
+            constexpr int st = decltype(st_c)::value;
+            using NX = std::integral_constant<int, (st + 1) % 3>;
+            read_frags(st_c, C1{}, f1);
+            run_mfmas(f0);
+            if (kt + 1 < nk) {                          // uniform
+                store_tiles((st + 1) % 3);              // tile kt+1: loaded since the middle of tile kt-1
+                __syncthreads();
+                if (kt + 2 < nk) { next_tile(); issue_loads(kbeg + (kt + 2) * BK); }
+                read_frags(NX{}, C0{}, f0);             // next tile's first fragments, under this tile's last MFMAs
+            }
+            run_mfmas(f1);
+        };
+        int kt = 0;
+        if (r3 == 1) { tile3(C2{}, 0); kt = 1; }
+        else if (r3 == 2) { tile3(C1{}, 0); tile3(C2{}, 1); kt = 2; }
+        for (; kt < nk; kt += 3) {
+            tile3(C0{}, kt);
+            tile3(C1{}, kt + 1);
+            tile3(C2{}, kt + 2);
         }
+    } else {
+    issue_loads(kbeg);
+    store_tiles(nk & 1);                            // first tile's buffer chosen so that the loop ends on buffer 1
+    __syncthreads();
+    if (a.trace) tr1 = __builtin_readcyclecounter();
+    // One k-tile with a COMPILE-TIME buffer index (see mfma_steps).
+    auto k_tile = [&](auto buf_c, int kt) {
+        constexpr int buf = decltype(buf_c)::value;
+        if (kt + 1 < nk) {                          // uniform branch
+            next_tile();
+            issue_loads(kbeg + (kt + 1) * BK);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_steps(buf_c, C0{}, CS_{});
         __builtin_amdgcn_sched_barrier(0);
         if (kt + 1 < nk) {
             store_tiles(buf ^ 1);
@@ -861,11 +975,12 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     };
     {   // an odd tile count peels its FIRST tile (from buffer 1); the rest is whole (buffer 0, buffer 1) pairs
         int kt = 0;
-        if (nk & 1) { k_tile(std::integral_constant<int, 1>{}, 0); kt = 1; }
+        if (nk & 1) { k_tile(C1{}, 0); kt = 1; }
         for (; kt < nk; kt += 2) {
-            k_tile(std::integral_constant<int, 0>{}, kt);
-            k_tile(std::integral_constant<int, 1>{}, kt + 1);
+            k_tile(C0{}, kt);
+            k_tile(C1{}, kt + 1);
         }
+    }
     }
 
     if (a.trace) tr2 = __builtin_readcyclecounter();
@@ -887,7 +1002,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             }
         }
         if constexpr (N16) {
-            const int n = n0 + 4 * quad;
+            const int n = n0 + wn * 16 + 4 * quad;
             const float4 bq = bias_q[0][0];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -918,10 +1033,11 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false>
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
+          bool PIPE3 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, PIPE3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // forward convolution straight from planar u8 observations (see igemm_body, U8)
@@ -1322,16 +1438,16 @@ int allow_big_lds(K kernel, size_t lds) {           // > 64 KiB of dynamic LDS n
     return 0;
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16 = false>
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16 = false, bool PIPE3 = false>
 int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hipStream_t s) {
-    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? 16 : WGN * TN * 32;
-    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? 20 : BN);
-    const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * TN * 32;
+    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
+    const size_t lds = (size_t)(PIPE3 ? 3 : 2) * (A_SZ + B_SZ) * sizeof(float);
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
     int rc = 0;
 #define ARL_IGEMM(MT, HP)                                                                                  \
     do {                                                                                                   \
-        auto k = igemm_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16>;                                    \
+        auto k = igemm_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16, PIPE3>;                             \
         rc = allow_big_lds(k, lds);                                                                        \
         if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
     } while (0)
@@ -1374,6 +1490,7 @@ constexpr int TARGET_WGS = 256;     // one workgroup per CU is already MFMA-boun
 constexpr int BKT = 32;             // k-tile of the skinny configurations (host-side split granularity)
 
 unsigned long long* g_trace = nullptr;
+int g_tile_choice = 0;             // arl_conv_tile_choice: 0 = by the cost model, 1 = 64x64, 2 = 112x64 (tuning aid)
 bool g_force_generic = false;       // arl_conv_force_generic: route every call to the generic kernels (tests)
 
 struct Geom {
@@ -1413,6 +1530,21 @@ unsigned div_magic(int64_t rows, int d) {
     return (unsigned)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d);
 }
 
+// 33 .. 64 output columns: 64x64 tiles (each wave one 32x32 MFMA tile) or 112x64 tiles (each wave 7 16x16 tiles
+// of one 16-column stripe: v_mfma_f32_16x16x4_f32, same rate; three LDS stages, PIPE3)?  All workgroups of these
+// launches are resident at once, so a launch lasts as long as its busiest CU.  At the PPO minibatch (55 296 rows)
+// that is 4 workgroups of 64 rows on 96 CUs (8 units of MFMA work against 6.75 for a perfect spread) or 2 of 112
+// rows on 238 CUs (7 units) -- but per-workgroup timestamps inside the learner (tools/context_trace.py) show the
+// busiest CU taking 66-69 k cycles with four 64x64 workgroups (matrix pipe 99 % busy: four waves per SIMD cover
+// each other's barriers and LDS waits) and 71-74 k with two 112x64 ones (81 %; a lone one: 64 %), mid-tile barrier
+// and register double-buffered fragments included.  Isolated and L2-hot the 112-row tiles are 9-12 % faster; in the
+// learner the two are equal (482 vs 485 us per minibatch), so the cost model keeps the 64x64 tiles and the other
+// shape stays reachable for tests and tuning (arl_conv_tile_choice).
+bool balanced_rows_pay(int M) {
+    (void)M;
+    return g_tile_choice > 1;
+}
+
 // split the reduction so that tiles * splits ~ TARGET_WGS, each split a multiple of BKT
 void plan_split(int tiles, int red, int* splits, int* per, int want = TARGET_WGS) {
     int s = tiles >= want ? 1 : want / tiles;
@@ -1430,6 +1562,8 @@ extern "C" int64_t arl_conv_workspace_bytes(void) { return (int64_t)64 << 20; }
 extern "C" void arl_conv_trace_buffer(void* device_u64_or_null) { g_trace = (unsigned long long*)device_u64_or_null; }
 
 extern "C" void arl_conv_force_generic(int32_t on) { g_force_generic = on != 0; }
+
+extern "C" void arl_conv_tile_choice(int32_t choice) { g_tile_choice = choice; }
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {
@@ -1484,6 +1618,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 1, 1, 16, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        else if (a.N <= 64 && splits == 1 && balanced_rows_pay(a.M)) rc = launch_igemm<1, 4, 7, 1, FBK, true, true, true>(a, 1, multi_tap, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, true>(a, splits, multi_tap, has_pad, s);
@@ -1591,6 +1726,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         }
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
+        else if (a.N <= 64 && balanced_rows_pay(a.M)) rc = launch_igemm<1, 4, 7, 1, FBK, false, true, true>(a, 1, false, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, 1, false, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
         return rc;

@@ -346,6 +346,10 @@ void arl_conv_trace_buffer(void* device_u64_or_null);
  * of the scalar-addressed fast path, so that both are covered by the parity tests.  Not thread-safe. */
 void arl_conv_force_generic(int32_t on);
 
+/* Tuning / test hook for layers with 33 .. 64 output columns: 0 (default) = tile shape by the cost model
+ * (busiest CU's work), 1 = always 64x64 tiles (32x32 MFMA), 2 = always 112x64 tiles (16x16 MFMA).  Not thread-safe. */
+void arl_conv_tile_choice(int32_t choice);
+
 /* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
  * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,
  * policies/layers.py:22-41; the reference's flipped filters are stored pre-flipped).

@@ -46,14 +46,17 @@ def _tol(want, k_red):
     return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
 
 
-@pytest.fixture(params=["fast", "generic"])
+@pytest.fixture(params=["fast", "generic", "fast_tiles64", "fast_tiles112"])
 def path(request):
     """Both kernel families: the scalar-addressed fast path (taken whenever a k-tile of 32 stays inside
-    one filter row) and the generic fallback (any multiple-of-4 channel count, any K)."""
+    one filter row) and the generic fallback (any multiple-of-4 channel count, any K); and, on the fast path,
+    both tile shapes of the 33 .. 64-column layers forced (the cost model picks 112x64 only from ~29 000 rows)."""
     from accel_rl_amd import _lib
     _lib.load().arl_conv_force_generic(1 if request.param == "generic" else 0)
+    _lib.load().arl_conv_tile_choice({"fast_tiles64": 1, "fast_tiles112": 2}.get(request.param, 0))
     yield request.param
     _lib.load().arl_conv_force_generic(0)
+    _lib.load().arl_conv_tile_choice(0)
 
 
 ODD_CASES = [(9, 20, 14, 12, 20, 3, 1, 1),      # channels 12 / 20: no power-of-two anywhere -> generic kernels

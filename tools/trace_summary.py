@@ -17,7 +17,7 @@ rows.sort()
 t0, t1 = rows[0][0], max(r[1] for r in rows)
 a, b = t0 + (t1 - t0) * lo, t0 + (t1 - t0) * hi
 if lo >= 1.0:       # lo, hi >= 1: window = from the lo-th to the hi-th optimiser update (update_kernel launches)
-    ups = [r[0] for r in rows if "update_kernel" in r[2]]
+    ups = [r[0] for r in rows if "update_kernel" in r[2] or "update_noclip_kernel" in r[2]]
     a, b = ups[int(lo)], ups[int(hi)]
 rows = [r for r in rows if r[0] >= a and r[1] <= b]
 span = rows[-1][1] - rows[0][0]
