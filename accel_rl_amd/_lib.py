@@ -57,7 +57,7 @@ class ArlConvGeom(C.Structure):
 
 
 class ArlFoldItem(C.Structure):
-    _fields_ = [("part", _vp), ("out", _vp), ("total", _i64), ("splits", _i32), ("reserved", _i32)]
+    _fields_ = [("part", _vp), ("out", _vp), ("total", _i64), ("splits", _i32), ("valid", _i32)]
 
 
 FOLD_MAX_ITEMS = 24
@@ -101,6 +101,7 @@ _SIGNATURES = {
     "arl_pg_head_workspace_bytes": (_i64, []),
     "arl_pg_head_infer": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 7),
+    "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv_trace_buffer": (None, [_vp]),
     "arl_conv_force_generic": (None, [_i32]),
@@ -531,6 +532,21 @@ class FoldList(object):
         _check(load().arl_relu_bwd_bias_parts(dy.data_ptr(), y.data_ptr(), rows, channels, dbias.data_ptr(),
                                               ptr(workspace), self._next(), stream_ptr(stream)),
                "arl_relu_bwd_bias_parts")
+
+    def pg_head_loss(self, h, w_head, b_head, actions, advantages, returns, old_prob, valids, idx, lr_mult,
+                     inv_count, n_actions, kind, clip_param, v_loss_coeff, ent_loss_coeff,
+                     dout, dh, dw_head, db_head, loss4, workspace, stream=None, relu_mask_dh=False):
+        """pg_head_loss with its three small folds (dw_head, db_head, loss4) left to run()."""
+        batch, hid = h.shape
+        assert self._n + 3 <= FOLD_MAX_ITEMS, "too many pending folds"
+        first = C.byref(self._items[self._n])
+        self._n += 3
+        _check(load().arl_pg_head_loss_parts(
+            ptr(h), w_head.data_ptr(), b_head.data_ptr(), ptr(actions), ptr(advantages), ptr(returns),
+            ptr(old_prob), ptr(valids), ptr(idx), ptr(lr_mult), ptr(inv_count), batch, hid, n_actions,
+            kind, float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), int(bool(relu_mask_dh)), ptr(dout),
+            ptr(dh), dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), first, stream_ptr(stream)),
+            "arl_pg_head_loss_parts")
 
     def run(self, stream=None):
         n, self._n = self._n, 0

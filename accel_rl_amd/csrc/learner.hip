@@ -312,12 +312,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
 // Partial head weight gradient: part[rs][k][c] = sum_{b in row split rs} dout[b][k] h[b][c],
 // k == K holds the bias gradient (h := 1).  grid = (hid/64 column tiles, row splits); the
 // 4 waves of a block take rows b = wave, wave+4, ... of the split; dout rows sit in LDS.
-// Folded over row splits by fold_partials_kernel => deterministic.
+// Folded over row splits by arl_fold_many (fixed order) => deterministic.
 constexpr int WG_SPLITS = 16;
 
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dout,
                                                          const float* __restrict__ h, int batch,
-                                                         int hid, int K, float* __restrict__ part) {
+                                                         int hid, int K, int Kp, float* __restrict__ part,
+                                                         float* __restrict__ part_b) {
     __shared__ float lds[4][K_MAX][64];
     extern __shared__ __attribute__((aligned(16))) float s_dout[];   // [rows_in_split][K]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -344,53 +345,16 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict
     __syncthreads();
     if (wave == 0 && c < hid) {
         for (int k = 0; k < K; ++k)
-            part[((int64_t)blockIdx.y * (K + 1) + k) * hid + c] =
+            part[((int64_t)blockIdx.y * K + k) * hid + c] =
                 ((lds[0][k][lane] + lds[1][k][lane]) + lds[2][k][lane]) + lds[3][k][lane];
     }
-    // bias gradient rides along as row K of the partial: column c < K holds sum_b dout[b][c]
-    if (blockIdx.x == 0 && wave == 1) {
-        for (int cc = lane; cc < hid; cc += 64) {
-            float sb = 0.f;
-            if (cc < K)
-                for (int r = 0; r < n_rows; ++r) sb += s_dout[r * K + cc];
-            part[((int64_t)blockIdx.y * (K + 1) + K) * hid + cc] = sb;
-        }
+    // bias gradient: part_b[split][Kp], column c < K holds sum_b dout[b][c] (Kp = K rounded up to 4, padding zero)
+    if (blockIdx.x == 0 && wave == 1 && lane < Kp) {
+        float sb = 0.f;
+        if (lane < K)
+            for (int r = 0; r < n_rows; ++r) sb += s_dout[r * K + lane];
+        part_b[(int64_t)blockIdx.y * Kp + lane] = sb;
     }
-}
-
-// Fold the head weight-gradient partials straight into the gradient bucket: rows 0..K-1 of the staged
-// [(K+1)][hid] matrix -> dw_head, row K (first K columns) -> db_head; fixed summation order.
-// The last block instead folds the per-workgroup loss partials [n_loss][4] into loss4 (16 interleaved
-// chains per component, then a fixed-order sum).
-__global__ __launch_bounds__(256) void head_fold_kernel(const float* __restrict__ part, int splits, int K, int hid,
-                                                        float* __restrict__ dw, float* __restrict__ db,
-                                                        const float* __restrict__ loss_part, int n_loss,
-                                                        float* __restrict__ loss4) {
-    if (blockIdx.x == gridDim.x - 1) {
-        __shared__ float l[16][4];
-        const int c = threadIdx.x & 3, lanes = threadIdx.x >> 2;
-        if (lanes < 16) {
-            float s = 0.f;
-            for (int g = lanes; g < n_loss; g += 16) s += loss_part[g * 4 + c];
-            l[lanes][c] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < 4) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < 16; ++w) s += l[w][threadIdx.x];
-            loss4[threadIdx.x] = s;
-        }
-        return;
-    }
-    const int width = (K + 1) * hid;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K * hid + K) return;
-    const int src = i < K * hid ? i : K * hid + (i - K * hid);
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += part[(int64_t)z * width + src];
-    if (i < K * hid) dw[i] = s;
-    else db[i - K * hid] = s;
 }
 
 }  // namespace
@@ -457,7 +421,7 @@ extern "C" int arl_relu_bwd_bias_parts(float* dy, const float* y, int64_t rows, 
     ARL_REQUIRE(item, ARL_E_ARG, "null pointer");
     int grid = 0;
     int rc = relu_bwd_bias_launch(dy, y, rows, channels, dbias, workspace, &grid, stream);
-    item->part = (const float*)workspace; item->out = dbias; item->total = channels; item->splits = grid;
+    item->part = (const float*)workspace; item->out = dbias; item->total = channels; item->splits = grid; item->valid = 0;
     return rc;
 }
 
@@ -489,16 +453,17 @@ extern "C" int arl_pg_head_infer(const float* h, const float* w_head, const floa
     return arl::check_launch("head_kernel<infer>");
 }
 
-extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
+extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const float* b_head,
                                 const uint8_t* actions, const float* advantages, const float* returns,
                                 const float* old_prob, const int8_t* valids_or_null,
                                 const int32_t* idx_or_null, const float* lr_mult,
                                 const float* inv_count_or_null, int64_t batch, int32_t hid,
                                 int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
                                 float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
-                                float* dw_head, float* db_head, float* loss4, void* workspace, void* stream) {
+                                float* dw_head, float* db_head, float* loss4, void* workspace, arl_fold_item* items3,
+                                      void* stream) {
     ARL_REQUIRE(h && w_head && b_head && actions && advantages && returns && lr_mult && dout && dh &&
-                    dw_head && db_head && loss4 && workspace, ARL_E_ARG, "null pointer");
+                    dw_head && db_head && loss4 && workspace && items3, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(kind == 0 || (kind == 1 && old_prob), ARL_E_ARG, "kind must be 0 (A2C) or 1 (PPO, needs old_prob)");
     int rc = check_head(batch, hid, n_actions);
     if (rc) return rc;
@@ -521,18 +486,38 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
 #undef ARL_HEAD_TRAIN
     rc = arl::check_launch("head_kernel<train>");
     if (rc) return rc;
+    // head weight / bias gradient: row-split partials [WG_SPLITS][K][hid] and [WG_SPLITS][Kp]; their folds and the
+    // fold of the per-workgroup loss partials [grid][4] are left to arl_fold_many (one launch per backward pass)
     float* ws = (float*)workspace;
-    // head weight / bias gradient: row-split partials, then one fold into a staging
-    // matrix [(K+1)][hid]; rows 0..K-1 -> dw_head, row K (first K columns) -> db_head
+    const int Kp = (K + 3) & ~3;
     float* part = ws + 256 * 4;
+    float* part_b = part + (int64_t)WG_SPLITS * K * hid;
     const int rows_per = ((int)batch + WG_SPLITS - 1) / WG_SPLITS;
     hipLaunchKernelGGL(head_wgrad_kernel, dim3((hid + 63) / 64, WG_SPLITS), dim3(256),
-                       (size_t)rows_per * K * 4, s, dout, h, (int)batch, (int)hid, K, part);
+                       (size_t)rows_per * K * 4, s, dout, h, (int)batch, (int)hid, K, Kp, part, part_b);
     rc = arl::check_launch("head_wgrad_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(head_fold_kernel, dim3((K * hid + K + 255) / 256 + 1), dim3(256), 0, s, (const float*)part,
-                       WG_SPLITS, K, (int)hid, dw_head, db_head, (const float*)ws, grid, loss4);
-    rc = arl::check_launch("head_fold_kernel");
-    if (rc) return rc;
+    items3[0].part = part; items3[0].out = dw_head; items3[0].total = (int64_t)K * hid; items3[0].splits = WG_SPLITS;
+    items3[1].part = part_b; items3[1].out = db_head; items3[1].total = Kp; items3[1].splits = WG_SPLITS;
+    items3[2].part = ws; items3[2].out = loss4; items3[2].total = 4; items3[2].splits = grid;
+    items3[0].valid = items3[2].valid = 0;
+    items3[1].valid = K;                                // db_head holds K floats, the partials are padded to Kp
     return 0;
+}
+
+extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
+                                const uint8_t* actions, const float* advantages, const float* returns,
+                                const float* old_prob, const int8_t* valids_or_null,
+                                const int32_t* idx_or_null, const float* lr_mult,
+                                const float* inv_count_or_null, int64_t batch, int32_t hid,
+                                int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
+                                float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
+                                float* dw_head, float* db_head, float* loss4, void* workspace, void* stream) {
+    arl_fold_item items[3];
+    int rc = arl_pg_head_loss_parts(h, w_head, b_head, actions, advantages, returns, old_prob, valids_or_null,
+                                    idx_or_null, lr_mult, inv_count_or_null, batch, hid, n_actions, kind, clip_param,
+                                    v_loss_coeff, ent_loss_coeff, relu_mask_dh, dout, dh, dw_head, db_head, loss4,
+                                    workspace, items, stream);
+    if (rc) return rc;
+    return arl_fold_many(items, 3, stream);
 }

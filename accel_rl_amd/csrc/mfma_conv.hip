@@ -1406,7 +1406,15 @@ __global__ __launch_bounds__(256) void fold_many_kernel(const FoldManyArgs a) {
             const float4 v = lds[k][o];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        out[i] = s;
+        const int64_t valid = a.items[it].valid;            // > 0: `out` holds only this many floats
+        if (valid <= 0 || 4 * i + 3 < valid) {
+            out[i] = s;
+        } else {
+            float* o1 = reinterpret_cast<float*>(out + i);
+            if (4 * i < valid) o1[0] = s.x;
+            if (4 * i + 1 < valid) o1[1] = s.y;
+            if (4 * i + 2 < valid) o1[2] = s.z;
+        }
     }
 }
 
@@ -1843,6 +1851,7 @@ namespace {
 void bias_item(arl_fold_item* item, const float* bias_part, float* dbias, int splits, int channels) {
     item->part = bias_part; item->out = dbias; item->total = channels;
     item->splits = bias_part ? splits : -1;             // -1: not produced (generic kernels ran)
+    item->valid = 0;
 }
 }  // namespace
 
@@ -1858,6 +1867,7 @@ extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, floa
                         dbias_or_null ? &bias_part : nullptr, nullptr, stream);
     item->part = (const float*)workspace; item->out = dw; item->total = total;
     item->splits = splits > 1 ? splits : 0;             // 0: dw is already final
+    item->valid = 0;
     if (dbias_or_null) bias_item(bias_item_or_null, bias_part, dbias_or_null, splits, geom->out_c);
     return rc;
 }
@@ -1963,6 +1973,7 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     else hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
     item->part = (const float*)workspace; item->out = dw; item->total = total;
     item->splits = splits > 1 ? splits : 0;
+    item->valid = 0;
     if (dbias_or_null) bias_item(bias_item_or_null, a.bias_part, dbias_or_null, splits, g.K);
     return arl::check_launch("wgrad_u8_kernel");
 }
@@ -2028,6 +2039,7 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
     rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2>(dp, wp, has_pad, s);
     item->part = (const float*)workspace; item->out = dw; item->total = wp.total;
     item->splits = wp.splits > 1 ? wp.splits : 0;
+    item->valid = 0;
     if (dbias_or_null) bias_item(bias_item_or_null, bias_part, dbias_or_null, wp.splits, geom->out_c);
     return rc;
 }

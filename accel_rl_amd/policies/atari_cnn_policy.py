@@ -356,7 +356,7 @@ class AtariCnnPolicy(object):
             dout = self._buffer(("dout", b), (b, self.n_act + 1))
             dh = self._buffer(("dh", b), (b, hid))
             loss4 = self._buffer(("loss", b), (4,))
-            _lib.pg_head_loss(hids[-1], self.params[k_head], self.params[k_head + 1], mb["actions"],
+            self._folds.pg_head_loss(hids[-1], self.params[k_head], self.params[k_head + 1], mb["actions"],
                               mb["advantages"], mb["returns"], mb.get("old_prob"), mb.get("valids"),
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
                               ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws,

@@ -280,7 +280,7 @@ typedef struct arl_fold_item {
     float*       out;       /* f32[total], 16-byte aligned */
     int64_t      total;     /* multiple of 4 */
     int32_t      splits;
-    int32_t      reserved;
+    int32_t      valid;     /* > 0: `out` holds only this many floats (the partials are padded to `total`); 0 = total */
 } arl_fold_item;
 #define ARL_FOLD_MAX_ITEMS 24
 
@@ -318,6 +318,19 @@ int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
                      int32_t kind, float clip_param, float v_loss_coeff, float ent_loss_coeff,
                      int32_t relu_mask_dh, float* dout, float* dh, float* dw_head, float* db_head,
                      float* loss4, void* workspace, void* stream);
+/* Same, stopping before the three small folds (dw_head, db_head, loss4): they are described in items3[0..2] for
+ * arl_fold_many, so that a backward pass ends in ONE fold launch.  The bias partials are n_actions + 1 rounded
+ * up to a multiple of 4 floats in the partials only (items3[1].valid = n_actions + 1); workspace stays live until the
+ * fold has run.                                                                                                  */
+int arl_pg_head_loss_parts(const float* h, const float* w_head, const float* b_head,
+                           const uint8_t* actions, const float* advantages, const float* returns,
+                           const float* old_prob, const int8_t* valids_or_null,
+                           const int32_t* idx_or_null, const float* lr_mult,
+                           const float* inv_count_or_null, int64_t batch, int32_t hid,
+                           int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
+                           float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
+                           float* dw_head, float* db_head, float* loss4, void* workspace,
+                           struct arl_fold_item* items3, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * The policy network's dense contractions on the matrix cores (fp32 MFMA)
