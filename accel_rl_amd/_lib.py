@@ -13,7 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libaccel_rl_hip.so")
 
 ARL_ABI_VERSION = 1
-PROMO_NEP50, PROMO_LEGACY = 0, 1
+PROMO_NEP50, PROMO_LEGACY, PROMO_ASSOC = 0, 1, 2
 OPT_ADAM, OPT_RMSPROP = 0, 1
 MAX_ACTIONS = 18
 REPLAY_MAX_HORIZON = 16
@@ -105,6 +105,7 @@ _SIGNATURES = {
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv_trace_buffer": (None, [_vp]),
     "arl_conv_force_generic": (None, [_i32]),
+    "arl_scan_force_wave": (None, [_i32]),
     "arl_conv_tile_choice": (None, [_i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),

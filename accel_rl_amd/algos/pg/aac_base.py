@@ -36,7 +36,9 @@ class AdvActorCriticBase(RLAlgorithm):
                              "in: {}".format(lr_schedule, LR_SCHEDULES))
         save_args(vars(), underscore=False)
         self.need_extra_obs = True          # (signal sent to the sampler)
-        self._promo = dict(nep50=_lib.PROMO_NEP50, legacy=_lib.PROMO_LEGACY)[promo]
+        # promo: numeric contract of the return / advantage scans (include/accel_rl_hip.h): "nep50" / "legacy" = the
+        # reference's arithmetic bit for bit under numpy >= 2 / 1.x; "assoc" = wavefront suffix scan, within 1e-5
+        self._promo = dict(nep50=_lib.PROMO_NEP50, legacy=_lib.PROMO_LEGACY, assoc=_lib.PROMO_ASSOC)[promo]
 
     def initialize(self, policy, env_spec, sample_size, horizon, mid_batch_reset):
         if mid_batch_reset and policy.recurrent:

@@ -302,6 +302,143 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(
     }
 }
 
+// ARL_PROMO_ASSOC: the recurrence as a wavefront suffix scan.  Both scans are chains of affine maps
+//   GAE     carry_t = delta_t + (gamma lambda nd_t) carry_{t+1},  delta_t = r_t + gamma v_{t+1} nd_t - v_t   (util.py:13-17)
+//   n-step  run_t   = r_t     + (gamma nd_t)        run_{t+1}                                             (util.py:29-35)
+// and affine maps compose associatively: (c1, d1) o (c2, d2) = (c1 c2, d1 + c1 d2).  A segment of T steps sits on
+// SEG lanes of a wave (E consecutive steps per lane, SEG * E >= T; 64 / SEG segments per wave): every lane composes
+// its own steps, a log2(SEG)-step shuffle scan composes the lanes' maps from the right, and each lane re-walks its
+// steps from the carry that enters it.  All in f64 with the LEGACY promotion's operand types, so the result differs
+// from the exact walks only by the reassociation of f64 sums (<= 1e-5 asserted in the tests, usually bit-identical
+// after the cast to f32).  T steps cost T / (64 E) x (E + log2 SEG) dependent f64 steps per wave instead of T per
+// lane, and the loads are 4 E contiguous bytes per lane straight from HBM (no LDS staging, no transposition).
+template <bool NSTEP, int E>
+__global__ __launch_bounds__(256) void scan_wave_kernel(
+    const float* __restrict__ r, const float* __restrict__ v, const uint8_t* __restrict__ d,
+    const float* __restrict__ lv, double gamma, double gl, int64_t n_env, int T, int seg, int vec_ok,
+    float* __restrict__ out0, float* __restrict__ out1) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int sl = lane & (seg - 1);
+    const int64_t env = wave * (64 / seg) + lane / seg;
+    const bool live = env < n_env;
+    const int t0 = sl * E;
+    const int64_t base = (live ? env : 0) * (int64_t)T;
+    float rr[E], vv[E];
+    uint8_t dd[E];
+    // vector form: the lane's E steps lie inside the segment and start on an E-float boundary (T % E == 0)
+    const bool vec = vec_ok && live && t0 < T;
+    if (E >= 4 && vec) {
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            const float4 a = nt_load4(reinterpret_cast<const float4*>(r + base + t0 + 4 * q));
+            const float4 b = nt_load4(reinterpret_cast<const float4*>(v + base + t0 + 4 * q));
+            const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(d + base + t0 + 4 * q));
+            rr[(4 * q) % E] = a.x; rr[(4 * q + 1) % E] = a.y; rr[(4 * q + 2) % E] = a.z; rr[(4 * q + 3) % E] = a.w;
+            vv[(4 * q) % E] = b.x; vv[(4 * q + 1) % E] = b.y; vv[(4 * q + 2) % E] = b.z; vv[(4 * q + 3) % E] = b.w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dd[(4 * q + k) % E] = (uint8_t)(w >> (8 * k));
+        }
+    } else if (E == 2 && vec) {
+        const float2 a = *reinterpret_cast<const float2*>(r + base + t0);
+        const float2 b = *reinterpret_cast<const float2*>(v + base + t0);
+        const uint16_t w = *reinterpret_cast<const uint16_t*>(d + base + t0);
+        rr[0] = a.x; rr[1 % E] = a.y; vv[0] = b.x; vv[1 % E] = b.y;
+        dd[0] = (uint8_t)w; dd[1 % E] = (uint8_t)(w >> 8);
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+            const bool in = live && t0 + k < T;
+            rr[k] = in ? r[base + t0 + k] : 0.f;
+            vv[k] = in ? v[base + t0 + k] : 0.f;
+            dd[k] = in ? d[base + t0 + k] : (uint8_t)0;
+        }
+    }
+    const float last_v = live ? lv[env] : 0.f;
+    // value that follows the lane's last step: the next lane's first value, the bootstrap value after step T - 1
+    float v_after = __shfl_down(vv[0], 1, 64);
+    if (t0 + E >= T) v_after = last_v;
+    // ---- the lane's own steps as one affine map x -> D + C x (x = what enters after its last step)
+    double cc[E], dl[E];
+    double C = 1.0, D = 0.0;
+#pragma unroll
+    for (int k = E - 1; k >= 0; --k) {
+        const bool in = t0 + k < T;
+        const double nd = dd[k] ? 0.0 : 1.0;                                // util.py:8
+        const float vn = (t0 + k + 1 >= T) ? last_v : (k == E - 1) ? v_after : vv[(k + 1) % E];
+        if (NSTEP) { cc[k] = gamma * nd; dl[k] = (double)rr[k]; }
+        else { cc[k] = gl * nd; dl[k] = ((double)rr[k] + (gamma * (double)vn) * nd) - (double)vv[k]; }
+        if (!in) { cc[k] = 1.0; dl[k] = 0.0; }                              // identity beyond the segment
+        D = dl[k] + cc[k] * D;
+        C = cc[k] * C;
+    }
+    // ---- suffix scan over the segment's lanes: (C, D) <- (C, D) o (C, D)[lane + off]
+    for (int off = 1; off < seg; off <<= 1) {
+        const double Co = __shfl_down(C, off, 64), Do = __shfl_down(D, off, 64);
+        if (sl + off < seg) { D = D + C * Do; C = C * Co; }
+    }
+    // what enters this lane = the map of all lanes to its right applied to the end value
+    const double x_end = NSTEP ? (double)last_v : 0.0;
+    const double Cn = __shfl_down(C, 1, 64), Dn = __shfl_down(D, 1, 64);
+    double x = (sl + 1 < seg) ? Dn + Cn * x_end : x_end;
+    float o0[E], o1[E];
+#pragma unroll
+    for (int k = E - 1; k >= 0; --k) {
+        x = dl[k] + cc[k] * x;
+        const float a = (float)x;
+        o0[k] = a;
+        o1[k] = NSTEP ? a - vv[k] : a + vv[k];                              // aac_base.py:121 / util.py:21
+    }
+    if (!live) return;
+    if (E >= 4 && vec) {
+#pragma unroll
+        for (int q = 0; q < E / 4; ++q) {
+            nt_store4(reinterpret_cast<float4*>(out0 + base + t0 + 4 * q),
+                      make_float4(o0[(4 * q) % E], o0[(4 * q + 1) % E], o0[(4 * q + 2) % E], o0[(4 * q + 3) % E]));
+            nt_store4(reinterpret_cast<float4*>(out1 + base + t0 + 4 * q),
+                      make_float4(o1[(4 * q) % E], o1[(4 * q + 1) % E], o1[(4 * q + 2) % E], o1[(4 * q + 3) % E]));
+        }
+    } else if (E == 2 && vec) {
+        *reinterpret_cast<float2*>(out0 + base + t0) = make_float2(o0[0], o0[1 % E]);
+        *reinterpret_cast<float2*>(out1 + base + t0) = make_float2(o1[0], o1[1 % E]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k)
+            if (t0 + k < T) { out0[base + t0 + k] = o0[k]; out1[base + t0 + k] = o1[k]; }
+    }
+}
+
+bool g_force_wave = false;      // arl_scan_force_wave: tests run the wave scan at every horizon <= 512
+
+// E steps per lane (1, 2, 4 or 8) x SEG lanes per segment (a power of two <= 64) for horizons T <= 512;
+// returns -1 beyond that (the caller falls back to the exact walk)
+template <bool NSTEP>
+int launch_wave(const float* r, const float* v, const uint8_t* d, const float* lv, double gamma, double gl,
+                int64_t n_env, int T, float* o0, float* o1, hipStream_t s) {
+    // Below ~100 steps the exact LDS-tile walk is the faster kernel (T = 32: 0.76 vs 0.71 of the HBM peak, T = 64: 0.75
+    // vs 0.71; T = 128: 0.66 vs 0.70, T = 256: 0.68 vs 0.73): the tolerance mode then simply runs it.
+    if (T > 512 || (T < 96 && !g_force_wave)) return -1;
+    const bool al = arl::aligned16(r) && arl::aligned16(v) && arl::aligned16(o0) && arl::aligned16(o1) && arl::aligned4(d);
+    int e = T > 256 ? 8 : T > 128 ? 4 : T > 64 ? 2 : 1;            // fewest steps per lane that fit 64 lanes
+    // more steps per lane where that makes the accesses 16 (8) bytes wide and still leaves >= 8 lanes per segment
+    // (measured at 2^26 elements, fraction of the HBM peak -- T = 32: E = 1 0.33, 2 0.62, 4 0.71, 8 0.70; T = 128: 2 0.57,
+    //  4 0.70, 8 0.66; T = 256: 4 0.73, 8 0.69)
+    if (al && e < 4 && T % 4 == 0 && T / 4 >= 8) e = 4;
+    else if (al && e < 2 && T % 2 == 0 && T / 2 >= 8) e = 2;
+    const int vec_ok = al && T % e == 0 && e > 1;
+    int seg = 1;
+    while (seg * e < T) seg <<= 1;
+    const int64_t waves = (n_env + (64 / seg) - 1) / (64 / seg);
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+#define ARL_WAVE_SCAN(E_) hipLaunchKernelGGL((scan_wave_kernel<NSTEP, E_>), dim3(grid), dim3(256), 0, s, r, v, d, lv, gamma, gl, n_env, T, seg, vec_ok, o0, o1)
+    if (e == 1) ARL_WAVE_SCAN(1);
+    else if (e == 2) ARL_WAVE_SCAN(2);
+    else if (e == 4) ARL_WAVE_SCAN(4);
+    else ARL_WAVE_SCAN(8);
+#undef ARL_WAVE_SCAN
+    return arl::check_launch("scan_wave_kernel");
+}
+
 // valids[e,t] = (t <= first set flag); zero adv/ret/value past it.
 __global__ __launch_bounds__(256) void valids_kernel(
     const uint8_t* __restrict__ flags, int64_t n_env, int T, int8_t* __restrict__ valids,
@@ -375,11 +512,13 @@ int check_scan_args(const void* a, const void* b, const void* c, const void* d, 
     if (!a || !b || !c || !d || !e || !f) { arl::set_error("scan: null pointer"); return ARL_E_ARG; }
     if (n_env < 0 || T <= 0) { arl::set_error("scan: bad n_env/horizon"); return ARL_E_ARG; }
     if (n_env * (int64_t)T > ((int64_t)1 << 40)) { arl::set_error("scan: too large"); return ARL_E_RANGE; }
-    if (promo != ARL_PROMO_NEP50 && promo != ARL_PROMO_LEGACY) { arl::set_error("scan: bad promo"); return ARL_E_ARG; }
+    if (promo != ARL_PROMO_NEP50 && promo != ARL_PROMO_LEGACY && promo != ARL_PROMO_ASSOC) { arl::set_error("scan: bad promo"); return ARL_E_ARG; }
     return 0;
 }
 
 }  // namespace
+
+extern "C" void arl_scan_force_wave(int32_t on) { g_force_wave = on != 0; }
 
 extern "C" int arl_gae_scan(const float* rewards, const float* values, const uint8_t* dones,
                             const float* last_values, double discount, double gae_lambda,
@@ -390,6 +529,11 @@ extern "C" int arl_gae_scan(const float* rewards, const float* values, const uin
     if (n_env == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const double gl = discount * gae_lambda;          // util.py:17, python floats
+    if (promo == ARL_PROMO_ASSOC) {
+        const int rc2 = launch_wave<false>(rewards, values, dones, last_values, discount, gl, n_env, horizon, advantages, returns, s);
+        if (rc2 >= 0) return rc2;
+        promo = ARL_PROMO_LEGACY;                     // horizon beyond the wave scan: the exact walk with the same operand types
+    }
     if (promo == ARL_PROMO_NEP50)
         return dispatch<false, ARL_PROMO_NEP50>(rewards, values, dones, last_values, discount, gl, n_env, horizon, advantages, returns, s);
     return dispatch<false, ARL_PROMO_LEGACY>(rewards, values, dones, last_values, discount, gl, n_env, horizon, advantages, returns, s);
@@ -403,6 +547,11 @@ extern "C" int arl_nstep_return(const float* rewards, const uint8_t* dones, cons
     if (rc) return rc;
     if (n_env == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (promo == ARL_PROMO_ASSOC) {
+        const int rc2 = launch_wave<true>(rewards, values, dones, last_values, discount, 0.0, n_env, horizon, returns, advantages, s);
+        if (rc2 >= 0) return rc2;
+        promo = ARL_PROMO_LEGACY;
+    }
     if (promo == ARL_PROMO_NEP50)
         return dispatch<true, ARL_PROMO_NEP50>(rewards, values, dones, last_values, discount, 0.0, n_env, horizon, returns, advantages, s);
     return dispatch<true, ARL_PROMO_LEGACY>(rewards, values, dones, last_values, discount, 0.0, n_env, horizon, returns, advantages, s);

@@ -38,9 +38,14 @@ extern "C" {
 /* numpy promotion the reference arithmetic is reproduced under:
  * NEP50  = numpy >= 2 (python float x float32 -> float32), bit-exact with the
  *          reference as it runs today;
- * LEGACY = numpy 1.x (python float x float32 scalar -> float64), as in 2018. */
+ * LEGACY = numpy 1.x (python float x float32 scalar -> float64), as in 2018;
+ * ASSOC  = (scans only) LEGACY's operand types with the recurrence evaluated as a wavefront suffix scan of affine
+ *          maps instead of a sequential walk: f64 sums are reassociated, results agree with both exact modes to
+ *          1e-5 (the tolerance BASELINE.json states for returns / advantages) but not bit for bit.  Used for
+ *          horizons of 96 .. 512 steps, where it is the faster kernel; others take the LEGACY walk.            */
 #define ARL_PROMO_NEP50   0
 #define ARL_PROMO_LEGACY  1
+#define ARL_PROMO_ASSOC   2
 
 int         arl_abi_version(void);
 const char* arl_last_error(void);
@@ -48,6 +53,10 @@ const char* arl_last_error(void);
 /* ------------------------------------------------------------------------- *
  * Return / advantage scans
  * ------------------------------------------------------------------------- */
+
+/* Test hook: with ARL_PROMO_ASSOC run the wave suffix scan at EVERY horizon <= 512 (not only where it is the faster
+ * kernel).  Not thread-safe.                                                                                     */
+void arl_scan_force_wave(int32_t on);
 
 /* GAE(lambda).  Replaces gen_adv_est, accel_rl/algos/pg/util.py:6-23, and the
  * per-env Python loop around it, accel_rl/algos/pg/aac_base.py:122-127.

@@ -102,6 +102,49 @@ def test_scans_vs_oracle_shapes(L, n, t):
         np.testing.assert_array_equal(adv, a1)
 
 
+@pytest.mark.parametrize("n,t", [(8, 128), (33, 32), (256, 5), (1000, 1), (513, 2), (300, 8), (129, 9), (77, 17),
+                                 (65, 34), (50, 35), (200, 64), (40, 100), (31, 130), (70, 136), (30, 137), (9, 256),
+                                 (19, 500), (7, 512), (5, 545)])
+def test_wave_suffix_scan_within_tolerance(L, n, t):
+    """ARL_PROMO_ASSOC: the scans as a wavefront suffix scan of affine maps (every steps-per-lane / lanes-per-segment
+    shape: T <= 64 one step per lane, 2 / 4 / 8 steps per lane with vector accesses when T divides, scalar otherwise;
+    T > 512 falls back to the exact walk).  Tolerance: BASELINE.json's 1e-5 for returns / advantages, relative to
+    max(1, |x|), against BOTH exact modes of the oracle; identical results run to run."""
+    L.load().arl_scan_force_wave(1)                  # (by default horizons below 96 take the exact walk: it is faster there)
+    try:
+        _wave_scan_checks(L, n, t)
+    finally:
+        L.load().arl_scan_force_wave(0)
+
+
+def _wave_scan_checks(L, n, t):
+    rs = np.random.RandomState(n * 1000 + t)
+    r = rs.randn(n, t).astype(np.float32)
+    v = (rs.randn(n, t) * 2).astype(np.float32)
+    d = rs.rand(n, t) < (0.15 if t < 64 else 0.03)
+    lv = rs.randn(n).astype(np.float32)
+    close = lambda got, want: np.all(np.abs(got - want) <= 1e-5 * np.maximum(1., np.abs(want)))     # noqa: E731
+    adv, ret = run_gae(L, r, v, d, lv, 0.99, 0.95, promo=2)
+    adv2, ret2 = run_gae(L, r, v, d, lv, 0.99, 0.95, promo=2)
+    np.testing.assert_array_equal(adv, adv2)
+    np.testing.assert_array_equal(ret, ret2)
+    for pname in ("nep50", "legacy"):
+        a0, r0 = P.gae_scan(r, v, d, lv, 0.99, 0.95, pname)
+        assert close(adv, a0) and close(ret, r0), (pname, np.abs(adv - a0).max())
+    a_leg, _ = P.gae_scan(r, v, d, lv, 0.99, 0.95, "legacy")
+    assert np.mean(adv == a_leg) > 0.98              # reassociated f64 sums round to the same f32 almost everywhere
+    nret, nadv = run_nstep(L, r, d, v, lv, 0.99, promo=2)
+    for pname in ("nep50", "legacy"):
+        r1, a1 = P.nstep_returns(r, d, v, lv, 0.99, pname)
+        assert close(nret, r1) and close(nadv, a1), (pname, np.abs(nret - r1).max())
+    # lambda = 1, gamma = 1, no terminals: advantages are plain suffix sums of the TD errors
+    z = np.zeros_like(d)
+    adv1, _ = run_gae(L, r, v, z, lv, 1.0, 1.0, promo=2)
+    vn = np.concatenate([v[:, 1:], lv[:, None]], axis=1).astype(np.float64)
+    want = np.cumsum((r.astype(np.float64) + vn - v)[:, ::-1], axis=1)[:, ::-1]
+    assert np.all(np.abs(adv1 - want) <= 1e-5 * np.maximum(1., np.abs(want)))
+
+
 def test_scan_unaligned_views_take_the_direct_path(L):
     rs = np.random.RandomState(5)
     n, t = 100, 5

@@ -35,9 +35,11 @@ def main():
             lv = torch.randn(n, device=DEV, generator=gen)
             adv, ret = torch.empty_like(r), torch.empty_like(r)
             us = ev(lambda: _lib.gae_scan(r, v, d, lv, 0.99, 0.95, n, t, adv, ret))
+            us2 = ev(lambda: _lib.gae_scan(r, v, d, lv, 0.99, 0.95, n, t, adv, ret, promo=_lib.PROMO_ASSOC))
             nbytes = 17 * n * t + 4 * n
-            gbs = nbytes / us / 1e3
-            print("%8d %5d %12d %10.1f %10.1f %8.3f" % (lg, t, n, us, gbs, gbs / 8000.))
+            gbs, gbs2 = nbytes / us / 1e3, nbytes / us2 / 1e3
+            print("%8d %5d %12d %10.1f %10.1f %8.3f   | wave suffix scan (ARL_PROMO_ASSOC) %10.1f us %10.1f GB/s %8.3f" %
+                  (lg, t, n, us, gbs, gbs / 8000., us2, gbs2, gbs2 / 8000.))
             del r, v, d, lv, adv, ret
 
 
