@@ -148,10 +148,30 @@ __device__ __forceinline__ void store_tiles_rowmajor(const f32x16 (&acc)[TM][TN]
 template <int TM, int TN>
 __device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
                                                   const long long (&row_off)[TM], int N, int col_base, int lane,
-                                                  const float4 (&bias_q)[TN][4], const float* mask, int relu) {
+                                                  const float4 (&bias_q)[TN][4], const float* mask, int relu,
+                                                  const float4 (*pre)[TM] = nullptr) {
     const int half = lane >> 5;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j) {
+        // the rectifier mask of a column tile: every load issued before the first one is consumed (one latency
+        // per column tile instead of one per store; per-workgroup timestamps had the epilogue of the stride-2
+        // data gradient at 10 k cycles of a 66 k lifetime)
+        float4 mk[4][TM];
+        if (mask && pre) {                              // (TN == 1: loaded in the prologue, see igemm_body)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) mk[q][i] = pre[q][i];
+        } else if (mask) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int n = col_base + j * 32 + 8 * q + 4 * half;
+                    mk[q][i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (row_off[i] >= 0 && n < N) mk[q][i] = *reinterpret_cast<const float4*>(mask + row_off[i] + n);
+                }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int n = col_base + j * 32 + 8 * q + 4 * half;
@@ -164,17 +184,17 @@ __device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], _
                 if (relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
                 const unsigned voff = ok ? (unsigned)((row_off[i] + n) << 2) : OOB;
                 if (mask) {
-                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (ok) mk = *reinterpret_cast<const float4*>(mask + row_off[i] + n);
-                    if (!(mk.x > 0.f)) val.x = 0.f;
-                    if (!(mk.y > 0.f)) val.y = 0.f;
-                    if (!(mk.z > 0.f)) val.z = 0.f;
-                    if (!(mk.w > 0.f)) val.w = 0.f;
+                    const float4 m = mk[q][i];
+                    if (!(m.x > 0.f)) val.x = 0.f;
+                    if (!(m.y > 0.f)) val.y = 0.f;
+                    if (!(m.z > 0.f)) val.z = 0.f;
+                    if (!(m.w > 0.f)) val.w = 0.f;
                 }
                 u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
                 __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff, 0, 0);
             }
         }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -792,6 +812,37 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             bias_q[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.o.bias && n < a.N && (!N16 || q == 0)) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
         }
+    // The epilogue's output rows -- and, for the one-tile-per-wave shapes, the rectifier mask of the layer below
+    // (a data gradient's epilogue otherwise starts with a dependent global load per store: 8-10 k cycles of a 65 k
+    // workgroup lifetime in the stride-2 data gradient) -- are fetched here, a whole main loop ahead of their use.
+    long long row_off[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
+        if (a.o.dense) {
+            row_off[i] = m < M ? (long long)m * a.N : -1;
+        } else {                                        // stride-parity data gradient: rows map to scattered pixels
+            const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
+            const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
+            row_off[i] = m < M ? ((long long)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N
+                               : -1;
+        }
+    }
+    constexpr bool PRE_MASK = TN == 1 && TM <= 2;
+    float4 mk_pre[4][TM];
+    // issued at the start of the LAST k-tile: behind every operand load (an earlier issue would sit in front of the
+    // tile loads in the in-order vmcnt queue and stall the first LDS store on scattered, cache-cold addresses)
+    auto issue_mask_loads = [&]() {
+        if (!(PRE_MASK && a.o.mask)) return;
+#pragma unroll
+        for (int q = 0; q < (N16 ? 1 : 4); ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int n = N16 ? n0 + wn * 16 + 4 * quad : n0 + wn * TN * 32 + 8 * q + 4 * half;
+                mk_pre[q][i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (row_off[i] >= 0 && n < a.N) mk_pre[q][i] = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
+            }
+    };
     const int nk = (kend - kbeg) / BK;
     // The MFMAs of sub-steps [LO, HI) of the k-tile in LDS stage BUF (16 k per sub-step with the 16-wide tiles, 8
     // otherwise).  Compile-time stage: every LDS address is then a per-thread constant plus an immediate (with a
@@ -942,6 +993,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                 __syncthreads();
                 if (kt + 2 < nk) { next_tile(); issue_loads(kbeg + (kt + 2) * BK); }
                 read_frags(NX{}, C0{}, f0);             // next tile's first fragments, under this tile's last MFMAs
+            } else {
+                issue_mask_loads();
             }
             run_mfmas(f1);
         };
@@ -964,6 +1017,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         if (kt + 1 < nk) {                          // uniform branch
             next_tile();
             issue_loads(kbeg + (kt + 1) * BK);
+        } else {
+            issue_mask_loads();
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_steps(buf_c, C0{}, CS_{});
@@ -988,30 +1043,25 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     {
         // operands are swapped (acc = W-tile x X-tile^T): every lane owns ONE output row per 32-row tile
         const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out, a.o.out_bytes);
-        long long row_off[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
-            if (a.o.dense) {
-                row_off[i] = m < M ? (long long)m * a.N : -1;
-            } else {                                    // stride-parity data gradient: rows map to scattered pixels
-                const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
-                const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
-                row_off[i] = m < M ? ((long long)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N
-                                   : -1;
-            }
-        }
         if constexpr (N16) {
             const int n = n0 + wn * 16 + 4 * quad;
             const float4 bq = bias_q[0][0];
+            float4 mks[TM];
+            if (a.o.mask) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (PRE_MASK) { mks[i] = mk_pre[0][i]; continue; }
+                    mks[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (row_off[i] >= 0 && n < a.N) mks[i] = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bool ok = row_off[i] >= 0 && n < a.N;
                 float4 val = make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
                 if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
                 if (a.o.mask) {
-                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (ok) mk = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
+                    const float4 mk = mks[i];
                     if (!(mk.x > 0.f)) val.x = 0.f;
                     if (!(mk.y > 0.f)) val.y = 0.f;
                     if (!(mk.z > 0.f)) val.z = 0.f;
@@ -1021,7 +1071,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                 __builtin_amdgcn_raw_buffer_store_b128(raw, rsO, ok ? (unsigned)((row_off[i] + n) << 2) : OOB, 0, 0);
             }
         } else {
-            store_tiles_quads<TM, TN>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu);
+            store_tiles_quads<TM, TN>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu,
+                                      PRE_MASK ? mk_pre : nullptr);
         }
     }
     if (a.trace && tid == 0) {
@@ -1033,6 +1084,11 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     }
 }
 
+// (Register allocation: the 128-row x 32-column, 16-deep shape takes 100-106 registers = FOUR workgroups per CU.  Capping
+// it at 96 for a fifth (__launch_bounds__(256, 5): 4-9 spilled registers) was measured inside the learner: the fifth
+// workgroup is resident, the CU's timeline stays at ~105 k cycles for 8 x 8 192 matrix-pipe cycles of work -- with five
+// waves per SIMD in their main loops the pipe is still only ~2/3 busy, so residency is not what holds these two kernels
+// (conv 1 forward, stride-2 data gradient) back; tools/context_trace.py prints the timelines.)
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
           bool PIPE3 = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {

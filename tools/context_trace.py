@@ -1,7 +1,7 @@
 """Per-workgroup timeline (arl_conv_trace_buffer) of ONE conv kernel launch as the learner runs it: inside an eager
 PPO minibatch (B = 512, spec 1), i.e. on activations the previous layer has just written, after a long busy stretch.
-usage: python tools/context_trace.py [which]   (which = index of the conv2d_fwd call inside a minibatch: 0 conv2,
-1 conv3, 2 dense)"""
+usage: python tools/context_trace.py [c1f | c2f | c3f | df | c3d | c2d]   (forward conv 1..3 / dense, data gradient
+of conv 3 / conv 2)"""
 import os, sys, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +12,6 @@ from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
 from accel_rl_amd.spaces import Discrete, UintBox, EnvSpec
 DEV = "cuda:0"
 lib = _lib.load()
-which = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 policy = AtariCnnPolicy(**cnn_specs[1])
 policy.initialize(EnvSpec(UintBox((4, 104, 80)), Discrete(4)), device=DEV)
 n = 1280
@@ -23,23 +22,29 @@ mb = dict(observations=obs, actions=torch.randint(0, 4, (n,), device=DEV, dtype=
 idxs = [torch.randperm(n, device=DEV)[:512].to(torch.int32) for _ in range(8)]
 lr = torch.ones(1, device=DEV)
 tr = torch.zeros(8192 * 8, dtype=torch.int64, device=DEV)
-state = dict(calls=0, armed=False)
-orig = _lib.conv2d_fwd
+# which: c1f | c2f | c3f | df (forward conv 1..3, dense)  |  c3d | c2d (data gradient of conv 3 / conv 2)
+TARGETS = dict(c1f=("u8", 0), c2f=("fwd", 0), c3f=("fwd", 1), df=("fwd", 2), c3d=("pair", 1), c2d=("pair", 2))
+kind, nth = TARGETS[sys.argv[1] if len(sys.argv) > 1 else "c2f"]
+which = sys.argv[1] if len(sys.argv) > 1 else "c2f"
+state = dict(calls=dict(u8=0, fwd=0, pair=0), armed=False)
 
 
-def wrapped(*a, **k):
-    hit = state["armed"] and state["calls"] == which
-    state["calls"] += 1
-    if hit:
-        lib.arl_conv_trace_buffer(tr.data_ptr())
-    orig(*a, **k)
-    if hit:
-        lib.arl_conv_trace_buffer(None)
+def wrap(fn, k):
+    def wrapped(*a, **kw):
+        hit = state["armed"] and kind == k and state["calls"][k] == nth
+        state["calls"][k] += 1
+        if hit:
+            lib.arl_conv_trace_buffer(tr.data_ptr())
+        out = fn(*a, **kw)
+        if hit:
+            lib.arl_conv_trace_buffer(None)
+        return out
+    return wrapped
 
 
-_lib.conv2d_fwd = wrapped
-import accel_rl_amd.policies.atari_cnn_policy as pol
-pol._lib.conv2d_fwd = wrapped
+_lib.conv2d_fwd = wrap(_lib.conv2d_fwd, "fwd")
+_lib.conv2d_u8_fwd = wrap(_lib.conv2d_u8_fwd, "u8")
+_lib.FoldList.conv2d_bwd_pair = wrap(_lib.FoldList.conv2d_bwd_pair, "pair")
 
 
 def report(tag):
@@ -71,6 +76,11 @@ def report(tag):
     for k in sorted(by_n):
         arr = np.array(by_n[k])
         print("   CUs with %d WGs (%d): median loop cycles, fastest -> slowest: %s" % (k, len(arr), np.median(arr, axis=0).astype(int).tolist()))
+    # one busy CU's timeline (cycles since its first workgroup's start): start, loop begin, loop end, end
+    big = max(by_cu, key=lambda c: (len(by_cu[c]), -c))
+    rows = sorted((int(t[j, 0]), int(t[j, 1]), int(t[j, 2]), int(t[j, 3])) for j in by_cu[big])
+    z = rows[0][0]
+    print("   timeline of CU %#x: %s" % (big, [tuple(x - z for x in r_) for r_ in rows]))
     xcc_med = {int(x): int(np.median(loop[(cu >> 8) == x])) for x in np.unique(cu >> 8)}
     print("   median loop by XCD: %s" % xcc_med)
     rs = (t[:, 4] - t[:, 4].min()) / 100.0
@@ -79,16 +89,16 @@ def report(tag):
                                                       np.median(epi), np.median(t[:, 3] - t[:, 0]), np.median(rs), rs.max(), hist))
 
 
-for choice in (1, 2):
+for choice in ((1, 2) if which in ('c2f', 'c3f', 'c3d') else (1,)):
     lib.arl_conv_tile_choice(choice)
     policy._scratch.clear()
     for rep in range(3):                       # two warm passes over the 8 minibatches, then the traced one
         for j, ix in enumerate(idxs):
-            state["calls"] = 0
+            state["calls"] = dict(u8=0, fwd=0, pair=0)
             state["armed"] = rep == 2 and j == 6
             if state["armed"]:
                 tr.zero_()
             policy.loss_and_grads(dict(mb, idx=ix), 1, 0.2, 1.0, 0.01, lr)
     torch.cuda.synchronize()
-    report("call %d, tiles %s" % (which, "64x64" if choice == 1 else "112x64"))
+    report("%s, 64-column tiles %s" % (which, "64x64" if choice == 1 else "112x64"))
 lib.arl_conv_tile_choice(0)
