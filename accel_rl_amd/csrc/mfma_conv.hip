@@ -604,6 +604,22 @@ __device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned v
     // imask bit set = tap invalid for this row -> force the offset out of range
     return ((unsigned)__builtin_amdgcn_sbfe(imask, bit, 1) & OOB) | voff;
 }
+// Inverted tap mask of a gathered row whose tap (ty, tx) reads pixel (ry + step*ty, rx + step*tx): bit
+// ty*taps_x + tx is SET when that pixel lies outside the Hs x Ws image (taps_y * taps_x <= 32, step = +-1).
+// Closed form -- the valid taps of a row are a contiguous range in x and in y -- instead of a loop over the taps:
+// these kernels pay for every vector instruction in matrix-pipe issue slots (fp32 MFMA shares the VALU), and the
+// loops cost 28 instructions per tap row / column, per gathered row, in every workgroup's prologue and in the
+// weight gradient's row table refresh (conv 2 forward: 224 of ~400 non-MFMA vector instructions per workgroup).
+__device__ __forceinline__ unsigned low_bits(int n) { return n >= 32 ? ~0u : (1u << n) - 1u; }
+__device__ __forceinline__ unsigned tap_mask(int ry, int rx, int Hs, int Ws, int taps_y, int taps_x, int step) {
+    // x + step*t in [0, W)  <=>  t in [p, p + W) with p = -x (step = 1) or x - W + 1 (step = -1)
+    const int px = step > 0 ? -rx : rx - Ws + 1, py = step > 0 ? -ry : ry - Hs + 1;
+    const int xlo = min(max(px, 0), 31), xhi = min(px + Ws, taps_x), ylo = max(py, 0), yhi = min(py + Hs, taps_y);
+    const int xn = max(xhi - xlo, 0), yn = max(yhi - ylo, 0);
+    unsigned good = low_bits(xn) << xlo;                // one tap row's pattern ...
+    for (int sh = taps_x; sh < 32; sh *= 2) good |= good << sh;         // ... over every tap row (uniform trip count)
+    return ~(good & (low_bits(yn * taps_x) << min(ylo * taps_x, 31))); // rows [ylo, yhi) keep it, the others are out
+}
 
 // N16: layers with <= 16 output columns (spec 0's 16-filter conv 1, the data gradient into 16 channels) use
 // v_mfma_f32_16x16x4_f32 -- a 32-wide tile would spend half of every MFMA on columns that do not exist.
@@ -685,17 +701,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             }
         }
         imask[p] = 0;
-        if (HAS_PAD) {                              // bit (ty*taps_x + tx) set <=> that tap is outside the image
-            unsigned xbad = 0, im = 0;
-            for (int tx = 0; tx < taps_x; ++tx)
-                xbad |= (unsigned)!((unsigned)(rx + step * (tx + tpt)) < (unsigned)Ws) << tx;
-            const unsigned row_all = (1u << taps_x) - 1u;
-            for (int ty = 0; ty < g.taps_y; ++ty) {
-                const bool yok = (unsigned)(ry + step * ty) < (unsigned)g.Hs;
-                im |= (yok ? xbad : row_all) << (ty * taps_x);
-            }
-            imask[p] = im;
-        }
+        // bit (ty*taps_x + tx) set <=> tap (ty, tx + tpt) is outside the image
+        if (HAS_PAD) imask[p] = tap_mask(ry, rx + step * tpt, g.Hs, Ws, g.taps_y, taps_x, step);
     }
 #pragma unroll
     for (int p = 0; p < RB; ++p) {
@@ -816,19 +823,22 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     // (a data gradient's epilogue otherwise starts with a dependent global load per store: 8-10 k cycles of a 65 k
     // workgroup lifetime in the stride-2 data gradient) -- are fetched here, a whole main loop ahead of their use.
     long long row_off[TM];
+    auto decode_out_rows = [&]() {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
-        if (a.o.dense) {
-            row_off[i] = m < M ? (long long)m * a.N : -1;
-        } else {                                        // stride-parity data gradient: rows map to scattered pixels
-            const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
-            const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
-            row_off[i] = m < M ? ((long long)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N
-                               : -1;
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
+            if (a.o.dense) {
+                row_off[i] = m < M ? (long long)m * a.N : -1;
+            } else {                                    // stride-parity data gradient: rows map to scattered pixels
+                const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
+                const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
+                row_off[i] = m < M ? ((long long)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N
+                                   : -1;
+            }
         }
-    }
-    constexpr bool PRE_MASK = TN == 1 && TM <= 2;
+    };
+    constexpr bool PRE_MASK = TN == 1 && TM <= 2;       // (larger register tiles keep their registers for the main loop)
+    if (PRE_MASK) decode_out_rows();
     float4 mk_pre[4][TM];
     // issued at the start of the LAST k-tile: behind every operand load (an earlier issue would sit in front of the
     // tile loads in the in-order vmcnt queue and stall the first LDS store on scattered, cache-cold addresses)
@@ -914,89 +924,26 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     using CH_ = std::integral_constant<int, STEPS / 2>;
     using CS_ = std::integral_constant<int, STEPS>;
     if constexpr (PIPE3) {
-        static_assert(STEPS == 2, "PIPE3: two sub-steps per k-tile (16-wide tiles with BK = 32, 32-wide with BK = 16)");
-        // Fragments are double-buffered in registers: the LDS reads of the NEXT sub-step (after the barrier: of the
-        // next tile's first sub-step) are issued before the MFMAs of the current one, so a wave that has its SIMD to
-        // itself does not wait for LDS between MFMA bursts either.
-        constexpr int NA = TM, NB = N16 ? 1 : TN;
-        struct Frags { float a[NA][4], b[NB][4]; };
-        auto read_frags = [&](auto buf_c, auto ks_c, Frags& f) {
-            constexpr int buf = decltype(buf_c)::value, ks = decltype(ks_c)::value;
-            if constexpr (N16) {
-                const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
-                const float* cB = B_KC ? sB + buf * B_SZ + (wn * 16 + l15) * LDB + quad * 4
-                                       : sB + buf * B_SZ + (quad * 4) * LDB + wn * 16 + l15;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 16 * LDA + ks * 16);
-                    f.a[i][0] = t.x; f.a[i][1] = t.y; f.a[i][2] = t.z; f.a[i][3] = t.w;
-                }
-                if (B_KC) {
-                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 16);
-                    f.b[0][0] = t.x; f.b[0][1] = t.y; f.b[0][2] = t.z; f.b[0][3] = t.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) f.b[0][q] = cB[(ks * 16 + q) * LDB];
-                }
-            } else {
-                const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
-                const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
-                                       : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
-                    f.a[i][0] = t.x; f.a[i][1] = t.y; f.a[i][2] = t.z; f.a[i][3] = t.w;
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (B_KC) {
-                        const float4 t = *reinterpret_cast<const float4*>(cB + j * 32 * LDB + ks * 8);
-                        f.b[j][0] = t.x; f.b[j][1] = t.y; f.b[j][2] = t.z; f.b[j][3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) f.b[j][q] = cB[(ks * 8 + q) * LDB + j * 32];
-                    }
-                }
-            }
-        };
-        auto run_mfmas = [&](const Frags& f) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if constexpr (N16) {
-                        acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[0][q], f.a[i][q], acc16[i], 0, 0, 0);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.b[j][q], f.a[i][q], acc[i][j], 0, 0, 0);
-                    }
-                }
-        };
+        static_assert(STEPS >= 2, "PIPE3 splits a k-tile's MFMAs in two");
+        // (Register double-buffering of the fragments on top of this -- the next sub-step's LDS reads issued before the
+        //  current MFMAs -- was measured too: 206-221 registers, one workgroup per CU for some shapes, slower.)
         const int r3 = nk % 3;                          // stage of tile kt = (kt + 3 - r3) % 3: the last tile ends on stage 2
         issue_loads(kbeg);
         store_tiles((3 - r3) % 3);
         __syncthreads();
         if (nk > 1) { next_tile(); issue_loads(kbeg + BK); }
         if (a.trace) tr1 = __builtin_readcyclecounter();
-        Frags f0, f1;                                   // f0: a tile's first sub-step, f1: its second
-        if (r3 == 0) read_frags(C0{}, C0{}, f0);
-        else if (r3 == 1) read_frags(C2{}, C0{}, f0);
-        else read_frags(C1{}, C0{}, f0);
         auto tile3 = [&](auto st_c, int kt) {
             constexpr int st = decltype(st_c)::value;
-            using NX = std::integral_constant<int, (st + 1) % 3>;
-            read_frags(st_c, C1{}, f1);
-            run_mfmas(f0);
+            mfma_steps(st_c, C0{}, CH_{});
             if (kt + 1 < nk) {                          // uniform
                 store_tiles((st + 1) % 3);              // tile kt+1: loaded since the middle of tile kt-1
                 __syncthreads();
                 if (kt + 2 < nk) { next_tile(); issue_loads(kbeg + (kt + 2) * BK); }
-                read_frags(NX{}, C0{}, f0);             // next tile's first fragments, under this tile's last MFMAs
             } else {
                 issue_mask_loads();
             }
-            run_mfmas(f1);
+            mfma_steps(st_c, CH_{}, CS_{});
         };
         int kt = 0;
         if (r3 == 1) { tile3(C2{}, 0); kt = 1; }
@@ -1043,25 +990,19 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     {
         // operands are swapped (acc = W-tile x X-tile^T): every lane owns ONE output row per 32-row tile
         const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out, a.o.out_bytes);
+        if (!PRE_MASK) decode_out_rows();
         if constexpr (N16) {
             const int n = n0 + wn * 16 + 4 * quad;
             const float4 bq = bias_q[0][0];
-            float4 mks[TM];
-            if (a.o.mask) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if (PRE_MASK) { mks[i] = mk_pre[0][i]; continue; }
-                    mks[i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (row_off[i] >= 0 && n < a.N) mks[i] = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
-                }
-            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bool ok = row_off[i] >= 0 && n < a.N;
                 float4 val = make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
                 if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
                 if (a.o.mask) {
-                    const float4 mk = mks[i];
+                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (PRE_MASK) mk = mk_pre[0][i < TM ? i : 0];
+                    else if (ok) mk = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
                     if (!(mk.x > 0.f)) val.x = 0.f;
                     if (!(mk.y > 0.f)) val.y = 0.f;
                     if (!(mk.z > 0.f)) val.z = 0.f;
@@ -1094,6 +1035,13 @@ template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, b
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, PIPE3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// probe: the same body compiled for MINW waves per SIMD (small tiles, many resident workgroups)
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, int MINW>
+__global__ __launch_bounds__(256, MINW) void igemm_occ_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, false>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // forward convolution straight from planar u8 observations (see igemm_body, U8)
@@ -1177,13 +1125,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         } else if (pm < mend) {
             off = (unsigned)(((pb * a.g.Hs + ry) * Ws + rx) * Cs - a.g.rmin) << 2;
             im = 0;
-            if (HAS_PAD) {
-                unsigned xbad = 0;
-                for (int tx = 0; tx < taps_x; ++tx) xbad |= (unsigned)!((unsigned)(rx + step * tx) < (unsigned)Ws) << tx;
-                const unsigned row_all = (1u << taps_x) - 1u;
-                for (int ty = 0; ty < a.g.taps_y; ++ty)
-                    im |= (((unsigned)(ry + step * ty) < (unsigned)a.g.Hs) ? xbad : row_all) << (ty * taps_x);
-            }
+            if (HAS_PAD) im = tap_mask(ry, rx, a.g.Hs, Ws, a.g.taps_y, taps_x, step);
         }
         s_row[slot][tid] = make_uint2(off, im);
         // advance this thread's row by 256 (host-provided decomposition 256 = qb*out_h*out_w + qw*out_w + rw)
@@ -1523,6 +1465,18 @@ int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hi
     return rc ? rc : arl::check_launch("igemm_kernel");
 }
 
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16, int MINW>
+int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s) {
+    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * TN * 32;
+    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
+    const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : 1);
+    if (multi_tap) { arl::set_error("probe tile: single-tap layers only"); return ARL_E_ARG; }
+    if (has_pad) hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, true, N16, MINW>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, false, N16, MINW>), grid, dim3(256), lds, s, a);
+    return arl::check_launch("igemm_occ_kernel");
+}
+
 template <int WGM, int WGN, int TM, int TN, int BK, bool M16 = false>
 int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t s) {
     constexpr int BM = M16 ? 16 : WGM * TM * 32, BN = WGN * TN * 32;
@@ -1598,15 +1552,34 @@ unsigned div_magic(int64_t rows, int d) {
 // of one 16-column stripe: v_mfma_f32_16x16x4_f32, same rate; three LDS stages, PIPE3)?  All workgroups of these
 // launches are resident at once, so a launch lasts as long as its busiest CU.  At the PPO minibatch (55 296 rows)
 // that is 4 workgroups of 64 rows on 96 CUs (8 units of MFMA work against 6.75 for a perfect spread) or 2 of 112
-// rows on 238 CUs (7 units) -- but per-workgroup timestamps inside the learner (tools/context_trace.py) show the
-// busiest CU taking 66-69 k cycles with four 64x64 workgroups (matrix pipe 99 % busy: four waves per SIMD cover
-// each other's barriers and LDS waits) and 71-74 k with two 112x64 ones (81 %; a lone one: 64 %), mid-tile barrier
-// and register double-buffered fragments included.  Isolated and L2-hot the 112-row tiles are 9-12 % faster; in the
-// learner the two are equal (482 vs 485 us per minibatch), so the cost model keeps the 64x64 tiles and the other
-// shape stays reachable for tests and tuning (arl_conv_tile_choice).
+// rows on 238 CUs (7 units).  Per-workgroup timestamps inside the learner (tools/context_trace.py) show the busiest
+// CU taking 66-69 k cycles with four 64x64 workgroups (matrix pipe 99 % busy: four waves per SIMD cover each other's
+// barriers and LDS waits) and 71-74 k with two 112x64 ones (81 %; a lone one: 64 %) -- the balance is paid for in
+// latency cover.  Net, measured: alone and L2-hot the 112-row tiles are 9-14 % faster (conv 2 / conv 3 forward,
+// conv 3 data gradient at 512 images), inside the learner 1 % (482 vs 488 us per minibatch); at the rollout's
+// 27 648 rows one 112-row workgroup would be alone on its CU and loses (25.3 vs 23.1 us), hence t112 > 256.
 bool balanced_rows_pay(int M) {
-    (void)M;
-    return g_tile_choice > 1;
+    if (g_tile_choice) return g_tile_choice > 1;
+    const int64_t t64 = (M + 63) / 64, t112 = (M + 111) / 112;
+    return t112 > 256 && ((t112 + 255) / 256) * 7 < ((t64 + 255) / 256) * 4;
+}
+
+// tuning aid (arl_conv_tile_choice >= 3): finer 16-wide-MFMA row tiles for the 64-column layers
+template <bool B_KC>
+int launch_n64_probe(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s) {
+    switch (g_tile_choice) {
+    case 3: return launch_igemm<1, 4, 2, 1, 32, B_KC, true, false>(a, 1, multi_tap, has_pad, s);   // 32x64, two stages
+    case 4: return launch_igemm<1, 4, 3, 1, 32, B_KC, true, false>(a, 1, multi_tap, has_pad, s);   // 48x64
+    case 5: return launch_igemm<1, 4, 2, 1, 32, B_KC, true, true>(a, 1, multi_tap, has_pad, s);    // 32x64, three stages
+    case 6: return launch_igemm<1, 4, 3, 1, 32, B_KC, true, true>(a, 1, multi_tap, has_pad, s);    // 48x64
+    case 7: return launch_igemm<1, 4, 4, 1, 32, B_KC, true, false>(a, 1, multi_tap, has_pad, s);   // 64x64 on 16-wide MFMAs
+    case 8: return launch_igemm_occ<1, 4, 2, 1, 16, B_KC, true, 8>(a, multi_tap, has_pad, s);       // 32x64, 16-deep, 8 waves / SIMD
+    case 9: return launch_igemm_occ<1, 4, 2, 1, 16, B_KC, true, 6>(a, multi_tap, has_pad, s);
+    case 10: return launch_igemm_occ<1, 4, 2, 1, 32, B_KC, true, 5>(a, multi_tap, has_pad, s);
+    case 11: return launch_igemm_occ<2, 2, 1, 1, 16, B_KC, false, 6>(a, multi_tap, has_pad, s);     // 64x64 on 32-wide MFMAs, 16-deep
+    case 12: return launch_igemm_occ<1, 4, 3, 1, 16, B_KC, true, 6>(a, multi_tap, has_pad, s);      // 48x64, 16-deep
+    default: return launch_igemm_occ<1, 4, 4, 1, 16, B_KC, true, 6>(a, multi_tap, has_pad, s);      // 64x64 n16, 16-deep
+    }
 }
 
 // split the reduction so that tiles * splits ~ TARGET_WGS, each split a multiple of BKT
@@ -1682,6 +1655,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 1, 1, 16, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        else if (a.N <= 64 && splits == 1 && g_tile_choice >= 3) rc = launch_n64_probe<true>(a, multi_tap, has_pad, s);
         else if (a.N <= 64 && splits == 1 && balanced_rows_pay(a.M)) rc = launch_igemm<1, 4, 7, 1, FBK, true, true, true>(a, 1, multi_tap, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
@@ -1790,6 +1764,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         }
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
+        else if (a.N <= 64 && g_tile_choice >= 3) rc = launch_n64_probe<false>(a, false, has_pad, s);
         else if (a.N <= 64 && balanced_rows_pay(a.M)) rc = launch_igemm<1, 4, 7, 1, FBK, false, true, true>(a, 1, false, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, 1, false, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);

@@ -219,7 +219,13 @@ def test_learner_matches_plain_torch(case):
             assert np.allclose(got[0], want, rtol=1e-5, atol=5e-5), (itr, k, np.abs(got[0] - want).max())
             # (PPO: a sample whose ratio sits on a clip edge may fall on the other side by round-off and moves the
             #  minibatch gradient by its own 1 / B share -- observed 1.4e-4 of the largest entry at B = 512)
-            assert np.allclose(got[1], m, rtol=2e-3, atol=5e-4 * max(np.abs(m).max(), 1e-3)), (itr, k, np.abs(got[1] - m).max())
+            # First moment = 0.9 m + 0.1 g, i.e. the gradient itself.  Bar: 2e-3 of the largest entry, the same as in
+            # test_explicit_backward_matches_autograd.  (The dense / head tensors agree to 1e-9; the conv tensors carry
+            # rectifier flips: of the 1.8 M conv-3 activations of a 512-row minibatch a few sit within round-off of zero,
+            # the two sides gate them differently, and each flip moves that channel's gradients by one element's share
+            # -- observed 7.5e-4 of the largest entry on one conv-3 bias, 1e-9 everywhere when no flip occurs.)
+            m_tol = 2e-3
+            assert np.allclose(got[1], m, rtol=2e-3, atol=m_tol * max(np.abs(m).max(), 1e-3)), (itr, k, np.abs(got[1] - m).max())
             if adam:
                 assert float(got[3]) == float(t)
     print("worst parameter deviation after one step: %.3g" % worst)

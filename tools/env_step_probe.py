@@ -1,5 +1,6 @@
-"""Time arl_env_step inside a hipGraph of 40 chained launches (ARL_ENV_DBG bit mask: 1 no pixels, 2 no ticket,
-4 no commit -- debugging knobs)."""
+"""Time arl_env_step (the env side of one rollout step, one launch) inside a hipGraph of 40 chained launches, with the
+stacked observation written twice (step_obs kept current) and once (policies that serve rows of the rollout buffer).
+usage: python tools/env_step_probe.py [n_envs]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,4 +36,4 @@ for single in (0, 1):
     t0 = time.perf_counter()
     for _ in range(20): g.replay()
     torch.cuda.synchronize()
-    print("dbg=%s n_env=%d single_write=%d: %.2f us per launch" % (os.environ.get("ARL_ENV_DBG", "0"), n_env, single, (time.perf_counter() - t0) / 800 * 1e6))
+    print("dbg n_env=%d single_write=%d: %.2f us per launch" % (n_env, single, (time.perf_counter() - t0) / 800 * 1e6))

@@ -1,19 +1,29 @@
+# Regenerates profiles/r02 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root; ~6 GPU-minutes)
 set -x
-R=/root/repo; O=$R/gpurun_out/fin; mkdir -p $O
-cd $R && timeout 900 python bench.py > $O/bench.log 2>$O/bench.err; tail -1 $O/bench.log > $O/bench.json
+R=$(pwd); O=$R/gpurun_out/fin; mkdir -p $O
+timeout 900 python bench.py > $O/bench.log 2>$O/bench.err; tail -n 1 $O/bench.log > $O/bench.json
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pA -o b -- python $R/bench.py --steps 60 --warmup 20 --no-cpu-baseline > $O/prof.log 2>&1
-tail -200 $O/prof.log | grep '^{"metric' | tail -1 > $O/bench_profiled.json
-cp $(find /tmp/pA -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
-python $R/tools/trace_summary.py $(find /tmp/pA -name "*kernel_trace.csv" | head -1) 200 560 40 > $O/bench_steady_state_summary.txt
+tail -n 200 $O/prof.log | grep '^{"metric' | tail -n 1 > $O/bench_profiled.json
+cp $(find /tmp/pA -name "*kernel_stats.csv" | head -n 1) $O/bench_kernel_stats.csv
+python $R/tools/trace_summary.py $(find /tmp/pA -name "*kernel_trace.csv" | head -n 1) 200 560 40 > $O/bench_steady_state_summary.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pB -o g -- python $R/bench.py --roofline-only > $O/gae.log 2>&1
-cp $(find /tmp/pB -name "*kernel_stats.csv" | head -1) $O/gae_kernel_stats.csv
+cp $(find /tmp/pB -name "*kernel_stats.csv" | head -n 1) $O/gae_kernel_stats.csv
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pC -o f -- python $R/bench.py --roofline-only > $O/gaef.log 2>&1
-cp $(find /tmp/pC -name "*counter_collection.csv" | head -1) $O/gae_pmc_FETCH_SIZE.csv
+cp $(find /tmp/pC -name "*counter_collection.csv" | head -n 1) $O/gae_pmc_FETCH_SIZE.csv
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pD -o w -- python $R/bench.py --roofline-only > $O/gaew.log 2>&1
-cp $(find /tmp/pD -name "*counter_collection.csv" | head -1) $O/gae_pmc_WRITE_SIZE.csv
+cp $(find /tmp/pD -name "*counter_collection.csv" | head -n 1) $O/gae_pmc_WRITE_SIZE.csv
 python $R/tools/gae_pmc_traffic.py $O/gae_pmc_FETCH_SIZE.csv $O/gae_pmc_WRITE_SIZE.csv > $O/gae_pmc_traffic.json
 cd $R; timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d /tmp/pE -o m -- python tools/conv_bench.py 512 o > $O/mfma.log 2>&1
-cp $(find /tmp/pE -name "*counter_collection.csv" | head -1) $O/mfma_pmc_counter_collection.csv
-python tools/mfma_pmc_summary.py $O/mfma_pmc_counter_collection.csv > $O/mfma_pmc_summary.json
+python tools/mfma_pmc_summary.py $(find /tmp/pE -name "*counter_collection.csv" | head -n 1) > $O/mfma_pmc_summary.json
+python tools/gae_sweep.py > $O/gae_sweep.txt 2>&1
+(for w in c1f c2f c3f df c3d c2d; do python tools/context_trace.py $w 2>&1 | grep -v amdgpu.ids; done) > $O/context_trace.txt
+python tools/conv_trace.py 512 2>&1 | grep -v amdgpu.ids > $O/conv_trace.txt
+python tools/env_step_probe.py 256 2>&1 | grep dbg > $O/env_step_probe.txt; python tools/env_step_probe.py 2048 2>&1 | grep dbg >> $O/env_step_probe.txt
+python tools/learner_probe.py 2>&1 | grep tile > $O/learner_probe.txt
+python tools/tile_probe.py 512 256 2>&1 | grep "B=\|dev" > $O/tile_probe.txt
+timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/null | tail -n 1 > $O/bench_a2c1024.json
+timeout 300 python bench.py --scaling strong --total-envs 2048 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > $O/bench_strong_2048_n1.json
+timeout 300 python bench.py --workload catdqn --steps 30 --warmup 5 --dqn-batch 512 2>/dev/null | tail -n 1 > $O/bench_catdqn_batch512.json
+ARL_BENCH_ONE_GPU=1 ARL_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 3 --warmup 2 --no-graph 2>/dev/null | tail -n 1 > $O/bench_spawn_2ranks_devmode.json
 ls -la $O

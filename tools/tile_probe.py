@@ -6,6 +6,8 @@ import torch
 import __graft_entry__; __graft_entry__.build()
 from accel_rl_amd import _lib
 DEV = "cuda:0"
+CHOICES = (1, 2, 3, 7, 8, 9, 10, 11, 12, 13)
+NAMES = {1: "64x64", 2: "112x64/3", 3: "32x64", 4: "48x64", 5: "32x64/3", 6: "48x64/3", 7: "64x64n16", 8: "32x64k16w8", 9: "32x64k16w6", 10: "32x64k32w5", 11: "64x64k16w6", 12: "48x64k16w6", 13: "64x64n16k16w6"}
 
 
 def gt(fn, per=20, rep=5):
@@ -32,14 +34,15 @@ for b in [int(x) for x in sys.argv[1:]] or [512, 256]:
         bias = torch.randn(k, device=DEV); dy = torch.randn(b, ho, wo, k, device=DEV)
         flops = 2.0 * b * ho * wo * k * ks * ks * c
         outs = {}
-        for choice in (1, 2):
+        for choice in CHOICES:
             lib.arl_conv_tile_choice(choice)
             y = torch.empty(b, ho, wo, k, device=DEV); dx = torch.empty_like(x)
             tf = gt(lambda: _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws))
             td = gt(lambda: _lib.conv2d_bwd_data(dy, wt, None, dx, geom)) if st == 1 else float("nan")
             outs[choice] = (y.clone(), dx.clone())
             print("B=%d %s tiles=%s fwd %.1f us (%.1f TF/s)  dgrad %.1f us (%.1f TF/s)" %
-                  (b, name, "64x64" if choice == 1 else "112x64", tf, flops / tf / 1e6, td, flops / td / 1e6))
+                  (b, name, NAMES[choice], tf, flops / tf / 1e6, td, flops / td / 1e6))
         lib.arl_conv_tile_choice(0)
-        d = (outs[1][0] - outs[2][0]).abs().max().item() / outs[1][0].abs().max().item()
-        print("   fwd rel dev %.2e" % d, " dgrad rel dev %.2e" % ((outs[1][1] - outs[2][1]).abs().max().item() / max(outs[1][1].abs().max().item(), 1e-9)) if st == 1 else "")
+        for c in CHOICES[1:]:
+            d = (outs[1][0] - outs[c][0]).abs().max().item() / outs[1][0].abs().max().item()
+            print("   %s vs 64x64: fwd rel dev %.2e" % (NAMES[c], d), " dgrad rel dev %.2e" % ((outs[1][1] - outs[c][1]).abs().max().item() / max(outs[1][1].abs().max().item(), 1e-9)) if st == 1 else "")
