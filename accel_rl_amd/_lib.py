@@ -107,6 +107,7 @@ _SIGNATURES = {
     "arl_conv_force_generic": (None, [_i32]),
     "arl_scan_force_wave": (None, [_i32]),
     "arl_conv_tile_choice": (None, [_i32]),
+    "arl_conv_persistent": (None, [_i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),

@@ -86,6 +86,8 @@ struct GemmArgs {
     unsigned long long* trace;  // tuning aid: per-workgroup timestamps (arl_conv_trace_buffer), or null
     // stride-s data gradient: the s*s input-pixel parity classes are independent implicit GEMMs that
     // differ only in the fields below; one launch runs them all, blockIdx.z = class (igemm_kernel only)
+    // persistent launches (igemm_persist_kernel): p_tiles row tiles in all, class c owns [p_first[c], p_first[c + 1])
+    int p_tiles, p_first[5];
     int n_par;
     struct Parity {
         int M, out_h, out_w, add_y, add_x, rmin, dmin, origin, i0, j0, oadd_y, oadd_x;
@@ -1037,7 +1039,375 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, PIPE3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
-// probe: the same body compiled for MINW waves per SIMD (small tiles, many resident workgroups)
+// ==========================================================================================
+// Persistent variant of igemm_body for launches of MANY row tiles (conv 1 forward: 1 900 tiles of 128 rows, the
+// stride-2 data gradient: 4 x 475): gridDim.x resident workgroups walk the tiles t = blockIdx.x, + gridDim.x, ...
+// Per-workgroup timestamps of the one-tile-per-workgroup launch showed what a second wave of workgroups costs:
+// a workgroup that starts while its CU mates are in their main loops spends 10-16 k cycles in its prologue (the
+// address arithmetic competes with their MFMAs, the first tile's loads are cold), the CU drops to 0-2 workgroups
+// inside a main loop between the waves and again at the end -- 108 k cycles for 65 k of matrix-pipe work.  Here the
+// NEXT tile's rows are decoded and its first k-tile's loads issued at the start of the current tile's LAST k-tile
+// (under its MFMAs), the epilogue's stores are left in flight, and the main loop continues with one barrier between
+// tiles: the pipeline never drains.  One column tile (N <= BN), no reduction split, TN == 1.
+// ==========================================================================================
+template <int WGM, int WGN, int TM, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, bool U8>
+__device__ __forceinline__ void igemm_persist_body(const GemmArgs& a, float* smem) {
+    constexpr int TN = 1;
+    constexpr int MT = N16 ? 16 : 32;
+    constexpr int BM = WGM * TM * MT, BN = N16 ? WGN * 16 : WGN * TN * 32, CH = BK / 4;
+    constexpr int LDA = BK + 4;
+    constexpr int LDB = B_KC ? BK + 4 : (N16 ? BN + 4 : BN);
+    constexpr int ROWS_PER_PASS = 256 / CH;
+    constexpr int RA = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
+    constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
+    constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
+    constexpr int RB = (NB4 + 255) / 256;
+    static_assert(WGM * WGN == 4 && BK % 8 == 0 && (!N16 || BK % 16 == 0), "tile shape");
+    float* sA = smem;
+    float* sB = smem + 2 * A_SZ;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, quad = lane >> 4;
+    const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
+    if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
+    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.o.out, a.o.out_bytes);
+
+    // ---- what a tile's class decides (uniform: scalar registers) ---------------------------------
+    struct Cls {
+        int M, out_h, out_w, add_y, add_x, rmin, dmin, i0, j0, oadd_y, oadd_x;
+        unsigned mg_w, mg_h;
+        __amdgpu_buffer_rsrc_t rsA;
+    };
+    auto load_cls = [&](int c) {
+        Cls k;
+        if (a.n_par) {
+            const GemmArgs::Parity& q = a.par[c];
+            k.M = q.M; k.out_h = q.out_h; k.out_w = q.out_w; k.add_y = q.add_y; k.add_x = q.add_x;
+            k.rmin = q.rmin; k.dmin = q.dmin; k.i0 = q.i0; k.j0 = q.j0; k.oadd_y = q.oadd_y; k.oadd_x = q.oadd_x;
+            k.mg_w = q.mg_w; k.mg_h = q.mg_h;
+            k.rsA = make_rsrc(a.g.src + q.origin, q.src_bytes);
+        } else {
+            k.M = a.M; k.out_h = a.g.out_h; k.out_w = a.g.out_w; k.add_y = a.g.add_y; k.add_x = a.g.add_x;
+            k.rmin = a.g.rmin; k.dmin = a.g.dmin; k.i0 = a.b.i0; k.j0 = a.b.j0; k.oadd_y = a.o.oadd_y; k.oadd_x = a.o.oadd_x;
+            k.mg_w = a.g.mg_w; k.mg_h = a.g.mg_h;
+            k.rsA = U8 ? make_rsrc(reinterpret_cast<const float*>(a.g.src8), a.g.src_bytes)
+                       : make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
+        }
+        return k;
+    };
+    // ---- what a tile decides per thread ------------------------------------------------------------
+    struct Tile { unsigned voffA[RA], imask[RA]; long long row_off[TM]; };
+    const int a_chunk = tid % CH, a_row0 = tid / CH;
+    const int cpr8 = a.g.kw8 >> 2, rpt8 = U8 ? CH / cpr8 : 0;
+    int tpt = 0, chl = a_chunk * 4;
+    if (MULTI_TAP) { tpt = chl / Cs; chl -= tpt * Cs; }
+    auto setup = [&](int t, Cls& k, Tile& T) {
+        int c = 0;
+        if (a.n_par) c = (t >= a.p_first[1]) + (t >= a.p_first[2]) + (t >= a.p_first[3]);
+        k = load_cls(c);
+        const int m0 = (t - a.p_first[c]) * BM;
+#pragma unroll
+        for (int p = 0; p < RA; ++p) {
+            const int m = m0 + a_row0 + p * ROWS_PER_PASS;
+            const bool row_ok = m < k.M && (BM % ROWS_PER_PASS == 0 || a_row0 + p * ROWS_PER_PASS < BM);
+            const int q = div_u(m, k.out_w, k.mg_w), ox = m - q * k.out_w;
+            const int b = div_u(q, k.out_h, k.mg_h), oy = q - b * k.out_h;
+            const int ry = oy * a.g.mul + k.add_y, rx = ox * a.g.mul + k.add_x;
+            const int rbase = ((b * a.g.Hs + ry) * Ws + rx) * Cs;
+            T.voffA[p] = row_ok ? (unsigned)(rbase - k.rmin + tpt * Cs + chl) << 2 : OOB;
+            if constexpr (U8) {
+                const int tyl = a_chunk / cpr8, txq = a_chunk - tyl * cpr8;
+                T.voffA[p] = OOB;
+                if (row_ok) {
+                    const int row = a.g.idx ? a.g.idx[b] : b;
+                    T.voffA[p] = (unsigned)(row * a.g.img_bytes + (ry + tyl) * Ws + rx + 4 * txq);
+                }
+            }
+            T.imask[p] = 0;
+            if (HAS_PAD) T.imask[p] = tap_mask(ry, rx + step * tpt, a.g.Hs, Ws, a.g.taps_y, taps_x, step);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
+            if (a.o.dense) {
+                T.row_off[i] = m < k.M ? (long long)m * a.N : -1;
+            } else {
+                const int q = div_u(m, k.out_w, k.mg_w), ox = m - q * k.out_w;
+                const int b = div_u(q, k.out_h, k.mg_h), oy = q - b * k.out_h;
+                T.row_off[i] = m < k.M ? ((long long)(b * a.o.OH + oy * a.o.omul + k.oadd_y) * a.o.OW + ox * a.o.omul + k.oadd_x) * a.N
+                                       : -1;
+            }
+        }
+    };
+    unsigned voffB[RB];
+#pragma unroll
+    for (int p = 0; p < RB; ++p) {
+        const int idx = tid + p * 256;
+        if (B_KC) {
+            const int nl = idx / CH, chunk = idx - nl * CH;
+            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && nl < a.N) ? (unsigned)(nl * a.b.ld + chunk * 4) << 2 : OOB;
+        } else {
+            constexpr int NC4 = BN / 4;
+            const int kl = idx / NC4, nch = idx - kl * NC4;
+            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && nch * 4 < a.N) ? (unsigned)(kl * a.b.ld + nch * 4) << 2 : OOB;
+        }
+    }
+    // the lane's bias values (one column tile: the same for every row tile)
+    float4 bias_q[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = N16 ? wn * 16 + 4 * quad : wn * 32 + 8 * q + 4 * half;
+        bias_q[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.o.bias && n < a.N && (!N16 || q == 0)) bias_q[q] = *reinterpret_cast<const float4*>(a.o.bias + n);
+    }
+
+    // ---- k-tile machinery (as igemm_body) ----------------------------------------------------------
+    // Two k-tiles are in flight: k-tile j of a row tile lands in register set j & 1 while k-tile j - 1 waits in the
+    // other set for its turn in LDS (a whole k-tile of extra latency cover: with 16-deep k-tiles and four workgroups
+    // sharing the matrix pipe one k-tile lasts ~1 us, less than a load that misses the L2 takes).
+    struct Regs { float4 va[RA], vb[RB]; unsigned va8[RA]; };
+    Regs R0, R1;
+    int ty = 0, tx = 0, ch0 = 0, kk = 0;            // tap state / reduction index of the NEXT k-tile to be issued
+    auto issue_loads = [&](Regs& R, const Cls& k, const Tile& T) {
+        if constexpr (U8) {
+            const unsigned soffA = (unsigned)(ch0 * a.g.plane + ty * Ws);
+#pragma unroll
+            for (int p = 0; p < RA; ++p) R.va8[p] = buf_ld1s(k.rsA, T.voffA[p], soffA);
+#pragma unroll
+            for (int p = 0; p < RB; ++p) R.vb[p] = buf_ld4s(rsB, voffB[p], (unsigned)kk << 2);
+        } else {
+            const unsigned soffA = (unsigned)(step * (ty * Ws + tx) * Cs + ch0 - k.dmin) << 2;
+            unsigned soffB;
+            if (B_KC) soffB = (unsigned)kk << 2;
+            else soffB = (unsigned)(ch0 * a.b.ld + ((k.i0 + a.b.si * ty) * a.b.kw + (k.j0 + a.b.si * tx)) * a.b.c) << 2;
+            const int bit = ty * taps_x + tx;
+#pragma unroll
+            for (int p = 0; p < RA; ++p)
+                R.va[p] = buf_ld4s(k.rsA, HAS_PAD ? mask_off(T.imask[p], bit, T.voffA[p]) : T.voffA[p], soffA);
+#pragma unroll
+            for (int p = 0; p < RB; ++p) R.vb[p] = buf_ld4s(rsB, voffB[p], soffB);
+        }
+        // advance to the following k-tile
+        kk += BK;
+        if constexpr (U8) {
+            ty += rpt8;
+            if (ty >= a.g.kh8) { ty = 0; ++ch0; }
+        } else if (MULTI_TAP) {
+            tx += BK / Cs;
+            if (tx >= taps_x) { tx = 0; ++ty; }
+        } else {
+            ch0 += BK;
+            if (ch0 >= Cs) {
+                ch0 = 0;
+                if (++tx >= taps_x) { tx = 0; ++ty; }
+            }
+        }
+    };
+    auto first_tap = [&]() { ty = 0; tx = 0; ch0 = 0; kk = 0; };
+    auto store_tiles = [&](int buf, const Regs& R) {
+        float* dA = sA + buf * A_SZ;
+        float* dB = sB + buf * B_SZ;
+#pragma unroll
+        for (int p = 0; p < RA; ++p) {
+            if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
+            *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) =
+                U8 ? bytes_to_f4(R.va8[p], a.g.scale) : R.va[p];
+        }
+#pragma unroll
+        for (int p = 0; p < RB; ++p) {
+            const int idx = tid + p * 256;
+            if (NB4 % 256 != 0 && idx >= NB4) continue;
+            if (B_KC) {
+                const int nl = idx / CH, chunk = idx - nl * CH;
+                *reinterpret_cast<float4*>(dB + nl * LDB + chunk * 4) = R.vb[p];
+            } else {
+                constexpr int NC4 = BN / 4;
+                const int kl = idx / NC4, nch = idx - kl * NC4;
+                *reinterpret_cast<float4*>(dB + kl * LDB + nch * 4) = R.vb[p];
+            }
+        }
+    };
+    f32x16 acc[TM];
+    f32x4 acc16[TM];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc16[i][v] = 0.f;
+        }
+    };
+    auto mfma_tile = [&](auto buf_c) {
+        constexpr int buf = decltype(buf_c)::value;
+        if constexpr (N16) {
+            const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
+            const float* cB = B_KC ? sB + buf * B_SZ + (wn * 16 + l15) * LDB + quad * 4
+                                   : sB + buf * B_SZ + (quad * 4) * LDB + wn * 16 + l15;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                float fa[TM][4], fb[4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 16 * LDA + ks * 16);
+                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
+                }
+                if (B_KC) {
+                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 16);
+                    fb[0] = t.x; fb[1] = t.y; fb[2] = t.z; fb[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fb[q] = cB[(ks * 16 + q) * LDB];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[q], fa[i][q], acc16[i], 0, 0, 0);
+            }
+        } else {
+            const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
+            const float* cB = B_KC ? sB + buf * B_SZ + (wn * 32 + l31) * LDB + half * 4
+                                   : sB + buf * B_SZ + (half * 4) * LDB + wn * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < BK / 8; ++ks) {
+                float fa[TM][4], fb[4];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
+                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
+                }
+                if (B_KC) {
+                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 8);
+                    fb[0] = t.x; fb[1] = t.y; fb[2] = t.z; fb[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) fb[q] = cB[(ks * 8 + q) * LDB];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q], fa[i][q], acc[i], 0, 0, 0);
+            }
+        }
+    };
+    // the rectifier mask of the layer below (data gradients), fetched during the last k-tile
+    constexpr int NQ = N16 ? 1 : 4;
+    float4 mk_pre[NQ][TM];
+    auto issue_mask_loads = [&](const Tile& T) {
+        if (!a.o.mask) return;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int n = N16 ? wn * 16 + 4 * quad : wn * 32 + 8 * q + 4 * half;
+                mk_pre[q][i] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (T.row_off[i] >= 0 && n < a.N) mk_pre[q][i] = *reinterpret_cast<const float4*>(a.o.mask + T.row_off[i] + n);
+            }
+    };
+    auto epilogue = [&](const Tile& T) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int n = N16 ? wn * 16 + 4 * quad : wn * 32 + 8 * q + 4 * half;
+            const float4 bq = bias_q[q];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bool ok = T.row_off[i] >= 0 && n < a.N;
+                float4 val;
+                if constexpr (N16) val = make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
+                else val = make_float4(acc[i][4 * q] + bq.x, acc[i][4 * q + 1] + bq.y, acc[i][4 * q + 2] + bq.z, acc[i][4 * q + 3] + bq.w);
+                if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
+                if (a.o.mask) {
+                    const float4 m = mk_pre[q][i];
+                    if (!(m.x > 0.f)) val.x = 0.f;
+                    if (!(m.y > 0.f)) val.y = 0.f;
+                    if (!(m.z > 0.f)) val.z = 0.f;
+                    if (!(m.w > 0.f)) val.w = 0.f;
+                }
+                u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(raw, rsO, ok ? (unsigned)((T.row_off[i] + n) << 2) : OOB, 0, 0);
+            }
+        }
+    };
+
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    const int nk = a.K / BK;                        // even, >= 2 (checked on the host): k-tile j sits in LDS buffer j & 1
+    int t = blockIdx.x;
+    if (t >= a.p_tiles) return;
+    Cls kc, kn;
+    Tile T, Tn;
+    setup(t, kc, T);
+    first_tap();
+    issue_loads(R0, kc, T);
+    issue_loads(R1, kc, T);
+    store_tiles(0, R0);
+    __syncthreads();
+    if (a.trace) tr1 = __builtin_readcyclecounter();
+    for (;;) {
+        const int tn = t + (int)gridDim.x;
+        const bool more = tn < a.p_tiles;           // uniform
+        zero_acc();
+        // k-tile kt (LDS buffer kt & 1): k-tile kt + 2 leaves for register set kt & 1, k-tile kt + 1 moves from the
+        // other set into the other buffer once this tile's MFMAs are issued
+        for (int kt = 0; kt + 2 < nk; kt += 2) {
+            issue_loads(R0, kc, T);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(C0{});
+            __builtin_amdgcn_sched_barrier(0);
+            store_tiles(1, R1);
+            __syncthreads();
+            issue_loads(R1, kc, T);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tile(C1{});
+            __builtin_amdgcn_sched_barrier(0);
+            store_tiles(0, R0);
+            __syncthreads();
+        }
+        // second-to-last k-tile: the NEXT row tile is decoded and its first k-tile requested
+        if (more) {
+            setup(tn, kn, Tn);
+            first_tap();
+            issue_loads(R0, kn, Tn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(C0{});
+        __builtin_amdgcn_sched_barrier(0);
+        store_tiles(1, R1);
+        __syncthreads();
+        // last k-tile: the epilogue's mask and the next row tile's second k-tile
+        issue_mask_loads(T);
+        if (more) issue_loads(R1, kn, Tn);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile(C1{});
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(T);
+        if (!more) break;
+        store_tiles(0, R0);                         // buffer 0 was last read before the previous barrier
+        __syncthreads();
+        t = tn; kc = kn; T = Tn;
+    }
+    if (a.trace && tid == 0) {
+        tr2 = __builtin_readcyclecounter();
+        unsigned long long* tp = a.trace + (size_t)blockIdx.x * 8;
+        tp[0] = tr0; tp[1] = tr1; tp[2] = tr2; tp[3] = tr2;
+        tp[4] = rt0; tp[5] = __builtin_amdgcn_s_memrealtime();
+        tp[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+        tp[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+    }
+}
+
+template <int WGM, int WGN, int TM, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, bool U8, int MINW>
+__global__ __launch_bounds__(256, MINW) void igemm_persist_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    igemm_persist_body<WGM, WGN, TM, BK, B_KC, MULTI_TAP, HAS_PAD, N16, U8>(a, smem);
+}
+
+// the same body compiled for at least MINW waves per SIMD (small tiles, many resident workgroups)
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, int MINW>
 __global__ __launch_bounds__(256, MINW) void igemm_occ_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1435,6 +1805,8 @@ int launch_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
     return arl::check_launch("wgrad_kernel");
 }
 
+constexpr bool lds_fits(int floats) { return floats * 4 <= 65536; }
+
 template <typename K>
 int allow_big_lds(K kernel, size_t lds) {           // > 64 KiB of dynamic LDS needs an explicit opt-in
     if (lds <= 65536) return 0;
@@ -1465,16 +1837,70 @@ int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hi
     return rc ? rc : arl::check_launch("igemm_kernel");
 }
 
+int g_tile_choice = 0;             // arl_conv_tile_choice (tuning aid): 0 / 3 = 32x64 tiles for 33 .. 64 columns, 1 = 64x64, 2 = 112x64
+int g_persist = 0;                  // arl_conv_persistent: resident workgroups per CU of the persistent launches (0 = off)
+int g_cus = 0;
+int num_cus() {
+    if (!g_cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_cus <= 0)
+            g_cus = 256;
+    }
+    return g_cus;
+}
+
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16, int MINW>
 int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s) {
     constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * TN * 32;
     constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
     const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    static_assert(lds_fits(2 * (A_SZ + B_SZ)), "<= 64 KiB of LDS");
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : 1);
-    if (multi_tap) { arl::set_error("probe tile: single-tap layers only"); return ARL_E_ARG; }
-    if (has_pad) hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, true, N16, MINW>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, false, N16, MINW>), grid, dim3(256), lds, s, a);
+#define ARL_IGEMM_OCC(MT, HP) \
+    hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16, MINW>), grid, dim3(256), lds, s, a)
+    if (multi_tap && has_pad) ARL_IGEMM_OCC(true, true);
+    else if (multi_tap) ARL_IGEMM_OCC(true, false);
+    else if (has_pad) ARL_IGEMM_OCC(false, true);
+    else ARL_IGEMM_OCC(false, false);
+#undef ARL_IGEMM_OCC
     return arl::check_launch("igemm_occ_kernel");
+}
+
+// more row tiles than resident workgroups?  (g_persist < 0, tests: always, walked by -g_persist workgroups)
+// (the callers also check that the reduction is an even number of k-tiles: the two-deep load pipeline's invariant)
+bool persist_pays(int tiles) { return g_persist < 0 || (g_persist > 0 && tiles > num_cus() * g_persist); }
+
+// persistent launch of igemm_persist_body: the tile plan rides in the arguments
+template <int WGM, int WGN, int TM, int BK, bool B_KC, bool N16, bool U8, int MINW>
+int launch_igemm_persist(GemmArgs a, bool multi_tap, bool has_pad, hipStream_t s) {
+    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * 32;
+    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
+    const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
+    int n = 0;
+    for (int c = 0; c < 5; ++c) a.p_first[c] = 0x7fffffff;
+    if (a.n_par) {
+        for (int c = 0; c < a.n_par; ++c) { a.p_first[c] = n; n += (a.par[c].M + BM - 1) / BM; }
+    } else {
+        a.p_first[0] = 0; n = (a.M + BM - 1) / BM;
+    }
+    a.p_tiles = n;
+    const int resident = g_persist < 0 ? -g_persist : num_cus() * (g_persist > 0 ? g_persist : MINW);
+    const dim3 grid(n < resident ? n : resident);
+    int rc = 0;
+#define ARL_PERSIST(MT, HP)                                                                                \
+    do {                                                                                                   \
+        auto k = igemm_persist_kernel<WGM, WGN, TM, BK, B_KC, MT, HP, N16, U8, MINW>;                      \
+        rc = allow_big_lds(k, lds);                                                                        \
+        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
+    } while (0)
+    if constexpr (U8) ARL_PERSIST(false, false);
+    else if (multi_tap && has_pad) ARL_PERSIST(true, true);
+    else if (multi_tap) ARL_PERSIST(true, false);
+    else if (has_pad) ARL_PERSIST(false, true);
+    else ARL_PERSIST(false, false);
+#undef ARL_PERSIST
+    return rc ? rc : arl::check_launch("igemm_persist_kernel");
 }
 
 template <int WGM, int WGN, int TM, int TN, int BK, bool M16 = false>
@@ -1508,7 +1934,6 @@ constexpr int TARGET_WGS = 256;     // one workgroup per CU is already MFMA-boun
 constexpr int BKT = 32;             // k-tile of the skinny configurations (host-side split granularity)
 
 unsigned long long* g_trace = nullptr;
-int g_tile_choice = 0;             // arl_conv_tile_choice: 0 = by the cost model, 1 = 64x64, 2 = 112x64 (tuning aid)
 bool g_force_generic = false;       // arl_conv_force_generic: route every call to the generic kernels (tests)
 
 struct Geom {
@@ -1548,38 +1973,19 @@ unsigned div_magic(int64_t rows, int d) {
     return (unsigned)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d);
 }
 
-// 33 .. 64 output columns: 64x64 tiles (each wave one 32x32 MFMA tile) or 112x64 tiles (each wave 7 16x16 tiles
-// of one 16-column stripe: v_mfma_f32_16x16x4_f32, same rate; three LDS stages, PIPE3)?  All workgroups of these
-// launches are resident at once, so a launch lasts as long as its busiest CU.  At the PPO minibatch (55 296 rows)
-// that is 4 workgroups of 64 rows on 96 CUs (8 units of MFMA work against 6.75 for a perfect spread) or 2 of 112
-// rows on 238 CUs (7 units).  Per-workgroup timestamps inside the learner (tools/context_trace.py) show the busiest
-// CU taking 66-69 k cycles with four 64x64 workgroups (matrix pipe 99 % busy: four waves per SIMD cover each other's
-// barriers and LDS waits) and 71-74 k with two 112x64 ones (81 %; a lone one: 64 %) -- the balance is paid for in
-// latency cover.  Net, measured: alone and L2-hot the 112-row tiles are 9-14 % faster (conv 2 / conv 3 forward,
-// conv 3 data gradient at 512 images), inside the learner 1 % (482 vs 488 us per minibatch); at the rollout's
-// 27 648 rows one 112-row workgroup would be alone on its CU and loses (25.3 vs 23.1 us), hence t112 > 256.
-bool balanced_rows_pay(int M) {
-    if (g_tile_choice) return g_tile_choice > 1;
-    const int64_t t64 = (M + 63) / 64, t112 = (M + 111) / 112;
-    return t112 > 256 && ((t112 + 255) / 256) * 7 < ((t64 + 255) / 256) * 4;
-}
-
-// tuning aid (arl_conv_tile_choice >= 3): finer 16-wide-MFMA row tiles for the 64-column layers
+// 33 .. 64 output columns, the default: 32x64 tiles -- each wave two 16-row groups of one 16-column stripe
+// (v_mfma_f32_16x16x4_f32), 32-deep k-tiles, two LDS stages (28 KB), compiled for five waves per SIMD.  Small tiles
+// spread the rows evenly (1 728 tiles at the PPO minibatch: 7 on the busiest CU against 6.75 on average, where 864
+// tiles of 64 rows leave it 4 against 3.375) and five or six resident workgroups per CU cover each other's barriers,
+// prologues and epilogues.  Measured, 20 launches per hipGraph, conv 2 / conv 3 forward at 512 images: 36.6 / 40.1 us
+// (64x64: 44.7 / 47.9, 112x64: 40.6 / 42.0); at 256: 22.4 / 24.1 (25.0 / 27.6, 25.4 / 26.7); at 128: 14.2 / 15.7
+// (15.6 / 17.3, 22.9 / 25.2); 16-deep k-tiles at 6-8 waves per SIMD and 48-row tiles were slower everywhere
+// (tools/tile_probe.py).  arl_conv_tile_choice: 1 = 64x64, 2 = 112x64, 3 = 32x64.
 template <bool B_KC>
-int launch_n64_probe(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s) {
-    switch (g_tile_choice) {
-    case 3: return launch_igemm<1, 4, 2, 1, 32, B_KC, true, false>(a, 1, multi_tap, has_pad, s);   // 32x64, two stages
-    case 4: return launch_igemm<1, 4, 3, 1, 32, B_KC, true, false>(a, 1, multi_tap, has_pad, s);   // 48x64
-    case 5: return launch_igemm<1, 4, 2, 1, 32, B_KC, true, true>(a, 1, multi_tap, has_pad, s);    // 32x64, three stages
-    case 6: return launch_igemm<1, 4, 3, 1, 32, B_KC, true, true>(a, 1, multi_tap, has_pad, s);    // 48x64
-    case 7: return launch_igemm<1, 4, 4, 1, 32, B_KC, true, false>(a, 1, multi_tap, has_pad, s);   // 64x64 on 16-wide MFMAs
-    case 8: return launch_igemm_occ<1, 4, 2, 1, 16, B_KC, true, 8>(a, multi_tap, has_pad, s);       // 32x64, 16-deep, 8 waves / SIMD
-    case 9: return launch_igemm_occ<1, 4, 2, 1, 16, B_KC, true, 6>(a, multi_tap, has_pad, s);
-    case 10: return launch_igemm_occ<1, 4, 2, 1, 32, B_KC, true, 5>(a, multi_tap, has_pad, s);
-    case 11: return launch_igemm_occ<2, 2, 1, 1, 16, B_KC, false, 6>(a, multi_tap, has_pad, s);     // 64x64 on 32-wide MFMAs, 16-deep
-    case 12: return launch_igemm_occ<1, 4, 3, 1, 16, B_KC, true, 6>(a, multi_tap, has_pad, s);      // 48x64, 16-deep
-    default: return launch_igemm_occ<1, 4, 4, 1, 16, B_KC, true, 6>(a, multi_tap, has_pad, s);      // 64x64 n16, 16-deep
-    }
+int launch_n64(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s) {
+    if (g_tile_choice == 1) return launch_igemm<2, 2, 1, 1, 32, B_KC>(a, 1, multi_tap, has_pad, s);
+    if (g_tile_choice == 2) return launch_igemm<1, 4, 7, 1, 32, B_KC, true, true>(a, 1, multi_tap, has_pad, s);
+    return launch_igemm_occ<1, 4, 2, 1, 32, B_KC, true, 5>(a, multi_tap, has_pad, s);
 }
 
 // split the reduction so that tiles * splits ~ TARGET_WGS, each split a multiple of BKT
@@ -1601,6 +2007,8 @@ extern "C" void arl_conv_trace_buffer(void* device_u64_or_null) { g_trace = (uns
 extern "C" void arl_conv_force_generic(int32_t on) { g_force_generic = on != 0; }
 
 extern "C" void arl_conv_tile_choice(int32_t choice) { g_tile_choice = choice; }
+
+extern "C" void arl_conv_persistent(int32_t workgroups_per_cu) { g_persist = workgroups_per_cu; }
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {
@@ -1655,8 +2063,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 1, 1, 16, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
-        else if (a.N <= 64 && splits == 1 && g_tile_choice >= 3) rc = launch_n64_probe<true>(a, multi_tap, has_pad, s);
-        else if (a.N <= 64 && splits == 1 && balanced_rows_pay(a.M)) rc = launch_igemm<1, 4, 7, 1, FBK, true, true, true>(a, 1, multi_tap, has_pad, s);
+        else if (a.N <= 64 && splits == 1) rc = launch_n64<true>(a, multi_tap, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, true>(a, splits, multi_tap, has_pad, s);
@@ -1763,10 +2170,10 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, nullptr, 4, 0, dx, s, mask_or_null);
         }
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
+        else if (a.N <= 32 && a.K % 32 == 0 && persist_pays((a.n_par ? a.n_par : 1) * ((a.M + 127) / 128)))
+            rc = launch_igemm_persist<4, 1, 1, 16, false, false, false, 4>(a, false, has_pad, s);
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
-        else if (a.N <= 64 && g_tile_choice >= 3) rc = launch_n64_probe<false>(a, false, has_pad, s);
-        else if (a.N <= 64 && balanced_rows_pay(a.M)) rc = launch_igemm<1, 4, 7, 1, FBK, false, true, true>(a, 1, false, has_pad, s);
-        else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, 1, false, has_pad, s);
+        else if (a.N <= 64) rc = launch_n64<false>(a, false, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
         return rc;
     }
@@ -1960,6 +2367,8 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     if (a.N <= 16) {
         const size_t lds = (size_t)2 * (BM * (BK + 4) + 16 * (BK + 4)) * sizeof(float);
         hipLaunchKernelGGL((igemm_u8_kernel<4, 1, 2, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else if (a.K % (2 * BK) == 0 && persist_pays((int)grid.x)) {
+        return launch_igemm_persist<4, 1, 1, BK, true, false, true, 4>(a, false, false, (hipStream_t)stream);
     } else {
         const size_t lds = (size_t)2 * (BM * (BK + 4) + 32 * (BK + 4)) * sizeof(float);
         hipLaunchKernelGGL((igemm_u8_kernel<4, 1, 1, 1, BK, false>), grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -368,9 +368,15 @@ void arl_conv_trace_buffer(void* device_u64_or_null);
  * of the scalar-addressed fast path, so that both are covered by the parity tests.  Not thread-safe. */
 void arl_conv_force_generic(int32_t on);
 
-/* Tuning / test hook for layers with 33 .. 64 output columns: 0 (default) = tile shape by the cost model
- * (busiest CU's work), 1 = always 64x64 tiles (32x32 MFMA), 2 = always 112x64 tiles (16x16 MFMA).  Not thread-safe. */
+/* Tuning / test hook for layers with 33 .. 64 output columns: 0 (default) and 3 = 32x64 tiles (16x16 MFMA, five
+ * waves per SIMD), 1 = 64x64 tiles (32x32 MFMA), 2 = 112x64 tiles (16x16 MFMA, three LDS stages).  Not thread-safe. */
 void arl_conv_tile_choice(int32_t choice);
+
+/* Tuning / test hook: launches of many row tiles (conv 1 forward, the stride-2 data gradient) as
+ * `workgroups_per_cu` persistent workgroups per CU that walk the tiles with the next tile's first loads in
+ * flight under the current tile's last MFMAs (0 = one workgroup per tile; < 0, tests: every eligible launch,
+ * walked by -workgroups_per_cu workgroups in all).  Same results bit for bit.  Not thread-safe. */
+void arl_conv_persistent(int32_t workgroups_per_cu);
 
 /* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
  * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,

@@ -46,17 +46,20 @@ def _tol(want, k_red):
     return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
 
 
-@pytest.fixture(params=["fast", "generic", "fast_tiles64", "fast_tiles112"])
+@pytest.fixture(params=["fast", "generic", "fast_tiles64", "fast_tiles112", "fast_persistent"])
 def path(request):
     """Both kernel families: the scalar-addressed fast path (taken whenever a k-tile of 32 stays inside
     one filter row) and the generic fallback (any multiple-of-4 channel count, any K); and, on the fast path,
-    both tile shapes of the 33 .. 64-column layers forced (the cost model picks 112x64 only from ~29 000 rows)."""
+    the other two tile shapes of the 33 .. 64-column layers (the default is 32x64), and the persistent launches of
+    the many-tile layers walked by three workgroups."""
     from accel_rl_amd import _lib
     _lib.load().arl_conv_force_generic(1 if request.param == "generic" else 0)
     _lib.load().arl_conv_tile_choice({"fast_tiles64": 1, "fast_tiles112": 2}.get(request.param, 0))
+    _lib.load().arl_conv_persistent(-3 if request.param == "fast_persistent" else 0)    # 3 workgroups walk every tile
     yield request.param
     _lib.load().arl_conv_force_generic(0)
     _lib.load().arl_conv_tile_choice(0)
+    _lib.load().arl_conv_persistent(0)
 
 
 ODD_CASES = [(9, 20, 14, 12, 20, 3, 1, 1),      # channels 12 / 20: no power-of-two anywhere -> generic kernels
@@ -321,3 +324,58 @@ def test_random_geometries_against_torch_and_the_generic_kernels(case):
         res[generic] = (y, dx, dw)
     for a, g_ in zip(res[0], res[1]):                      # the two families agree to round-off too
         assert torch.allclose(a, g_, rtol=1e-4, atol=1e-4 * max(g_.abs().max().item(), 1e-6))
+
+
+@pytest.mark.parametrize("walkers", [-1, -3, -7, 1])
+def test_persistent_launches_are_bit_identical(walkers):
+    """arl_conv_persistent: the same tiles, walked by a few resident workgroups with the next tile's loads in flight,
+    must give the one-workgroup-per-tile results bit for bit -- conv 1 forward from u8 rows picked by index (ragged last
+    tile), the stride-2 data gradient into 32 channels with and without the rectifier mask (four parity classes of
+    different sizes), and a stride-1 data gradient into 32 channels (dense rows)."""
+    from accel_rl_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, device=DEV, generator=gen)                 # noqa: E731
+
+    def both(fn):
+        outs = []
+        for w in (0, walkers):
+            lib.arl_conv_persistent(w)
+            try:
+                outs.append(fn())
+            finally:
+                lib.arl_conv_persistent(0)
+        return outs
+    # conv 1 forward, u8 rows by index: 37 images of 104 x 80 -> 37 * 475 rows = 138 tiles of 128 and a ragged one
+    obs = torch.randint(0, 256, (50, 4, 104, 80), device=DEV, dtype=torch.int32, generator=gen).to(torch.uint8)
+    idx = torch.randperm(50, device=DEV, generator=gen)[:37].to(torch.int32)
+    g1 = _lib.conv_geom(37, 104, 80, 4, 32, 8, 8, 4, 0, 0)
+    w1, b1 = rnd(32, 4, 8, 8) * 0.05, rnd(32)
+
+    def fwd_u8():
+        y = torch.full((37, 25, 19, 32), float("nan"), device=DEV)
+        _lib.conv2d_u8_fwd(obs, idx, 1. / 255, w1, b1, y, g1, True)
+        return y
+    a, b = both(fwd_u8)
+    assert torch.isfinite(a).all() and torch.equal(a, b)
+    # stride-2 data gradient into 32 channels (conv 2 of spec 1), classes of 13x10, 13x9, 12x10, 12x9 pixels per image
+    g2 = _lib.conv_geom(9, 25, 19, 32, 64, 4, 4, 2, 1, 1)
+    ho, wo = _lib.conv_out_hw(g2)
+    dy, w2, x2 = rnd(9, ho, wo, 64), rnd(64, 4, 4, 32) * 0.05, rnd(9, 25, 19, 32)
+    for mask in (None, x2):
+        def dgrad():
+            dx = torch.full((9, 25, 19, 32), float("nan"), device=DEV)
+            _lib.conv2d_bwd_data(dy, w2, mask, dx, g2)
+            return dx
+        a, b = both(dgrad)
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    # stride-1 data gradient into 32 channels
+    g3 = _lib.conv_geom(5, 12, 9, 32, 64, 3, 3, 1, 1, 1)
+    dy3, w3 = rnd(5, 12, 9, 64), rnd(64, 3, 3, 32) * 0.05
+
+    def dgrad1():
+        dx = torch.full((5, 12, 9, 32), float("nan"), device=DEV)
+        _lib.conv2d_bwd_data(dy3, w3, None, dx, g3)
+        return dx
+    a, b = both(dgrad1)
+    assert torch.isfinite(a).all() and torch.equal(a, b)

@@ -89,6 +89,7 @@ def report(tag):
                                                       np.median(epi), np.median(t[:, 3] - t[:, 0]), np.median(rs), rs.max(), hist))
 
 
+lib.arl_conv_persistent(int(os.environ.get("ARL_PERSIST", "0")))      # persistent launches: lifetimes span all of a workgroup's tiles
 for choice in ((1, 2) if which in ('c2f', 'c3f', 'c3d') else (1,)):
     lib.arl_conv_tile_choice(choice)
     policy._scratch.clear()

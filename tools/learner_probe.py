@@ -10,6 +10,7 @@ from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
 from accel_rl_amd.spaces import Discrete, UintBox, EnvSpec
 DEV = "cuda:0"
 lib = _lib.load()
+lib.arl_conv_persistent(int(os.environ.get("ARL_PERSIST", "0")))
 policy = AtariCnnPolicy(**cnn_specs[1])
 policy.initialize(EnvSpec(UintBox((4, 104, 80)), Discrete(4)), device=DEV)
 n = 1280

@@ -1,13 +1,13 @@
-"""64x64 (32x32 MFMA) vs 112x64 (16x16 MFMA) tiles for the 64-column layers: time (20 launches per hipGraph) and
-max deviation between the two.  usage: python tools/tile_probe.py [batch ...]"""
+"""64x64 (32x32 MFMA) vs 112x64 and 32x64 (16x16 MFMA) tiles for the 64-column layers: time (20 launches per hipGraph)
+and max deviation from the first.  usage: python tools/tile_probe.py [batch ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__; __graft_entry__.build()
 from accel_rl_amd import _lib
 DEV = "cuda:0"
-CHOICES = (1, 2, 3, 7, 8, 9, 10, 11, 12, 13)
-NAMES = {1: "64x64", 2: "112x64/3", 3: "32x64", 4: "48x64", 5: "32x64/3", 6: "48x64/3", 7: "64x64n16", 8: "32x64k16w8", 9: "32x64k16w6", 10: "32x64k32w5", 11: "64x64k16w6", 12: "48x64k16w6", 13: "64x64n16k16w6"}
+CHOICES = (1, 2, 3)
+NAMES = {1: "64x64", 2: "112x64 (3 stages)", 3: "32x64 (5 waves / SIMD)"}
 
 
 def gt(fn, per=20, rep=5):
