@@ -56,7 +56,7 @@ class AdvActorCriticBase(RLAlgorithm):
                 getattr(self.optimizer, "_minibatch_size", None) is not None:
             # the reference's PpoOptimizer slices rows, not trajectories (ppo_optimizer.py:67-75): recurrent
             # policies are trained with the whole-batch optimizers only
-            raise NotImplementedError("recurrent policies need a whole-batch optimizer (A2C)")
+            raise NotImplementedError("recurrent policies need a whole-batch optimizer (A2C) (INTEGRATION.md, section E)")
         opt_examples = dict(advantages=np.float32(1), returns=np.float32(1))
         if self._use_valids:
             input_names.append("valids")

@@ -22,7 +22,7 @@ class AtariDqnPolicy(QPolicyBase):
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=(),
                  pixel_scale=255., epsilon=1, dueling=False, shared_last_bias=False, initial_param_values=None):
         if shared_last_bias:
-            raise NotImplementedError("shared_last_bias (dqn_cnn.py:73-88) is not built")
+            raise NotImplementedError("shared_last_bias (dqn_cnn.py:73-88) is not built (INTEGRATION.md, section E)")
         super().__init__(conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=hidden_sizes,
                          pixel_scale=pixel_scale, initial_param_values=initial_param_values)
         self._epsilon = epsilon

@@ -36,7 +36,7 @@ class QPolicyBase(AtariCnnPolicy):
         self._dueling = bool(dueling)
         if self._dueling:
             if len(self.hidden_sizes) != 1:
-                raise NotImplementedError("dueling networks are built for one hidden layer")
+                raise NotImplementedError("dueling networks are built for one hidden layer (INTEGRATION.md, section E)")
             # construction order [hid W, b, hid_Val W, b, out W, b, Val W, b] -> the reference's flat order
             self._tail_perm = [2, 3, 6, 7, 0, 1, 4, 5]
 

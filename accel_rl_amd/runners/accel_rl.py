@@ -54,7 +54,7 @@ class AccelRLBase(Runner):
 
     def init_policy(self, env_spec):
         if not self.use_gpu:
-            raise NotImplementedError("accel_rl_amd has no CPU learner: use_gpu must be True")
+            raise NotImplementedError("accel_rl_amd has no CPU learner: use_gpu must be True (INTEGRATION.md, section E)")
         self.policy.initialize(env_spec, device=self.sampler.device)
         logger.log("Policy trainable params -- number: {:,}   size: {:,.1f} {}".format(
             self.policy.n_params, *nbytes_unit(self.policy.n_params * 4)))

@@ -21,7 +21,9 @@ python tools/gae_sweep.py > $O/gae_sweep.txt 2>&1
 python tools/conv_trace.py 512 2>&1 | grep -v amdgpu.ids > $O/conv_trace.txt
 python tools/env_step_probe.py 256 2>&1 | grep dbg > $O/env_step_probe.txt; python tools/env_step_probe.py 2048 2>&1 | grep dbg >> $O/env_step_probe.txt
 python tools/learner_probe.py 2>&1 | grep tile > $O/learner_probe.txt
-python tools/tile_probe.py 512 256 2>&1 | grep "B=\|dev" > $O/tile_probe.txt
+python tools/tile_probe.py 512 256 128 2>&1 | grep "B=\|dev" > $O/tile_probe.txt
+python tools/persist_probe.py 0 3 4 5 0 2>&1 | grep persistent > $O/persist_probe.txt
+(for w in c1f c2d; do ARL_PERSIST=4 python tools/context_trace.py $w 2>&1 | grep -v amdgpu.ids; done) > $O/context_trace_persistent.txt
 timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/null | tail -n 1 > $O/bench_a2c1024.json
 timeout 300 python bench.py --scaling strong --total-envs 2048 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > $O/bench_strong_2048_n1.json
 timeout 300 python bench.py --workload catdqn --steps 30 --warmup 5 --dqn-batch 512 2>/dev/null | tail -n 1 > $O/bench_catdqn_batch512.json
