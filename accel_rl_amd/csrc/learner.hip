@@ -158,6 +158,8 @@ struct HeadLossArgs {
     float* dout;             // [B][K] gradient wrt (logits, value)
     float* dh;               // [B][hid] gradient wrt h (before the relu mask)
     float* loss_partials;    // [gridDim][4] = pi, v, ent, their sum
+    float* wpart;            // [gridDim][K][hid] this workgroup's share of dW_head = sum_b dout[b] x h[b], or null
+    float* bpart;            // [gridDim][Kp]     ... of db_head = sum_b dout[b]                (with wpart)
     int batch, hid, n_act, kind;
     float clip_param, v_coeff, ent_coeff;
     int mask_dh;             // dh *= (h > 0): h is a rectifier's output and the caller wants the gradient before it
@@ -172,8 +174,9 @@ template <bool TRAIN, int HVT = 0>
 __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __restrict__ prob_out,
                                                    float* __restrict__ value_out) {
     constexpr int HV = HVT ? HVT : HID_MAX / 64;
-    extern __shared__ __attribute__((aligned(16))) float s_w[];     // [K][hid]
+    extern __shared__ __attribute__((aligned(16))) float s_w[];     // [K][hid] (+ [4][K][hid] head-gradient slices)
     __shared__ float s_loss[4][4];
+    __shared__ float s_db[4][64];
     const int A = a.n_act, K = A + 1, hid = a.hid, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // A row's scalars hang off a three-deep chain of dependent loads (idx -> action -> old probability): they
     // are fetched one row ahead -- the first row's before the weights are even staged -- so the chain's
@@ -213,6 +216,18 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
     const float inv_n = TRAIN ? (a.inv_count ? a.inv_count[0] : 1.f / (float)a.batch) : 0.f;
     const float clip = TRAIN ? a.clip_param * a.lr_mult[0] : 0.f;
     float l_pi = 0.f, l_v = 0.f, l_ent = 0.f;
+    // The head's own weight / bias gradient rides along (no second pass over dout and h): every wave adds its rows'
+    // outer products dout[b] x h[b] into its LDS slice, the workgroup sums the four slices in wave order and leaves
+    // ONE partial per workgroup for arl_fold_many (fixed order => deterministic).
+    const bool fused_wgrad = TRAIN && a.wpart != nullptr;            // uniform
+    float* s_dw = s_w + K * hid + wave * K * hid;
+    float db_lane = 0.f;
+    if (fused_wgrad) {
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int j = 0; j < HV; ++j)
+                if (HVT || lane + 64 * j < hid) s_dw[k * hid + lane + 64 * j] = 0.f;
+    }
     const int waves = waves_total;
     for (int b = blockIdx.x * (blockDim.x >> 6) + wave; b < a.batch; b += waves) {
         const RowMeta cur = meta;
@@ -290,7 +305,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
 #pragma unroll
             for (int j = 0; j < HV; ++j)
                 if (HVT || lane + 64 * j < hid) sdh[j] += dl_k * s_w[k * hid + lane + 64 * j];
+            if (fused_wgrad) {
+#pragma unroll
+                for (int j = 0; j < HV; ++j)
+                    if (HVT || lane + 64 * j < hid) s_dw[k * hid + lane + 64 * j] += dl_k * hv[j];
+            }
         }
+        if (lane < K) db_lane += dlk;
         float* dhrow = a.dh + (int64_t)b * hid;
 #pragma unroll
         for (int j = 0; j < HV; ++j) {
@@ -306,6 +327,18 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
             for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) sl += s_loss[wv][threadIdx.x];
             a.loss_partials[blockIdx.x * 4 + threadIdx.x] = sl;
         }
+        if (fused_wgrad) {                                               // (the barrier above covers the slices too)
+            s_db[wave][lane] = db_lane;
+            const float* s0 = s_w + K * hid;
+            float* out = a.wpart + (int64_t)blockIdx.x * K * hid;
+            for (int i = threadIdx.x; i < K * hid; i += blockDim.x)
+                out[i] = ((s0[i] + s0[K * hid + i]) + s0[2 * K * hid + i]) + s0[3 * K * hid + i];
+            __syncthreads();
+            const int Kp = (K + 3) & ~3;
+            if (threadIdx.x < Kp)
+                a.bpart[(int64_t)blockIdx.x * Kp + threadIdx.x] =
+                    threadIdx.x < K ? ((s_db[0][threadIdx.x] + s_db[1][threadIdx.x]) + s_db[2][threadIdx.x]) + s_db[3][threadIdx.x] : 0.f;
+        }
     }
 }
 
@@ -314,6 +347,9 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
 // 4 waves of a block take rows b = wave, wave+4, ... of the split; dout rows sit in LDS.
 // Folded over row splits by arl_fold_many (fixed order) => deterministic.
 constexpr int WG_SPLITS = 16;
+// the head kernel sums the head's weight gradient itself while its four LDS slices [4][K][hid] (next to the staged
+// weights [K][hid]) fit 64 KB: K * hid <= 3 072, e.g. 5 x 512, 19 x 128
+constexpr int FUSED_WGRAD_MAX = 3072;
 
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const float* __restrict__ dout,
                                                          const float* __restrict__ h, int batch,
@@ -387,7 +423,9 @@ extern "C" int arl_bias_relu(float* x, const float* bias, int64_t rows, int32_t 
 
 extern "C" int64_t arl_relu_bwd_workspace_bytes(void) { return (int64_t)256 * HID_MAX * sizeof(float); }
 extern "C" int64_t arl_pg_head_workspace_bytes(void) {
-    return (int64_t)(256 * 4 + WG_SPLITS * (K_MAX + 1) * HID_MAX + (K_MAX + 1) * HID_MAX) * sizeof(float);
+    // loss partials [256][4]; head-gradient partials: [WG_SPLITS][K][hid] (separate kernel) or [<= 256][K][hid] with
+    // K * hid <= FUSED_WGRAD_MAX (summed inside the head kernel); bias partials [<= 256][Kp]
+    return (int64_t)(256 * 4 + 256 * FUSED_WGRAD_MAX + WG_SPLITS * (K_MAX + 1) * HID_MAX + 256 * (K_MAX + 4)) * sizeof(float);
 }
 
 static int relu_bwd_bias_launch(float* dy, const float* y, int64_t rows, int32_t channels, float* dbias,
@@ -477,7 +515,14 @@ extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const
     a.clip_param = clip_param; a.v_coeff = v_loss_coeff; a.ent_coeff = ent_loss_coeff; a.mask_dh = relu_mask_dh;
     const int grid = (int)((batch + 3) / 4 < 256 ? (batch + 3) / 4 : 256);
     const int K = n_actions + 1;
-#define ARL_HEAD_TRAIN(HVT_) hipLaunchKernelGGL((head_kernel<true, HVT_>), dim3(grid), dim3(256), (size_t)K * hid * 4, s, a, (float*)nullptr, (float*)nullptr)
+    const int Kp = (K + 3) & ~3;
+    float* ws = (float*)workspace;
+    float* part = ws + 256 * 4;
+    const bool fused = K * hid <= FUSED_WGRAD_MAX;
+    float* part_b = part + (fused ? (int64_t)grid : (int64_t)WG_SPLITS) * K * hid;
+    if (fused) { a.wpart = part; a.bpart = part_b; }
+    const size_t head_lds = (size_t)(fused ? 5 : 1) * K * hid * 4;
+#define ARL_HEAD_TRAIN(HVT_) hipLaunchKernelGGL((head_kernel<true, HVT_>), dim3(grid), dim3(256), head_lds, s, a, (float*)nullptr, (float*)nullptr)
     if (hid == 512) ARL_HEAD_TRAIN(8);
     else if (hid == 256) ARL_HEAD_TRAIN(4);
     else if (hid == 1024) ARL_HEAD_TRAIN(16);
@@ -488,17 +533,16 @@ extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const
     if (rc) return rc;
     // head weight / bias gradient: row-split partials [WG_SPLITS][K][hid] and [WG_SPLITS][Kp]; their folds and the
     // fold of the per-workgroup loss partials [grid][4] are left to arl_fold_many (one launch per backward pass)
-    float* ws = (float*)workspace;
-    const int Kp = (K + 3) & ~3;
-    float* part = ws + 256 * 4;
-    float* part_b = part + (int64_t)WG_SPLITS * K * hid;
-    const int rows_per = ((int)batch + WG_SPLITS - 1) / WG_SPLITS;
-    hipLaunchKernelGGL(head_wgrad_kernel, dim3((hid + 63) / 64, WG_SPLITS), dim3(256),
-                       (size_t)rows_per * K * 4, s, dout, h, (int)batch, (int)hid, K, Kp, part, part_b);
-    rc = arl::check_launch("head_wgrad_kernel");
-    if (rc) return rc;
-    items3[0].part = part; items3[0].out = dw_head; items3[0].total = (int64_t)K * hid; items3[0].splits = WG_SPLITS;
-    items3[1].part = part_b; items3[1].out = db_head; items3[1].total = Kp; items3[1].splits = WG_SPLITS;
+    if (!fused) {
+        const int rows_per = ((int)batch + WG_SPLITS - 1) / WG_SPLITS;
+        hipLaunchKernelGGL(head_wgrad_kernel, dim3((hid + 63) / 64, WG_SPLITS), dim3(256),
+                           (size_t)rows_per * K * 4, s, dout, h, (int)batch, (int)hid, K, Kp, part, part_b);
+        rc = arl::check_launch("head_wgrad_kernel");
+        if (rc) return rc;
+    }
+    const int n_parts = fused ? grid : WG_SPLITS;
+    items3[0].part = part; items3[0].out = dw_head; items3[0].total = (int64_t)K * hid; items3[0].splits = n_parts;
+    items3[1].part = part_b; items3[1].out = db_head; items3[1].total = Kp; items3[1].splits = n_parts;
     items3[2].part = ws; items3[2].out = loss4; items3[2].total = 4; items3[2].splits = grid;
     items3[0].valid = items3[2].valid = 0;
     items3[1].valid = K;                                // db_head holds K floats, the partials are padded to Kp
