@@ -1851,12 +1851,12 @@ int num_cus() {
 }
 
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16, int MINW>
-int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s) {
+int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s, int splits = 1) {
     constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * TN * 32;
     constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
     const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
     static_assert(lds_fits(2 * (A_SZ + B_SZ)), "<= 64 KiB of LDS");
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : 1);
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
 #define ARL_IGEMM_OCC(MT, HP) \
     hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16, MINW>), grid, dim3(256), lds, s, a)
     if (multi_tap && has_pad) ARL_IGEMM_OCC(true, true);
@@ -2028,7 +2028,8 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     a.o.dense = 1; a.trace = g_trace;
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
-    if (small) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
+    const bool small32 = small && g_tile_choice != 1;       // 32x64 tiles: half the splits (and partial bytes) for the same grid
+    if (small) plan_split(((a.M + (small32 ? 31 : 63)) / (small32 ? 32 : 64)) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
     // ... and wider ones whose 128x128 tiles still leave CUs idle (spec-0 dense at the A2C batch: 5120 x 256 =
     // 80 tiles walking 88 k-tiles each, 231 us)
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -2065,6 +2066,7 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 64 && splits == 1) rc = launch_n64<true>(a, multi_tap, has_pad, s);
         else if (a.N <= 64) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
+        else if (small32) rc = launch_igemm_occ<1, 4, 2, 1, 32, true, true, 5>(a, multi_tap, has_pad, s, splits);
         else if (small) rc = launch_igemm<2, 2, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, true>(a, splits, multi_tap, has_pad, s);
     } else {

@@ -157,19 +157,30 @@ __global__ __launch_bounds__(256) void update_noclip_kernel(arl_opt_state o, int
     float4* m4 = reinterpret_cast<float4*>(o.slot0);
     float4* v4 = reinterpret_cast<float4*>(o.slot1);
     double s = 0;
+    // gradient and optimiser slots are streamed (touched once per step): non-temporal, so that they do not push the
+    // parameters -- which the next forward pass reads -- out of the caches
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    auto ld_nt = [](const float4* q) {
+        const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(q));
+        return make_float4(t.x, t.y, t.z, t.w);
+    };
+    auto st_nt = [](float4* q, const float4& x) {
+        f32x4_t t = {x.x, x.y, x.z, x.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(q));
+    };
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 p = p4[i];
-        const float4 g = g4[i];
-        float4 m = m4[i];
-        float4 v = (METHOD == ARL_OPT_ADAM) ? v4[i] : make_float4(0, 0, 0, 0);
+        const float4 g = ld_nt(g4 + i);
+        float4 m = ld_nt(m4 + i);
+        float4 v = (METHOD == ARL_OPT_ADAM) ? ld_nt(v4 + i) : make_float4(0, 0, 0, 0);
         s += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
         update_one<METHOD>(p.x, g.x, m.x, v.x, avg, 1.f, lr, a_t, b1, b2, eps);
         update_one<METHOD>(p.y, g.y, m.y, v.y, avg, 1.f, lr, a_t, b1, b2, eps);
         update_one<METHOD>(p.z, g.z, m.z, v.z, avg, 1.f, lr, a_t, b1, b2, eps);
         update_one<METHOD>(p.w, g.w, m.w, v.w, avg, 1.f, lr, a_t, b1, b2, eps);
         p4[i] = p;
-        m4[i] = m;
-        if (METHOD == ARL_OPT_ADAM) v4[i] = v;
+        st_nt(m4 + i, m);
+        if (METHOD == ARL_OPT_ADAM) st_nt(v4 + i, v);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (n4 << 2) + threadIdx.x;
