@@ -141,12 +141,18 @@ def roofline_gae(device, log2_elems, reps):
 
 def pmc_traffic(log2_elems):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (bench.py cannot
-    read PMC counters itself); None if no profile for this size is committed."""
+    read PMC counters itself); None if no profile for this size is committed -- or if it was taken from another
+    version of the scan kernels (the record carries the sha1 of scan.hip; tools/refresh_profiles.sh renews it)."""
+    import hashlib
     path = os.path.join(ROOT, "profiles", "gae_pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
-        return rec["hbm_bytes_per_launch"] if rec.get("log2_elems") == log2_elems else None
+        with open(os.path.join(ROOT, "accel_rl_amd", "csrc", "scan.hip"), "rb") as f:
+            sha = hashlib.sha1(f.read()).hexdigest()
+        if rec.get("log2_elems") != log2_elems or rec.get("scan_hip_sha1") != sha:
+            return None
+        return rec["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         return None
 
@@ -329,16 +335,22 @@ def _host_cpu():
     return model, (len(cores) or max(1, logical // 2)), logical
 
 
-def _windows(one_batch, n_windows, seconds, min_batches=3):
-    """env-steps/s of `one_batch()` over n_windows back-to-back windows; returns (rates, batches, total time)."""
+def _windows(one_batch, n_windows, seconds, min_batches=3, batch_times=None):
+    """env-steps/s of `one_batch()` over n_windows back-to-back windows; returns (rates, batches, total time).
+    batch_times (optional list): every batch's duration in seconds is appended."""
     one_batch()                                      # warm-up batch
     rates, total_b, total_t = [], 0, 0.0
     for _ in range(n_windows):
         t0, batches = time.time(), 0
-        while time.time() - t0 < seconds or batches < min_batches:
+        t1 = t0
+        while t1 - t0 < seconds or batches < min_batches:
             one_batch()
             batches += 1
-        dt = time.time() - t0
+            t2 = time.time()
+            if batch_times is not None:
+                batch_times.append(t2 - t1)
+            t1 = t2
+        dt = t1 - t0
         rates.append(batches * N_ENVS * HORIZON / dt)
         total_b += batches
         total_t += dt
@@ -397,8 +409,10 @@ def cpu_baseline(device, policy, smp, sampler, algo, itr0, seconds=4.0, n_window
         torch.cuda.synchronize()
 
     np.random.seed(12345)
+    load0 = os.getloadavg()[0]                       # the host's 1-minute load before the pool starts working
+    bt = []
     try:
-        rates, batches, dt = _windows(lambda: sample_and_process(smp), n_windows, seconds)
+        rates, batches, dt = _windows(lambda: sample_and_process(smp), n_windows, seconds, batch_times=bt)
         loop_rates, loop_batches, loop_dt = _windows(whole_loop, n_windows, seconds * 0.75)
     finally:
         smp.shutdown()
@@ -412,6 +426,13 @@ def cpu_baseline(device, policy, smp, sampler, algo, itr0, seconds=4.0, n_window
                 whole_loop_windows=[round(r, 1) for r in loop_rates],
                 single_core=round(med(one_rates), 1), cpu_model=model, physical_cores=physical,
                 logical_cores=logical,
+                # The GPU boxes share their host: other tenants' load moves the CPU figure by 2-3x inside one run.
+                # batch_ms = 10th / 50th / 90th percentile of the sampler's batch time over all windows (the 10th
+                # is the undisturbed sampler: 1280 env-steps per batch); host_load_1min = load average before the
+                # pool started.
+                batch_ms=[round(1e3 * float(x), 2) for x in np.percentile(bt, [10, 50, 90])],
+                undisturbed=round(N_ENVS * HORIZON / float(np.percentile(bt, 10)), 1),
+                host_load_1min=round(load0, 1),
                 sample="median of %d windows (%d batches, %.1f s in all) of the same workload's rollout + "
                        "process_samples (256 envs x 5 steps): numpy restatement of the reference sampler / "
                        "AtariEnv / GAE, master + %d worker processes (2 alternating groups x %d, %d envs each, "
@@ -629,9 +650,11 @@ def main():
             line["gpu_over_cpu"] = {
                 "rollout_only": round(line["phases"]["rollout_only_env_steps_per_s"] / cb["value"], 2),
                 "whole_loop": round(line["value"] / cb["whole_loop"], 2),
-                "note": "rollout_only: GPU rollout (sampler only) vs the CPU sampler port; whole_loop: `value` "
-                        "(rollout + PPO learner on the device) vs the CPU sampler port feeding the same device "
-                        "learner serially, as the reference's runner does"}
+                "rollout_only_vs_undisturbed_cpu": round(line["phases"]["rollout_only_env_steps_per_s"] / cb["undisturbed"], 2),
+                "note": "rollout_only: GPU rollout (sampler only) vs the CPU sampler port (median window); whole_loop: "
+                        "`value` (rollout + PPO learner on the device) vs the CPU sampler port feeding the same device "
+                        "learner serially, as the reference's runner does; rollout_only_vs_undisturbed_cpu: against "
+                        "the CPU sampler's 10th-percentile batch time (what it does when the shared host is quiet)"}
     runner.shutdown()
     if dist.is_initialized():
         dist.barrier()

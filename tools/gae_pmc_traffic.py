@@ -3,8 +3,12 @@ runs of `python bench.py --roofline-only`), corrected as /opt/skills/guides/MI35
 (gfx950 reports half of the wide coalesced read traffic).
 usage: gae_pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [log2_elems] > gae_pmc_traffic.json"""
 import csv
+import hashlib
 import json
+import os
 import sys
+
+SCAN_SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "accel_rl_amd", "csrc", "scan.hip")
 
 
 def median_of(path, counter):
@@ -27,6 +31,7 @@ print(json.dumps(dict(
     log2_elems=log2, kernel="scan_lds_kernel<false,0,256>", FETCH_SIZE_KB=fetch_kb, WRITE_SIZE_KB=write_kb,
     fetch_bytes_corrected=fetch_b, write_bytes=write_b, hbm_bytes_per_launch=fetch_b + write_b,
     algorithmic_bytes_per_launch=17 * n_env * t + 4 * n_env,
+    scan_hip_sha1=hashlib.sha1(open(SCAN_SRC, "rb").read()).hexdigest(),      # bench.py drops the figure when scan.hip changes
     note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py "
          "--roofline-only`; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced "
-         "reads); median over %d launches; raw CSVs in profiles/r01/" % n), indent=1))
+         "reads); median over %d launches; raw CSVs next to this file's per-round copy (profiles/rNN/)" % n), indent=1))
