@@ -147,11 +147,11 @@ __device__ __forceinline__ void store_tiles_rowmajor(const f32x16 (&acc)[TM][TN]
 // sixteen.  row_off[i] = element offset of the lane's row in tile i (or < 0: row out of range);
 // bias_q[j][q] = the lane's four bias values of quad q of column tile j (zeros without a bias);
 // N % 4 == 0 (checked on the host).  mask: same layout as out, out = 0 where mask <= 0.
-template <int TM, int TN>
+template <int TM, int TN, bool SCALED = false>
 __device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
                                                   const long long (&row_off)[TM], int N, int col_base, int lane,
                                                   const float4 (&bias_q)[TN][4], const float* mask, int relu,
-                                                  const float4 (*pre)[TM] = nullptr) {
+                                                  const float4 (*pre)[TM] = nullptr, float scale = 1.f) {
     const int half = lane >> 5;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -181,8 +181,11 @@ __device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], _
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bool ok = row_off[i] >= 0 && n < N;
-                float4 val = make_float4(acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
-                                         acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w);
+                float4 val = SCALED     // (the u8 kernels: the pixel scale on the finished sum, see bytes_to_f4)
+                    ? make_float4(acc[i][j][4 * q] * scale + bq.x, acc[i][j][4 * q + 1] * scale + bq.y,
+                                  acc[i][j][4 * q + 2] * scale + bq.z, acc[i][j][4 * q + 3] * scale + bq.w)
+                    : make_float4(acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
+                                  acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w);
                 if (relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
                 const unsigned voff = ok ? (unsigned)((row_off[i] + n) << 2) : OOB;
                 if (mask) {
@@ -591,10 +594,12 @@ __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t rsrc, unsigned
 __device__ __forceinline__ unsigned buf_ld1s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0);
 }
-// four packed bytes -> four scaled floats (v_cvt_f32_ubyte0..3 + multiplies; same values as arl_gather_scale_obs)
-__device__ __forceinline__ float4 bytes_to_f4(unsigned v, float sc) {
-    return make_float4((float)(v & 0xffu) * sc, (float)((v >> 8) & 0xffu) * sc, (float)((v >> 16) & 0xffu) * sc,
-                       (float)(v >> 24) * sc);
+// four packed bytes -> four floats (v_cvt_f32_ubyte0..3).  The pixel scale (1/255) is NOT applied here: a
+// convolution is linear in its input, so the u8 kernels accumulate sum(x * w) on the exact integers and multiply the
+// finished sum once -- conv(x * s, w) = s * conv(x, w) up to the rounding of one multiply per output instead of one
+// per operand element (two v_pk_mul_f32 per loaded dword, a third of the loader's vector work).
+__device__ __forceinline__ float4 bytes_to_f4(unsigned v) {
+    return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
 }
 // n / d for a uniform runtime divisor: one v_mul_hi instead of the ~40-instruction division sequence
 // (vector instructions in these kernels are paid for in MFMA issue slots); magic == 0 -> plain division
@@ -781,7 +786,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         for (int p = 0; p < RA; ++p) {
             if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
             *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) =
-                U8 ? bytes_to_f4(va8[p], g.scale) : va[p];
+                U8 ? bytes_to_f4(va8[p]) : va[p];
         }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
@@ -999,7 +1004,9 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const bool ok = row_off[i] >= 0 && n < a.N;
-                float4 val = make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
+                float4 val = U8 ? make_float4(acc16[i][0] * g.scale + bq.x, acc16[i][1] * g.scale + bq.y,
+                                              acc16[i][2] * g.scale + bq.z, acc16[i][3] * g.scale + bq.w)
+                                : make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
                 if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
                 if (a.o.mask) {
                     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -1014,8 +1021,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                 __builtin_amdgcn_raw_buffer_store_b128(raw, rsO, ok ? (unsigned)((row_off[i] + n) << 2) : OOB, 0, 0);
             }
         } else {
-            store_tiles_quads<TM, TN>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu,
-                                      PRE_MASK ? mk_pre : nullptr);
+            store_tiles_quads<TM, TN, U8>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu,
+                                          PRE_MASK ? mk_pre : nullptr, g.scale);
         }
     }
     if (a.trace && tid == 0) {
@@ -1214,7 +1221,7 @@ __device__ __forceinline__ void igemm_persist_body(const GemmArgs& a, float* sme
         for (int p = 0; p < RA; ++p) {
             if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
             *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) =
-                U8 ? bytes_to_f4(R.va8[p], a.g.scale) : R.va[p];
+                U8 ? bytes_to_f4(R.va8[p]) : R.va[p];
         }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
@@ -1318,8 +1325,10 @@ __device__ __forceinline__ void igemm_persist_body(const GemmArgs& a, float* sme
             for (int i = 0; i < TM; ++i) {
                 const bool ok = T.row_off[i] >= 0 && n < a.N;
                 float4 val;
-                if constexpr (N16) val = make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
-                else val = make_float4(acc[i][4 * q] + bq.x, acc[i][4 * q + 1] + bq.y, acc[i][4 * q + 2] + bq.z, acc[i][4 * q + 3] + bq.w);
+                if constexpr (N16) val = make_float4(acc16[i][0], acc16[i][1], acc16[i][2], acc16[i][3]);
+                else val = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+                if constexpr (U8) { val.x *= a.g.scale; val.y *= a.g.scale; val.z *= a.g.scale; val.w *= a.g.scale; }
+                val.x += bq.x; val.y += bq.y; val.z += bq.z; val.w += bq.w;
                 if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
                 if (a.o.mask) {
                     const float4 m = mk_pre[q][i];
@@ -1545,7 +1554,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
 #pragma unroll
         for (int p = 0; p < RB; ++p)
             *reinterpret_cast<float4*>(dB + (b_k0 + p * KROWS) * BN + b_c4 * 4) =
-                U8 ? bytes_to_f4(vb8[p], a.g.scale) : vb[p];
+                U8 ? bytes_to_f4(vb8[p]) : vb[p];
     };
 
     f32x16 acc[TM][TN];
@@ -1662,10 +1671,18 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const int row = i0 + 4 * quad + v;
-                if (row < a.K_out && col < a.N) out[(int64_t)row * a.N + col] = acc16[gq][v];
+                if (row < a.K_out && col < a.N) out[(int64_t)row * a.N + col] = U8 ? acc16[gq][v] * a.g.scale : acc16[gq][v];
             }
         }
     } else {
+        if constexpr (U8) {                         // the pixel scale on the finished sums (see bytes_to_f4)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][j][v] *= a.g.scale;
+        }
         store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
     }
 }

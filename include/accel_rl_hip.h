@@ -426,8 +426,9 @@ int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_nu
  * f32[out_c][in_c][kh][kw] (correlation kernels).  geom->batch = rows of the batch; in_c any count >= 1.
  * Requires pad 0, stride % 4 == 0, in_w % 4 == 0, (in_h * in_w) % 4 == 0, kw in {4, 8, 16},
  * kh % (16 / kw) == 0, out_c % 4 == 0 and <= 32 (else ARL_E_RANGE: use arl_gather_scale_obs_nhwc +
- * arl_conv2d_fwd).  Same arithmetic as those two (the products are accumulated plane by plane instead
- * of pixel by pixel).  */
+ * arl_conv2d_fwd).  The sums run over the exact integer pixels, plane by plane, and `scale` multiplies the
+ * finished sum once (a convolution is linear in its input: y = scale * conv(byte, w) + bias) -- equal to the
+ * gather + scale route up to f32 round-off, not bit for bit.  */
 int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int32_t* idx_or_null, float scale,
                       const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom,
                       int32_t relu, void* stream);

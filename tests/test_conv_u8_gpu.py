@@ -95,8 +95,9 @@ def test_weight_gradient(case):
 
 
 def test_matches_the_gather_route():
-    """Same operand values as gather+scale followed by the NHWC kernels: the results differ only by the
-    order of the reduction (plane by plane instead of pixel by pixel)."""
+    """Against gather + scale followed by the NHWC kernels: the u8 kernels sum over the exact integer pixels plane
+    by plane and apply the pixel scale to the finished sum, the other route scales every pixel first and sums pixel by
+    pixel -- the same numbers up to f32 round-off."""
     from accel_rl_amd import _lib
     case = (300, 256, 4, 104, 80, 32, 8, 8, 4)
     obs, idx, wt, bias, geom = _mk(case, seed=3)
