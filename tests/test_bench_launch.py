@@ -1,0 +1,59 @@
+"""bench.py's own launch paths (the driver starts it as `python bench.py --gpus N ...`): started without a launcher it
+must spawn its N ranks itself (as the reference's runner forks its n - 1 workers, multigpu_rl_base.py:20-45), and the
+strong-scaling mode must split the job it is given.  On a one-GPU box N > 1 runs in the development mode (both ranks on
+GPU 0, gloo: RCCL refuses two ranks on one device) -- a launch-path check, never a measurement."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, extra_env=None, timeout=600):
+    env = dict(os.environ)
+    env.update(extra_env or {})
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def _line(out):
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, (out.stdout[-2000:], out.stderr[-2000:])      # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def test_spawns_its_ranks_without_a_gpu():
+    """No GPU here: both spawned ranks must get as far as the product's refusal to run on a CPU -- i.e. the re-exec under
+    torch.distributed.run (127.0.0.1 rendezvous, RANK / WORLD_SIZE in the environment) works."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered by the GPU test below")
+    out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-roofline"])
+    assert out.returncode != 0
+    assert (out.stdout + out.stderr).count("bench.py needs a GPU") >= 2, (out.stdout[-2000:], out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_two_ranks_spawned_in_development_mode():
+    out = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-roofline"],
+               dict(ARL_BENCH_ONE_GPU="1", ARL_BENCH_BACKEND="gloo"))
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    d = _line(out)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["steps"] == 2 and d["config"]["total_envs"] == 512 and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_strong_scaling_mode_splits_the_job():
+    """--scaling strong: --total-envs environments and one global minibatch of 512 x 8 rows per update in all; at N = 1
+    the single rank owns all of it."""
+    out = _run(["--scaling", "strong", "--total-envs", "2048", "--steps", "2", "--warmup", "1"])
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    d = _line(out)
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["total_envs"] == 2048
+    assert d["config"]["global_minibatch"] == 4096 and d["value"] > 0
+    assert "cpu_baseline" not in d and "roofline" not in d
