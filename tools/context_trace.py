@@ -90,7 +90,8 @@ def report(tag):
 
 
 lib.arl_conv_persistent(int(os.environ.get("ARL_PERSIST", "0")))      # persistent launches: lifetimes span all of a workgroup's tiles
-for choice in ((1, 2) if which in ('c2f', 'c3f', 'c3d') else (1,)):
+TILES = {1: "64x64", 2: "112x64", 3: "32x64 (default)"}
+for choice in ((3, 1, 2) if which in ('c2f', 'c3f', 'c3d') else (3,)):
     lib.arl_conv_tile_choice(choice)
     policy._scratch.clear()
     for rep in range(3):                       # two warm passes over the 8 minibatches, then the traced one
@@ -101,5 +102,5 @@ for choice in ((1, 2) if which in ('c2f', 'c3f', 'c3d') else (1,)):
                 tr.zero_()
             policy.loss_and_grads(dict(mb, idx=ix), 1, 0.2, 1.0, 0.01, lr)
     torch.cuda.synchronize()
-    report("%s, 64-column tiles %s" % (which, "64x64" if choice == 1 else "112x64"))
+    report("%s, 64-column tiles %s" % (which, TILES[choice]))
 lib.arl_conv_tile_choice(0)

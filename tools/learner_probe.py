@@ -41,7 +41,7 @@ def gt(rep=10):
     return a.elapsed_time(b) / (8 * rep) * 1e3
 
 
-for choice in [int(x) for x in sys.argv[1:]] or (1, 2, 1, 2, 0):
+for choice in [int(x) for x in sys.argv[1:]] or (1, 2, 3, 1, 2, 3):
     lib.arl_conv_tile_choice(choice)
     policy._scratch.clear()
     print("tile choice %d: %.1f us per minibatch (forward + backward, no update)" % (choice, gt()))
