@@ -141,6 +141,12 @@ _SIGNATURES = {
     "arl_opt_step": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "arl_opt_step_noclip": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp, _vp]),
     "arl_opt_finish": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _vp, _vp, _vp]),
+    "arl_opt_step_noclip_split": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp,
+                                         _i64, _i64, _i32, _vp]),
+    "arl_opt_finish_split": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _vp, _vp, _i64, _vp]),
+    "arl_conv_corun_update": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp,
+                                     _i64, _i64]),
+    "arl_conv_corun_flush": (_i32, [_vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -320,9 +326,35 @@ def opt_step_noclip(opt, method, learning_rate, avg_factor, beta1_or_rho, beta2,
                                       int(k), ptr(step_pp), ptr(norm_parts), stream_ptr(stream)), "arl_opt_step_noclip")
 
 
-def opt_finish(opt, n_updates, avg_factor, step_pp, norm_parts, stream=None):
-    _check(load().arl_opt_finish(C.byref(opt), int(n_updates), avg_factor, ptr(step_pp), ptr(norm_parts),
-                                 stream_ptr(stream)), "arl_opt_finish")
+def opt_finish(opt, n_updates, avg_factor, step_pp, norm_parts, stream=None, hole_count=0):
+    """Close a call of no-clip updates; hole_count: the call's updates were split around a hole of that size."""
+    _check(load().arl_opt_finish_split(C.byref(opt), int(n_updates), avg_factor, ptr(step_pp), ptr(norm_parts),
+                                       int(hole_count), stream_ptr(stream)), "arl_opt_finish_split")
+
+
+def opt_step_noclip_split(opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k, step_pp,
+                          norm_parts, hole_first, hole_count, part, stream=None):
+    """part 0: the no-clip update of everything but [hole_first, hole_first + hole_count); part 1: of that range."""
+    _check(load().arl_opt_step_noclip_split(C.byref(opt), method, learning_rate, avg_factor, beta1_or_rho, beta2,
+                                            epsilon, int(k), ptr(step_pp), ptr(norm_parts), int(hole_first),
+                                            int(hole_count), int(part), stream_ptr(stream)),
+           "arl_opt_step_noclip_split")
+
+
+def conv_corun_update(opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k, step_pp, norm_parts,
+                      hole_first, hole_count):
+    """Hand part 1 of update k to the next data-gradient launch of a 33 .. 64-column layer (extra workgroups)."""
+    _check(load().arl_conv_corun_update(C.byref(opt), method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon,
+                                        int(k), ptr(step_pp), ptr(norm_parts), int(hole_first), int(hole_count)),
+           "arl_conv_corun_update")
+
+
+def conv_corun_flush(stream=None):
+    """Run a still-pending co-run job as its own launch; True if there was one."""
+    rc = load().arl_conv_corun_flush(stream_ptr(stream))
+    if rc < 0:
+        _check(rc, "arl_conv_corun_flush")
+    return rc == 1
 
 
 # ---------------------------------------------------------------------------
@@ -467,6 +499,7 @@ class FoldList(object):
     def __init__(self):
         self._items = (ArlFoldItem * FOLD_MAX_ITEMS)()
         self._n = 0
+        self.last_dw_in_place = False
 
     def _next(self):
         assert self._n < FOLD_MAX_ITEMS, "too many pending folds"
@@ -523,11 +556,13 @@ class FoldList(object):
         assert x.numel() == dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x / dx size"
         assert dw.numel() == w.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w / dw size"
         item = self._next()
+        slot = self._n - 1
         pb, ib = self._bias_slot(dbias)
         _check(load().arl_conv2d_bwd_pair(dy.data_ptr(), w.data_ptr(), ptr(mask), dx.data_ptr(), x.data_ptr(),
                                           dw.data_ptr(), C.byref(geom), ptr(workspace),
                                           workspace.numel() * workspace.element_size(), item, pb, ib,
                                           stream_ptr(stream)), "arl_conv2d_bwd_pair")
+        self.last_dw_in_place = self._items[slot].splits == 0      # no split partials: dw is final as written
         return self._bias_done(dbias)
 
     def relu_bwd_bias_grad(self, dy, y, rows, channels, dbias, workspace, stream=None):

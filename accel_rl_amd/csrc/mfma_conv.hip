@@ -21,7 +21,7 @@
 // whose reduction index is contiguous are padded to BK+4 floats per row so that the
 // ds_read_b128 fragment reads (4 consecutive k per lane -> 4 MFMAs) are conflict-free.
 
-#include "arl_common.h"
+#include "arl_optim_dev.h"
 
 #include <stdlib.h>
 #include <type_traits>
@@ -1417,9 +1417,27 @@ __global__ __launch_bounds__(256, MINW) void igemm_persist_kernel(const GemmArgs
 }
 
 // the same body compiled for at least MINW waves per SIMD (small tiles, many resident workgroups)
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, int MINW>
-__global__ __launch_bounds__(256, MINW) void igemm_occ_kernel(const GemmArgs a) {
+// CORUN: the grid's first c.co_blocks workgroups do not compute tiles but stream an optimiser update of a finished
+// gradient range (arl_conv_corun_update): HBM-bound work inside an MFMA-bound launch.  PPO step, spec 1: conv 3's data
+// gradient 42.6 -> ~48 us with the first dense layer's 99 MB adam update riding along, the update launch at the end of
+// the step 19.9 -> 4.9 us (a second stream inside the learner's hipGraph costs ~50 us per dependency instead).
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, int MINW, bool CORUN = false>
+__global__ __launch_bounds__(256, MINW) void igemm_occ_kernel(const GemmArgs a, const arl::OptSeg c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (CORUN) {
+        // The update's workgroups come FIRST in the grid -- one per CU, streaming from the start of the launch, while
+        // the tile workgroups fill the other four slots of every CU (appended behind the tiles they ran in the tail
+        // and lengthened it: +8.8 us inside the learner instead of +1).
+        if ((int)blockIdx.x < c.co_blocks) {
+            __shared__ double lds[8];
+            if (blockIdx.y || blockIdx.z) return;
+            if (c.method == ARL_OPT_ADAM) arl::opt_update_block<ARL_OPT_ADAM>(c, (int)blockIdx.x, c.co_blocks, lds);
+            else arl::opt_update_block<ARL_OPT_RMSPROP>(c, (int)blockIdx.x, c.co_blocks, lds);
+            return;
+        }
+        igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, false>(a, blockIdx.x - c.co_blocks, blockIdx.y, blockIdx.z, smem);
+        return;
+    }
     igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, false>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
@@ -1855,6 +1873,11 @@ int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hi
 }
 
 int g_tile_choice = 0;             // arl_conv_tile_choice (tuning aid): 0 / 3 = 32x64 tiles for 33 .. 64 columns, 1 = 64x64, 2 = 112x64
+// arl_conv_corun_update: an optimiser job waiting for a data-gradient launch to carry it
+arl::OptSeg g_corun_job = {};
+int g_corun_blocks = 0;
+int g_corun_host_blocks = 256;          // workgroups that run a co-run job inside its host launch (tuning: ARL_CORUN_BLOCKS)
+bool g_corun_pending = false;
 int g_persist = 0;                  // arl_conv_persistent: resident workgroups per CU of the persistent launches (0 = off)
 int g_cus = 0;
 int num_cus() {
@@ -1874,8 +1897,20 @@ int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_
     const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
     static_assert(lds_fits(2 * (A_SZ + B_SZ)), "<= 64 KiB of LDS");
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
+    arl::OptSeg c = {};
+    if constexpr (!B_KC) {                          // a data gradient hosts the pending optimiser job, if any
+        if (g_corun_pending && !multi_tap) {
+            c = g_corun_job;
+            c.co_blocks = g_corun_blocks < g_corun_host_blocks ? g_corun_blocks : g_corun_host_blocks;
+            grid.x += (unsigned)c.co_blocks;
+            g_corun_pending = false;
+            if (has_pad) hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, true, N16, MINW, true>), grid, dim3(256), lds, s, a, c);
+            else hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, false, N16, MINW, true>), grid, dim3(256), lds, s, a, c);
+            return arl::check_launch("igemm_occ_kernel (co-run)");
+        }
+    }
 #define ARL_IGEMM_OCC(MT, HP) \
-    hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16, MINW>), grid, dim3(256), lds, s, a)
+    hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16, MINW>), grid, dim3(256), lds, s, a, c)
     if (multi_tap && has_pad) ARL_IGEMM_OCC(true, true);
     else if (multi_tap) ARL_IGEMM_OCC(true, false);
     else if (has_pad) ARL_IGEMM_OCC(false, true);
@@ -2026,6 +2061,25 @@ extern "C" void arl_conv_force_generic(int32_t on) { g_force_generic = on != 0; 
 extern "C" void arl_conv_tile_choice(int32_t choice) { g_tile_choice = choice; }
 
 extern "C" void arl_conv_persistent(int32_t workgroups_per_cu) { g_persist = workgroups_per_cu; }
+
+extern "C" int arl_conv_corun_update(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
+                                     float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
+                                     double* norm_parts, int64_t hole_first, int64_t hole_count) {
+    ARL_REQUIRE(!g_corun_pending, ARL_E_ARG, "a job is already pending (arl_conv_corun_flush first)");
+    int rc = arl::make_opt_seg(&g_corun_job, opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k,
+                               step_pp, norm_parts, hole_first, hole_count, 1, &g_corun_blocks);
+    if (rc) return rc;
+    if (const char* e = getenv("ARL_CORUN_BLOCKS")) g_corun_host_blocks = atoi(e) > 0 ? atoi(e) : 256;
+    g_corun_pending = true;
+    return 0;
+}
+
+extern "C" int arl_conv_corun_flush(void* stream) {
+    if (!g_corun_pending) return 0;
+    g_corun_pending = false;
+    const int rc = arl::launch_opt_seg(g_corun_job, g_corun_blocks, (hipStream_t)stream);
+    return rc ? (rc > 0 ? -rc : rc) : 1;
+}
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {

@@ -14,31 +14,12 @@
 // call order of optimizers/sync/sync_ppo_optimizer.py:27-34.
 // Bound: HBM (adam: read p,g,m,v + write p,m,v = 28 B/param; + 4 B/param for the norm).
 
-#include "arl_common.h"
+#include "arl_optim_dev.h"
 
 namespace {
 
-__device__ __forceinline__ double wave_sum_d(double x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    return x;
-}
-
-__device__ __forceinline__ double block_sum_d(double x, double* lds) {
-    x = wave_sum_d(x);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (lane == 0) lds[w] = x;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0;
-        for (int i = 0; i < nw; ++i) s += lds[i];
-        lds[0] = s;
-    }
-    __syncthreads();
-    const double r = lds[0];
-    __syncthreads();
-    return r;
-}
+using arl::block_sum_d;
+using arl::update_one;
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n,
                                                     double* __restrict__ partials,
@@ -60,25 +41,6 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) {
         partials[blockIdx.x] = s;
         if (blockIdx.x == 0) step_count[0] += 1.0f;       // t = t_prev + 1 (update_methods_stats.py:66)
-    }
-}
-
-template <int METHOD>
-__device__ __forceinline__ void update_one(float& p, float g, float& s0, float& s1, float avg,
-                                           float cscale, float lr, float a_t, float b1, float b2,
-                                           float eps) {
-    const float gg = (g * avg) * cscale;                     // util.py:66, then total_norm_constraint
-    if (METHOD == ARL_OPT_ADAM) {
-        const float m = b1 * s0 + (1.f - b1) * gg;          // :76
-        const float v = b2 * s1 + (1.f - b2) * (gg * gg);    // :77
-        const float step = a_t * m / (sqrtf(v) + eps);       // :78
-        s0 = m; s1 = v;
-        p = p - step;
-    } else {
-        const float acc = b1 * s0 + (1.f - b1) * (gg * gg);  // :24 (rho = b1)
-        const float step = lr * gg / sqrtf(acc + eps);       // :28
-        s0 = acc;
-        p = p - step;
     }
 }
 
@@ -141,62 +103,9 @@ __global__ __launch_bounds__(256) void update_kernel(arl_opt_state o, int n_part
 // (k = 0 .. n - 1) into logged norms.  Lasagne's t: update k reads step_pp[k & 1] and block 0 writes t to
 // step_pp[(k + 1) & 1] (and to the public step_count) -- never the word the other blocks are reading.
 template <int METHOD>
-__global__ __launch_bounds__(256) void update_noclip_kernel(arl_opt_state o, int k, float lr_base, float avg,
-                                                            float b1, float b2, float eps, float* step_pp,
-                                                            double* __restrict__ norm_parts) {
+__global__ __launch_bounds__(256) void update_noclip_kernel(const arl::OptSeg c) {
     __shared__ double lds[8];
-    const float t = step_pp[k & 1] + 1.0f;                          // update_methods_stats.py:66
-    const float lr = lr_base * o.lr_mult[0];
-    float a_t = 0.f;
-    if (METHOD == ARL_OPT_ADAM)
-        a_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));   // :67
-    const int64_t n = o.n_params, n4 = n >> 2;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    float4* p4 = reinterpret_cast<float4*>(o.params);
-    const float4* g4 = reinterpret_cast<const float4*>(o.grads);
-    float4* m4 = reinterpret_cast<float4*>(o.slot0);
-    float4* v4 = reinterpret_cast<float4*>(o.slot1);
-    double s = 0;
-    // gradient and optimiser slots are streamed (touched once per step): non-temporal, so that they do not push the
-    // parameters -- which the next forward pass reads -- out of the caches
-    typedef float f32x4_t __attribute__((ext_vector_type(4)));
-    auto ld_nt = [](const float4* q) {
-        const f32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(q));
-        return make_float4(t.x, t.y, t.z, t.w);
-    };
-    auto st_nt = [](float4* q, const float4& x) {
-        f32x4_t t = {x.x, x.y, x.z, x.w};
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t*>(q));
-    };
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 p = p4[i];
-        const float4 g = ld_nt(g4 + i);
-        float4 m = ld_nt(m4 + i);
-        float4 v = (METHOD == ARL_OPT_ADAM) ? ld_nt(v4 + i) : make_float4(0, 0, 0, 0);
-        s += (double)g.x * g.x + (double)g.y * g.y + (double)g.z * g.z + (double)g.w * g.w;
-        update_one<METHOD>(p.x, g.x, m.x, v.x, avg, 1.f, lr, a_t, b1, b2, eps);
-        update_one<METHOD>(p.y, g.y, m.y, v.y, avg, 1.f, lr, a_t, b1, b2, eps);
-        update_one<METHOD>(p.z, g.z, m.z, v.z, avg, 1.f, lr, a_t, b1, b2, eps);
-        update_one<METHOD>(p.w, g.w, m.w, v.w, avg, 1.f, lr, a_t, b1, b2, eps);
-        p4[i] = p;
-        st_nt(m4 + i, m);
-        if (METHOD == ARL_OPT_ADAM) st_nt(v4 + i, v);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-        const int64_t i = (n4 << 2) + threadIdx.x;
-        const float g = o.grads[i];
-        float p = o.params[i], m = o.slot0[i], v = (METHOD == ARL_OPT_ADAM) ? o.slot1[i] : 0.f;
-        s += (double)g * g;
-        update_one<METHOD>(p, g, m, v, avg, 1.f, lr, a_t, b1, b2, eps);
-        o.params[i] = p;
-        o.slot0[i] = m;
-        if (METHOD == ARL_OPT_ADAM) o.slot1[i] = v;
-    }
-    s = block_sum_d(s, lds);
-    if (threadIdx.x == 0) {
-        norm_parts[(int64_t)k * ARL_OPT_NORM_BLOCKS + blockIdx.x] = s;
-        if (blockIdx.x == 0) { step_pp[(k + 1) & 1] = t; o.step_count[0] = t; }
-    }
+    arl::opt_update_block<METHOD>(c, (int)blockIdx.x, (int)gridDim.x, lds);
 }
 
 // one block per update of the call: fold its partials in block order, log the norm; block 0 also levels the
@@ -229,31 +138,89 @@ int check_opt(const arl_opt_state* opt, int32_t method) {
 
 }  // namespace
 
-extern "C" int arl_opt_step_noclip(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
-                                   float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
-                                   double* norm_parts, void* stream) {
+namespace {
+int check_noclip(const arl_opt_state* opt, int32_t method, int32_t k, const float* step_pp, const double* norm_parts) {
     int rc = check_opt(opt, method);
     if (rc) return rc;
     ARL_REQUIRE(step_pp && norm_parts, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(k >= 0 && k < ARL_OPT_NORM_SLOTS, ARL_E_RANGE, "update index outside the call's slots");
-    const unsigned grid = arl::stream_grid(opt->n_params >> 2, 256);      // <= 2048 = ARL_OPT_NORM_BLOCKS
-    hipStream_t s = (hipStream_t)stream;
-    if (method == ARL_OPT_ADAM)
-        hipLaunchKernelGGL((update_noclip_kernel<ARL_OPT_ADAM>), dim3(grid), dim3(256), 0, s, *opt, (int)k,
-                           learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, step_pp, norm_parts);
+    return 0;
+}
+
+}  // namespace
+
+namespace arl {
+int launch_opt_seg(const OptSeg& c, int blocks, hipStream_t s) {
+    if (c.method == ARL_OPT_ADAM)
+        hipLaunchKernelGGL((update_noclip_kernel<ARL_OPT_ADAM>), dim3((unsigned)blocks), dim3(256), 0, s, c);
     else
-        hipLaunchKernelGGL((update_noclip_kernel<ARL_OPT_RMSPROP>), dim3(grid), dim3(256), 0, s, *opt, (int)k,
-                           learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, step_pp, norm_parts);
-    return arl::check_launch("update_noclip_kernel");
+        hipLaunchKernelGGL((update_noclip_kernel<ARL_OPT_RMSPROP>), dim3((unsigned)blocks), dim3(256), 0, s, c);
+    return check_launch("update_noclip_kernel");
+}
+
+
+// the segment description of one no-clip update: part 0 = everything but the hole (the whole bucket when the hole is
+// empty), part 1 = the hole
+int make_opt_seg(OptSeg* c, const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
+                 float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp, double* norm_parts,
+                 int64_t hole_first, int64_t hole_count, int part, int* blocks) {
+    int rc = check_noclip(opt, method, k, step_pp, norm_parts);
+    if (rc) return rc;
+    ARL_REQUIRE(hole_first >= 0 && hole_count >= 0 && hole_first + hole_count <= opt->n_params &&
+                    (hole_first & 3) == 0 && (hole_count & 3) == 0, ARL_E_ARG,
+                "hole: a float4-aligned range inside the bucket");
+    ARL_REQUIRE(part == 0 || hole_count > 0, ARL_E_ARG, "part 1 needs a hole");
+    int rest, hole;
+    opt_split_plan(opt->n_params, hole_count, &rest, &hole);
+    *c = OptSeg{};
+    c->o = *opt; c->method = method; c->k = k;
+    c->lr_base = learning_rate; c->avg = avg_factor; c->b1 = beta1_or_rho; c->b2 = beta2; c->eps = epsilon;
+    c->step_pp = step_pp; c->norm_parts = norm_parts;
+    const long long n4 = opt->n_params >> 2, h0 = hole_first >> 2, hn = hole_count >> 2;
+    if (part == 0) {
+        c->a0 = 0; c->an = h0; c->b0 = h0 + hn; c->bn = n4 - (h0 + hn);
+        c->block0 = 0; c->finish = 1; c->slots = rest; *blocks = rest;
+    } else {
+        c->a0 = h0; c->an = hn; c->b0 = 0; c->bn = 0;
+        c->block0 = rest; c->finish = 0; c->slots = hole; *blocks = hole;
+    }
+    return 0;
+}
+}  // namespace arl
+
+extern "C" int arl_opt_step_noclip(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
+                                   float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
+                                   double* norm_parts, void* stream) {
+    return arl_opt_step_noclip_split(opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k, step_pp,
+                                     norm_parts, 0, 0, 0, stream);
+}
+
+extern "C" int arl_opt_step_noclip_split(const arl_opt_state* opt, int32_t method, float learning_rate,
+                                         float avg_factor, float beta1_or_rho, float beta2, float epsilon, int32_t k,
+                                         float* step_pp, double* norm_parts, int64_t hole_first, int64_t hole_count,
+                                         int32_t part, void* stream) {
+    arl::OptSeg c;
+    int blocks = 0;
+    int rc = arl::make_opt_seg(&c, opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k, step_pp,
+                               norm_parts, hole_first, hole_count, part, &blocks);
+    if (rc) return rc;
+    return arl::launch_opt_seg(c, blocks, (hipStream_t)stream);
 }
 
 extern "C" int arl_opt_finish(const arl_opt_state* opt, int32_t n_updates, float avg_factor, float* step_pp,
                               const double* norm_parts, void* stream) {
+    return arl_opt_finish_split(opt, n_updates, avg_factor, step_pp, norm_parts, 0, stream);
+}
+
+extern "C" int arl_opt_finish_split(const arl_opt_state* opt, int32_t n_updates, float avg_factor, float* step_pp,
+                                    const double* norm_parts, int64_t hole_count, void* stream) {
     ARL_REQUIRE(opt && opt->step_count && step_pp && norm_parts, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(n_updates >= 1 && n_updates <= ARL_OPT_NORM_SLOTS, ARL_E_RANGE, "n_updates outside 1 .. ARL_OPT_NORM_SLOTS");
-    const unsigned grid = arl::stream_grid(opt->n_params >> 2, 256);
+    ARL_REQUIRE(hole_count >= 0 && hole_count <= opt->n_params && (hole_count & 3) == 0, ARL_E_ARG, "hole size");
+    int rest, hole;
+    arl::opt_split_plan(opt->n_params, hole_count, &rest, &hole);
     hipLaunchKernelGGL(opt_finish_kernel, dim3((unsigned)n_updates), dim3(256), 0, (hipStream_t)stream, *opt,
-                       (int)n_updates, (int)grid, avg_factor, step_pp, norm_parts);
+                       (int)n_updates, rest + hole, avg_factor, step_pp, norm_parts);
     return arl::check_launch("opt_finish_kernel");
 }
 

@@ -70,6 +70,8 @@ class BaseOptimizer(object):
         self._norm_log = torch.zeros(NORM_LOG_LEN, dtype=torch.float32, device=dev)
         self._n_updates = 0
         self._step_pp = self._norm_parts = None      # the no-clip update's state (see _apply_update)
+        self._hole = None                            # (first, count): range whose update a conv launch carries
+        self._hole_count = 0                         # ... as used by this call's updates (0: plain updates)
         st = _lib.ArlOptState()
         st.n_params = n
         st.params, st.grads = target.flat_params.data_ptr(), target.flat_grads.data_ptr()
@@ -95,18 +97,50 @@ class BaseOptimizer(object):
         update's pass over the gradient and `_recent_grad_norms` finishes the call's norms in one small launch."""
         b1, b2, eps = self._kernel_args
         if self._grad_norm_clip is None:
-            if self._step_pp is None:
-                dev = self._target.device
-                self._step_pp = self._step_count.repeat(2).contiguous()
-                self._norm_parts = torch.zeros(_lib.OPT_NORM_SLOTS * _lib.OPT_NORM_BLOCKS, dtype=torch.float64, device=dev)
+            self._noclip_state()
             k = self._n_updates % self._opt_state.norm_log_len      # position inside the call
-            _lib.opt_step_noclip(self._opt_state, self._update_method.kernel_id, self._learning_rate, avg_factor,
-                                 b1, b2, eps, k, self._step_pp, self._norm_parts)
+            hole, self._hole = self._hole, None
+            count = hole[1] if hole else 0
+            assert k == 0 or count == self._hole_count, "a call's updates must all be split the same way"
+            self._hole_count = count
+            if hole:
+                _lib.conv_corun_flush()              # no data-gradient launch took the job: it runs on its own now
+                _lib.opt_step_noclip_split(self._opt_state, self._update_method.kernel_id, self._learning_rate,
+                                           avg_factor, b1, b2, eps, k, self._step_pp, self._norm_parts, hole[0],
+                                           hole[1], 0)
+            else:
+                _lib.opt_step_noclip(self._opt_state, self._update_method.kernel_id, self._learning_rate, avg_factor,
+                                     b1, b2, eps, k, self._step_pp, self._norm_parts)
             self._pending_avg = avg_factor
         else:
             _lib.opt_step(self._opt_state, self._update_method.kernel_id, self._learning_rate,
                           avg_factor, self._grad_norm_clip, b1, b2, eps)
         self._n_updates += 1
+
+    corun_update = True             # (tests switch it off to compare with the plain one-launch update)
+
+    def _noclip_state(self):
+        if self._step_pp is None:
+            dev = self._target.device
+            self._step_pp = self._step_count.repeat(2).contiguous()
+            self._norm_parts = torch.zeros(_lib.OPT_NORM_SLOTS * _lib.OPT_NORM_BLOCKS, dtype=torch.float64, device=dev)
+
+    def _corun_hook(self, avg_factor=1.0):
+        """For the policy's `dense_w_hook`: without norm clipping nothing has to wait for the whole gradient, so the
+        update of a range that is final early -- the first dense layer's weights, 98 % of the bucket's bytes for
+        spec 1 -- rides inside the next data-gradient launch (HBM-bound streaming in extra workgroups of an
+        MFMA-bound kernel: measured free) and `_apply_update` only updates the rest.  Same arithmetic per element."""
+        if self._grad_norm_clip is not None or not self.corun_update:
+            return None
+        b1, b2, eps = self._kernel_args
+
+        def hook(first, count):
+            self._noclip_state()
+            k = self._n_updates % self._opt_state.norm_log_len
+            _lib.conv_corun_update(self._opt_state, self._update_method.kernel_id, self._learning_rate, avg_factor,
+                                   b1, b2, eps, k, self._step_pp, self._norm_parts, first, count)
+            self._hole = (first, count)
+        return hook
 
     def _set_updates_per_call(self, count):
         """The update kernel logs the grad norm of update number t at slot (t-1) % len.
@@ -126,4 +160,5 @@ class BaseOptimizer(object):
     def _finish_updates(self, count):
         """Close a call of `count` no-clip updates (norm log, Lasagne's t); every call must end with this."""
         if self._grad_norm_clip is None and self._step_pp is not None:
-            _lib.opt_finish(self._opt_state, count, self._pending_avg, self._step_pp, self._norm_parts)
+            _lib.opt_finish(self._opt_state, count, self._pending_avg, self._step_pp, self._norm_parts,
+                            hole_count=self._hole_count)

@@ -97,8 +97,12 @@ class PpoOptimizer(BaseOptimizer):
         if self._overlap_allreduce:
             return self._overlapped_minibatches(data)
         losses = []
+        corun = self._corun_hook() if self.parallelism_tag == "single" else None
         for k in range(self._n_minibatches):
-            losses.append(self._backward(self._losses, self._minibatch(data, self._idx_dev[k])))
+            mb = self._minibatch(data, self._idx_dev[k])
+            if corun is not None:
+                mb["dense_w_hook"] = corun
+            losses.append(self._backward(self._losses, mb))
             self._share_grad()
             self._apply_update(self._avg_factor())
         return losses, self._recent_grad_norms(self._n_minibatches)

@@ -361,13 +361,18 @@ class AtariCnnPolicy(object):
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
                               ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws,
                               relu_mask_dh=True)
-            self._backward_trunk(x, acts, hids, dh, masked=True, split_hook=mb.get("split_hook"))
+            self._backward_trunk(x, acts, hids, dh, masked=True, split_hook=mb.get("split_hook"),
+                                 dense_w_hook=mb.get("dense_w_hook"))
             return loss4
 
-    def _backward_trunk(self, x, acts, hids, dh, masked=False, split_hook=None):
+    def _backward_trunk(self, x, acts, hids, dh, masked=False, split_hook=None, dense_w_hook=None):
         """Gradients of every trunk layer into flat_grads, given dh = d loss / d (last hidden
         activation); masked: dh is already multiplied by that activation's rectifier mask.
-        x, acts, hids as returned by _scaled / _trunk."""
+        x, acts, hids as returned by _scaled / _trunk.
+        dense_w_hook(first, count): called once the FIRST dense layer's weight gradient -- by far the largest tensor
+        of the bucket, elements [first, first + count) -- is final in flat_grads (its kernel wrote it in place, no
+        fold pending), i.e. before the conv layers' backward: the optimizer can hand that range's update to the next
+        data-gradient launch (arl_conv_corun_update)."""
         b = x.shape[0]
         conv_g, dense_g = self._layer_geoms(b)
         # ---- dense layers, last to first; the split folds of the whole pass run once, at the end
@@ -378,6 +383,8 @@ class AtariCnnPolicy(object):
             inp = hids[j - 1] if j > 0 else acts[-1]
             d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
             self._layer_grads(d_cur, masked, hids[j], b, hs, k, dense_g[j], inp, d_prev)
+            if j == 0 and dense_w_hook is not None and self._folds.last_dw_in_place:
+                dense_w_hook(self._offsets[k], (self._g[k].numel() + 3) // 4 * 4)
             d_cur, masked = d_prev, True
         if split_hook is not None and self._n_hid:      # dense + head gradients are final from here on
             self._folds.run()

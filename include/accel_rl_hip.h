@@ -656,6 +656,30 @@ int arl_opt_step_noclip(const arl_opt_state* opt, int32_t method, float learning
 int arl_opt_finish(const arl_opt_state* opt, int32_t n_updates, float avg_factor, float* step_pp,
                    const double* norm_parts, void* stream);
 
+/* The no-clip update in two parts, so that the bulk of it can leave the step's critical path: once the gradient of a
+ * range [hole_first, hole_first + hole_count) of the bucket is final (spec 1: the first dense layer's 3.5 M weights,
+ * written by its weight-gradient kernel long before the conv layers' backward ends), that range's update -- HBM-bound
+ * streaming -- can run INSIDE the launch of a later MFMA-bound data-gradient kernel, in extra workgroups
+ * (arl_conv_corun_update below; inside the PPO step: the host launch 42.6 -> ~48 us, the step's own update launch
+ * 19.9 -> 4.9 us), and the step ends with the update of the small rest.  part 0 = everything but the hole (advances t; hole_count = 0: the
+ * plain arl_opt_step_noclip), part 1 = the hole as a launch of its own.  hole_first, hole_count multiples of 4.
+ * Per element the arithmetic is arl_opt_step_noclip's; a call that used a hole ends with arl_opt_finish_split.       */
+int arl_opt_step_noclip_split(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
+                              float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
+                              double* norm_parts, int64_t hole_first, int64_t hole_count, int32_t part, void* stream);
+int arl_opt_finish_split(const arl_opt_state* opt, int32_t n_updates, float avg_factor, float* step_pp,
+                         const double* norm_parts, int64_t hole_count, void* stream);
+/* Hand part 1 of update k to the NEXT data-gradient launch of a 33 .. 64-column layer (arl_conv2d_bwd_data /
+ * arl_conv2d_bwd_pair on the scalar-addressed fast path): its grid gets one extra workgroup per CU (the first of the
+ * grid; ARL_CORUN_BLOCKS overrides the count, a tuning aid) that streams the update while the others keep the matrix
+ * pipe busy.  arl_conv_corun_flush: if no launch has taken the job yet, run it as its own
+ * launch on `stream` (returns 1 then, 0 if nothing was pending, < 0 on error) -- call it before part 0.
+ * One pending job at a time; not thread-safe.                                                                        */
+int arl_conv_corun_update(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
+                          float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
+                          double* norm_parts, int64_t hole_first, int64_t hole_count);
+int arl_conv_corun_flush(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

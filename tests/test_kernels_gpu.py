@@ -407,6 +407,67 @@ def test_noclip_single_launch_update_vs_oracle(L, n, method):
         assert keep["t"].item() == float(t) and step_pp.cpu().tolist() == [float(t)] * 2
 
 
+@pytest.mark.parametrize("method", ["adam", "rmsprop"])
+@pytest.mark.parametrize("carrier", ["own launch", "data gradient"])
+def test_split_update_is_the_plain_update(L, method, carrier):
+    """arl_opt_step_noclip_split / arl_conv_corun_update: the update of a hole of the bucket as its own launch, or in
+    extra workgroups of a data-gradient launch (whose own result must not change), plus the update of the rest ==
+    the one-launch update bit for bit: parameters, slots, t, and the call's logged norms (same f64 partial sums up to
+    their grouping)."""
+    n, first, count = 3620004, 57312, 3538944                   # spec 1's bucket and its first dense weight tensor
+    adam = method == "adam"
+    mid, args = (L.OPT_ADAM, (1e-3, 0.5, 0.9, 0.999, 1e-5)) if adam else (L.OPT_RMSPROP, (7e-4, 0.5, 0.9, 0.0, 1e-6))
+    rs = np.random.RandomState(3)
+    p0 = rs.randn(n).astype(np.float32)
+    twins = []
+    for _ in range(2):
+        p, g = dev(p0), torch.zeros(n, device=DEV)
+        st, keep = _opt_state(L, p, g, with_v=adam)
+        twins.append((st, keep, p, g, torch.zeros(2, device=DEV),
+                      torch.zeros(L.OPT_NORM_SLOTS * L.OPT_NORM_BLOCKS, dtype=torch.float64, device=DEV)))
+    # the hosting launch: conv 3's data gradient at 64 images
+    geom = L.conv_geom(64, 12, 9, 64, 64, 3, 3, 1, 1, 1)
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    dy = torch.randn(64, 12, 9, 64, device=DEV, generator=gen)
+    wt = torch.randn(64, 3, 3, 64, device=DEV, generator=gen) * 0.05
+    dx_ref = torch.empty(64, 12, 9, 64, device=DEV)
+    L.conv2d_bwd_data(dy, wt, None, dx_ref, geom)
+    for call, n_upd in enumerate((3, 2)):
+        for k in range(n_upd):
+            gh = (rs.randn(n) * (0.01 if (call + k) else 3.0)).astype(np.float32)
+            for st, keep, p, g, step_pp, parts in twins:
+                g.copy_(dev(gh))
+                keep["lr"].fill_(1.0 - 0.1 * k)
+            st, keep, p, g, step_pp, parts = twins[0]
+            L.opt_step_noclip(st, mid, *args, k, step_pp, parts)
+            st, keep, p, g, step_pp, parts = twins[1]
+            if carrier == "own launch":
+                L.opt_step_noclip_split(st, mid, *args, k, step_pp, parts, first, count, 1)
+            else:
+                L.conv_corun_update(st, mid, *args, k, step_pp, parts, first, count)
+                dx = torch.full_like(dx_ref, float("nan"))
+                L.conv2d_bwd_data(dy, wt, None, dx, geom)
+                assert torch.equal(dx, dx_ref)
+                assert not L.conv_corun_flush()                 # the launch took the job
+            L.opt_step_noclip_split(st, mid, *args, k, step_pp, parts, first, count, 0)
+            for key in ("p", "m") + (("v",) if adam else ()):
+                assert torch.equal(twins[0][1][key], twins[1][1][key]), (call, k, key)
+            assert twins[0][1]["t"].item() == twins[1][1]["t"].item()
+        L.opt_finish(twins[0][0], n_upd, 0.5, twins[0][4], twins[0][5])
+        L.opt_finish(twins[1][0], n_upd, 0.5, twins[1][4], twins[1][5], hole_count=count)
+        a, b = twins[0][1]["log"][:n_upd].cpu().numpy(), twins[1][1]["log"][:n_upd].cpu().numpy()
+        assert np.allclose(a, b, rtol=1e-6), (a, b)
+        assert twins[0][4].cpu().tolist() == twins[1][4].cpu().tolist()
+    # a job nobody carries runs on its own when flushed
+    st, keep, p, g, step_pp, parts = twins[1]
+    before = keep["p"].clone()
+    L.conv_corun_update(st, mid, *args, 0, step_pp, parts, first, count)
+    assert L.conv_corun_flush() and not L.conv_corun_flush()
+    torch.cuda.synchronize()
+    assert not torch.equal(before[first:first + count], keep["p"][first:first + count])
+    assert torch.equal(before[:first], keep["p"][:first]) and torch.equal(before[first + count:], keep["p"][first + count:])
+
+
 @pytest.mark.parametrize("clip", [None, 0.5])
 def test_rmsprop_vs_oracle(L, clip):
     n = 898613

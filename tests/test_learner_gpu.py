@@ -259,6 +259,35 @@ def test_graph_learner_is_bit_identical_to_eager(case):
     assert twins[1][1]._graph is not None and twins[0][1]._graph is None
 
 
+def test_corun_update_is_bit_identical_to_the_plain_update():
+    """PPO at the headline shape: the first dense layer's update riding inside conv 3's data-gradient launch (the
+    default) against the one-launch update at the end of the step -- parameters and optimiser slots bit-identical after
+    every call, logged gradient norms equal to f32 round-off."""
+    kind, n_env, kw = LEARNER_CASES["ppo_config2"]
+    twins = [make(kind, n_env, 5, False, **kw) for _ in range(2)]
+    twins[1][1].optimizer.corun_update = False
+    rs = np.random.RandomState(2)
+    for itr in range(2):
+        fill(twins[0][2], twins[0][0], rs, n_env, 5)
+        for k in ("observations", "extra_observations", "rewards", "dones", "actions"):
+            twins[1][2][k].copy_(twins[0][2][k])
+        twins[1][2].env_infos["need_reset"].copy_(twins[0][2].env_infos["need_reset"])
+        for k in ("prob", "value"):
+            twins[1][2].agent_infos[k].copy_(twins[0][2].agent_infos[k])
+        rng_state = np.random.get_state()
+        outs = []
+        for policy, algo, buf, _ in twins:
+            np.random.set_state(rng_state)
+            _, infos = algo.optimize_policy(itr, buf)
+            torch.cuda.synchronize()
+            opt = algo.optimizer
+            outs.append((policy.flat_params.clone(), opt._slot0.clone(), opt._slot1.clone(), infos["GradNorm"].clone()))
+        for a, b in list(zip(*outs))[:3]:
+            assert torch.equal(a, b), itr
+        assert torch.allclose(outs[0][3], outs[1][3], rtol=1e-6)
+    assert twins[0][1].optimizer._hole_count == 6912 * 512 and twins[1][1].optimizer._hole_count == 0
+
+
 def test_param_vector_roundtrip_and_reference_layout():
     policy, algo, buf, spec = make("ppo", 4, 5, False, spec_id=1)
     flat = policy.get_param_values()
