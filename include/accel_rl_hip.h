@@ -368,8 +368,10 @@ void arl_conv_trace_buffer(void* device_u64_or_null);
  * of the scalar-addressed fast path, so that both are covered by the parity tests.  Not thread-safe. */
 void arl_conv_force_generic(int32_t on);
 
-/* Tuning / test hook for layers with 33 .. 64 output columns: 0 (default) and 3 = 32x64 tiles (16x16 MFMA, five
- * waves per SIMD), 1 = 64x64 tiles (32x32 MFMA), 2 = 112x64 tiles (16x16 MFMA, three LDS stages).  Not thread-safe. */
+/* Tuning / test hook.  Layers with 33 .. 64 output columns: 0 (default) and 3 = 32x64 tiles (16x16 MFMA, five
+ * waves per SIMD), 1 = 64x64 tiles (32x32 MFMA), 2 = 112x64 tiles (16x16 MFMA, three LDS stages).  Layers with
+ * 17 .. 32 columns (data gradient, u8 forward): 1 = the 128x32 tiles on 32x32 MFMAs, anything else (default) =
+ * 64x32 tiles on 16x16 MFMAs at five waves per SIMD.  Not thread-safe. */
 void arl_conv_tile_choice(int32_t choice);
 
 /* Tuning / test hook: launches of many row tiles (conv 1 forward, the stride-2 data gradient) as

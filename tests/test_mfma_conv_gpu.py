@@ -339,12 +339,14 @@ def test_persistent_launches_are_bit_identical(walkers):
 
     def both(fn):
         outs = []
+        lib.arl_conv_tile_choice(1)                 # the persistent kernels walk the classic 128-row tiles (32x32 MFMAs)
         for w in (0, walkers):
             lib.arl_conv_persistent(w)
             try:
                 outs.append(fn())
             finally:
                 lib.arl_conv_persistent(0)
+        lib.arl_conv_tile_choice(0)
         return outs
     # conv 1 forward, u8 rows by index: 37 images of 104 x 80 -> 37 * 475 rows = 138 tiles of 128 and a ragged one
     obs = torch.randint(0, 256, (50, 4, 104, 80), device=DEV, dtype=torch.int32, generator=gen).to(torch.uint8)

@@ -36,8 +36,10 @@ dx2 = torch.empty(B, 25, 19, 32, device=DEV)
 f1 = 2.0 * B * 25 * 19 * 32 * 256
 f2 = 2.0 * B * 12 * 9 * 64 * 16 * 32
 WAYS = [int(x) for x in sys.argv[1:]] or [0, 2, 3, 4, 5, 6, 0]
+TC = int(os.environ.get("ARL_TC", "0"))
 for w in WAYS:
     lib.arl_conv_persistent(w)
+    lib.arl_conv_tile_choice(TC)
     t1 = gt(lambda: _lib.conv2d_u8_fwd(obs, idx, 1. / 255, w1, b1, y1, g1, True))
     t2 = gt(lambda: _lib.conv2d_bwd_data(dy2, w2, y1, dx2, g2))
     print("persistent %d: conv1 fwd (u8) %.1f us (%.1f TF/s)   conv2 dgrad %.1f us (%.1f TF/s)" %
