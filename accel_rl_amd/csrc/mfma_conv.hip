@@ -1707,14 +1707,14 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
 }
 
 template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false>
-__global__ __launch_bounds__(256) void wgrad_fast_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, (TM * TN > 1 ? 2 : 4)) void wgrad_fast_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, M16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
 // weight gradient of a convolution whose input is the planar u8 observations (see wgrad_fast_body, U8)
 template <int WGM, int WGN, int TM, int TN, int BK, bool M16>
-__global__ __launch_bounds__(256) void wgrad_u8_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 4) void wgrad_u8_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     wgrad_fast_body<WGM, WGN, TM, TN, BK, false, M16, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
