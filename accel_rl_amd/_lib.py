@@ -108,6 +108,7 @@ _SIGNATURES = {
     "arl_scan_force_wave": (None, [_i32]),
     "arl_conv_tile_choice": (None, [_i32]),
     "arl_conv_persistent": (None, [_i32]),
+    "arl_conv_precision": (_i32, [_i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
@@ -171,6 +172,8 @@ def load():
     if lib.arl_abi_version() != ARL_ABI_VERSION:
         raise RuntimeError("libaccel_rl_hip.so ABI %d != binding %d" % (lib.arl_abi_version(), ARL_ABI_VERSION))
     _lib = lib
+    if os.environ.get("ARL_CONV_PRECISION"):     # measurement switch (tools/, bench A/B): see arl_conv_precision
+        _check(lib.arl_conv_precision(int(os.environ["ARL_CONV_PRECISION"])), "arl_conv_precision")
     return lib
 
 

@@ -628,6 +628,62 @@ __device__ __forceinline__ unsigned tap_mask(int ry, int rx, int Hs, int Ws, int
     return ~(good & (low_bits(yn * taps_x) << min(ylo * taps_x, 31))); // rows [ylo, yhi) keep it, the others are out
 }
 
+// ==========================================================================================
+// SPLIT: fp32 contractions on the bf16 matrix pipe (arl_conv_precision).
+//
+// gfx950 has no fast fp32 matrix path: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (157 TF/s) and takes the
+// SIMD's vector issue with it, while v_mfma_f32_32x32x16_bf16 sustains 2.1-2.4 PF/s next to 4-6 vector instructions
+// per MFMA (tools/mfma_bf16_mix.hip).  An fp32 number is EXACTLY the sum of three bf16 numbers (24 significand bits =
+// 3 x 8: h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m, every step exact), so
+//     x * y = sum over the nine (or the six largest) products of their pieces,
+// each product exact in the fp32 accumulator (8 x 8 significand bits).  SPLIT = 9: all nine -- every product term of
+// the fp32 contraction enters the sum exactly, only the accumulation rounds (as it does in the fp32 MFMA chain);
+// SPLIT = 6: the terms below 2^-24 |x y| (m l, l m, l l) are dropped.  The split happens between the global load
+// and the LDS store (11 vector instructions per pair of elements, hidden under the MFMAs of the co-resident waves);
+// LDS holds three bf16 planes per operand tile.  u8 observations are exact in ONE bf16 plane (255 < 2^8): conv 1
+// needs three products, not nine.
+// LDS images per plane: k-contiguous operands [row][BK] bf16, 16-byte slots XOR-swizzled by the row so that the
+// ds_read_b128 fragment reads (lane = row, 8 consecutive k) are conflict-free without padding; k-major operands
+// (the data gradient's weights, both operands of the weight gradient) as [BK / 2][col] dwords of (k even, k odd)
+// pairs, a fragment = 4 ds_read_b32 -- the loader threads fetch two adjacent k rows and pack them.
+// ==========================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr unsigned HI16 = 0xffff0000u;
+// (bf16 of x0, bf16 of x1) truncated, x0 in the low half (k order = memory order)
+__device__ __forceinline__ unsigned hi_pair(float x0, float x1) {
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float lo_part(float x) { return x - __uint_as_float(__float_as_uint(x) & HI16); }   // exact
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = hi_pair(x0, x1);
+    const float r0 = lo_part(x0), r1 = lo_part(x1);
+    m = hi_pair(r0, r1);
+    l = hi_pair(lo_part(r0), lo_part(r1));
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += sum of the piece products, smallest terms first.  PA / PB = planes of the two operands (1: exact in bf16)
+// (the accumulators of a wave's TM x TN tiles take turns inside each piece pair: no back-to-back dependent MFMAs)
+template <int SPLIT, int PA, int PB, bool SWAP, int TM, int TN>
+__device__ __forceinline__ void split_products(const u32x4 (&fa)[TM][3], const u32x4 (&fb)[TN][3], f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int s = 4; s >= 0; --s)
+#pragma unroll
+        for (int pa = 0; pa < PA; ++pa) {
+            const int pb = s - pa;
+            if (pb < 0 || pb >= PB) continue;
+            if (SPLIT == 6 && PA == 3 && PB == 3 && s > 2) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = SWAP ? mfma_bf16(fb[j][pb], fa[i][pa], acc[i][j]) : mfma_bf16(fa[i][pa], fb[j][pb], acc[i][j]);
+        }
+}
+// 16-byte slot swizzle of the k-contiguous LDS image: NS = BK / 8 slots per row
+template <int NS> __device__ __forceinline__ int kc_swz(int row) { return (row / (16 / NS)) % NS; }
+
 // N16: layers with <= 16 output columns (spec 0's 16-filter conv 1, the data gradient into 16 channels) use
 // v_mfma_f32_16x16x4_f32 -- a 32-wide tile would spend half of every MFMA on columns that do not exist.
 // A wave then owns TM groups of 16 rows x 16 columns; lane (l & 15, l >> 4) holds row l & 15 and the four
@@ -643,22 +699,30 @@ __device__ __forceinline__ unsigned tap_mask(int ry, int rx, int Hs, int Ws, int
 // wave has left since it passed the previous barrier --, so that nothing separates the last MFMA of a tile from the
 // first of the next; the loads of tile t+2 are issued right after the barrier (a full tile of latency cover).
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
-          bool U8 = false, bool PIPE3 = false>
+          bool U8 = false, bool PIPE3 = false, int SPLIT = 0>
 __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* smem) {
+    constexpr bool SP = SPLIT != 0;                 // bf16-split products (see above): other LDS images, other MFMAs
     constexpr int MT = N16 ? 16 : 32;               // rows per MFMA tile
     constexpr int BM = WGM * TM * MT, BN = N16 ? WGN * 16 : WGN * TN * 32, CH = BK / 4;
     constexpr int LDA = BK + 4;
     constexpr int LDB = B_KC ? BK + 4 : (N16 ? BN + 4 : BN);    // + 4: the four k-quads of a 16-wide read hit distinct banks
     static_assert(!N16 || (TN == 1 && BK % 16 == 0), "16-wide tiles: one column tile per wave");
+    static_assert(!SP || (!N16 && !PIPE3 && BK % 16 == 0), "split products: 32-wide tiles, two LDS stages");
     constexpr int ROWS_PER_PASS = 256 / CH;
     constexpr int RA = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;        // BM need not be a multiple of a loader pass:
     constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;   // the last pass's surplus rows load and store nothing
     constexpr int NST = PIPE3 ? 3 : 2;                                  // LDS stages
     constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
-    constexpr int RB = (NB4 + 255) / 256;
+    // split, k-major weights: a loader task = two adjacent k rows of four columns (packed into (k, k + 1) dwords)
+    constexpr int NPAIR = (BK / 2) * (BN / 4);
+    constexpr int RB = (SP && !B_KC) ? 2 * ((NPAIR + 255) / 256) : (NB4 + 255) / 256;
     static_assert(WGM * WGN == 4 && BK % 8 == 0, "tile shape");
     float* sA = smem;
     float* sB = smem + NST * A_SZ;
+    // split images (bytes): PA planes of BM x BK bf16 + 3 planes of BK x BN bf16 per stage
+    constexpr int PA = U8 ? 1 : 3, ROWB = BK * 2, NS = BK / 8;
+    constexpr int SPA = BM * ROWB, SPB = BN * ROWB, STAGE = PA * SPA + 3 * SPB;
+    char* const sS = reinterpret_cast<char*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -718,6 +782,12 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             const int nl = idx / CH, chunk = idx - nl * CH;
             const int n = n0 + nl;
             voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && n < a.N) ? (unsigned)(n * a.b.ld + chunk * 4) << 2 : OOB;
+        } else if (SP) {                            // passes 2q, 2q + 1: rows 2 kl2, 2 kl2 + 1 of task tid + 256 q
+            constexpr int NC4 = BN / 4;
+            const int t = tid + (p >> 1) * 256;
+            const int kl2 = t / NC4, nch = t - kl2 * NC4;
+            const int n = n0 + nch * 4;
+            voffB[p] = (t < NPAIR && n < a.N) ? (unsigned)((2 * kl2 + (p & 1)) * a.b.ld + n) << 2 : OOB;
         } else {
             constexpr int NC4 = BN / 4;
             const int kl = idx / NC4, nch = idx - kl * NC4;
@@ -725,6 +795,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && n < a.N) ? (unsigned)(kl * a.b.ld + n) << 2 : OOB;
         }
     }
+    // split: byte offset (inside a plane) of the 8 bytes this thread's 4-k chunk of a k-contiguous row lands on
+    auto kc_write_off = [&](int row, int chunk) { return row * ROWB + (((chunk >> 1) ^ kc_swz<NS>(row)) << 4) + ((chunk & 1) << 3); };
 
     // ---- uniform per-tile state (scalar unit) ------------------------------------------------
     int ty, tx, ch0;
@@ -740,9 +812,14 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         ty = (kbeg - ch0 * khw) / g.kw8;
         tx = 0;
     }
-    float4 va[RA], vb[RB];
-    unsigned va8[RA];
-    auto issue_loads = [&](int kk) {                // tile starting at reduction index kk, tap state (ty, tx, ch0)
+    // split products: TWO register sets -- tile j rests in set j & 1 for a whole k-tile before it is split into LDS
+    // stage j & 1 under the MFMAs of tile j - 1 (the split is ~130 vector instructions per thread and k-tile: it has to
+    // run in the MFMAs' shadow, so its operands must have arrived long before)
+    constexpr int NR = SP ? 2 : 1;
+    float4 va_[NR][RA], vb_[NR][RB];
+    unsigned va8_[NR][RA];
+    auto issue_loads = [&](int kk, int rs = 0) {    // tile starting at reduction index kk, tap state (ty, tx, ch0)
+        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs];
         if constexpr (U8) {
             const unsigned soffA = (unsigned)(ch0 * g.plane + ty * Ws);
 #pragma unroll
@@ -779,7 +856,62 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             }
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, int rs = 0) {
+        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs];
+        if constexpr (SP) {
+            char* dS = sS + buf * STAGE;
+#pragma unroll
+            for (int p = 0; p < RA; ++p) {
+                if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
+                char* d = dS + kc_write_off(a_row0 + p * ROWS_PER_PASS, a_chunk);
+                if constexpr (U8) {                 // 0 .. 255 is exact in bf16: one plane
+                    const float4 f = bytes_to_f4(va8[p]);
+                    *reinterpret_cast<uint2*>(d) = make_uint2(hi_pair(f.x, f.y), hi_pair(f.z, f.w));
+                } else {
+                    uint2 h, m, l;
+                    split_pair(va[p].x, va[p].y, h.x, m.x, l.x);
+                    split_pair(va[p].z, va[p].w, h.y, m.y, l.y);
+                    *reinterpret_cast<uint2*>(d) = h;
+                    *reinterpret_cast<uint2*>(d + SPA) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * SPA) = l;
+                }
+            }
+            char* dB = dS + PA * SPA;
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int p = 0; p < RB; ++p) {
+                    const int idx = tid + p * 256;
+                    if (NB4 % 256 != 0 && idx >= NB4) continue;
+                    const int nl = idx / CH, chunk = idx - nl * CH;
+                    char* d = dB + kc_write_off(nl, chunk);
+                    uint2 h, m, l;
+                    split_pair(vb[p].x, vb[p].y, h.x, m.x, l.x);
+                    split_pair(vb[p].z, vb[p].w, h.y, m.y, l.y);
+                    *reinterpret_cast<uint2*>(d) = h;
+                    *reinterpret_cast<uint2*>(d + SPB) = m;
+                    *reinterpret_cast<uint2*>(d + 2 * SPB) = l;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < RB / 2; ++q) {
+                    constexpr int NC4 = BN / 4;
+                    const int t = tid + q * 256;
+                    if (NPAIR % 256 != 0 && t >= NPAIR) continue;
+                    const int kl2 = t / NC4, nch = t - kl2 * NC4;
+                    char* d = dB + (kl2 * BN + nch * 4) * 4;
+                    const float4 v0 = vb[2 * q], v1 = vb[2 * q + 1];
+                    uint4 h, m, l;
+                    split_pair(v0.x, v1.x, h.x, m.x, l.x);
+                    split_pair(v0.y, v1.y, h.y, m.y, l.y);
+                    split_pair(v0.z, v1.z, h.z, m.z, l.z);
+                    split_pair(v0.w, v1.w, h.w, m.w, l.w);
+                    *reinterpret_cast<uint4*>(d) = h;
+                    *reinterpret_cast<uint4*>(d + SPB) = m;
+                    *reinterpret_cast<uint4*>(d + 2 * SPB) = l;
+                }
+            }
+            return;
+        }
         float* dA = sA + buf * A_SZ;
         float* dB = sB + buf * B_SZ;
 #pragma unroll
@@ -865,10 +997,38 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     // otherwise).  Compile-time stage: every LDS address is then a per-thread constant plus an immediate (with a
     // run-time buffer index the compiler re-derived four base addresses per tile with vector adds, and every vector
     // instruction here is taken from the MFMAs' issue slots).
-    constexpr int STEPS = N16 ? BK / 16 : BK / 8;
+    constexpr int STEPS = (N16 || SP) ? BK / 16 : BK / 8;
     auto mfma_steps = [&](auto buf_c, auto lo_c, auto hi_c) {
         constexpr int buf = decltype(buf_c)::value, LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        if constexpr (N16) {
+        if constexpr (SP) {
+            // a lane's fragment = row l31 (of its 32-row tile), k octet 2 ks + half: one 16-byte slot per plane
+            const char* cA = sS + buf * STAGE + (wm * TM * 32) * ROWB + l31 * ROWB;
+            const char* cB = sS + buf * STAGE + PA * SPA + (B_KC ? (wn * TN * 32) * ROWB + l31 * ROWB
+                                                                  : (half * 4 * BN + wn * TN * 32 + l31) * 4);
+            const int swz = kc_swz<NS>(l31);
+#pragma unroll
+            for (int ks = LO; ks < HI; ++ks) {
+                const int slot = ((2 * ks + half) ^ swz) << 4;
+                u32x4 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < PA; ++pl)
+                        fa[i][pl] = *reinterpret_cast<const u32x4*>(cA + pl * SPA + i * 32 * ROWB + slot);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        if constexpr (B_KC) {
+                            fb[j][pl] = *reinterpret_cast<const u32x4*>(cB + pl * SPB + j * 32 * ROWB + slot);
+                        } else {
+                            const unsigned* q = reinterpret_cast<const unsigned*>(cB + pl * SPB + (ks * 8 * BN + j * 32) * 4);
+                            fb[j][pl] = u32x4{q[0], q[BN], q[2 * BN], q[3 * BN]};
+                        }
+                    }
+                split_products<SPLIT, PA, 3, true, TM, TN>(fa, fb, acc);
+            }
+        } else if constexpr (N16) {
             const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
             const float* cB = B_KC ? sB + buf * B_SZ + (wn * 16 + l15) * LDB + quad * 4
                                    : sB + buf * B_SZ + (quad * 4) * LDB + wn * 16 + l15;
@@ -960,6 +1120,58 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             tile3(C1{}, kt + 1);
             tile3(C2{}, kt + 2);
         }
+    } else if constexpr (SP) {
+        // tile j: register set and LDS stage (j + nk) & 1 (the loop ends on stage 1)
+        if (nk & 1) {                                   // uniform
+            issue_loads(kbeg, 1);
+            if (nk > 1) { next_tile(); issue_loads(kbeg + BK, 0); }
+            store_tiles(1, 1);
+        } else {
+            issue_loads(kbeg, 0);
+            next_tile(); issue_loads(kbeg + BK, 1);
+            store_tiles(0, 0);
+        }
+        __syncthreads();
+        if (a.trace) tr1 = __builtin_readcyclecounter();
+        // One basic block per steady-state k-tile: the MFMAs of tile kt (LDS stage buf) and the split + LDS stores of
+        // tile kt + 1 (register set and stage buf ^ 1) -- left to itself the scheduler issues the MFMAs in one clump
+        // and the ~130 vector instructions of the split after them; the group barriers below deal the vector work and
+        // the LDS stores out between the MFMAs, where they cost nothing (tools/mfma_bf16_mix.hip: 4-6 per MFMA are free).
+        constexpr int NPROD = PA == 1 ? 3 : SPLIT;
+        constexpr int NM = TM * TN * NPROD * STEPS;                                     // MFMAs per k-tile and wave
+        constexpr int NV = RA * (U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44);       // the split's vector instructions
+        constexpr int NW = RA * PA + (B_KC ? RB * 3 : (RB / 2) * 3);                    // its LDS stores
+        constexpr int VPM = (NV + NM - 1) / NM < 6 ? (NV + NM - 1) / NM : 6;
+        constexpr int WEV = NM / NW > 0 ? NM / NW : 1;
+        auto mid_tile = [&](auto buf_c, int kt) {       // tiles 0 .. nk - 2
+            constexpr int buf = decltype(buf_c)::value;
+            if (kt + 2 < nk) {                          // uniform: tile kt + 2 -> the set tile kt has left
+                next_tile();
+                issue_loads(kbeg + (kt + 2) * BK, buf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_steps(buf_c, C0{}, CS_{});
+            store_tiles(buf ^ 1, buf ^ 1);
+            // (every fragment read first: the LDS stores of the other stage cannot be proven not to alias them and would
+            //  otherwise queue up behind the last read, at the end of the tile)
+            __builtin_amdgcn_sched_group_barrier(0x100, STEPS * (TM * PA + TN * 3 * (B_KC ? 1 : 4)), 0);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                if (m % WEV == WEV - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __syncthreads();
+        };
+        int kt = 0;
+        if (!(nk & 1)) { mid_tile(C0{}, 0); kt = 1; }
+        for (; kt + 1 < nk; kt += 2) {
+            mid_tile(C1{}, kt);
+            mid_tile(C0{}, kt + 1);
+        }
+        issue_mask_loads();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_steps(C1{}, C0{}, CS_{});                  // the last tile
     } else {
     issue_loads(kbeg);
     store_tiles(nk & 1);                            // first tile's buffer chosen so that the loop ends on buffer 1
@@ -1044,6 +1256,25 @@ template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, b
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, PIPE3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
+// bf16-split products (igemm_body, SPLIT): MINW waves per SIMD; the co-run of arl_conv_corun_update as in igemm_occ_kernel
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool U8, int SPLIT, int MINW,
+          bool CORUN = false>
+__global__ __launch_bounds__(256, MINW) void igemm_split_kernel(const GemmArgs a, const arl::OptSeg c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int bx = blockIdx.x;
+    if constexpr (CORUN) {
+        if (bx < c.co_blocks) {
+            __shared__ double lds[8];
+            if (blockIdx.y || blockIdx.z) return;
+            if (c.method == ARL_OPT_ADAM) arl::opt_update_block<ARL_OPT_ADAM>(c, bx, c.co_blocks, lds);
+            else arl::opt_update_block<ARL_OPT_RMSPROP>(c, bx, c.co_blocks, lds);
+            return;
+        }
+        bx -= c.co_blocks;
+    }
+    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, false, U8, false, SPLIT>(a, bx, blockIdx.y, blockIdx.z, smem);
 }
 
 // ==========================================================================================
@@ -1460,13 +1691,22 @@ constexpr int WG_ROWS = 256;
 // (a 32-row tile would spend half of every MFMA on channels that do not exist).
 // U8: the gathered rows come from planar u8 images (GatherDesc::src8; column r = (ch * kh8 + ty) * kw8 + tx,
 // so dw is (K, C, kh, kw)); the row count needs no rounding (the last tile's missing rows read as zeros).
-template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false, bool U8 = false>
+// SPLIT: bf16-split products (see igemm_body): both operands are k-major here, so both LDS images are pair-packed --
+// every loader task fetches two adjacent reduction rows of its four columns.
+template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false, bool U8 = false, int SPLIT = 0>
 __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx, const int by, const int bz, float* smem) {
+    constexpr bool SP = SPLIT != 0;
     constexpr int BM = M16 ? 16 : WGM * TM * 32, BN = WGN * TN * 32;
     static_assert(!M16 || (WGM == 1 && TM == 1 && BK % 16 == 0), "16-row tiles: one row tile");
+    static_assert(!SP || (!M16 && BK % 16 == 0), "split products: 32-row tiles");
     constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
-    constexpr int NA4 = BK * BM / 4, RA = (NA4 + 255) / 256, MC4 = BM / 4;
+    constexpr int MC4 = BM / 4, NPA = (BK / 2) * MC4;        // split: pair tasks of the dy tile
+    constexpr int NA4 = BK * BM / 4, RA = SP ? 2 * ((NPA + 255) / 256) : (NA4 + 255) / 256;
     constexpr int NC4 = BN / 4, KROWS = 256 / NC4, RB = BK / KROWS;
+    static_assert(!SP || RB % 2 == 0, "split products: an even number of gather passes (row pairs)");
+    constexpr int PB = U8 ? 1 : 3;
+    constexpr int SPA = BK * BM * 2, SPB = BK * BN * 2, STAGE = 3 * SPA + PB * SPB;   // bytes per plane / stage
+    char* const sS = reinterpret_cast<char*>(smem);
     constexpr int TILES_PER_GROUP = WG_ROWS / BK;
     static_assert(WGM * WGN == 4 && 256 % NC4 == 0 && BK % KROWS == 0 && BK % 8 == 0 && WG_ROWS % BK == 0, "tile shape");
     __shared__ uint2 s_row[2][WG_ROWS];     // per gathered row: byte offset of its tap origin, inverted tap mask
@@ -1488,11 +1728,21 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     unsigned voffA[RA];
 #pragma unroll
     for (int p = 0; p < RA; ++p) {
-        const int idx = tid + p * 256;
-        const int kl = idx / MC4, c4 = idx - kl * MC4;
+        int idx = tid + p * 256;
+        int kl = idx / MC4, c4 = idx - kl * MC4;
+        bool in_tile = NA4 % 256 == 0 || idx < NA4;
+        if constexpr (SP) {                         // passes 2q, 2q + 1: rows 2 kl2, 2 kl2 + 1 of task tid + 256 q
+            idx = tid + (p >> 1) * 256;
+            const int kl2 = idx / MC4;
+            c4 = idx - kl2 * MC4;
+            kl = 2 * kl2 + (p & 1);
+            in_tile = NPA % 256 == 0 || idx < NPA;
+        }
         const int ko = i0 + c4 * 4;
-        voffA[p] = ((NA4 % 256 == 0 || idx < NA4) && ko < a.K_out) ? (unsigned)(kl * a.K_out + ko) << 2 : OOB;
+        voffA[p] = (in_tile && ko < a.K_out) ? (unsigned)(kl * a.K_out + ko) << 2 : OOB;
     }
+    // the reduction row (within a k-tile) that dy pass p of this thread covers
+    auto a_row_of = [&](int p) { return SP ? 2 * ((tid + (p >> 1) * 256) / MC4) + (p & 1) : (tid + p * 256) / MC4; };
     const int b_c4 = tid % NC4, b_k0 = tid / NC4;
     const int r = n0 + b_c4 * 4;
     const int tap = r / Cs, ch = r - tap * Cs;
@@ -1544,23 +1794,63 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     auto issue_loads = [&](int tile) {              // tile index within the split
         const unsigned soffA = (unsigned)((mbeg + tile * BK) * a.K_out) << 2;
         const int grp = tile / TILES_PER_GROUP, tin = tile - grp * TILES_PER_GROUP;
-        const uint2* rows = &s_row[grp & 1][tin * BK + b_k0];
+        const uint2* rows = &s_row[grp & 1][tin * BK + (SP ? 2 * b_k0 : b_k0)];
         // (the buffer range check does not see soffset: U8's ragged last tile switches its missing dy rows off here)
         const int rows_left = mend - (mbeg + tile * BK);
 #pragma unroll
         for (int p = 0; p < RA; ++p) {
-            const bool row_ok = !U8 || rows_left >= BK || (tid + p * 256) / MC4 < rows_left;
+            const bool row_ok = !U8 || rows_left >= BK || a_row_of(p) < rows_left;
             va[p] = buf_ld4s(rsA, row_ok ? voffA[p] : OOB, soffA);
         }
 #pragma unroll
         for (int p = 0; p < RB; ++p) {
-            const uint2 e = rows[p * KROWS];
+            // split: passes 2q, 2q + 1 gather rows 2 (b_k0 + q KROWS), + 1
+            const uint2 e = rows[SP ? (p >> 1) * 2 * KROWS + (p & 1) : p * KROWS];
             const unsigned off = e.x + cdelta;      // either term may be the OOB marker (sum stays >= OOB, < 2^32)
             if constexpr (U8) vb8[p] = buf_ld1s(rsB, off, 0);
             else vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
         }
     };
+    auto pack4 = [&](const float4& v0, const float4& v1, char* d, int plane_bytes) {     // rows k, k + 1 -> three planes
+        uint4 h, m, l;
+        split_pair(v0.x, v1.x, h.x, m.x, l.x);
+        split_pair(v0.y, v1.y, h.y, m.y, l.y);
+        split_pair(v0.z, v1.z, h.z, m.z, l.z);
+        split_pair(v0.w, v1.w, h.w, m.w, l.w);
+        *reinterpret_cast<uint4*>(d) = h;
+        *reinterpret_cast<uint4*>(d + plane_bytes) = m;
+        *reinterpret_cast<uint4*>(d + 2 * plane_bytes) = l;
+    };
     auto store_tiles = [&](int buf, bool fresh) {   // fresh: va holds a tile not stored before
+        if constexpr (SP) {
+            char* dS = sS + buf * STAGE;
+#pragma unroll
+            for (int q = 0; q < RA / 2; ++q) {
+                const int t = tid + q * 256;
+                if (NPA % 256 != 0 && t >= NPA) continue;
+                pack4(va[2 * q], va[2 * q + 1], dS + t * 16, SPA);             // [kl2][c4 * 4] dwords, ld = BM
+                if (do_bias && fresh) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int p = 2 * q + e;
+                        bsum[p].x += va[p].x; bsum[p].y += va[p].y; bsum[p].z += va[p].z; bsum[p].w += va[p].w;
+                    }
+                }
+            }
+            char* dB = dS + 3 * SPA;
+#pragma unroll
+            for (int q = 0; q < RB / 2; ++q) {
+                char* d = dB + ((b_k0 + q * KROWS) * BN + b_c4 * 4) * 4;
+                if constexpr (U8) {                 // 0 .. 255 is exact in bf16: one plane
+                    const float4 f0 = bytes_to_f4(vb8[2 * q]), f1 = bytes_to_f4(vb8[2 * q + 1]);
+                    *reinterpret_cast<uint4*>(d) = make_uint4(hi_pair(f0.x, f1.x), hi_pair(f0.y, f1.y), hi_pair(f0.z, f1.z),
+                                                              hi_pair(f0.w, f1.w));
+                } else {
+                    pack4(vb[2 * q], vb[2 * q + 1], d, SPB);
+                }
+            }
+            return;
+        }
         float* dA = sA + buf * A_SZ;
         float* dB = sB + buf * B_SZ;
 #pragma unroll
@@ -1608,7 +1898,30 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         // slot is rewritten (group + 2) one iteration later, after this iteration's barrier.
         if (kt % TILES_PER_GROUP == 0 && kt >= TILES_PER_GROUP) produce_rows(((kt / TILES_PER_GROUP) + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (M16) {
+        if constexpr (SP) {
+            // fragment = column l31 (of its 32-wide tile), k octet 2 ks + half = pair rows 8 ks + 4 half .. + 3
+            const unsigned* cA = reinterpret_cast<const unsigned*>(sS + buf * STAGE) + (half * 4) * BM + wm * TM * 32 + l31;
+            const unsigned* cB = reinterpret_cast<const unsigned*>(sS + buf * STAGE + 3 * SPA) + (half * 4) * BN + wn * TN * 32 + l31;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                u32x4 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned* q = cA + pl * (SPA / 4) + ks * 8 * BM + i * 32;
+                        fa[i][pl] = u32x4{q[0], q[BM], q[2 * BM], q[3 * BM]};
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < PB; ++pl) {
+                        const unsigned* q = cB + pl * (SPB / 4) + ks * 8 * BN + j * 32;
+                        fb[j][pl] = u32x4{q[0], q[BN], q[2 * BN], q[3 * BN]};
+                    }
+                split_products<SPLIT, 3, PB, false, TM, TN>(fa, fb, acc);
+            }
+        } else if constexpr (M16) {
             const float* cA = sA + buf * A_SZ + (quad * 4) * BM + l15;
             const float* cB = sB + buf * B_SZ + (quad * 4) * BN + wn * TN * 32 + l15;
 #pragma unroll
@@ -1667,6 +1980,11 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         float4* red = reinterpret_cast<float4*>(sA);
 #pragma unroll
         for (int p = 0; p < RA; ++p) {
+            if constexpr (SP) {
+                const int t = tid + (p >> 1) * 256;
+                if (NPA % 256 == 0 || t < NPA) red[a_row_of(p) * MC4 + t % MC4] = bsum[p];
+                continue;
+            }
             const int idx = tid + p * 256;
             if (NA4 % 256 == 0 || idx < NA4) red[idx] = bsum[p];
         }
@@ -1719,21 +2037,28 @@ __global__ __launch_bounds__(256, 4) void wgrad_u8_kernel(const WgradArgs a) {
     wgrad_fast_body<WGM, WGN, TM, TN, BK, false, M16, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
 }
 
+// bf16-split products (wgrad_fast_body, SPLIT), from f32 activations or (U8) the planar u8 observations
+template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool U8, int SPLIT, int MINW>
+__global__ __launch_bounds__(256, MINW) void wgrad_split_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, false, U8, SPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
+
 // One launch for a layer's data gradient AND weight gradient (independent of each other, both read dy):
 // workgroups [0, n_ig) run data-gradient tiles, the rest weight-gradient tiles.  One ramp-up and one
 // tail instead of two, and the dispatcher fills the CUs the first problem's last wave leaves idle.
-template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK, bool HAS_PAD>
+template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK, bool HAS_PAD, int SPLIT = 0>
 __global__ __launch_bounds__(256) void bwd_pair_kernel(const GemmArgs a, const WgradArgs w, const int dgx, const int dgy,
                                                        const int n_ig, const int wgx, const int wgy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int id = blockIdx.x;
     if (id < n_ig) {
         const int bx = id % dgx, t = id / dgx;
-        igemm_body<DWGM, DWGN, DTM, DTN, BK, false, false, HAS_PAD>(a, bx, t % dgy, t / dgy, smem);
+        igemm_body<DWGM, DWGN, DTM, DTN, BK, false, false, HAS_PAD, false, false, false, SPLIT>(a, bx, t % dgy, t / dgy, smem);
     } else {
         id -= n_ig;
         const int bx = id % wgx, t = id / wgx;
-        wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD>(w, bx, t % wgy, t / wgy, smem);
+        wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD, false, false, SPLIT>(w, bx, t % wgy, t / wgy, smem);
     }
 }
 
@@ -1920,6 +2245,51 @@ int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_
     return arl::check_launch("igemm_occ_kernel");
 }
 
+// arl_conv_precision: 0 = fp32 MFMA chain, 6 / 9 = bf16-split products (see igemm_body, SPLIT)
+int g_split = 9;
+
+// the launch of igemm_split_kernel: two LDS stages of (1 or 3) + 3 bf16 planes; a data gradient hosts the pending
+// optimiser job like launch_igemm_occ
+template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool U8, int MINW>
+int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s, int splits = 1) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    const size_t lds = (size_t)2 * ((U8 ? 1 : 3) * BM + 3 * BN) * BK * 2;
+    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
+    arl::OptSeg c = {};
+    int rc = 0;
+#define ARL_SPLIT_K(MT, HP, SPL, CO)                                                                       \
+    do {                                                                                                   \
+        auto k = igemm_split_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, U8, SPL, MINW, CO>;                \
+        rc = allow_big_lds(k, lds + (CO ? 64 : 0));                                                        \
+        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, c);                                     \
+    } while (0)
+#define ARL_SPLIT_MODE(MT, HP, CO)                                                                         \
+    do {                                                                                                   \
+        if (g_split == 6) ARL_SPLIT_K(MT, HP, 6, CO); else ARL_SPLIT_K(MT, HP, 9, CO);                     \
+    } while (0)
+    if constexpr (U8) {
+        ARL_SPLIT_MODE(false, false, false);
+    } else {
+        if constexpr (!B_KC) {
+            if (g_corun_pending && !multi_tap) {
+                c = g_corun_job;
+                c.co_blocks = g_corun_blocks < g_corun_host_blocks ? g_corun_blocks : g_corun_host_blocks;
+                grid.x += (unsigned)c.co_blocks;
+                g_corun_pending = false;
+                if (has_pad) ARL_SPLIT_MODE(false, true, true); else ARL_SPLIT_MODE(false, false, true);
+                return rc ? rc : arl::check_launch("igemm_split_kernel (co-run)");
+            }
+        }
+        if (multi_tap && has_pad) ARL_SPLIT_MODE(true, true, false);
+        else if (multi_tap) ARL_SPLIT_MODE(true, false, false);
+        else if (has_pad) ARL_SPLIT_MODE(false, true, false);
+        else ARL_SPLIT_MODE(false, false, false);
+    }
+#undef ARL_SPLIT_MODE
+#undef ARL_SPLIT_K
+    return rc ? rc : arl::check_launch("igemm_split_kernel");
+}
+
 // more row tiles than resident workgroups?  (g_persist < 0, tests: always, walked by -g_persist workgroups)
 // (the callers also check that the reduction is an even number of k-tiles: the two-deep load pipeline's invariant)
 bool persist_pays(int tiles) { return g_persist < 0 || (g_persist > 0 && tiles > num_cus() * g_persist); }
@@ -1972,6 +2342,29 @@ int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t 
         if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
     }
     return rc ? rc : arl::check_launch("wgrad_fast_kernel");
+}
+
+template <int WGM, int WGN, int TM, int TN, int BK, bool U8, int MINW>
+int launch_wgrad_split(const WgradArgs& a, int splits, bool has_pad, hipStream_t s) {
+    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
+    const size_t lds = (size_t)2 * (3 * BM + (U8 ? 1 : 3) * BN) * BK * 2;
+    dim3 grid((a.N + BN - 1) / BN, (a.K_out + BM - 1) / BM, splits);
+    int rc = 0;
+#define ARL_WSPLIT(HP, SPL)                                                                                \
+    do {                                                                                                   \
+        auto k = wgrad_split_kernel<WGM, WGN, TM, TN, BK, HP, U8, SPL, MINW>;                              \
+        rc = allow_big_lds(k, lds + 4096);                                                                 \
+        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
+    } while (0)
+    if constexpr (U8) {
+        if (g_split == 6) ARL_WSPLIT(false, 6); else ARL_WSPLIT(false, 9);
+    } else if (has_pad) {
+        if (g_split == 6) ARL_WSPLIT(true, 6); else ARL_WSPLIT(true, 9);
+    } else {
+        if (g_split == 6) ARL_WSPLIT(false, 6); else ARL_WSPLIT(false, 9);
+    }
+#undef ARL_WSPLIT
+    return rc ? rc : arl::check_launch("wgrad_split_kernel");
 }
 
 int launch_fold(const float* part, int splits, int64_t total, const float* bias, int n_bias, int relu,
@@ -2063,6 +2456,12 @@ extern "C" void arl_conv_tile_choice(int32_t choice) { g_tile_choice = choice; }
 
 extern "C" void arl_conv_persistent(int32_t workgroups_per_cu) { g_persist = workgroups_per_cu; }
 
+extern "C" int arl_conv_precision(int32_t mode) {
+    ARL_REQUIRE(mode == 0 || mode == 6 || mode == 9, ARL_E_ARG, "conv precision: 0 (fp32 MFMA), 6 or 9 (bf16-split products)");
+    g_split = mode;
+    return 0;
+}
+
 extern "C" int arl_conv_corun_update(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
                                      float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
                                      double* norm_parts, int64_t hole_first, int64_t hole_count) {
@@ -2100,7 +2499,8 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     a.o.dense = 1; a.trace = g_trace;
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
-    const bool small32 = small && g_tile_choice != 1;       // 32x64 tiles: half the splits (and partial bytes) for the same grid
+    // (the bf16-split kernels have no 16-wide tiles: 64x64 there)
+    const bool small32 = small && g_tile_choice != 1 && !g_split;  // 32x64 tiles: half the splits (and partial bytes) for the same grid
     if (small) plan_split(((a.M + (small32 ? 31 : 63)) / (small32 ? 32 : 64)) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
     // ... and wider ones whose 128x128 tiles still leave CUs idle (spec-0 dense at the A2C batch: 5120 x 256 =
     // 80 tiles walking 88 k-tiles each, 231 us)
@@ -2133,6 +2533,10 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
         // (the 128x32 tile at BK = 32 would allow only 3: a 16-wide k-tile, 5-6 resident, is 3-5 us faster)
         if (a.N <= 16 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 2, 1, 16, true, true>(a, splits, multi_tap, has_pad, s);        // 16-wide MFMA tiles
+        else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
+        else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
+        else if (g_split && small) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
+        else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, true, false, 1>(a, multi_tap, has_pad, s, splits);
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 1, 1, 16, true>(a, splits, multi_tap, has_pad, s);
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, FBK, true>(a, splits, multi_tap, has_pad, s);
@@ -2239,11 +2643,15 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             if (splits > 1) {
                 a.o.out = (float*)workspace; a.o.mask = nullptr; a.split_stride = (int64_t)a.M * a.N;
             }
-            rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, splits, false, has_pad, s);
+            if (g_split) rc = launch_igemm_split<2, 2, 1, 1, FBK, false, false, 3>(a, false, has_pad, s, splits);
+            else rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, splits, false, has_pad, s);
             if (rc || splits == 1) return rc;
             return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, nullptr, 4, 0, dx, s, mask_or_null);
         }
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
+        else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, false, false, 2>(a, false, has_pad, s);
+        else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, false, false, 2>(a, false, has_pad, s);
+        else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, false, false, 1>(a, false, has_pad, s);
         else if (a.N <= 32 && a.K % 32 == 0 && persist_pays((a.n_par ? a.n_par : 1) * ((a.M + 127) / 128)))
             rc = launch_igemm_persist<4, 1, 1, 16, false, false, false, 4>(a, false, has_pad, s);
         // 17 .. 32 columns: 64x32 tiles on 16-wide MFMAs at five waves per SIMD (3 800 tiles instead of 1 900 of 128 rows
@@ -2333,6 +2741,9 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
             return 0;
         }
         if (g.K <= 16) rc = launch_wgrad_fast<1, 4, 1, 1, FBK, true>(a, splits, has_pad, s);       // 16-row MFMA tiles
+        else if (g_split && g.K <= 32) rc = launch_wgrad_split<1, 4, 1, 1, FBK, false, 2>(a, splits, has_pad, s);
+        else if (g_split && g.K <= 64) rc = launch_wgrad_split<2, 2, 1, 1, FBK, false, 2>(a, splits, has_pad, s);
+        else if (g_split) rc = launch_wgrad_split<2, 2, 2, 2, FBK, false, 1>(a, splits, has_pad, s);
         else if (g.K <= 32) rc = launch_wgrad_fast<1, 4, 1, 1, FBK>(a, splits, has_pad, s);
         else if (g.K <= 64) rc = launch_wgrad_fast<2, 2, 1, 1, FBK>(a, splits, has_pad, s);
         else rc = launch_wgrad_fast<2, 2, 2, 2, FBK>(a, splits, has_pad, s);
@@ -2444,6 +2855,9 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     if (a.N <= 16) {
         const size_t lds = (size_t)2 * (BM * (BK + 4) + 16 * (BK + 4)) * sizeof(float);
         hipLaunchKernelGGL((igemm_u8_kernel<4, 1, 2, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else if (g_split && g.kh % (8 / (g.kw >> 2)) == 0) {
+        // bf16-split products: the pixels are exact in one bf16 plane (three products), 32-deep k-tiles = whole filter rows
+        return launch_igemm_split<4, 1, 2, 1, 32, true, true, 2>(a, false, false, (hipStream_t)stream);
     } else if (a.K % (2 * BK) == 0 && persist_pays((int)grid.x)) {
         return launch_igemm_persist<4, 1, 1, BK, true, false, true, 4>(a, false, false, (hipStream_t)stream);
     } else if (g_tile_choice != 1 && g.kh % (8 / (g.kw >> 2)) == 0) {
@@ -2496,7 +2910,10 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     constexpr int BK = 32;
     const size_t lds = (size_t)2 * BK * (bm + bn) * sizeof(float);
     const dim3 grid((a.N + bn - 1) / bn, (a.K_out + bm - 1) / bm, splits);
-    if (g.K <= 16) hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
+    if (g.K > 16 && g_split) {
+        rc = launch_wgrad_split<1, 4, 1, 1, BK, true, 2>(a, splits, false, (hipStream_t)stream);
+        if (rc) return rc;
+    } else if (g.K <= 16) hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, false>), grid, dim3(256), lds, (hipStream_t)stream, a);
     item->part = (const float*)workspace; item->out = dw; item->total = total;
     item->splits = splits > 1 ? splits : 0;
@@ -2517,7 +2934,18 @@ int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_
     const int wgx = (w.a.N + WBN - 1) / WBN, wgy = (w.a.K_out + WBM - 1) / WBM, wgz = w.splits;
     const int n_ig = dgx * dgy * dgz, n_wg = wgx * wgy * wgz;
     int rc;
-    if (has_pad) {
+    if (g_split) {
+        const size_t lds_s = (size_t)2 * 3 * ((DBM + DBN) > (WBM + WBN) ? (DBM + DBN) : (WBM + WBN)) * BK * 2;
+#define ARL_PSPLIT(HP, SPL)                                                                                \
+    do {                                                                                                   \
+        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, HP, SPL>;                 \
+        rc = allow_big_lds(k, lds_s + 4096);                                                               \
+        if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds_s, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy); \
+    } while (0)
+        if (has_pad) { if (g_split == 6) ARL_PSPLIT(true, 6); else ARL_PSPLIT(true, 9); }
+        else { if (g_split == 6) ARL_PSPLIT(false, 6); else ARL_PSPLIT(false, 9); }
+#undef ARL_PSPLIT
+    } else if (has_pad) {
         auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, true>;
         rc = allow_big_lds(k, lds + 4096);
         if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy);

@@ -380,6 +380,19 @@ void arl_conv_tile_choice(int32_t choice);
  * walked by -workgroups_per_cu workgroups in all).  Same results bit for bit.  Not thread-safe. */
 void arl_conv_persistent(int32_t workgroups_per_cu);
 
+/* How the fp32 contractions of every following conv / dense call are computed (the reference's floatX is
+ * float32: accel_rl/policies/pg/networks/pg_cnn.py:45-86 through Theano).  Operands and results are fp32 in
+ * every mode; only the route through the matrix cores differs:
+ *   0  v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain (157 TF/s peak on gfx950);
+ *   9  (default) each fp32 operand is split EXACTLY into three bf16 pieces (24 significand bits = 3 x 8) and all
+ *      nine piece products -- each exact in fp32 -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: every
+ *      product term of the fp32 contraction enters the sum exactly, only the accumulation rounds;
+ *   6  as 9 without the three smallest piece products (each below 2^-24 of |x y|).
+ * u8 observations are exact in one bf16 piece (three products in both split modes).  Layers with <= 16 output
+ * columns and the generic (any channel count) kernels always take route 0.  Deterministic in every mode.
+ * Returns ARL_E_ARG for any other value.  Not thread-safe. */
+int arl_conv_precision(int32_t mode);
+
 /* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
  * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,
  * policies/layers.py:22-41; the reference's flipped filters are stored pre-flipped).

@@ -46,20 +46,24 @@ def _tol(want, k_red):
     return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
 
 
-@pytest.fixture(params=["fast", "generic", "fast_tiles64", "fast_tiles112", "fast_persistent"])
+@pytest.fixture(params=["fast", "fast_split6", "fast_fp32", "generic", "fast_tiles64", "fast_tiles112", "fast_persistent"])
 def path(request):
     """Both kernel families: the scalar-addressed fast path (taken whenever a k-tile of 32 stays inside
-    one filter row) and the generic fallback (any multiple-of-4 channel count, any K); and, on the fast path,
-    the other two tile shapes of the 33 .. 64-column layers (the default is 32x64), and the persistent launches of
+    one filter row) and the generic fallback (any multiple-of-4 channel count, any K); on the fast path the three
+    routes of arl_conv_precision (default: nine bf16-split products; six; the fp32 MFMA chain) and, on the fp32 chain,
+    the other two tile shapes of the 33 .. 64-column layers (the default is 32x64) and the persistent launches of
     the many-tile layers walked by three workgroups."""
     from accel_rl_amd import _lib
-    _lib.load().arl_conv_force_generic(1 if request.param == "generic" else 0)
-    _lib.load().arl_conv_tile_choice({"fast_tiles64": 1, "fast_tiles112": 2}.get(request.param, 0))
-    _lib.load().arl_conv_persistent(-3 if request.param == "fast_persistent" else 0)    # 3 workgroups walk every tile
+    lib = _lib.load()
+    lib.arl_conv_force_generic(1 if request.param == "generic" else 0)
+    assert lib.arl_conv_precision({"fast": 9, "fast_split6": 6}.get(request.param, 0)) == 0
+    lib.arl_conv_tile_choice({"fast_tiles64": 1, "fast_tiles112": 2}.get(request.param, 0))
+    lib.arl_conv_persistent(-3 if request.param == "fast_persistent" else 0)    # 3 workgroups walk every tile
     yield request.param
-    _lib.load().arl_conv_force_generic(0)
-    _lib.load().arl_conv_tile_choice(0)
-    _lib.load().arl_conv_persistent(0)
+    lib.arl_conv_force_generic(0)
+    lib.arl_conv_tile_choice(0)
+    lib.arl_conv_persistent(0)
+    lib.arl_conv_precision(9)
 
 
 ODD_CASES = [(9, 20, 14, 12, 20, 3, 1, 1),      # channels 12 / 20: no power-of-two anywhere -> generic kernels
@@ -340,6 +344,7 @@ def test_persistent_launches_are_bit_identical(walkers):
     def both(fn):
         outs = []
         lib.arl_conv_tile_choice(1)                 # the persistent kernels walk the classic 128-row tiles (32x32 MFMAs)
+        lib.arl_conv_precision(0)                   # ... of the fp32 MFMA chain
         for w in (0, walkers):
             lib.arl_conv_persistent(w)
             try:
@@ -347,6 +352,7 @@ def test_persistent_launches_are_bit_identical(walkers):
             finally:
                 lib.arl_conv_persistent(0)
         lib.arl_conv_tile_choice(0)
+        lib.arl_conv_precision(9)
         return outs
     # conv 1 forward, u8 rows by index: 37 images of 104 x 80 -> 37 * 475 rows = 138 tiles of 128 and a ragged one
     obs = torch.randint(0, 256, (50, 4, 104, 80), device=DEV, dtype=torch.int32, generator=gen).to(torch.uint8)
@@ -381,3 +387,76 @@ def test_persistent_launches_are_bit_identical(walkers):
         return dx
     a, b = both(dgrad1)
     assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+SPEC1 = [("conv1", 104, 80, 4, 32, 8, 4, 0), ("conv2", 25, 19, 32, 64, 4, 2, 1), ("conv3", 12, 9, 64, 64, 3, 1, 1),
+         ("dense", 1, 1, 3456, 512, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("layer", SPEC1, ids=[c[0] for c in SPEC1])
+def test_every_precision_route_is_fp32_accurate_against_float64(layer):
+    """arl_conv_precision: the bf16-split routes (nine / six piece products accumulated in fp32 by the bf16 MFMAs) must be
+    as close to the EXACT (float64) contraction as the fp32 MFMA chain is -- at the spec-1 layer shapes, forward, data and
+    weight gradient, and conv 1 from u8 rows.  Bar: rms error <= 6e-7 of the rms of the exact result for every route
+    (observed 0.7e-7 .. 4.1e-7, the fp32 chain the largest), and a split route at most 1.5x the fp32 chain's error + 3e-8.
+    Also: every route is run-to-run bit-identical, and an unknown mode is refused."""
+    from accel_rl_amd import _lib
+    lib = _lib.load()
+    name, h, w, c, k, ks, st, p = layer
+    b = 48
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p)
+    ho, wo = _lib.conv_out_hw(geom)
+    ws = _lib.conv_workspace(DEV)
+    x = torch.randn(b, h, w, c, device=DEV, generator=gen).relu()
+    wt = torch.randn(k, ks, ks, c, device=DEV, generator=gen) / np.sqrt(ks * ks * c)
+    bias = torch.randn(k, device=DEV, generator=gen)
+    dy = torch.randn(b, ho, wo, k, device=DEV, generator=gen)
+    nchw = lambda t: t.double().permute(0, 3, 1, 2)                              # noqa: E731
+    xr, wr = nchw(x).detach().requires_grad_(), nchw(wt).detach().requires_grad_()
+    out = F.conv2d(xr, wr, None, stride=st, padding=p)
+    gx, gw = torch.autograd.grad(out, (xr, wr), nchw(dy))
+    ref = dict(fwd=(out + bias.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).detach(), dgrad=gx.permute(0, 2, 3, 1),
+               wgrad=gw.permute(0, 2, 3, 1))
+    obs = w8 = None
+    if name == "conv1":
+        obs = torch.randint(0, 256, (b, c, h, w), device=DEV, dtype=torch.int32, generator=gen).to(torch.uint8)
+        w8 = wt.permute(0, 3, 1, 2).contiguous()
+        o8r, w8r = (obs.double() / 255.0).requires_grad_(), w8.double().detach().requires_grad_()
+        out8 = F.conv2d(o8r, w8r, None, stride=st)
+        ref["u8fwd"] = (out8 + bias.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).detach()
+        ref["u8wgrad"] = torch.autograd.grad(out8, w8r, nchw(dy))[0]
+
+    def run_all():
+        y, dx, dw = torch.empty(b, ho, wo, k, device=DEV), torch.empty_like(x), torch.empty_like(wt)
+        _lib.conv2d_fwd(x, wt, bias, y, geom, False, ws)
+        _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
+        _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+        got = dict(fwd=y, dgrad=dx, wgrad=dw)
+        if obs is not None:
+            y8, dw8, db = torch.empty_like(y), torch.empty_like(w8), torch.empty(k, device=DEV)
+            _lib.conv2d_u8_fwd(obs, None, 1.0 / 255.0, w8, bias, y8, geom, False)
+            folds = _lib.FoldList()
+            folds.conv2d_u8_bwd_weight(dy, obs, None, 1.0 / 255.0, dw8, geom, ws, dbias=db)
+            folds.run()
+            got.update(u8fwd=y8, u8wgrad=dw8)
+        torch.cuda.synchronize()
+        return got
+
+    def rel_rms(got, want):
+        return ((got.double() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+    errs = {}
+    try:
+        for mode in (0, 6, 9):
+            assert lib.arl_conv_precision(mode) == 0
+            got, again = run_all(), run_all()
+            for op in got:
+                assert torch.equal(got[op], again[op]), (mode, op)
+                errs[mode, op] = rel_rms(got[op], ref[op])
+                assert errs[mode, op] <= 6e-7, (mode, op, errs[mode, op])
+        for mode in (6, 9):
+            for op in ref:
+                assert errs[mode, op] <= 1.5 * errs[0, op] + 3e-8, (mode, op, errs[mode, op], errs[0, op])
+        assert lib.arl_conv_precision(7) != 0 and b"conv precision" in lib.arl_last_error()
+    finally:
+        lib.arl_conv_precision(9)
