@@ -15,8 +15,16 @@ SOURCES = ["batch_ops.hip", "scan.hip", "env.hip", "optim.hip", "learner.hip", "
 ARCH = "gfx950"
 
 
+def _flags_stamp():
+    return os.path.join(CSRC, "_obj", ".flags")
+
+
 def _stale():
     if not os.path.exists(LIB_PATH):
+        return True
+    extra = os.environ.get("ARL_HIPCC_FLAGS", "")           # a library built with other (development) flags is stale
+    stamp = _flags_stamp()
+    if os.path.exists(stamp) and open(stamp).read().split("||")[-1] != extra:
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
@@ -50,11 +58,22 @@ def _build_locked(verbose):
     common = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC",
               "-ffp-contract=off",           # numpy-exact arithmetic (no implicit fma)
               "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    extra = os.environ.get("ARL_HIPCC_FLAGS", "").split()     # development only (e.g. -DARL_NO_SPLIT6: fewer kernels)
+    common += extra
+    stamp = _flags_stamp()
+    flags_now = " ".join(common) + "||" + os.environ.get("ARL_HIPCC_FLAGS", "")
+    flags_same = os.path.exists(stamp) and open(stamp).read() == flags_now
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(ROOT, "include", "accel_rl_hip.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
     procs = []
     for src in SOURCES:
         obj = os.path.join(build_dir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        path = os.path.join(CSRC, src)
+        if flags_same and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), newest_header):
+            continue                                # object is current: only the changed sources recompile
+        cmd = common + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -68,6 +87,8 @@ def _build_locked(verbose):
     if out.returncode != 0:
         raise RuntimeError("link failed:\n%s" % out.stdout.decode(errors="replace"))
     os.replace(tmp, LIB_PATH)
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     return LIB_PATH
 
 

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "arl_conv_tile_choice": (None, [_i32]),
     "arl_conv_persistent": (None, [_i32]),
     "arl_conv_precision": (_i32, [_i32]),
+    "arl_conv_pieces": (_i32, [_vp, _vp]),
+    "arl_conv_pieces_supported": (_i32, [C.POINTER(ArlConvGeom), _i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
@@ -435,6 +437,32 @@ def conv_out_hw(g):
 
 def conv_workspace(device):
     return torch.empty(load().arl_conv_workspace_bytes() // 4, dtype=torch.float32, device=device)
+
+
+PIECES_IN, PIECES_OUT = 1, 2
+PIECES_FWD, PIECES_DGRAD, PIECES_U8FWD = 0, 1, 2
+
+
+def conv_pieces_supported(geom, op):
+    """Bit mask (PIECES_IN | PIECES_OUT) of what the route of (geom, op) can do with bf16 pieces (arl_conv_pieces)."""
+    caps = load().arl_conv_pieces_supported(C.byref(geom), op)
+    if caps < 0:
+        _check(caps, "arl_conv_pieces_supported")
+    return caps
+
+
+def pieces_like(t):
+    """An (uninitialised) bf16 pieces tensor of the fp32 tensor t: [3, numel] (see arl_conv_pieces)."""
+    assert t.numel() % 8 == 0
+    return torch.empty((3, t.numel()), dtype=torch.bfloat16, device=t.device)
+
+
+def conv_pieces(in_pieces=None, out_pieces=None):
+    """Hand bf16 pieces to the NEXT forward / data-gradient call (which consumes them)."""
+    for p in (in_pieces, out_pieces):
+        if p is not None:
+            _want(p, torch.bfloat16, "pieces")
+    _check(load().arl_conv_pieces(ptr(in_pieces), ptr(out_pieces)), "arl_conv_pieces")
 
 
 def conv2d_fwd(x, w, bias, y, geom, relu, workspace, stream=None):

@@ -56,6 +56,10 @@ struct GatherDesc {
     const int* idx;
     float scale;
     int plane, img_bytes, kh8, kw8;
+    // bf16-split kernels only (arl_conv_pieces): the three bf16 pieces of src, written by the launch that produced src
+    // -- piece q of element e at pieces + q * piece_bytes + 2 e -- or null: split in the kernel
+    const char* pieces;
+    long long piece_bytes;
 };
 
 // The weight operand.  B_KC:  element (n, r) at w[n*ld + r]                (r contiguous)
@@ -74,6 +78,10 @@ struct OutDesc {
     unsigned out_bytes;     // size of the whole output tensor (strided epilogue's buffer descriptor)
     int relu, dense;        // dense: out[m*N + n]
     int OH, OW, omul, oadd_y, oadd_x;   // else out[((b*OH + oy*omul + oadd_y)*OW + ox*omul + oadd_x)*N + n]
+    // bf16-split kernels only (arl_conv_pieces): where to leave the three bf16 pieces of out (same element order,
+    // piece q at pieces + q * piece_bytes), for the launch that gathers out next; or null
+    char* pieces;
+    long long piece_bytes;
 };
 
 struct GemmArgs {
@@ -140,6 +148,30 @@ __device__ __forceinline__ void store_tiles_rowmajor(const f32x16 (&acc)[TM][TN]
     }
 }
 
+// bf16 pieces of fp32 numbers (see SPLIT below): x = h + m + l exactly, h = top 16 bits of x, m = top 16 bits of x - h
+constexpr unsigned HI16 = 0xffff0000u;
+// (bf16 of x0, bf16 of x1) truncated, x0 in the low half (k order = memory order)
+__device__ __forceinline__ unsigned hi_pair(float x0, float x1) {
+    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+}
+__device__ __forceinline__ float lo_part(float x) { return x - __uint_as_float(__float_as_uint(x) & HI16); }   // exact
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    h = hi_pair(x0, x1);
+    const float r0 = lo_part(x0), r1 = lo_part(x1);
+    m = hi_pair(r0, r1);
+    l = hi_pair(lo_part(r0), lo_part(r1));
+}
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// four consecutive elements' pieces to the three piece tensors (byte offset voff2 inside each)
+__device__ __forceinline__ void store_pieces4(const float4& v, const __amdgpu_buffer_rsrc_t (&rp)[3], unsigned voff2) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(v.x, v.y, h0, m0, l0);
+    split_pair(v.z, v.w, h1, m1, l1);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, rp[0], voff2, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, rp[1], voff2, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, rp[2], voff2, 0, 0);
+}
+
 // Epilogue of the operand-swapped kernels (acc = W-tile x X-tile^T): D'[row][col] with col = lane & 31
 // the GEMM row m and row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) the output channel n, so a lane holds
 // four consecutive channels of ONE output row per register quad and stores them as one b128 -- four
@@ -151,8 +183,16 @@ template <int TM, int TN, bool SCALED = false>
 __device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
                                                   const long long (&row_off)[TM], int N, int col_base, int lane,
                                                   const float4 (&bias_q)[TN][4], const float* mask, int relu,
-                                                  const float4 (*pre)[TM] = nullptr, float scale = 1.f) {
+                                                  const float4 (*pre)[TM] = nullptr, float scale = 1.f,
+                                                  char* pieces = nullptr, long long piece_bytes = 0, unsigned out_bytes = 0) {
     const int half = lane >> 5;
+    // the bf16 pieces of the stored values (arl_conv_pieces): same element offsets at two bytes per element
+    __amdgpu_buffer_rsrc_t rp[3];
+    if (pieces) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            rp[c] = make_rsrc(reinterpret_cast<const float*>(pieces + c * piece_bytes), out_bytes >> 1);
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         // the rectifier mask of a column tile: every load issued before the first one is consumed (one latency
@@ -197,6 +237,7 @@ __device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], _
                 }
                 u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
                 __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff, 0, 0);
+                if (pieces) store_pieces4(val, rp, voff >> 1);          // (OOB >> 1 is still beyond every tensor)
             }
         }
     }
@@ -591,6 +632,12 @@ __device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t rsrc, unsigned
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ u32x4 buf_ld4u(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+}
+__device__ __forceinline__ u32x2 buf_ld2s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+}
 __device__ __forceinline__ unsigned buf_ld1s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0);
 }
@@ -648,18 +695,6 @@ __device__ __forceinline__ unsigned tap_mask(int ry, int rx, int Hs, int Ws, int
 // pairs, a fragment = 4 ds_read_b32 -- the loader threads fetch two adjacent k rows and pack them.
 // ==========================================================================================
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr unsigned HI16 = 0xffff0000u;
-// (bf16 of x0, bf16 of x1) truncated, x0 in the low half (k order = memory order)
-__device__ __forceinline__ unsigned hi_pair(float x0, float x1) {
-    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-}
-__device__ __forceinline__ float lo_part(float x) { return x - __uint_as_float(__float_as_uint(x) & HI16); }   // exact
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = hi_pair(x0, x1);
-    const float r0 = lo_part(x0), r1 = lo_part(x1);
-    m = hi_pair(r0, r1);
-    l = hi_pair(lo_part(r0), lo_part(r1));
-}
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -699,9 +734,18 @@ template <int NS> __device__ __forceinline__ int kc_swz(int row) { return (row /
 // wave has left since it passed the previous barrier --, so that nothing separates the last MFMA of a tile from the
 // first of the next; the loads of tile t+2 are issued right after the barrier (a full tile of latency cover).
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
-          bool U8 = false, bool PIPE3 = false, int SPLIT = 0>
+          bool U8 = false, bool PIPE3 = false, int SPLIT = 0, bool PIN = false, bool ADIR = false>
 __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* smem) {
     constexpr bool SP = SPLIT != 0;                 // bf16-split products (see above): other LDS images, other MFMAs
+    // ADIR: the gathered operand never enters LDS.  With WGN == 1 a wave owns its 32-row tiles outright, and a lane's
+    // MFMA fragment -- row l31, eight consecutive k -- is 32 contiguous bytes of that row in memory: two 16-byte loads
+    // per 16 k land where the MFMA reads them (fp32, split in registers) or three (PIN: the pieces themselves).  The
+    // split kernels are otherwise LDS-bound: three planes written and read back per operand tile is more LDS time
+    // than the nine products take on the matrix pipe (128x32 tiles: ~1 400 LDS cycles against 1 152 per k-tile and CU).
+    static_assert(!ADIR || (SP && WGN == 1 && !U8 && !MULTI_TAP), "direct operand: split kernels, one wave per row tile");
+    // PIN: the gathered operand arrives as bf16 pieces (GatherDesc::pieces, left by the launch that produced it): the
+    // loader copies three 8-byte chunks per 4 k straight into the LDS planes -- no split, no vector work on this operand
+    static_assert(!PIN || (SP && !U8 && !MULTI_TAP), "pieces: split kernels, one tap per k-tile");
     constexpr int MT = N16 ? 16 : 32;               // rows per MFMA tile
     constexpr int BM = WGM * TM * MT, BN = N16 ? WGN * 16 : WGN * TN * 32, CH = BK / 4;
     constexpr int LDA = BK + 4;
@@ -721,7 +765,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     float* sB = smem + NST * A_SZ;
     // split images (bytes): PA planes of BM x BK bf16 + 3 planes of BK x BN bf16 per stage
     constexpr int PA = U8 ? 1 : 3, ROWB = BK * 2, NS = BK / 8;
-    constexpr int SPA = BM * ROWB, SPB = BN * ROWB, STAGE = PA * SPA + 3 * SPB;
+    constexpr int LPA = ADIR ? 0 : PA;              // planes of the gathered operand that live in LDS
+    constexpr int SPA = BM * ROWB, SPB = BN * ROWB, STAGE = LPA * SPA + 3 * SPB;
     char* const sS = reinterpret_cast<char*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -747,6 +792,13 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     const __amdgpu_buffer_rsrc_t rsA = U8 ? make_rsrc(reinterpret_cast<const float*>(g.src8), g.src_bytes)
                                           : make_rsrc(g.src + g.origin, g.src_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
+    __amdgpu_buffer_rsrc_t rsP[3];                  // PIN: the same window, two bytes per element, in every piece tensor
+    if constexpr (PIN) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            rsP[c] = make_rsrc(reinterpret_cast<const float*>(g.pieces + c * g.piece_bytes + 2 * (long long)g.origin),
+                               g.src_bytes >> 1);
+    }
 
     // ---- per-thread constants -------------------------------------------------------------
     const int a_chunk = tid % CH, a_row0 = tid / CH;
@@ -754,8 +806,21 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     int tpt = 0, chl = a_chunk * 4;                 // tap within the tile / channel within the tap
     if (MULTI_TAP) { tpt = chl / Cs; chl -= tpt * Cs; }
     unsigned voffA[RA], imask[RA], voffB[RB];
+    unsigned voffD[TM], imaskD[TM];                 // ADIR: the lane's own row of each of its wave's row tiles
+    if constexpr (ADIR) {
 #pragma unroll
-    for (int p = 0; p < RA; ++p) {
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 32 + l31;
+            const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
+            const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
+            const int ry = oy * g.mul + g.add_y, rx = ox * g.mul + g.add_x;
+            const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
+            voffD[i] = m < M ? (unsigned)(rbase - g.rmin + half * 8) << 2 : OOB;        // k octet `half` of each 16 k
+            imaskD[i] = HAS_PAD ? tap_mask(ry, rx, g.Hs, Ws, g.taps_y, taps_x, step) : 0;
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < (ADIR ? 0 : RA); ++p) {
         const int m = m0 + a_row0 + p * ROWS_PER_PASS;
         const bool row_ok = m < M && (BM % ROWS_PER_PASS == 0 || a_row0 + p * ROWS_PER_PASS < BM);
         const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
@@ -818,8 +883,61 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     constexpr int NR = SP ? 2 : 1;
     float4 va_[NR][RA], vb_[NR][RB];
     unsigned va8_[NR][RA];
+    u32x2 vp_[NR][RA][3];
+    // ADIR: the gathered operand runs ONE tile ahead of the MFMAs (tap state tyA / txA / ch0A), the weights two (through
+    // LDS, as above).  fd_[s]: the pieces of tile j, j = s (mod 2) counted so that the last tile is set 1, in fragment
+    // layout [row tile][16-k step][piece]; rd_: the fp32 tile in flight, split into fd_ at the end of the tile before.
+    constexpr int DST = BK / 16;
+    int tyA = ty, txA = tx, ch0A = ch0;
+    float4 rd_[TM][DST][2];
+    u32x4 fd_[2][TM][DST][3];
+    auto issue_A = [&](auto rs_c) {
+        constexpr int rs = decltype(rs_c)::value;
+        const unsigned soffA = (unsigned)(step * (tyA * Ws + txA) * Cs + ch0A - g.dmin) << 2;
+        const int bit = tyA * taps_x + txA;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const unsigned off = HAS_PAD ? mask_off(imaskD[i], bit, voffD[i]) : voffD[i];
+#pragma unroll
+            for (int ks = 0; ks < DST; ++ks) {
+                if constexpr (PIN) {                // (every out-of-range marker stays out of range: OOB / 2 + 32 > any tensor)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) fd_[rs][i][ks][c] = buf_ld4u(rsP[c], (off >> 1) + ks * 32, soffA >> 1);
+                } else {
+                    rd_[i][ks][0] = buf_ld4s(rsA, off + ks * 64, soffA);
+                    rd_[i][ks][1] = buf_ld4s(rsA, off + ks * 64 + 16, soffA);
+                }
+            }
+        }
+    };
+    auto next_tile_A = [&]() {
+        ch0A += BK;
+        if (ch0A >= Cs) {
+            ch0A = 0;
+            if (++txA >= taps_x) { txA = 0; ++tyA; }
+        }
+    };
+    auto split_A = [&](auto rs_c) {                 // rd_ -> fd_[rs] (nothing to do when the pieces were loaded)
+        constexpr int rs = decltype(rs_c)::value;
+        if constexpr (!PIN) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int ks = 0; ks < DST; ++ks) {
+                    const float4 q0 = rd_[i][ks][0], q1 = rd_[i][ks][1];
+                    unsigned h[4], m[4], l[4];
+                    split_pair(q0.x, q0.y, h[0], m[0], l[0]);
+                    split_pair(q0.z, q0.w, h[1], m[1], l[1]);
+                    split_pair(q1.x, q1.y, h[2], m[2], l[2]);
+                    split_pair(q1.z, q1.w, h[3], m[3], l[3]);
+                    fd_[rs][i][ks][0] = u32x4{h[0], h[1], h[2], h[3]};
+                    fd_[rs][i][ks][1] = u32x4{m[0], m[1], m[2], m[3]};
+                    fd_[rs][i][ks][2] = u32x4{l[0], l[1], l[2], l[3]};
+                }
+        }
+    };
     auto issue_loads = [&](int kk, int rs = 0) {    // tile starting at reduction index kk, tap state (ty, tx, ch0)
-        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs];
+        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs]; auto& vp = vp_[rs];
         if constexpr (U8) {
             const unsigned soffA = (unsigned)(ch0 * g.plane + ty * Ws);
 #pragma unroll
@@ -834,8 +952,15 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         else soffB = (unsigned)(ch0 * a.b.ld + ((w_i0 + a.b.si * ty) * a.b.kw + (w_j0 + a.b.si * tx)) * a.b.c) << 2;
         const int bit = ty * taps_x + tx;
 #pragma unroll
-        for (int p = 0; p < RA; ++p)
-            va[p] = buf_ld4s(rsA, HAS_PAD ? mask_off(imask[p], bit, voffA[p]) : voffA[p], soffA);
+        for (int p = 0; p < (ADIR ? 0 : RA); ++p) {
+            const unsigned off = HAS_PAD ? mask_off(imask[p], bit, voffA[p]) : voffA[p];
+            if constexpr (PIN) {                    // (OOB >> 1 is still beyond every tensor)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) vp[p][c] = buf_ld2s(rsP[c], off >> 1, soffA >> 1);
+            } else {
+                va[p] = buf_ld4s(rsA, off, soffA);
+            }
+        }
 #pragma unroll
         for (int p = 0; p < RB; ++p) vb[p] = buf_ld4s(rsB, voffB[p], soffB);
     };
@@ -857,14 +982,17 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         }
     };
     auto store_tiles = [&](int buf, int rs = 0) {
-        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs];
+        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs]; auto& vp = vp_[rs];
         if constexpr (SP) {
             char* dS = sS + buf * STAGE;
 #pragma unroll
-            for (int p = 0; p < RA; ++p) {
+            for (int p = 0; p < (ADIR ? 0 : RA); ++p) {
                 if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
                 char* d = dS + kc_write_off(a_row0 + p * ROWS_PER_PASS, a_chunk);
-                if constexpr (U8) {                 // 0 .. 255 is exact in bf16: one plane
+                if constexpr (PIN) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x2*>(d + c * SPA) = vp[p][c];
+                } else if constexpr (U8) {                 // 0 .. 255 is exact in bf16: one plane
                     const float4 f = bytes_to_f4(va8[p]);
                     *reinterpret_cast<uint2*>(d) = make_uint2(hi_pair(f.x, f.y), hi_pair(f.z, f.w));
                 } else {
@@ -876,7 +1004,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                     *reinterpret_cast<uint2*>(d + 2 * SPA) = l;
                 }
             }
-            char* dB = dS + PA * SPA;
+            char* dB = dS + LPA * SPA;
             if constexpr (B_KC) {
 #pragma unroll
                 for (int p = 0; p < RB; ++p) {
@@ -1003,7 +1131,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         if constexpr (SP) {
             // a lane's fragment = row l31 (of its 32-row tile), k octet 2 ks + half: one 16-byte slot per plane
             const char* cA = sS + buf * STAGE + (wm * TM * 32) * ROWB + l31 * ROWB;
-            const char* cB = sS + buf * STAGE + PA * SPA + (B_KC ? (wn * TN * 32) * ROWB + l31 * ROWB
+            const char* cB = sS + buf * STAGE + LPA * SPA + (B_KC ? (wn * TN * 32) * ROWB + l31 * ROWB
                                                                   : (half * 4 * BN + wn * TN * 32 + l31) * 4);
             const int swz = kc_swz<NS>(l31);
 #pragma unroll
@@ -1013,8 +1141,10 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < PA; ++pl)
-                        fa[i][pl] = *reinterpret_cast<const u32x4*>(cA + pl * SPA + i * 32 * ROWB + slot);
+                    for (int pl = 0; pl < PA; ++pl) {
+                        if constexpr (ADIR) fa[i][pl] = fd_[buf][i][ks][pl];
+                        else fa[i][pl] = *reinterpret_cast<const u32x4*>(cA + pl * SPA + i * 32 * ROWB + slot);
+                    }
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -1123,13 +1253,17 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     } else if constexpr (SP) {
         // tile j: register set and LDS stage (j + nk) & 1 (the loop ends on stage 1)
         if (nk & 1) {                                   // uniform
+            if constexpr (ADIR) issue_A(C1{});
             issue_loads(kbeg, 1);
             if (nk > 1) { next_tile(); issue_loads(kbeg + BK, 0); }
             store_tiles(1, 1);
+            if constexpr (ADIR) split_A(C1{});
         } else {
+            if constexpr (ADIR) issue_A(C0{});
             issue_loads(kbeg, 0);
             next_tile(); issue_loads(kbeg + BK, 1);
             store_tiles(0, 0);
+            if constexpr (ADIR) split_A(C0{});
         }
         __syncthreads();
         if (a.trace) tr1 = __builtin_readcyclecounter();
@@ -1139,7 +1273,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         // the LDS stores out between the MFMAs, where they cost nothing (tools/mfma_bf16_mix.hip: 4-6 per MFMA are free).
         constexpr int NPROD = PA == 1 ? 3 : SPLIT;
         constexpr int NM = TM * TN * NPROD * STEPS;                                     // MFMAs per k-tile and wave
-        constexpr int NV = RA * (U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44);       // the split's vector instructions
+        constexpr int NV = RA * (PIN ? 0 : U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44);   // the split's vector instructions
         constexpr int NW = RA * PA + (B_KC ? RB * 3 : (RB / 2) * 3);                    // its LDS stores
         constexpr int VPM = (NV + NM - 1) / NM < 6 ? (NV + NM - 1) / NM : 6;
         constexpr int WEV = NM / NW > 0 ? NM / NW : 1;
@@ -1148,6 +1282,16 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             if (kt + 2 < nk) {                          // uniform: tile kt + 2 -> the set tile kt has left
                 next_tile();
                 issue_loads(kbeg + (kt + 2) * BK, buf);
+            }
+            if constexpr (ADIR) {                       // tile kt + 1 of the direct operand
+                next_tile_A();
+                issue_A(std::integral_constant<int, (buf ^ 1)>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_steps(buf_c, C0{}, CS_{});
+                store_tiles(buf ^ 1, buf ^ 1);
+                split_A(std::integral_constant<int, (buf ^ 1)>{});
+                __syncthreads();
+                return;
             }
             __builtin_amdgcn_sched_barrier(0);
             mfma_steps(buf_c, C0{}, CS_{});
@@ -1234,7 +1378,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             }
         } else {
             store_tiles_quads<TM, TN, U8>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu,
-                                          PRE_MASK ? mk_pre : nullptr, g.scale);
+                                          PRE_MASK ? mk_pre : nullptr, g.scale, SP ? a.o.pieces : nullptr,
+                                          a.o.piece_bytes, a.o.out_bytes);
         }
     }
     if (a.trace && tid == 0) {
@@ -1260,7 +1405,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
 
 // bf16-split products (igemm_body, SPLIT): MINW waves per SIMD; the co-run of arl_conv_corun_update as in igemm_occ_kernel
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool U8, int SPLIT, int MINW,
-          bool CORUN = false>
+          bool CORUN = false, bool PIN = false, bool ADIR = false>
 __global__ __launch_bounds__(256, MINW) void igemm_split_kernel(const GemmArgs a, const arl::OptSeg c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int bx = blockIdx.x;
@@ -1274,7 +1419,7 @@ __global__ __launch_bounds__(256, MINW) void igemm_split_kernel(const GemmArgs a
         }
         bx -= c.co_blocks;
     }
-    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, false, U8, false, SPLIT>(a, bx, blockIdx.y, blockIdx.z, smem);
+    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, false, U8, false, SPLIT, PIN, ADIR>(a, bx, blockIdx.y, blockIdx.z, smem);
 }
 
 // ==========================================================================================
@@ -2047,14 +2192,15 @@ __global__ __launch_bounds__(256, MINW) void wgrad_split_kernel(const WgradArgs 
 // One launch for a layer's data gradient AND weight gradient (independent of each other, both read dy):
 // workgroups [0, n_ig) run data-gradient tiles, the rest weight-gradient tiles.  One ramp-up and one
 // tail instead of two, and the dispatcher fills the CUs the first problem's last wave leaves idle.
-template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK, bool HAS_PAD, int SPLIT = 0>
+template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK, bool HAS_PAD, int SPLIT = 0,
+          bool PIN = false>
 __global__ __launch_bounds__(256) void bwd_pair_kernel(const GemmArgs a, const WgradArgs w, const int dgx, const int dgy,
                                                        const int n_ig, const int wgx, const int wgy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int id = blockIdx.x;
     if (id < n_ig) {
         const int bx = id % dgx, t = id / dgx;
-        igemm_body<DWGM, DWGN, DTM, DTN, BK, false, false, HAS_PAD, false, false, false, SPLIT>(a, bx, t % dgy, t / dgy, smem);
+        igemm_body<DWGM, DWGN, DTM, DTN, BK, false, false, HAS_PAD, false, false, false, SPLIT, PIN>(a, bx, t % dgy, t / dgy, smem);
     } else {
         id -= n_ig;
         const int bx = id % wgx, t = id / wgx;
@@ -2247,6 +2393,29 @@ int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_
 
 // arl_conv_precision: 0 = fp32 MFMA chain, 6 / 9 = bf16-split products (see igemm_body, SPLIT)
 int g_split = 9;
+#ifdef ARL_NO_SPLIT6        // development builds: half the split kernels (mode 6 then runs the nine-product kernels)
+#define ARL_BY_MODE(X6, X9) do { X9; } while (0)
+#else
+#define ARL_BY_MODE(X6, X9) do { if (g_split == 6) { X6; } else { X9; } } while (0)
+#endif
+
+// arl_conv_pieces: the bf16 pieces the NEXT forward / data-gradient launch reads its gathered operand from, and leaves
+// of its output (consumed -- cleared -- by that launch)
+struct Pieces { const void* in; void* out; };
+Pieces g_pieces = {nullptr, nullptr};
+Pieces grab_pieces() { const Pieces p = g_pieces; g_pieces = {nullptr, nullptr}; return p; }
+// caps bits (arl_conv_pieces_supported)
+constexpr int PIECES_IN = 1, PIECES_OUT = 2;
+// hand the pending pieces to a launch whose route has the capabilities `caps`; anything pending beyond them is refused
+int put_pieces(GemmArgs& a, const Pieces& pc, int caps, int64_t in_elems, int64_t out_elems) {
+    ARL_REQUIRE(!pc.in || (caps & PIECES_IN), ARL_E_ARG, "bf16 pieces of the input pending on a route that cannot read them (arl_conv_pieces_supported)");
+    ARL_REQUIRE(!pc.out || (caps & PIECES_OUT), ARL_E_ARG, "bf16 pieces of the output requested on a route that cannot write them (arl_conv_pieces_supported)");
+    ARL_REQUIRE((!pc.in || in_elems % 8 == 0) && (!pc.out || out_elems % 8 == 0), ARL_E_ALIGN,
+                "bf16 pieces: element count not a multiple of 8");
+    a.g.pieces = (const char*)pc.in; a.g.piece_bytes = in_elems * 2;
+    a.o.pieces = (char*)pc.out; a.o.piece_bytes = out_elems * 2;
+    return 0;
+}
 
 // the launch of igemm_split_kernel: two LDS stages of (1 or 3) + 3 bf16 planes; a data gradient hosts the pending
 // optimiser job like launch_igemm_occ
@@ -2254,19 +2423,36 @@ template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool U8, int MINW
 int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s, int splits = 1) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
     const size_t lds = (size_t)2 * ((U8 ? 1 : 3) * BM + 3 * BN) * BK * 2;
+    const size_t lds_dir = (size_t)2 * 3 * BN * BK * 2;         // direct gathered operand: only the weights live in LDS
+    (void)lds_dir;
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
     arl::OptSeg c = {};
     int rc = 0;
-#define ARL_SPLIT_K(MT, HP, SPL, CO)                                                                       \
+#define ARL_SPLIT_K(MT, HP, SPL, CO, PI, AD)                                                               \
     do {                                                                                                   \
-        auto k = igemm_split_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, U8, SPL, MINW, CO>;                \
-        rc = allow_big_lds(k, lds + (CO ? 64 : 0));                                                        \
-        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a, c);                                     \
+        auto k = igemm_split_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, U8, SPL, MINW, CO, PI, AD>;        \
+        const size_t lds_k = (AD) ? lds_dir : lds;                                                         \
+        rc = allow_big_lds(k, lds_k + (CO ? 64 : 0));                                                      \
+        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds_k, s, a, c);                                   \
+    } while (0)
+#define ARL_SPLIT_PIN(MT, HP, SPL, CO)                                                                     \
+    do {                                                                                                   \
+        if constexpr (!(MT) && !U8 && WGN == 1) {           /* the gathered operand straight into registers */ \
+            if (g_tile_choice != 3) {                                                                      \
+                if (a.g.pieces) ARL_SPLIT_K(MT, HP, SPL, CO, true, true); else ARL_SPLIT_K(MT, HP, SPL, CO, false, true); \
+                break;                                                                                     \
+            }                                                                                              \
+        }                                                                                                  \
+        if constexpr (!(MT) && !U8) {                                                                      \
+            if (a.g.pieces) { ARL_SPLIT_K(MT, HP, SPL, CO, true, false); break; }                          \
+        }                                                                                                  \
+        ARL_SPLIT_K(MT, HP, SPL, CO, false, false);                                                        \
     } while (0)
 #define ARL_SPLIT_MODE(MT, HP, CO)                                                                         \
     do {                                                                                                   \
-        if (g_split == 6) ARL_SPLIT_K(MT, HP, 6, CO); else ARL_SPLIT_K(MT, HP, 9, CO);                     \
+        ARL_BY_MODE(ARL_SPLIT_PIN(MT, HP, 6, CO), ARL_SPLIT_PIN(MT, HP, 9, CO));                           \
     } while (0)
+    if ((multi_tap || U8) && a.g.pieces) { arl::set_error("bf16 pieces on a kernel that cannot read them"); return ARL_E_ARG; }
     if constexpr (U8) {
         ARL_SPLIT_MODE(false, false, false);
     } else {
@@ -2285,6 +2471,7 @@ int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStrea
         else if (has_pad) ARL_SPLIT_MODE(false, true, false);
         else ARL_SPLIT_MODE(false, false, false);
     }
+#undef ARL_SPLIT_PIN
 #undef ARL_SPLIT_MODE
 #undef ARL_SPLIT_K
     return rc ? rc : arl::check_launch("igemm_split_kernel");
@@ -2357,11 +2544,11 @@ int launch_wgrad_split(const WgradArgs& a, int splits, bool has_pad, hipStream_t
         if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
     } while (0)
     if constexpr (U8) {
-        if (g_split == 6) ARL_WSPLIT(false, 6); else ARL_WSPLIT(false, 9);
+        ARL_BY_MODE(ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
     } else if (has_pad) {
-        if (g_split == 6) ARL_WSPLIT(true, 6); else ARL_WSPLIT(true, 9);
+        ARL_BY_MODE(ARL_WSPLIT(true, 6), ARL_WSPLIT(true, 9));
     } else {
-        if (g_split == 6) ARL_WSPLIT(false, 6); else ARL_WSPLIT(false, 9);
+        ARL_BY_MODE(ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
     }
 #undef ARL_WSPLIT
     return rc ? rc : arl::check_launch("wgrad_split_kernel");
@@ -2462,6 +2649,12 @@ extern "C" int arl_conv_precision(int32_t mode) {
     return 0;
 }
 
+extern "C" int arl_conv_pieces(const void* in_pieces_or_null, void* out_pieces_or_null) {
+    ARL_REQUIRE(arl::aligned16(in_pieces_or_null) && arl::aligned16(out_pieces_or_null), ARL_E_ALIGN, "16-byte alignment");
+    g_pieces = {in_pieces_or_null, out_pieces_or_null};
+    return 0;
+}
+
 extern "C" int arl_conv_corun_update(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
                                      float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
                                      double* norm_parts, int64_t hole_first, int64_t hole_count) {
@@ -2481,14 +2674,18 @@ extern "C" int arl_conv_corun_flush(void* stream) {
     return rc ? (rc > 0 ? -rc : rc) : 1;
 }
 
-extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
-                              const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {
-    ARL_REQUIRE(x && w && y && workspace, ARL_E_ARG, "null pointer");
+namespace {
+// caps_only: report the route's arl_conv_pieces capabilities instead of launching
+int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom, int32_t relu,
+             void* workspace, void* stream, const Pieces& pc, int* caps_only) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
-    ARL_REQUIRE(arl::aligned16(x) && arl::aligned16(w) && arl::aligned16(y) && arl::aligned16(workspace) &&
-                    (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN, "16-byte alignment");
+    if (!caps_only) {
+        ARL_REQUIRE(x && w && y && workspace, ARL_E_ARG, "null pointer");
+        ARL_REQUIRE(arl::aligned16(x) && arl::aligned16(w) && arl::aligned16(y) && arl::aligned16(workspace) &&
+                        (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN, "16-byte alignment");
+    }
     hipStream_t s = (hipStream_t)stream;
     GemmArgs a = {};
     a.g.src = x; a.g.Hs = g.H; a.g.Ws = g.W; a.g.Cs = g.C; a.g.out_h = g.Ho; a.g.out_w = g.Wo;
@@ -2520,6 +2717,11 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
     const bool fast = !g_force_generic && a.K % FBK == 0 && per % FBK == 0 && (single_tap || multi_tap) &&
                       (!has_pad || g.kh * g.kw <= 32) && a.N % 4 == 0;
+    // bf16 pieces ride with the split kernels: read when a k-tile is one tap, written when the launch stores the output
+    const int caps = (fast && g_split && a.N > 16 && !g_trace) ? (multi_tap ? 0 : PIECES_IN) | (splits == 1 ? PIECES_OUT : 0) : 0;
+    if (caps_only) { *caps_only = caps; return 0; }
+    rc = put_pieces(a, pc, caps, g.batch * g.H * g.W * g.C, (int64_t)a.M * a.N);
+    if (rc) return rc;
     if (fast) {
         a.o.out_bytes = (unsigned)((int64_t)a.M * a.N * 4);     // one split's output
         a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
@@ -2554,6 +2756,12 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, bias_or_null, a.N, relu, y, s);
 }
+}  // namespace
+
+extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
+                              const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {
+    return fwd_impl(x, w, bias_or_null, y, geom, relu, workspace, stream, grab_pieces(), nullptr);
+}
 
 namespace {
 // Fast-path launch descriptions, so that a layer's data and weight gradient can share one launch
@@ -2565,17 +2773,19 @@ struct WgradPlan { WgradArgs a; bool fast, has_pad; int cfg, splits; int64_t tot
 // plan_only: describe the fast launch instead of issuing it (fast == false: nothing was done)
 // workspace (optional): lets a dense layer whose output tiles cannot fill the chip split its reduction
 int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float* dx, const arl_conv_geom* geom,
-               DgradPlan* plan_only, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0) {
-    ARL_REQUIRE(dy && w && dx, ARL_E_ARG, "null pointer");
+               DgradPlan* plan_only, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0,
+               const Pieces& pc = Pieces{nullptr, nullptr}, int* caps_only = nullptr) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
+    ARL_REQUIRE(caps_only || (dy && w && dx), ARL_E_ARG, "null pointer");
     ARL_REQUIRE(g.kh % g.stride == 0 && g.kw % g.stride == 0, ARL_E_RANGE,
                 "data gradient needs kernel size divisible by stride");
     ARL_REQUIRE(arl::aligned16(dy) && arl::aligned16(w) && arl::aligned16(dx) &&
                     (!mask_or_null || arl::aligned16(mask_or_null)), ARL_E_ALIGN, "16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     const int st = g.stride;
+    const int64_t in_elems = g.batch * g.Ho * g.Wo * g.K, out_elems = g.batch * g.H * g.W * g.C;
     constexpr int FBK = 32;
     const int taps_y = g.kh / st, taps_x = g.kw / st;
     const bool has_pad = !(g.kh == 1 && g.kw == 1 && g.pad_h == 0 && g.pad_w == 0);
@@ -2635,10 +2845,16 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             plan_only->cfg = a.N <= 32 ? 0 : a.N <= 64 ? 1 : small ? 3 : 2;
             return 0;
         }
+        // bf16 pieces ride with the split kernels (a k-tile never straddles taps here: K % 32 == 0)
+        int caps = (g_split && a.N > 16 && !g_trace) ? PIECES_IN | PIECES_OUT : 0;
         if (small) {
             int splits = 1, per = a.k_per_split;
             if (workspace) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
             if ((int64_t)splits * a.M * a.N * 4 > workspace_bytes) { splits = 1; per = round_up(a.K, BKT); }
+            if (splits > 1) caps &= ~PIECES_OUT;
+            if (caps_only) { *caps_only = caps; return 0; }
+            rc = put_pieces(a, pc, caps, in_elems, out_elems);
+            if (rc) return rc;
             a.k_per_split = per;
             if (splits > 1) {
                 a.o.out = (float*)workspace; a.o.mask = nullptr; a.split_stride = (int64_t)a.M * a.N;
@@ -2648,6 +2864,9 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             if (rc || splits == 1) return rc;
             return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, nullptr, 4, 0, dx, s, mask_or_null);
         }
+        if (caps_only) { *caps_only = caps; return 0; }
+        rc = put_pieces(a, pc, caps, in_elems, out_elems);
+        if (rc) return rc;
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
         else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, false, false, 2>(a, false, has_pad, s);
         else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, false, false, 2>(a, false, has_pad, s);
@@ -2663,6 +2882,8 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         return rc;
     }
     if (plan_only) { plan_only->fast = false; return 0; }
+    if (caps_only) { *caps_only = 0; return 0; }
+    ARL_REQUIRE(!pc.in && !pc.out, ARL_E_ARG, "bf16 pieces pending on the generic data-gradient kernels (arl_conv_pieces_supported)");
     for (int ph = 0; ph < st && ph < g.H; ++ph) {
         for (int pw = 0; pw < st && pw < g.W; ++pw) {
             const GemmArgs a = describe(ph, pw);
@@ -2761,7 +2982,7 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
 
 extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
                                    const arl_conv_geom* geom, void* stream) {
-    return dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream);
+    return dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, nullptr, 0, grab_pieces());
 }
 
 extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
@@ -2850,6 +3071,9 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     a.k_per_split = a.K;                            // K % 16 == 0 by check_u8 (whole filter rows per k-tile)
     a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
     a.trace = g_trace;
+    const bool split_route = a.N > 16 && g_split && g.kh % (8 / (g.kw >> 2)) == 0;
+    rc = put_pieces(a, grab_pieces(), split_route ? PIECES_OUT : 0, 0, (int64_t)a.M * a.N);
+    if (rc) return rc;
     constexpr int BK = 16, BM = 128;
     const dim3 grid((a.M + BM - 1) / BM, 1, 1);
     if (a.N <= 16) {
@@ -2936,15 +3160,20 @@ int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_
     int rc;
     if (g_split) {
         const size_t lds_s = (size_t)2 * 3 * ((DBM + DBN) > (WBM + WBN) ? (DBM + DBN) : (WBM + WBN)) * BK * 2;
-#define ARL_PSPLIT(HP, SPL)                                                                                \
+#define ARL_PSPLIT_K(HP, SPL, PI)                                                                          \
     do {                                                                                                   \
-        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, HP, SPL>;                 \
+        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, HP, SPL, PI>;             \
         rc = allow_big_lds(k, lds_s + 4096);                                                               \
         if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds_s, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy); \
     } while (0)
-        if (has_pad) { if (g_split == 6) ARL_PSPLIT(true, 6); else ARL_PSPLIT(true, 9); }
-        else { if (g_split == 6) ARL_PSPLIT(false, 6); else ARL_PSPLIT(false, 9); }
+#define ARL_PSPLIT(HP, SPL)                                                                                \
+    do {                                                                                                   \
+        if (d.a.g.pieces) ARL_PSPLIT_K(HP, SPL, true); else ARL_PSPLIT_K(HP, SPL, false);                  \
+    } while (0)
+        if (has_pad) ARL_BY_MODE(ARL_PSPLIT(true, 6), ARL_PSPLIT(true, 9));
+        else ARL_BY_MODE(ARL_PSPLIT(false, 6), ARL_PSPLIT(false, 9));
 #undef ARL_PSPLIT
+#undef ARL_PSPLIT_K
     } else if (has_pad) {
         auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, true>;
         rc = allow_big_lds(k, lds + 4096);
@@ -2970,6 +3199,7 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
     int splits = 1;
     int64_t total = 0;
     float* bias_part = nullptr;
+    const Pieces pc = grab_pieces();
     int rc = dgrad_impl(dy, w, mask_or_null, dx, geom, &dp, stream);
     if (rc) return rc;
     rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total,
@@ -2985,12 +3215,15 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
         // the data gradient may split its reduction: it gets the upper half of the workspace (and is folded at
         // once), the weight gradient's deferred partials the lower half
         const int64_t half = (workspace_bytes / 2) & ~(int64_t)15;
-        rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, (char*)workspace + half, workspace_bytes - half);
+        rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, (char*)workspace + half, workspace_bytes - half, pc);
         if (rc) return rc;
         return arl_conv2d_bwd_weight_parts(dy, x, dw, geom, workspace, half, item, dbias_or_null,
                                            bias_item_or_null, stream);
     }
     hipStream_t s = (hipStream_t)stream;
+    rc = put_pieces(dp.a, pc, g_split ? PIECES_IN | PIECES_OUT : 0, (int64_t)geom->batch * dp.a.g.Hs * dp.a.g.Ws * dp.a.g.Cs,
+                    (int64_t)dp.a.M * dp.a.N);
+    if (rc) return rc;
     rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2>(dp, wp, has_pad, s);
     item->part = (const float*)workspace; item->out = dw; item->total = wp.total;
     item->splits = wp.splits > 1 ? wp.splits : 0;
@@ -3018,3 +3251,22 @@ extern "C" int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream
     hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return arl::check_launch("fold_many_kernel");
 }
+
+extern "C" int arl_conv_pieces_supported(const arl_conv_geom* geom, int32_t op) {
+    ARL_REQUIRE(geom && op >= 0 && op <= 2, ARL_E_ARG, "op: 0 forward, 1 data gradient, 2 forward from u8 rows");
+    int caps = 0, rc = 0;
+    const Pieces none = {nullptr, nullptr};
+    if (op == 0) rc = fwd_impl(nullptr, nullptr, nullptr, nullptr, geom, 0, nullptr, nullptr, none, &caps);
+    else if (op == 1) {
+        // (the paired dense launch -- the widest tiles of both gradients -- reads and writes pieces like the plain one;
+        //  a data gradient that would split its reduction when it runs apart is asked as it runs apart)
+        rc = dgrad_impl(nullptr, nullptr, nullptr, nullptr, geom, nullptr, nullptr, reinterpret_cast<void*>(16),
+                        arl_conv_workspace_bytes() / 2, none, &caps);
+    } else {
+        U8Geom g;
+        rc = check_u8(reinterpret_cast<const uint8_t*>(16), geom->batch, geom, &g);
+        if (!rc) caps = (g.K > 16 && g_split && g.kh % (8 / (g.kw >> 2)) == 0) ? PIECES_OUT : 0;
+    }
+    return rc ? (rc < 0 ? rc : -rc) : caps;
+}
+

@@ -393,6 +393,27 @@ void arl_conv_persistent(int32_t workgroups_per_cu);
  * Returns ARL_E_ARG for any other value.  Not thread-safe. */
 int arl_conv_precision(int32_t mode);
 
+/* bf16 pieces of activations travel between the bf16-split kernels (arl_conv_precision 6 / 9), so that a tensor is
+ * split ONCE, by the launch that produces it, instead of by every workgroup and filter tap that gathers it
+ * (a conv 3 input element is otherwise split nine times; the split is 5.5 vector instructions per element, taken
+ * from the issue slots of the matrix instructions).  A pieces tensor of an fp32 tensor t of n elements is
+ * 3 n bf16 = 6 n bytes: piece q of element e at byte q * 2 n + 2 e, with t[e] == piece0 + piece1 + piece2 exactly
+ * (piece0 = the top 16 bits of t[e], piece1 = the top 16 bits of t[e] - piece0, piece2 the rest).
+ * arl_conv_pieces hands two such tensors to the NEXT arl_conv2d_fwd / arl_conv2d_u8_fwd / arl_conv2d_bwd_data /
+ * arl_conv2d_bwd_pair call on this thread's library state, which consumes (clears) them:
+ *   in_pieces   pieces of that call's gathered operand (x of a forward call, dy of a data gradient), written by
+ *               the call that produced that tensor; the fp32 tensor is then not read.  NULL: split in the kernel.
+ *   out_pieces  where that call leaves the pieces of its output (y, dx) next to the fp32 output.  NULL: none.
+ * Results are bit-identical with and without pieces (same pieces, same products, same order).
+ * A call whose route cannot honour a pending pointer fails with ARL_E_ARG and launches nothing: ask
+ * arl_conv_pieces_supported first.  n % 8 == 0; 16-byte aligned (else ARL_E_ALIGN).  Not thread-safe. */
+int arl_conv_pieces(const void* in_pieces_or_null, void* out_pieces_or_null);
+
+/* What the route of a geometry can do under the current arl_conv_precision / tile settings: bit 0 = read in_pieces,
+ * bit 1 = write out_pieces (>= 0), or a negative ARL_E_* for a bad geometry.  op: 0 = arl_conv2d_fwd,
+ * 1 = arl_conv2d_bwd_data / the data-gradient half of arl_conv2d_bwd_pair, 2 = arl_conv2d_u8_fwd. */
+int arl_conv_pieces_supported(const arl_conv_geom* geom, int32_t op);
+
 /* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
  * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,
  * policies/layers.py:22-41; the reference's flipped filters are stored pre-flipped).
