@@ -465,6 +465,7 @@ struct WgradArgs {
     int m_per_split;        // multiple of BK
     int adv_b, adv_y, adv_x;    // fast path: 256 rows = adv_b images + adv_y output rows + adv_x pixels
     float* bias_part;       // fast path: [splits][K_out] column sums of dy (the bias gradient's partials), or null
+    unsigned long long* trace;  // tuning aid (arl_conv_trace_buffer): per-workgroup timestamps as in GemmArgs, or null
 };
 
 template <int WGM, int WGN, int TM, int TN, int BK>
@@ -742,7 +743,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     // per 16 k land where the MFMA reads them (fp32, split in registers) or three (PIN: the pieces themselves).  The
     // split kernels are otherwise LDS-bound: three planes written and read back per operand tile is more LDS time
     // than the nine products take on the matrix pipe (128x32 tiles: ~1 400 LDS cycles against 1 152 per k-tile and CU).
-    static_assert(!ADIR || (SP && WGN == 1 && !U8 && !MULTI_TAP), "direct operand: split kernels, one wave per row tile");
+    static_assert(!ADIR || (SP && WGN == 1 && !MULTI_TAP && !(U8 && PIN)), "direct operand: split kernels, one wave per row tile");
     // PIN: the gathered operand arrives as bf16 pieces (GatherDesc::pieces, left by the launch that produced it): the
     // loader copies three 8-byte chunks per 4 k straight into the LDS planes -- no split, no vector work on this operand
     static_assert(!PIN || (SP && !U8 && !MULTI_TAP), "pieces: split kernels, one tap per k-tile");
@@ -807,6 +808,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     if (MULTI_TAP) { tpt = chl / Cs; chl -= tpt * Cs; }
     unsigned voffA[RA], imask[RA], voffB[RB];
     unsigned voffD[TM], imaskD[TM];                 // ADIR: the lane's own row of each of its wave's row tiles
+    unsigned voffD8[TM][BK / 16][2];                // ... U8: the two 4-pixel chunks of the lane's k octet of every 16-k step
     if constexpr (ADIR) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -817,6 +819,16 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
             voffD[i] = m < M ? (unsigned)(rbase - g.rmin + half * 8) << 2 : OOB;        // k octet `half` of each 16 k
             imaskD[i] = HAS_PAD ? tap_mask(ry, rx, g.Hs, Ws, g.taps_y, taps_x, step) : 0;
+            if constexpr (U8) {                     // chunk c of the k-tile = filter row c / cpr8 (of the tile), pixels 4 (c % cpr8) ..
+                const int row = (m < M && g.idx) ? g.idx[b] : b;
+#pragma unroll
+                for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int c = 2 * (2 * ks + half) + j, tyl = c / cpr8, txq = c - tyl * cpr8;
+                        voffD8[i][ks][j] = m < M ? (unsigned)(row * g.img_bytes + (ry + tyl) * Ws + rx + 4 * txq) : OOB;
+                    }
+            }
         }
     }
 #pragma unroll
@@ -890,9 +902,21 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     constexpr int DST = BK / 16;
     int tyA = ty, txA = tx, ch0A = ch0;
     float4 rd_[TM][DST][2];
+    unsigned rd8_[TM][DST][2];
     u32x4 fd_[2][TM][DST][3];
     auto issue_A = [&](auto rs_c) {
         constexpr int rs = decltype(rs_c)::value;
+        if constexpr (U8) {
+            const unsigned soff8 = (unsigned)(ch0A * g.plane + tyA * Ws);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int ks = 0; ks < DST; ++ks) {
+                    rd8_[i][ks][0] = buf_ld1s(rsA, voffD8[i][ks][0], soff8);
+                    rd8_[i][ks][1] = buf_ld1s(rsA, voffD8[i][ks][1], soff8);
+                }
+            return;
+        }
         const unsigned soffA = (unsigned)(step * (tyA * Ws + txA) * Cs + ch0A - g.dmin) << 2;
         const int bit = tyA * taps_x + txA;
 #pragma unroll
@@ -911,6 +935,11 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         }
     };
     auto next_tile_A = [&]() {
+        if constexpr (U8) {
+            tyA += rpt8;
+            if (tyA >= g.kh8) { tyA = 0; ++ch0A; }
+            return;
+        }
         ch0A += BK;
         if (ch0A >= Cs) {
             ch0A = 0;
@@ -919,7 +948,15 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     };
     auto split_A = [&](auto rs_c) {                 // rd_ -> fd_[rs] (nothing to do when the pieces were loaded)
         constexpr int rs = decltype(rs_c)::value;
-        if constexpr (!PIN) {
+        if constexpr (U8) {                         // 0 .. 255 is exact in bf16: one piece
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int ks = 0; ks < DST; ++ks) {
+                    const float4 f0 = bytes_to_f4(rd8_[i][ks][0]), f1 = bytes_to_f4(rd8_[i][ks][1]);
+                    fd_[rs][i][ks][0] = u32x4{hi_pair(f0.x, f0.y), hi_pair(f0.z, f0.w), hi_pair(f1.x, f1.y), hi_pair(f1.z, f1.w)};
+                }
+        } else if constexpr (!PIN) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -941,7 +978,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         if constexpr (U8) {
             const unsigned soffA = (unsigned)(ch0 * g.plane + ty * Ws);
 #pragma unroll
-            for (int p = 0; p < RA; ++p) va8[p] = buf_ld1s(rsA, voffA[p], soffA);
+            for (int p = 0; p < (ADIR ? 0 : RA); ++p) va8[p] = buf_ld1s(rsA, voffA[p], soffA);
 #pragma unroll
             for (int p = 0; p < RB; ++p) vb[p] = buf_ld4s(rsB, voffB[p], (unsigned)kk << 2);
             return;
@@ -1857,6 +1894,8 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     __shared__ uint2 s_row[2][WG_ROWS];     // per gathered row: byte offset of its tap origin, inverted tap mask
     float* sA = smem;
     float* sB = smem + 2 * A_SZ;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
+    if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -2035,6 +2074,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     issue_loads(0);
     store_tiles(nk & 1, true);                      // first tile's buffer chosen so that the loop ends on buffer 1
     __syncthreads();
+    if (a.trace) tr1 = __builtin_readcyclecounter();
     // one k-tile with a compile-time buffer index (as in igemm_body: no vector address math between MFMAs)
     auto k_tile = [&](auto buf_c, int kt) {
         constexpr int buf = decltype(buf_c)::value;
@@ -2120,6 +2160,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
             k_tile(std::integral_constant<int, 1>{}, kt + 1);
         }
     }
+    if (a.trace) tr2 = __builtin_readcyclecounter();
     if (do_bias) __syncthreads();                   // every wave is done with the tile buffers
     if (do_bias) {                                  // [BK][MC4] float4 in the (now idle) A buffer, summed in row order
         float4* red = reinterpret_cast<float4*>(sA);
@@ -2166,6 +2207,13 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
                     for (int v = 0; v < 16; ++v) acc[i][j][v] *= a.g.scale;
         }
         store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
+    }
+    if (a.trace && tid == 0) {                      // (plain launches only: the slot is the workgroup's grid index)
+        unsigned long long* t = a.trace + ((size_t)(bz * gridDim.y + by) * gridDim.x + bx) * 8;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_readcyclecounter();
+        t[4] = rt0; t[5] = __builtin_amdgcn_s_memrealtime();
+        t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+        t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
     }
 }
 
@@ -2442,6 +2490,9 @@ int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStrea
                 if (a.g.pieces) ARL_SPLIT_K(MT, HP, SPL, CO, true, true); else ARL_SPLIT_K(MT, HP, SPL, CO, false, true); \
                 break;                                                                                     \
             }                                                                                              \
+        }                                                                                                  \
+        if constexpr (U8 && WGN == 1) {                                                                    \
+            if (g_tile_choice != 3) { ARL_SPLIT_K(MT, HP, SPL, CO, false, true); break; }                  \
         }                                                                                                  \
         if constexpr (!(MT) && !U8) {                                                                      \
             if (a.g.pieces) { ARL_SPLIT_K(MT, HP, SPL, CO, true, false); break; }                          \
@@ -2917,6 +2968,7 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
     a.K_out = g.K; a.N = g.kh * g.kw * g.C; a.Mred = (int)(g.batch * g.Ho * g.Wo);
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
+    a.trace = g_trace;
     int bm, bn;
     if (g.K <= 16) { bm = 16; bn = 128; }
     else if (g.K <= 32) { bm = 32; bn = 128; }
@@ -3117,6 +3169,7 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     fill_u8(&a.g, obs, obs_rows, idx_or_null, scale, g);
     a.K_out = g.K; a.N = g.C * g.kh * g.kw; a.Mred = (int)(g.batch * g.Ho * g.Wo);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
+    a.trace = g_trace;
     const int bm = g.K <= 16 ? 16 : 32, bn = 128;
     const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     int splits, per;
@@ -3147,9 +3200,8 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
 }
 
 namespace {
-template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN>
+template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK = 32>
 int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_t s) {
-    constexpr int BK = 32;
     constexpr int DBM = DWGM * DTM * 32, DBN = DWGN * DTN * 32, WBM = WWGM * WTM * 32, WBN = WWGN * WTN * 32;
     const size_t lds_d = (size_t)2 * (DBM * (BK + 4) + BK * DBN) * sizeof(float);
     const size_t lds_w = (size_t)2 * BK * (WBM + WBN) * sizeof(float);
@@ -3224,7 +3276,11 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
     rc = put_pieces(dp.a, pc, g_split ? PIECES_IN | PIECES_OUT : 0, (int64_t)geom->batch * dp.a.g.Hs * dp.a.g.Ws * dp.a.g.Cs,
                     (int64_t)dp.a.M * dp.a.N);
     if (rc) return rc;
-    rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2>(dp, wp, has_pad, s);
+    // split kernels: 16-deep k-tiles halve the LDS images (98 -> 49 KB), so that TWO workgroups share a CU and one's
+    // loads / splits / LDS stores run under the other's MFMAs (one 128x128 workgroup alone keeps the matrix pipe ~50 %
+    // busy): the dense pair of the PPO minibatch 89.4 -> 71.9 us, bit-identical
+    if (g_split && g_tile_choice != 6) rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2, 16>(dp, wp, has_pad, s);
+    else rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2>(dp, wp, has_pad, s);
     item->part = (const float*)workspace; item->out = dw; item->total = wp.total;
     item->splits = wp.splits > 1 ? wp.splits : 0;
     item->valid = 0;

@@ -14,6 +14,7 @@ DEV = "cuda:0"
 
 def main():
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    op = sys.argv[2] if len(sys.argv) > 2 else "fwd"          # fwd | wgrad | dgrad
     layers = [("conv1", 104, 80, 4, 32, 8, 4, 0), ("conv2", 25, 19, 32, 64, 4, 2, 1),
               ("conv3", 12, 9, 64, 64, 3, 1, 1), ("dense", 1, 1, 6912, 512, 1, 1, 0)]
     ws = _lib.conv_workspace(DEV)
@@ -25,12 +26,23 @@ def main():
         wt = torch.randn(k, ks, ks, c, device=DEV) * 0.05
         bias = torch.randn(k, device=DEV)
         y = torch.empty(b, ho, wo, k, device=DEV)
+        dy, dw, dx = torch.randn_like(y), torch.empty_like(wt), torch.empty_like(x)
+        if op == "dgrad" and name == "conv1":
+            continue
+
+        def launch():
+            if op == "fwd":
+                _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+            elif op == "wgrad":
+                _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+            else:
+                _lib.conv2d_bwd_data(dy, wt, x, dx, geom)
         for _ in range(3):
-            _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+            launch()
         torch.cuda.synchronize()
         tr = torch.zeros(8192 * 8, dtype=torch.int64, device=DEV)
         lib.arl_conv_trace_buffer(tr.data_ptr())
-        _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+        launch()
         torch.cuda.synchronize()
         lib.arl_conv_trace_buffer(None)
         t = tr.cpu().numpy().reshape(-1, 8)
@@ -57,9 +69,9 @@ def main():
             cur, last = cur + d, x
         in_loop = area / float(end.max()) / len(per_cu)
         hist = collections.Counter(per_cu.values())
-        print("%s fwd: %d WGs, wall %.1f us, counter/wall = %.2f ticks/ns; start skew p50/max %d/%d; prologue p50 %d, "
+        print("%s %s: %d WGs, wall %.1f us, counter/wall = %.2f ticks/ns; start skew p50/max %d/%d; prologue p50 %d, "
               "loop p50/max %d/%d, epilogue p50 %d, end max %d; CUs used %d, WGs/CU histogram %s" %
-              (name, n, real, clk, np.median(start), start.max(), np.median(pro), np.median(loop), loop.max(),
+              (name, op, n, real, clk, np.median(start), start.max(), np.median(pro), np.median(loop), loop.max(),
                np.median(epi), end.max(), len(per_cu), dict(sorted(hist.items()))))
         rs, re = (t[:, 4] - t[:, 4].min()) / 100.0, (t[:, 5] - t[:, 4].min()) / 100.0      # us, the GPU-wide 100 MHz clock
         wg_clk = np.median((t[:, 3] - t[:, 0]) / np.maximum(t[:, 5] - t[:, 4], 1) / 10.0)

@@ -10,8 +10,9 @@ import torch.nn.functional as F
 from accel_rl_amd import _lib
 
 DEV = "cuda:0"
+MODES = tuple(int(m) for m in os.environ.get("ARL_MODES", "0,6,9").split(","))
 LAYERS = [("conv1", 104, 80, 4, 32, 8, 4, 0), ("conv2", 25, 19, 32, 64, 4, 2, 1),
-          ("conv3", 12, 9, 64, 64, 3, 1, 1), ("dense", 1, 1, 3456, 512, 1, 1, 0)]
+          ("conv3", 12, 9, 64, 64, 3, 1, 1), ("dense", 1, 1, 6912, 512, 1, 1, 0)]
 
 
 def ev(fn, reps=20, warm=3):
@@ -34,6 +35,7 @@ def err(got, want):
 
 def run(b, timing):
     lib = _lib.load()
+    lib.arl_conv_tile_choice(int(os.environ.get("ARL_TILE_CHOICE", "0")))
     ws = _lib.conv_workspace(DEV)
     gen = torch.Generator(device=DEV).manual_seed(3)
     for name, h, w, c, k, ks, st, p in LAYERS:
@@ -59,7 +61,7 @@ def run(b, timing):
                 out8 = F.conv2d(o8r, w8r, None, stride=st)
                 ref["u8fwd"] = (out8 + bias.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).detach()
                 ref["u8wgrad"] = torch.autograd.grad(out8, w8r, dyd)[0]
-        for mode in (0, 6, 9):
+        for mode in MODES:
             assert lib.arl_conv_precision(mode) == 0
             ops = dict(fwd=lambda: _lib.conv2d_fwd(x, wt, bias, y, geom, False, ws),
                        dgrad=lambda: _lib.conv2d_bwd_data(dy, wt, None, dx, geom),
