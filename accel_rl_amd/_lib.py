@@ -109,6 +109,7 @@ _SIGNATURES = {
     "arl_conv_tile_choice": (None, [_i32]),
     "arl_conv_persistent": (None, [_i32]),
     "arl_conv_precision": (_i32, [_i32]),
+    "arl_conv_precision_get": (_i32, []),
     "arl_conv_pieces": (_i32, [_vp, _vp]),
     "arl_conv_pieces_supported": (_i32, [C.POINTER(ArlConvGeom), _i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),

@@ -97,11 +97,23 @@ struct GemmArgs {
     // persistent launches (igemm_persist_kernel): p_tiles row tiles in all, class c owns [p_first[c], p_first[c + 1])
     int p_tiles, p_first[5];
     int n_par;
+    int xcd;                // split kernels: tiles dealt to the XCDs in contiguous ranges (xcd_chunk)
     struct Parity {
         int M, out_h, out_w, add_y, add_x, rmin, dmin, origin, i0, j0, oadd_y, oadd_x;
         unsigned src_bytes, mg_w, mg_h;
     } par[4];
 };
+
+// XCD-aware placement.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own
+// 4 MB L2: tiles that share an operand panel (the column tiles of one weight-gradient split, the 64 tiles of one
+// forward split of a dense layer, the row tiles over one weight panel) and therefore have neighbouring ids end up on
+// eight different L2s, and every one of them pulls the panel over the fabric again -- measured 6-7 TB/s of L1 <- L2
+// requests, almost all L2 misses, in kernels whose unique operands are 28-45 MB.  Workgroup `id` of `n` takes tile
+// xcd_chunk(id, n): XCD x gets a CONTIGUOUS range of tile ids (bijective for any n).
+__device__ __forceinline__ int xcd_chunk(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, j = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
 
 // Hardware-bounds-checked 16-byte loads: a raw buffer load whose byte offset lies outside
 // the descriptor's range returns 0 and touches no memory, so padding taps, ragged rows and
@@ -466,6 +478,7 @@ struct WgradArgs {
     int adv_b, adv_y, adv_x;    // fast path: 256 rows = adv_b images + adv_y output rows + adv_x pixels
     float* bias_part;       // fast path: [splits][K_out] column sums of dy (the bias gradient's partials), or null
     unsigned long long* trace;  // tuning aid (arl_conv_trace_buffer): per-workgroup timestamps as in GemmArgs, or null
+    int xcd;                    // split kernels: tiles dealt to the XCDs in contiguous ranges (xcd_chunk)
 };
 
 template <int WGM, int WGN, int TM, int TN, int BK>
@@ -1456,7 +1469,15 @@ __global__ __launch_bounds__(256, MINW) void igemm_split_kernel(const GemmArgs a
         }
         bx -= c.co_blocks;
     }
-    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, false, U8, false, SPLIT, PIN, ADIR>(a, bx, blockIdx.y, blockIdx.z, smem);
+    int by = blockIdx.y, bz = blockIdx.z;
+    if (!CORUN && a.xcd) {                          // uniform
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int t = xcd_chunk((bz * gy + by) * gx + bx, gx * gy * (int)gridDim.z);
+        bx = t % gx;
+        const int u = t / gx;
+        by = u % gy; bz = u / gy;
+    }
+    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, false, U8, false, SPLIT, PIN, ADIR>(a, bx, by, bz, smem);
 }
 
 // ==========================================================================================
@@ -2234,7 +2255,15 @@ __global__ __launch_bounds__(256, 4) void wgrad_u8_kernel(const WgradArgs a) {
 template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool U8, int SPLIT, int MINW>
 __global__ __launch_bounds__(256, MINW) void wgrad_split_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, false, U8, SPLIT>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (a.xcd) {                                    // uniform
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int t = xcd_chunk((bz * gy + by) * gx + bx, gx * gy * (int)gridDim.z);
+        bx = t % gx;
+        const int u = t / gx;
+        by = u % gy; bz = u / gy;
+    }
+    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, false, U8, SPLIT>(a, bx, by, bz, smem);
 }
 
 // One launch for a layer's data gradient AND weight gradient (independent of each other, both read dy):
@@ -2246,13 +2275,19 @@ __global__ __launch_bounds__(256) void bwd_pair_kernel(const GemmArgs a, const W
                                                        const int n_ig, const int wgx, const int wgy) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int id = blockIdx.x;
+    if (a.xcd) id = xcd_chunk(id, (int)gridDim.x);     // uniform
     if (id < n_ig) {
-        const int bx = id % dgx, t = id / dgx;
+        const int bx = id % dgx, t = id / dgx;          // the row tiles over one weight panel are neighbours
         igemm_body<DWGM, DWGN, DTM, DTN, BK, false, false, HAS_PAD, false, false, false, SPLIT, PIN>(a, bx, t % dgy, t / dgy, smem);
     } else {
         id -= n_ig;
-        const int bx = id % wgx, t = id / wgx;
-        wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD, false, false, SPLIT>(w, bx, t % wgy, t / wgy, smem);
+        if (a.xcd) {                                    // ... and so are the row tiles over one panel of the layer's input
+            const int by = id % wgy, t = id / wgy;
+            wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD, false, false, SPLIT>(w, t % wgx, by, t / wgx, smem);
+        } else {
+            const int bx = id % wgx, t = id / wgx;
+            wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD, false, false, SPLIT>(w, bx, t % wgy, t / wgy, smem);
+        }
     }
 }
 
@@ -2694,6 +2729,8 @@ extern "C" void arl_conv_tile_choice(int32_t choice) { g_tile_choice = choice; }
 
 extern "C" void arl_conv_persistent(int32_t workgroups_per_cu) { g_persist = workgroups_per_cu; }
 
+extern "C" int arl_conv_precision_get(void) { return g_split; }
+
 extern "C" int arl_conv_precision(int32_t mode) {
     ARL_REQUIRE(mode == 0 || mode == 6 || mode == 9, ARL_E_ARG, "conv precision: 0 (fp32 MFMA), 6 or 9 (bf16-split products)");
     g_split = mode;
@@ -2744,7 +2781,7 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
     a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.kh * g.kw * g.C;
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.b.w = w; a.b.ld = a.K; a.b.w_bytes = (unsigned)((int64_t)a.N * a.K * 4);
-    a.o.dense = 1; a.trace = g_trace;
+    a.o.dense = 1; a.trace = g_trace; a.xcd = g_tile_choice != 9;
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
     // (the bf16-split kernels have no 16-wide tiles: 64x64 there)
@@ -2860,7 +2897,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         a.o.out_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
         a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
         a.k_per_split = round_up(a.K, BKT);
-        a.trace = g_trace;
+        a.trace = g_trace; a.xcd = g_tile_choice != 9;
         if (fast) {
             a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
             a.g.dmin = -((taps_y - 1) * g.Wo + (taps_x - 1)) * g.K;
@@ -2885,6 +2922,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
                     if (q.M > max_m) max_m = q.M;
                 }
             a.n_par = n; a.M = max_m;       // grid covers the largest class; smaller ones exit early
+            a.xcd = 0;                      // (classes of one image region are far apart in id: contiguous ranges measured slower)
         }
         // Dense layers at small batch (the DQN updates: 32 rows; or a narrow input such as the C51 head's 256):
         // a handful of 128x128 tiles walking the whole reduction is a latency chain (2 workgroups x 36 k-tiles:
@@ -2968,7 +3006,7 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
     a.K_out = g.K; a.N = g.kh * g.kw * g.C; a.Mred = (int)(g.batch * g.Ho * g.Wo);
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
-    a.trace = g_trace;
+    a.trace = g_trace; a.xcd = g_tile_choice != 9;
     int bm, bn;
     if (g.K <= 16) { bm = 16; bn = 128; }
     else if (g.K <= 32) { bm = 32; bn = 128; }
@@ -3122,7 +3160,7 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     a.o.out_bytes = (unsigned)((int64_t)a.M * a.N * 4);
     a.k_per_split = a.K;                            // K % 16 == 0 by check_u8 (whole filter rows per k-tile)
     a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
-    a.trace = g_trace;
+    a.trace = g_trace; a.xcd = g_tile_choice != 9;
     const bool split_route = a.N > 16 && g_split && g.kh % (8 / (g.kw >> 2)) == 0;
     rc = put_pieces(a, grab_pieces(), split_route ? PIECES_OUT : 0, 0, (int64_t)a.M * a.N);
     if (rc) return rc;
@@ -3169,7 +3207,7 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     fill_u8(&a.g, obs, obs_rows, idx_or_null, scale, g);
     a.K_out = g.K; a.N = g.C * g.kh * g.kw; a.Mred = (int)(g.batch * g.Ho * g.Wo);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
-    a.trace = g_trace;
+    a.trace = g_trace; a.xcd = g_tile_choice != 9;
     const int bm = g.K <= 16 ? 16 : 32, bn = 128;
     const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     int splits, per;

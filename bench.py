@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector rate
+MFMA_BF16_PEAK_TFS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 N_ENVS, HORIZON, GAME, CNN_SPEC, MINIBATCH = 256, 5, "breakout", 1, 512
 GAMES_8 = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_rider", "enduro", "ms_pacman"]
 
@@ -223,6 +224,10 @@ def mfma_table(device, policy, batch=512, reps=20):
     rows = []
     gen = torch.Generator(device=device).manual_seed(3)
     k = 0
+    # route of the fp32 contractions (arl_conv_precision): 0 = fp32 MFMA chain; 9 / 6 = every fp32 operand split exactly
+    # into three bf16 pieces, nine / six piece products per multiply on the bf16 matrix pipe (u8 pixels: one piece,
+    # three products) -- the matrix pipe then does `products` MFMA flops per fp32 flop, priced against the bf16 peak
+    mode = _lib.load().arl_conv_precision_get()
     for name, g in [("conv%d" % (i + 1), g) for i, g in enumerate(conv_g)] + \
                    [("dense%d" % (i + 1), g) for i, g in enumerate(dense_g)]:
         ho, wo = _lib.conv_out_hw(g)
@@ -251,14 +256,23 @@ def mfma_table(device, policy, batch=512, reps=20):
             iso_ms, _ = event_time_ms(fn, reps)
             mean_ms = graph_time_ms(fn)
             tfs = flops / (mean_ms * 1e-3) / 1e12
-            rows.append(dict(kernel="%s %s" % (name, tag), avg_launch_us=round(mean_ms * 1e3, 2),
-                             isolated_launch_us=round(iso_ms * 1e3, 2),
-                             flops_per_launch=int(flops), achieved_TFs=round(tfs, 1),
-                             frac_mfma_f32=round(tfs / MFMA_F32_PEAK_TFS, 4), launches_per_step=8))
+            row = dict(kernel="%s %s" % (name, tag), avg_launch_us=round(mean_ms * 1e3, 2),
+                       isolated_launch_us=round(iso_ms * 1e3, 2),
+                       flops_per_launch=int(flops), achieved_TFs=round(tfs, 1),
+                       frac_mfma_f32=round(tfs / MFMA_F32_PEAK_TFS, 4), launches_per_step=8)
+            if mode and g.out_c > 16:
+                products = 3 if "u8" in name else mode
+                row.update(products_per_multiply=products, matrix_pipe_TFs=round(tfs * products, 1),
+                           frac_mfma_bf16=round(tfs * products / MFMA_BF16_PEAK_TFS, 4))
+            rows.append(row)
         k += 2
     total_us = sum(r["avg_launch_us"] for r in rows)
     total_fl = sum(r["flops_per_launch"] for r in rows)
     out = dict(bound="mfma", dtype="f32", peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", batch=batch,
+               route=("fp32 MFMA chain (v_mfma_f32_32x32x2_f32)" if not mode else
+                      "fp32 operands split exactly into three bf16 pieces, %d piece products per multiply accumulated in fp32 "
+                      "(v_mfma_f32_32x32x16_bf16); achieved / frac count fp32 flops (2 x MACs) against the fp32 MFMA peak, "
+                      "matrix_pipe_TFs / frac_mfma_bf16 the bf16 MFMA flops actually issued against the dense bf16 peak" % mode),
                timing="avg_launch_us: 20 launches back to back in one hipGraph (as the learner runs them); "
                       "isolated_launch_us: one launch between its own pair of events",
                achieved=round(total_fl / total_us / 1e6, 1),

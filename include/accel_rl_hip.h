@@ -359,7 +359,7 @@ typedef struct arl_conv_geom {
 int64_t arl_conv_workspace_bytes(void);
 
 /* Diagnostic hook (tools/conv_trace.py): while a device buffer of u64[workgroups][8] is set,
- * the forward / data-gradient kernels record per-workgroup shader-clock timestamps
+ * the forward / data-gradient / weight-gradient kernels record per-workgroup shader-clock timestamps
  * (start, main loop begin, main loop end, end), two 100 MHz wall-clock samples, HW_ID and XCC_ID.
  * NULL (the default) disables it.  Not thread-safe; not for production use.             */
 void arl_conv_trace_buffer(void* device_u64_or_null);
@@ -371,7 +371,12 @@ void arl_conv_force_generic(int32_t on);
 /* Tuning / test hook.  Layers with 33 .. 64 output columns: 0 (default) and 3 = 32x64 tiles (16x16 MFMA, five
  * waves per SIMD), 1 = 64x64 tiles (32x32 MFMA), 2 = 112x64 tiles (16x16 MFMA, three LDS stages).  Layers with
  * 17 .. 32 columns (data gradient, u8 forward): 1 = the 128x32 tiles on 32x32 MFMAs, anything else (default) =
- * 64x32 tiles on 16x16 MFMAs at five waves per SIMD.  Not thread-safe. */
+ * 64x32 tiles on 16x16 MFMAs at five waves per SIMD.
+ * bf16-split routes (arl_conv_precision 6 / 9) -- every choice gives the same results bit for bit:
+ * 3 = the gathered operand of the one-wave-per-row-tile shapes passes through LDS like the weights (default: straight
+ * from memory into the MFMA fragment registers); 6 = 32-deep k-tiles for the paired dense data + weight gradient
+ * (default 16-deep: two 128x128 workgroups per CU); 9 = workgroups take tiles in launch order (default: XCD-aware,
+ * each XCD a contiguous range of tile ids so that tiles sharing an operand panel share an L2).  Not thread-safe. */
 void arl_conv_tile_choice(int32_t choice);
 
 /* Tuning / test hook: launches of many row tiles (conv 1 forward, the stride-2 data gradient) as
@@ -392,6 +397,8 @@ void arl_conv_persistent(int32_t workgroups_per_cu);
  * columns and the generic (any channel count) kernels always take route 0.  Deterministic in every mode.
  * Returns ARL_E_ARG for any other value.  Not thread-safe. */
 int arl_conv_precision(int32_t mode);
+/* The mode in force (0, 6 or 9). */
+int arl_conv_precision_get(void);
 
 /* bf16 pieces of activations travel between the bf16-split kernels (arl_conv_precision 6 / 9), so that a tensor is
  * split ONCE, by the launch that produces it, instead of by every workgroup and filter tap that gathers it
