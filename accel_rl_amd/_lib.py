@@ -106,6 +106,7 @@ _SIGNATURES = {
     "arl_conv_trace_buffer": (None, [_vp]),
     "arl_conv_force_generic": (None, [_i32]),
     "arl_scan_force_wave": (None, [_i32]),
+    "arl_scan_wave_groups": (None, [_i32]),
     "arl_conv_tile_choice": (None, [_i32]),
     "arl_conv_persistent": (None, [_i32]),
     "arl_conv_precision": (_i32, [_i32]),

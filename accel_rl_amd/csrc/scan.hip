@@ -312,103 +312,119 @@ __global__ __launch_bounds__(256) void scan_direct_kernel(
 // from the exact walks only by the reassociation of f64 sums (<= 1e-5 asserted in the tests, usually bit-identical
 // after the cast to f32).  T steps cost T / (64 E) x (E + log2 SEG) dependent f64 steps per wave instead of T per
 // lane, and the loads are 4 E contiguous bytes per lane straight from HBM (no LDS staging, no transposition).
-template <bool NSTEP, int E>
+// NCH: segment groups per wave.  A wave owns NCH consecutive groups of 64 E steps and issues the loads of ALL of them
+// before it scans the first, so the later groups' loads fly under the earlier groups' f64 work (one group per wave = a
+// wave per 4 KB, 262 144 waves at 2^26 elements and T = 128).  Measured at 2^26 elements (tools/wave_scan_probe.py):
+// T = 128 0.686 (1) / 0.687 (2) / 0.700 (4) of the HBM peak, T = 256 0.681 / 0.693 / 0.693 -- neither the wave count
+// nor the bytes in flight per wave is what holds this kernel at 0.70 (38-82 registers: 6-8 waves per SIMD either way).
+template <bool NSTEP, int E, int NCH>
 __global__ __launch_bounds__(256) void scan_wave_kernel(
     const float* __restrict__ r, const float* __restrict__ v, const uint8_t* __restrict__ d,
     const float* __restrict__ lv, double gamma, double gl, int64_t n_env, int T, int seg, int vec_ok,
     float* __restrict__ out0, float* __restrict__ out1) {
     const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t wave0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * NCH;
     const int sl = lane & (seg - 1);
-    const int64_t env = wave * (64 / seg) + lane / seg;
-    const bool live = env < n_env;
     const int t0 = sl * E;
-    const int64_t base = (live ? env : 0) * (int64_t)T;
-    float rr[E], vv[E];
-    uint8_t dd[E];
-    // vector form: the lane's E steps lie inside the segment and start on an E-float boundary (T % E == 0)
-    const bool vec = vec_ok && live && t0 < T;
-    if (E >= 4 && vec) {
+    float rr[NCH][E], vv[NCH][E], last_v[NCH];
+    uint8_t dd[NCH][E];
+    int64_t base[NCH];
+    bool live[NCH], vec[NCH];
 #pragma unroll
-        for (int q = 0; q < E / 4; ++q) {
-            const float4 a = nt_load4(reinterpret_cast<const float4*>(r + base + t0 + 4 * q));
-            const float4 b = nt_load4(reinterpret_cast<const float4*>(v + base + t0 + 4 * q));
-            const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(d + base + t0 + 4 * q));
-            rr[(4 * q) % E] = a.x; rr[(4 * q + 1) % E] = a.y; rr[(4 * q + 2) % E] = a.z; rr[(4 * q + 3) % E] = a.w;
-            vv[(4 * q) % E] = b.x; vv[(4 * q + 1) % E] = b.y; vv[(4 * q + 2) % E] = b.z; vv[(4 * q + 3) % E] = b.w;
+    for (int c = 0; c < NCH; ++c) {
+        const int64_t env = (wave0 + c) * (64 / seg) + lane / seg;
+        live[c] = env < n_env;
+        base[c] = (live[c] ? env : 0) * (int64_t)T;
+        // vector form: the lane's E steps lie inside the segment and start on an E-float boundary (T % E == 0)
+        vec[c] = vec_ok && live[c] && t0 < T;
+        const int64_t bs = base[c];
+        if (E >= 4 && vec[c]) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) dd[(4 * q + k) % E] = (uint8_t)(w >> (8 * k));
+            for (int q = 0; q < E / 4; ++q) {
+                const float4 a = nt_load4(reinterpret_cast<const float4*>(r + bs + t0 + 4 * q));
+                const float4 b = nt_load4(reinterpret_cast<const float4*>(v + bs + t0 + 4 * q));
+                const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(d + bs + t0 + 4 * q));
+                rr[c][(4 * q) % E] = a.x; rr[c][(4 * q + 1) % E] = a.y; rr[c][(4 * q + 2) % E] = a.z; rr[c][(4 * q + 3) % E] = a.w;
+                vv[c][(4 * q) % E] = b.x; vv[c][(4 * q + 1) % E] = b.y; vv[c][(4 * q + 2) % E] = b.z; vv[c][(4 * q + 3) % E] = b.w;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dd[c][(4 * q + k) % E] = (uint8_t)(w >> (8 * k));
+            }
+        } else if (E == 2 && vec[c]) {
+            const float2 a = *reinterpret_cast<const float2*>(r + bs + t0);
+            const float2 b = *reinterpret_cast<const float2*>(v + bs + t0);
+            const uint16_t w = *reinterpret_cast<const uint16_t*>(d + bs + t0);
+            rr[c][0] = a.x; rr[c][1 % E] = a.y; vv[c][0] = b.x; vv[c][1 % E] = b.y;
+            dd[c][0] = (uint8_t)w; dd[c][1 % E] = (uint8_t)(w >> 8);
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k) {
+                const bool in = live[c] && t0 + k < T;
+                rr[c][k] = in ? r[bs + t0 + k] : 0.f;
+                vv[c][k] = in ? v[bs + t0 + k] : 0.f;
+                dd[c][k] = in ? d[bs + t0 + k] : (uint8_t)0;
+            }
         }
-    } else if (E == 2 && vec) {
-        const float2 a = *reinterpret_cast<const float2*>(r + base + t0);
-        const float2 b = *reinterpret_cast<const float2*>(v + base + t0);
-        const uint16_t w = *reinterpret_cast<const uint16_t*>(d + base + t0);
-        rr[0] = a.x; rr[1 % E] = a.y; vv[0] = b.x; vv[1 % E] = b.y;
-        dd[0] = (uint8_t)w; dd[1 % E] = (uint8_t)(w >> 8);
-    } else {
+        last_v[c] = live[c] ? lv[env] : 0.f;
+    }
 #pragma unroll
-        for (int k = 0; k < E; ++k) {
-            const bool in = live && t0 + k < T;
-            rr[k] = in ? r[base + t0 + k] : 0.f;
-            vv[k] = in ? v[base + t0 + k] : 0.f;
-            dd[k] = in ? d[base + t0 + k] : (uint8_t)0;
+    for (int c = 0; c < NCH; ++c) {
+        // value that follows the lane's last step: the next lane's first value, the bootstrap value after step T - 1
+        float v_after = __shfl_down(vv[c][0], 1, 64);
+        if (t0 + E >= T) v_after = last_v[c];
+        // ---- the lane's own steps as one affine map x -> D + C x (x = what enters after its last step)
+        double cc[E], dl[E];
+        double C = 1.0, D = 0.0;
+#pragma unroll
+        for (int k = E - 1; k >= 0; --k) {
+            const bool in = t0 + k < T;
+            const double nd = dd[c][k] ? 0.0 : 1.0;                             // util.py:8
+            const float vn = (t0 + k + 1 >= T) ? last_v[c] : (k == E - 1) ? v_after : vv[c][(k + 1) % E];
+            if (NSTEP) { cc[k] = gamma * nd; dl[k] = (double)rr[c][k]; }
+            else { cc[k] = gl * nd; dl[k] = ((double)rr[c][k] + (gamma * (double)vn) * nd) - (double)vv[c][k]; }
+            if (!in) { cc[k] = 1.0; dl[k] = 0.0; }                              // identity beyond the segment
+            D = dl[k] + cc[k] * D;
+            C = cc[k] * C;
         }
-    }
-    const float last_v = live ? lv[env] : 0.f;
-    // value that follows the lane's last step: the next lane's first value, the bootstrap value after step T - 1
-    float v_after = __shfl_down(vv[0], 1, 64);
-    if (t0 + E >= T) v_after = last_v;
-    // ---- the lane's own steps as one affine map x -> D + C x (x = what enters after its last step)
-    double cc[E], dl[E];
-    double C = 1.0, D = 0.0;
-#pragma unroll
-    for (int k = E - 1; k >= 0; --k) {
-        const bool in = t0 + k < T;
-        const double nd = dd[k] ? 0.0 : 1.0;                                // util.py:8
-        const float vn = (t0 + k + 1 >= T) ? last_v : (k == E - 1) ? v_after : vv[(k + 1) % E];
-        if (NSTEP) { cc[k] = gamma * nd; dl[k] = (double)rr[k]; }
-        else { cc[k] = gl * nd; dl[k] = ((double)rr[k] + (gamma * (double)vn) * nd) - (double)vv[k]; }
-        if (!in) { cc[k] = 1.0; dl[k] = 0.0; }                              // identity beyond the segment
-        D = dl[k] + cc[k] * D;
-        C = cc[k] * C;
-    }
-    // ---- suffix scan over the segment's lanes: (C, D) <- (C, D) o (C, D)[lane + off]
-    for (int off = 1; off < seg; off <<= 1) {
-        const double Co = __shfl_down(C, off, 64), Do = __shfl_down(D, off, 64);
-        if (sl + off < seg) { D = D + C * Do; C = C * Co; }
-    }
-    // what enters this lane = the map of all lanes to its right applied to the end value
-    const double x_end = NSTEP ? (double)last_v : 0.0;
-    const double Cn = __shfl_down(C, 1, 64), Dn = __shfl_down(D, 1, 64);
-    double x = (sl + 1 < seg) ? Dn + Cn * x_end : x_end;
-    float o0[E], o1[E];
-#pragma unroll
-    for (int k = E - 1; k >= 0; --k) {
-        x = dl[k] + cc[k] * x;
-        const float a = (float)x;
-        o0[k] = a;
-        o1[k] = NSTEP ? a - vv[k] : a + vv[k];                              // aac_base.py:121 / util.py:21
-    }
-    if (!live) return;
-    if (E >= 4 && vec) {
-#pragma unroll
-        for (int q = 0; q < E / 4; ++q) {
-            nt_store4(reinterpret_cast<float4*>(out0 + base + t0 + 4 * q),
-                      make_float4(o0[(4 * q) % E], o0[(4 * q + 1) % E], o0[(4 * q + 2) % E], o0[(4 * q + 3) % E]));
-            nt_store4(reinterpret_cast<float4*>(out1 + base + t0 + 4 * q),
-                      make_float4(o1[(4 * q) % E], o1[(4 * q + 1) % E], o1[(4 * q + 2) % E], o1[(4 * q + 3) % E]));
+        // ---- suffix scan over the segment's lanes: (C, D) <- (C, D) o (C, D)[lane + off]
+        for (int off = 1; off < seg; off <<= 1) {
+            const double Co = __shfl_down(C, off, 64), Do = __shfl_down(D, off, 64);
+            if (sl + off < seg) { D = D + C * Do; C = C * Co; }
         }
-    } else if (E == 2 && vec) {
-        *reinterpret_cast<float2*>(out0 + base + t0) = make_float2(o0[0], o0[1 % E]);
-        *reinterpret_cast<float2*>(out1 + base + t0) = make_float2(o1[0], o1[1 % E]);
-    } else {
+        // what enters this lane = the map of all lanes to its right applied to the end value
+        const double x_end = NSTEP ? (double)last_v[c] : 0.0;
+        const double Cn = __shfl_down(C, 1, 64), Dn = __shfl_down(D, 1, 64);
+        double x = (sl + 1 < seg) ? Dn + Cn * x_end : x_end;
+        float o0[E], o1[E];
 #pragma unroll
-        for (int k = 0; k < E; ++k)
-            if (t0 + k < T) { out0[base + t0 + k] = o0[k]; out1[base + t0 + k] = o1[k]; }
+        for (int k = E - 1; k >= 0; --k) {
+            x = dl[k] + cc[k] * x;
+            const float a = (float)x;
+            o0[k] = a;
+            o1[k] = NSTEP ? a - vv[c][k] : a + vv[c][k];                        // aac_base.py:121 / util.py:21
+        }
+        if (!live[c]) continue;
+        const int64_t bs = base[c];
+        if (E >= 4 && vec[c]) {
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) {
+                nt_store4(reinterpret_cast<float4*>(out0 + bs + t0 + 4 * q),
+                          make_float4(o0[(4 * q) % E], o0[(4 * q + 1) % E], o0[(4 * q + 2) % E], o0[(4 * q + 3) % E]));
+                nt_store4(reinterpret_cast<float4*>(out1 + bs + t0 + 4 * q),
+                          make_float4(o1[(4 * q) % E], o1[(4 * q + 1) % E], o1[(4 * q + 2) % E], o1[(4 * q + 3) % E]));
+            }
+        } else if (E == 2 && vec[c]) {
+            *reinterpret_cast<float2*>(out0 + bs + t0) = make_float2(o0[0], o0[1 % E]);
+            *reinterpret_cast<float2*>(out1 + bs + t0) = make_float2(o1[0], o1[1 % E]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < E; ++k)
+                if (t0 + k < T) { out0[bs + t0 + k] = o0[k]; out1[bs + t0 + k] = o1[k]; }
+        }
     }
 }
 
-bool g_force_wave = false;      // arl_scan_force_wave: tests run the wave scan at every horizon <= 512
+bool g_force_wave = false;
+int g_wave_nch = 0;             // arl_scan_wave_groups: groups per wave of the wave scan (0 = chosen by size)      // arl_scan_force_wave: tests run the wave scan at every horizon <= 512
 
 // E steps per lane (1, 2, 4 or 8) x SEG lanes per segment (a power of two <= 64) for horizons T <= 512;
 // returns -1 beyond that (the caller falls back to the exact walk)
@@ -428,14 +444,21 @@ int launch_wave(const float* r, const float* v, const uint8_t* d, const float* l
     const int vec_ok = al && T % e == 0 && e > 1;
     int seg = 1;
     while (seg * e < T) seg <<= 1;
-    const int64_t waves = (n_env + (64 / seg) - 1) / (64 / seg);
+    const int64_t groups = (n_env + (64 / seg) - 1) / (64 / seg);
+    // groups per wave (ARL_SCAN_NCH overrides: measurement): one while the launch would not fill the chip otherwise
+    int nch = g_wave_nch > 0 ? g_wave_nch : (groups >= 8 * 4096 ? 4 : groups >= 2 * 4096 ? 2 : 1);
+    if (e == 8 && !g_wave_nch) nch = 1;                             // (T > 256: 0.64 vs 0.62 of the HBM peak with 2)
+    if (e == 8 && nch > 2) nch = 2;                                 // (registers)
+    const int64_t waves = (groups + nch - 1) / nch;
     const unsigned grid = (unsigned)((waves + 3) / 4);
-#define ARL_WAVE_SCAN(E_) hipLaunchKernelGGL((scan_wave_kernel<NSTEP, E_>), dim3(grid), dim3(256), 0, s, r, v, d, lv, gamma, gl, n_env, T, seg, vec_ok, o0, o1)
+#define ARL_WAVE_SCAN_N(E_, N_) hipLaunchKernelGGL((scan_wave_kernel<NSTEP, E_, N_>), dim3(grid), dim3(256), 0, s, r, v, d, lv, gamma, gl, n_env, T, seg, vec_ok, o0, o1)
+#define ARL_WAVE_SCAN(E_) do { if (nch >= 4) ARL_WAVE_SCAN_N(E_, 4); else if (nch == 2) ARL_WAVE_SCAN_N(E_, 2); else ARL_WAVE_SCAN_N(E_, 1); } while (0)
     if (e == 1) ARL_WAVE_SCAN(1);
     else if (e == 2) ARL_WAVE_SCAN(2);
     else if (e == 4) ARL_WAVE_SCAN(4);
-    else ARL_WAVE_SCAN(8);
+    else { if (nch == 2) ARL_WAVE_SCAN_N(8, 2); else ARL_WAVE_SCAN_N(8, 1); }
 #undef ARL_WAVE_SCAN
+#undef ARL_WAVE_SCAN_N
     return arl::check_launch("scan_wave_kernel");
 }
 
@@ -519,6 +542,7 @@ int check_scan_args(const void* a, const void* b, const void* c, const void* d, 
 }  // namespace
 
 extern "C" void arl_scan_force_wave(int32_t on) { g_force_wave = on != 0; }
+extern "C" void arl_scan_wave_groups(int32_t n) { g_wave_nch = (n == 1 || n == 2 || n == 4) ? n : 0; }
 
 extern "C" int arl_gae_scan(const float* rewards, const float* values, const uint8_t* dones,
                             const float* last_values, double discount, double gae_lambda,

@@ -57,6 +57,10 @@ const char* arl_last_error(void);
 /* Test hook: with ARL_PROMO_ASSOC run the wave suffix scan at EVERY horizon <= 512 (not only where it is the faster
  * kernel).  Not thread-safe.                                                                                     */
 void arl_scan_force_wave(int32_t on);
+/* Tuning / test hook: segment groups (64 lanes x E steps each) a wave of the wave suffix scan owns -- 1, 2 or 4; every
+ * value gives the same results bit for bit.  0 (default) = chosen by the launch's size (4 once the launch fills the
+ * chip several times over: all of a wave's loads are issued before its first scan).  Not thread-safe.            */
+void arl_scan_wave_groups(int32_t n);
 
 /* GAE(lambda).  Replaces gen_adv_est, accel_rl/algos/pg/util.py:6-23, and the
  * per-env Python loop around it, accel_rl/algos/pg/aac_base.py:122-127.

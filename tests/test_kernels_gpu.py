@@ -112,9 +112,15 @@ def test_wave_suffix_scan_within_tolerance(L, n, t):
     max(1, |x|), against BOTH exact modes of the oracle; identical results run to run."""
     L.load().arl_scan_force_wave(1)                  # (by default horizons below 96 take the exact walk: it is faster there)
     try:
-        _wave_scan_checks(L, n, t)
+        ref = _wave_scan_checks(L, n, t)
+        for groups in (1, 2, 4):                     # segment groups per wave (chosen by size otherwise): same bits
+            L.load().arl_scan_wave_groups(groups)
+            got = _wave_scan_checks(L, n, t)
+            for a, b in zip(ref, got):
+                np.testing.assert_array_equal(a, b)
     finally:
         L.load().arl_scan_force_wave(0)
+        L.load().arl_scan_wave_groups(0)
 
 
 def _wave_scan_checks(L, n, t):
@@ -143,6 +149,7 @@ def _wave_scan_checks(L, n, t):
     vn = np.concatenate([v[:, 1:], lv[:, None]], axis=1).astype(np.float64)
     want = np.cumsum((r.astype(np.float64) + vn - v)[:, ::-1], axis=1)[:, ::-1]
     assert np.all(np.abs(adv1 - want) <= 1e-5 * np.maximum(1., np.abs(want)))
+    return adv, ret, nret, nadv, adv1
 
 
 def test_scan_unaligned_views_take_the_direct_path(L):

@@ -11,9 +11,10 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
-        if not any(k in name for k in ("igemm_kernel", "igemm_u8_kernel", "wgrad_fast_kernel", "wgrad_u8_kernel", "bwd_pair_kernel")):
+        if not any(k in name for k in ("igemm_kernel", "igemm_occ_kernel", "igemm_split_kernel", "igemm_u8_kernel", "wgrad_fast_kernel",
+                                        "wgrad_split_kernel", "wgrad_u8_kernel", "bwd_pair_kernel")):
             continue
-        name = name[:name.index("(")]
+        name = name[:name.index("(")]           # (template arguments kept: they tell the tile shapes and routes apart)
         acc[(name, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = []
 for (name, grid), c in acc.items():
