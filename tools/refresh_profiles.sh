@@ -1,7 +1,6 @@
 # Regenerates profiles/r02 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root; ~6 GPU-minutes)
 set -x
 R=$(pwd); O=$R/gpurun_out/fin; mkdir -p $O
-timeout 900 python bench.py > $O/bench.log 2>$O/bench.err; tail -n 1 $O/bench.log > $O/bench.json
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pA -o b -- python $R/bench.py --steps 60 --warmup 20 --no-cpu-baseline > $O/prof.log 2>&1
 tail -n 200 $O/prof.log | grep '^{"metric' | tail -n 1 > $O/bench_profiled.json
@@ -14,6 +13,9 @@ cp $(find /tmp/pC -name "*counter_collection.csv" | head -n 1) $O/gae_pmc_FETCH_
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pD -o w -- python $R/bench.py --roofline-only > $O/gaew.log 2>&1
 cp $(find /tmp/pD -name "*counter_collection.csv" | head -n 1) $O/gae_pmc_WRITE_SIZE.csv
 python $R/tools/gae_pmc_traffic.py $O/gae_pmc_FETCH_SIZE.csv $O/gae_pmc_WRITE_SIZE.csv > $O/gae_pmc_traffic.json
+cp $O/gae_pmc_traffic.json $R/profiles/gae_pmc_traffic.json     # bench.py reads it (roofline.traffic; keyed by scan.hip's sha1)
+cd $R; timeout 900 python bench.py > $O/bench.log 2>$O/bench.err; tail -n 1 $O/bench.log > $O/bench.json
+cd /tmp
 cd $R; timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d /tmp/pE -o m -- python tools/conv_bench.py 512 o > $O/mfma.log 2>&1
 python tools/mfma_pmc_summary.py $(find /tmp/pE -name "*counter_collection.csv" | head -n 1) > $O/mfma_pmc_summary.json
 python tools/gae_sweep.py > $O/gae_sweep.txt 2>&1
@@ -34,4 +36,6 @@ timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/nu
 timeout 300 python bench.py --scaling strong --total-envs 2048 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > $O/bench_strong_2048_n1.json
 timeout 300 python bench.py --workload catdqn --steps 30 --warmup 5 --dqn-batch 512 2>/dev/null | tail -n 1 > $O/bench_catdqn_batch512.json
 ARL_BENCH_ONE_GPU=1 ARL_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 3 --warmup 2 --no-graph 2>/dev/null | tail -n 1 > $O/bench_spawn_2ranks_devmode.json
+(for k in "conv2 fwd" "conv2 wgrad" "conv2 dgrad" "dense pair"; do echo "== $k"; bash tools/pmc_one.sh $k 2>&1 | grep -v amdgpu; done) > $O/pmc_one_split_kernels.txt
+python tools/wave_scan_probe.py 26 2>&1 | grep -v amdgpu > $O/wave_scan_probe.txt
 ls -la $O
