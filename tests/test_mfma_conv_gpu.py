@@ -460,3 +460,60 @@ def test_every_precision_route_is_fp32_accurate_against_float64(layer):
         assert lib.arl_conv_precision(7) != 0 and b"conv precision" in lib.arl_last_error()
     finally:
         lib.arl_conv_precision(9)
+
+
+EXACT = [("conv2", 33, 25, 19, 32, 64, 4, 2, 1), ("conv3", 20, 12, 9, 64, 64, 3, 1, 1), ("dense", 512, 1, 1, 3456, 512, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("mode", [9, 6])
+@pytest.mark.parametrize("layer", EXACT, ids=[c[0] for c in EXACT])
+def test_split_routes_carry_full_fp32_significands_exactly(layer, mode):
+    """The bf16-split routes must not lose a bit of an fp32 operand: x = h + m + l exactly, so when the OTHER operand of
+    every multiply is a signed power of two (one bf16 piece) and every output is a single product, the result is the
+    24-bit operand times that power of two -- exact in fp32, whatever order the piece products are accumulated in.
+    One-hot filters (forward, data gradient) / one-hot dy (weight gradient) at the spec-1 shapes; reference = the same
+    contraction in float64; bit-for-bit equality.  (A route that dropped or rounded pieces -- plain bf16 inputs, or a
+    two-piece split -- fails this at the 2^-9 / 2^-17 level.)"""
+    from accel_rl_amd import _lib
+    lib = _lib.load()
+    name, b, h, w, c, k, ks, st, p = layer
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p)
+    ho, wo = _lib.conv_out_hw(geom)
+    ws = _lib.conv_workspace(DEV)
+    pow2 = lambda shape: (torch.randint(0, 2, shape, device=DEV, generator=gen) * 2 - 1).float() * \
+        torch.exp2(torch.randint(-3, 4, shape, device=DEV, generator=gen).float())          # noqa: E731
+    full = lambda shape: torch.randn(shape, device=DEV, generator=gen) * 37.0                # noqa: E731  (24-bit significands)
+    # one-hot filters: filter kk looks at ONE tap and ONE channel (channels distinct across the live filters, so that a
+    # data-gradient element also receives a single product); filters beyond the channel count stay zero
+    wt = torch.zeros(k, ks, ks, c, device=DEV)
+    live = min(k, c)
+    ty = torch.randint(0, ks, (live,), device=DEV, generator=gen)
+    tx = torch.randint(0, ks, (live,), device=DEV, generator=gen)
+    ch = torch.randperm(c, device=DEV, generator=gen)[:live]
+    wt[torch.arange(live, device=DEV), ty, tx, ch] = pow2((live,))
+    x, dy = full((b, h, w, c)), full((b, ho, wo, k))
+    # one-hot dy for the weight gradient: channel kk is non-zero at ONE (image, pixel)
+    dy1 = torch.zeros(b, ho, wo, k, device=DEV)
+    dy1[torch.randint(0, b, (k,), device=DEV, generator=gen), torch.randint(0, ho, (k,), device=DEV, generator=gen),
+        torch.randint(0, wo, (k,), device=DEV, generator=gen), torch.arange(k, device=DEV)] = pow2((k,))
+    nchw = lambda t: t.double().permute(0, 3, 1, 2)                                          # noqa: E731
+    xr, wr = nchw(x).detach().requires_grad_(), nchw(wt).detach().requires_grad_()
+    out = F.conv2d(xr, wr, None, stride=st, padding=p)
+    gx, = torch.autograd.grad(out, xr, nchw(dy), retain_graph=True)
+    gw, = torch.autograd.grad(out, wr, nchw(dy1))
+    want = dict(fwd=out.permute(0, 2, 3, 1).detach(), dgrad=gx.permute(0, 2, 3, 1), wgrad=gw.permute(0, 2, 3, 1))
+    for t in want.values():
+        assert torch.equal(t.float().double(), t)                                            # the references are fp32 numbers
+    assert lib.arl_conv_precision(mode) == 0
+    try:
+        y, dx, dw = torch.empty(b, ho, wo, k, device=DEV), torch.empty_like(x), torch.empty_like(wt)
+        _lib.conv2d_fwd(x, wt, None, y, geom, False, ws)
+        _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
+        _lib.conv2d_bwd_weight(dy1, x, dw, geom, ws)
+        torch.cuda.synchronize()
+        for op, got in (("fwd", y), ("dgrad", dx), ("wgrad", dw)):
+            assert want[op].abs().max() > 0
+            assert torch.equal(got.double(), want[op]), (op, (got.double() - want[op]).abs().max().item())
+    finally:
+        lib.arl_conv_precision(9)
