@@ -1,4 +1,4 @@
-"""fp32 MFMA implicit-GEMM convolution / dense kernels (csrc/mfma_conv.hip) against
+"""MFMA implicit-GEMM convolution / dense kernels (csrc/mfma_conv.hip; every route of arl_conv_precision) against
 plain PyTorch fp32 on the same inputs.  Floating point, so a tolerance: the kernels
 accumulate in fp32 in k order (bitwise an fmaf chain); torch's reference reduces in a
 different order, so results agree to fp32 round-off of the reduction:
