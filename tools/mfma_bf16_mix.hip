@@ -28,6 +28,13 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
         for (int r = 0; r < 2; ++r) {
             if (MODE == 9) { MF32(c0); MF32(c1); MF32(c2); MF32(c3); continue; }
             if (MODE == 8) { MFBV(c0); MFBV(c1); MFBV(c2); MFBV(c3); continue; }
+            // dependent chains: ONE accumulator (the 128x32-tile kernels: a wave owns one 32x32 tile), two taking turns
+            if (MODE == 10) { MFBV(c0); MFBV(c0); MFBV(c0); MFBV(c0); continue; }
+            if (MODE == 11) { MFBV(c0); MFBV(c1); MFBV(c0); MFBV(c1); continue; }
+            if (MODE == 12) { MFBV(c0); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2); MFBV(c0); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2);
+                              MFBV(c0); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2); MFBV(c0); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2); continue; }
+            if (MODE == 13) { MFBV(c0); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2); MFBV(c1); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2);
+                              MFBV(c0); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2); MFBV(c1); VAND(x0); VSUBF(fx0); VPERM(x1); VAND(x2); continue; }
             MFB(c0);
             if (MODE == 1) { VADD(x0); VADD(x1); VADD(x2); VADD(x3); }
             if (MODE == 2) { VADD(x0); VADD(x1); VADD(x2); VADD(x3); VADD(x0); VADD(x1); VADD(x2); VADD(x3); }
@@ -87,6 +94,10 @@ int main() {
         run<3>("bf16 mfma + (2 and, 2 sub_f32, 2 perm) per mfma", blocks, 2000);
         run<4>("bf16 mfma + 1 ds_read_b128 per 4 mfma", blocks, 2000);
         run<5>("bf16 mfma + 3 ds_read_b128 per 4 mfma", blocks, 2000);
+        run<10>("bf16 mfma, ONE accumulator (dependent chain)", blocks, 2000);
+        run<11>("bf16 mfma, two accumulators taking turns", blocks, 2000);
+        run<12>("one accumulator + 4 vector instructions per mfma", blocks, 2000);
+        run<13>("two accumulators + 4 vector instructions per mfma", blocks, 2000);
     }
     return 0;
 }
