@@ -178,6 +178,8 @@ def load():
     _lib = lib
     if os.environ.get("ARL_CONV_PRECISION"):     # measurement switch (tools/, bench A/B): see arl_conv_precision
         _check(lib.arl_conv_precision(int(os.environ["ARL_CONV_PRECISION"])), "arl_conv_precision")
+    if os.environ.get("ARL_CONV_TILE_CHOICE"):   # measurement switch: see arl_conv_tile_choice
+        lib.arl_conv_tile_choice(int(os.environ["ARL_CONV_TILE_CHOICE"]))
     return lib
 
 

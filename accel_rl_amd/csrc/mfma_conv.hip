@@ -2786,7 +2786,13 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
     // (the bf16-split kernels have no 16-wide tiles: 64x64 there)
     const bool small32 = small && g_tile_choice != 1 && !g_split;  // 32x64 tiles: half the splits (and partial bytes) for the same grid
-    if (small) plan_split(((a.M + (small32 ? 31 : 63)) / (small32 ? 32 : 64)) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
+    // bf16-split routes, tile choice 5: 128x64 tiles of the one-wave-per-row-tile kernel (the gathered operand straight
+    // into the fragment registers, the weights' LDS image shared by 128 rows), two workgroups per CU.  Same-box A/B at
+    // the PPO shapes: the launch 38.4 -> 36.8 us at 512 rows, but 16 / 31 splits instead of 12 / 24 for the fold to read:
+    // learner 3.29 -> 3.32 ms, rollout 0.564 -> 0.569 ms -- not the default.
+    const bool small128 = small && g_split && g_tile_choice == 5 && g.C % 32 == 0 && g.pad_h == 0 && g.pad_w == 0;
+    if (small128) plan_split(((a.M + 127) / 128) * ((a.N + 63) / 64), a.K, &splits, &per, 2 * TARGET_WGS);
+    else if (small) plan_split(((a.M + (small32 ? 31 : 63)) / (small32 ? 32 : 64)) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
     // ... and wider ones whose 128x128 tiles still leave CUs idle (spec-0 dense at the A2C batch: 5120 x 256 =
     // 80 tiles walking 88 k-tiles each, 231 us)
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -2825,6 +2831,7 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
             rc = launch_igemm<4, 1, 2, 1, 16, true, true>(a, splits, multi_tap, has_pad, s);        // 16-wide MFMA tiles
         else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
         else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
+        else if (small128 && !multi_tap) rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
         else if (g_split && small) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
         else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, true, false, 1>(a, multi_tap, has_pad, s, splits);
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))

@@ -379,7 +379,8 @@ void arl_conv_force_generic(int32_t on);
  * bf16-split routes (arl_conv_precision 6 / 9) -- every choice gives the same results bit for bit:
  * 3 = the gathered operand of the one-wave-per-row-tile shapes passes through LDS like the weights (default: straight
  * from memory into the MFMA fragment registers); 6 = 32-deep k-tiles for the paired dense data + weight gradient
- * (default 16-deep: two 128x128 workgroups per CU); 9 = workgroups take tiles in launch order (default: XCD-aware,
+ * (default 16-deep: two 128x128 workgroups per CU); 5 = split-K forward of the dense layers on 128x64 tiles, rows straight
+ * into the fragment registers (default: 64x64 tiles, both operands through LDS; measured equal end to end); 9 = workgroups take tiles in launch order (default: XCD-aware,
  * each XCD a contiguous range of tile ids so that tiles sharing an operand panel share an L2).  Not thread-safe. */
 void arl_conv_tile_choice(int32_t choice);
 

@@ -46,18 +46,20 @@ def _tol(want, k_red):
     return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
 
 
-@pytest.fixture(params=["fast", "fast_split6", "fast_fp32", "generic", "fast_tiles64", "fast_tiles112", "fast_persistent"])
+@pytest.fixture(params=["fast", "fast_split6", "fast_fp32", "generic", "fast_tiles64", "fast_tiles112", "fast_persistent",
+                        "fast_dense128"])
 def path(request):
     """Both kernel families: the scalar-addressed fast path (taken whenever a k-tile of 32 stays inside
     one filter row) and the generic fallback (any multiple-of-4 channel count, any K); on the fast path the three
     routes of arl_conv_precision (default: nine bf16-split products; six; the fp32 MFMA chain) and, on the fp32 chain,
     the other two tile shapes of the 33 .. 64-column layers (the default is 32x64) and the persistent launches of
-    the many-tile layers walked by three workgroups."""
+    the many-tile layers walked by three workgroups; on the nine-product route the 128x64 tiles of the dense layers' split-K
+    forward (tile choice 5)."""
     from accel_rl_amd import _lib
     lib = _lib.load()
     lib.arl_conv_force_generic(1 if request.param == "generic" else 0)
-    assert lib.arl_conv_precision({"fast": 9, "fast_split6": 6}.get(request.param, 0)) == 0
-    lib.arl_conv_tile_choice({"fast_tiles64": 1, "fast_tiles112": 2}.get(request.param, 0))
+    assert lib.arl_conv_precision({"fast": 9, "fast_split6": 6, "fast_dense128": 9}.get(request.param, 0)) == 0
+    lib.arl_conv_tile_choice({"fast_tiles64": 1, "fast_tiles112": 2, "fast_dense128": 5}.get(request.param, 0))
     lib.arl_conv_persistent(-3 if request.param == "fast_persistent" else 0)    # 3 workgroups walk every tile
     yield request.param
     lib.arl_conv_force_generic(0)
