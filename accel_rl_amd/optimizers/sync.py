@@ -25,8 +25,17 @@ class _SyncMixin(object):
         self._rank = rank
         self._n_gpu = n_gpu
 
+    # test hook: a list that receives (first element, clone of the LOCAL gradient slice) right before each all-reduce
+    # -- what this rank contributes to the sum (tests/test_sync_gpu.py pins the update to the mean of the ranks' taps)
+    _grad_tap = None
+
+    def _tap(self, g, first):
+        if self._grad_tap is not None:
+            self._grad_tap.append((int(first), g.detach().clone()))
+
     def _share_grad(self):
         if self._n_gpu > 1 or self._force_collective:
+            self._tap(self._target.flat_grads, 0)
             dist.all_reduce(self._target.flat_grads, op=dist.ReduceOp.SUM, group=self._comm)
 
     def _share_grad_async(self, tail):
@@ -34,12 +43,13 @@ class _SyncMixin(object):
         policy's `grad_split_offset`: everything behind it is final when the policy calls the split hook)."""
         if not (self._n_gpu > 1 or self._force_collective):
             return None
-        g = self._target.flat_grads
+        g, first = self._target.flat_grads, 0
         if tail is not None:
             off = int(getattr(self._target, "grad_split_offset", 0))
-            g = g[off:] if tail else g[:off]
+            g, first = (g[off:], off) if tail else (g[:off], 0)
             if g.numel() == 0:
                 return None
+        self._tap(g, first)
         return dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self._comm, async_op=True)
 
     def _avg_factor(self):
