@@ -11,7 +11,9 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libaccel_rl_hip.so")
-SOURCES = ["batch_ops.hip", "scan.hip", "env.hip", "optim.hip", "learner.hip", "mfma_conv.hip", "replay.hip", "dqn.hip", "lstm.hip", "gru.hip"]
+SOURCES = ["mfma_conv_p1.hip", "mfma_conv_p2.hip", "mfma_conv_p3.hip", "mfma_conv_p4.hip", "mfma_conv_p5.hip", "mfma_conv_p6.hip",
+           "mfma_conv_p7.hip", "mfma_conv.hip", "batch_ops.hip", "scan.hip", "env.hip", "optim.hip", "learner.hip", "replay.hip",
+           "dqn.hip", "lstm.hip", "gru.hip"]
 ARCH = "gfx950"
 
 
@@ -28,7 +30,7 @@ def _stale():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(ROOT, "include", "accel_rl_hip.h"))
+    deps += [os.path.join(ROOT, "include", h) for h in ("accel_rl_hip.h", "accel_rl_hip_dev.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -64,7 +66,7 @@ def _build_locked(verbose):
     flags_now = " ".join(common) + "||" + os.environ.get("ARL_HIPCC_FLAGS", "")
     flags_same = os.path.exists(stamp) and open(stamp).read() == flags_now
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(ROOT, "include", "accel_rl_hip.h"))
+    headers += [os.path.join(ROOT, "include", h) for h in ("accel_rl_hip.h", "accel_rl_hip_dev.h")]
     newest_header = max(os.path.getmtime(h) for h in headers)
     procs = []
     for src in SOURCES:

@@ -53,7 +53,11 @@ class ArlRollout(C.Structure):
 
 class ArlConvGeom(C.Structure):
     _fields_ = [("batch", _i64), ("in_h", _i32), ("in_w", _i32), ("in_c", _i32), ("out_c", _i32),
-                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad_h", _i32), ("pad_w", _i32)]
+                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad_h", _i32), ("pad_w", _i32), ("route", _i32)]
+
+
+class ArlCorunJob(C.Structure):
+    _fields_ = [("opaque", _i64 * 40)]
 
 
 class ArlFoldItem(C.Structure):
@@ -103,18 +107,8 @@ _SIGNATURES = {
     "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 7),
     "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
     "arl_conv_workspace_bytes": (_i64, []),
-    "arl_conv_trace_buffer": (None, [_vp]),
-    "arl_conv_force_generic": (None, [_i32]),
-    "arl_scan_force_wave": (None, [_i32]),
-    "arl_scan_wave_groups": (None, [_i32]),
-    "arl_conv_tile_choice": (None, [_i32]),
-    "arl_conv_persistent": (None, [_i32]),
-    "arl_conv_precision": (_i32, [_i32]),
-    "arl_conv_precision_get": (_i32, []),
-    "arl_conv_pieces": (_i32, [_vp, _vp]),
-    "arl_conv_pieces_supported": (_i32, [C.POINTER(ArlConvGeom), _i32]),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
-    "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp]),
+    "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), C.POINTER(ArlCorunJob), C.POINTER(_i32), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
     "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem),
                                            _vp, C.POINTER(ArlFoldItem), _vp]),
@@ -123,7 +117,8 @@ _SIGNATURES = {
     "arl_conv2d_u8_bwd_weight_parts": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
                                               C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_conv2d_bwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
-                                   C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), _vp]),
+                                   C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), C.POINTER(ArlCorunJob),
+                                   C.POINTER(_i32), _vp]),
     "arl_relu_bwd_bias_parts": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_replay_append": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _vp, _vp, _i32, _i32, _f64, _i32, _vp]),
     "arl_replay_extract": (_i32, [C.POINTER(ArlReplay), _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -149,12 +144,40 @@ _SIGNATURES = {
     "arl_opt_step_noclip_split": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp,
                                          _i64, _i64, _i32, _vp]),
     "arl_opt_finish_split": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _vp, _vp, _i64, _vp]),
-    "arl_conv_corun_update": (_i32, [C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _vp,
-                                     _i64, _i64]),
-    "arl_conv_corun_flush": (_i32, [_vp]),
+    "arl_corun_job_init": (_i32, [C.POINTER(ArlCorunJob), C.POINTER(ArlOptState), _i32, _f32, _f32, _f32, _f32, _f32,
+                                  _i32, _vp, _vp, _i64, _i64]),
+    "arl_corun_job_run": (_i32, [C.POINTER(ArlCorunJob), _vp]),
+}
+
+# include/accel_rl_hip_dev.h: development hooks (tests / tools), not part of the drop-in boundary
+_DEV_SIGNATURES = {
+    "arl_dev_conv_trace_buffer": (None, [_vp]),
+    "arl_dev_conv_force_generic": (None, [_i32]),
+    "arl_dev_scan_force_wave": (None, [_i32]),
+    "arl_dev_scan_wave_groups": (None, [_i32]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+DEV_SYMBOLS = tuple(_DEV_SIGNATURES)
+
+# arl_conv_geom.route (ARL_CONV_ROUTE_*): how the fp32 contractions are computed.  The library keeps no mode; this
+# module's default is what conv_geom() / dense_geom() stamp into the geometries they build (host-side policy).
+ROUTE_SPLIT9, ROUTE_FP32, ROUTE_SPLIT6 = 0, 1, 6
+_PRECISION_TO_ROUTE = {9: ROUTE_SPLIT9, 0: ROUTE_FP32, 6: ROUTE_SPLIT6}
+default_route = _PRECISION_TO_ROUTE[int(os.environ.get("ARL_CONV_PRECISION", "9"))]    # measurement switch (tools/, bench A/B)
+
+
+def set_conv_precision(mode):
+    """Route of the geometries built from now on: 9 = nine exact bf16-split products (the default), 6 = six,
+    0 = the fp32 MFMA chain.  Geometries already built keep theirs (ArlConvGeom.route)."""
+    global default_route
+    if mode not in _PRECISION_TO_ROUTE:
+        raise ValueError("conv precision: 0 (fp32 MFMA), 6 or 9 (bf16-split products)")
+    default_route = _PRECISION_TO_ROUTE[mode]
+
+
+def conv_precision():
+    return {v: k for k, v in _PRECISION_TO_ROUTE.items()}[default_route]
 
 _lib = None
 
@@ -169,17 +192,13 @@ def load():
             "libaccel_rl_hip.so is not built (%s).  Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `python accel_rl_amd/_build.py`.  There is no CPU fallback." % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_DEV_SIGNATURES.items()):
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.restype = res
         fn.argtypes = args
     if lib.arl_abi_version() != ARL_ABI_VERSION:
         raise RuntimeError("libaccel_rl_hip.so ABI %d != binding %d" % (lib.arl_abi_version(), ARL_ABI_VERSION))
     _lib = lib
-    if os.environ.get("ARL_CONV_PRECISION"):     # measurement switch (tools/, bench A/B): see arl_conv_precision
-        _check(lib.arl_conv_precision(int(os.environ["ARL_CONV_PRECISION"])), "arl_conv_precision")
-    if os.environ.get("ARL_CONV_TILE_CHOICE"):   # measurement switch: see arl_conv_tile_choice
-        lib.arl_conv_tile_choice(int(os.environ["ARL_CONV_TILE_CHOICE"]))
     return lib
 
 
@@ -350,20 +369,19 @@ def opt_step_noclip_split(opt, method, learning_rate, avg_factor, beta1_or_rho, 
            "arl_opt_step_noclip_split")
 
 
-def conv_corun_update(opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k, step_pp, norm_parts,
-                      hole_first, hole_count):
-    """Hand part 1 of update k to the next data-gradient launch of a 33 .. 64-column layer (extra workgroups)."""
-    _check(load().arl_conv_corun_update(C.byref(opt), method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon,
-                                        int(k), ptr(step_pp), ptr(norm_parts), int(hole_first), int(hole_count)),
-           "arl_conv_corun_update")
+def corun_job(opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k, step_pp, norm_parts,
+              hole_first, hole_count):
+    """Part 1 of update k (the hole) as a job for a data-gradient launch to carry (arl_corun_job): plain data, held
+    by the caller; conv2d_bwd_data / FoldList.conv2d_bwd_pair take it through `corun=`, corun_job_run runs it alone."""
+    job = ArlCorunJob()
+    _check(load().arl_corun_job_init(C.byref(job), C.byref(opt), method, learning_rate, avg_factor, beta1_or_rho, beta2,
+                                     epsilon, int(k), ptr(step_pp), ptr(norm_parts), int(hole_first), int(hole_count)),
+           "arl_corun_job_init")
+    return job
 
 
-def conv_corun_flush(stream=None):
-    """Run a still-pending co-run job as its own launch; True if there was one."""
-    rc = load().arl_conv_corun_flush(stream_ptr(stream))
-    if rc < 0:
-        _check(rc, "arl_conv_corun_flush")
-    return rc == 1
+def corun_job_run(job, stream=None):
+    _check(load().arl_corun_job_run(C.byref(job), stream_ptr(stream)), "arl_corun_job_run")
 
 
 # ---------------------------------------------------------------------------
@@ -427,12 +445,20 @@ def pg_head_loss(h, w_head, b_head, actions, advantages, returns, old_prob, vali
 # fp32 MFMA contractions (csrc/mfma_conv.hip); activations NHWC, weights (K, kh, kw, C)
 # ---------------------------------------------------------------------------
 
-def conv_geom(batch, in_h, in_w, in_c, out_c, kh, kw, stride, pad_h, pad_w):
-    return ArlConvGeom(batch, in_h, in_w, in_c, out_c, kh, kw, stride, pad_h, pad_w)
+def conv_geom(batch, in_h, in_w, in_c, out_c, kh, kw, stride, pad_h, pad_w, route=None):
+    return ArlConvGeom(batch, in_h, in_w, in_c, out_c, kh, kw, stride, pad_h, pad_w,
+                       default_route if route is None else route)
 
 
-def dense_geom(batch, fan_in, units):
-    return ArlConvGeom(batch, 1, 1, fan_in, units, 1, 1, 1, 0, 0)
+def dense_geom(batch, fan_in, units, route=None):
+    return ArlConvGeom(batch, 1, 1, fan_in, units, 1, 1, 1, 0, 0, default_route if route is None else route)
+
+
+def with_route(geom, route=None):
+    """A copy of geom on another route (default: this module's current default)."""
+    g = ArlConvGeom.from_buffer_copy(geom)
+    g.route = default_route if route is None else route
+    return g
 
 
 def conv_out_hw(g):
@@ -441,32 +467,6 @@ def conv_out_hw(g):
 
 def conv_workspace(device):
     return torch.empty(load().arl_conv_workspace_bytes() // 4, dtype=torch.float32, device=device)
-
-
-PIECES_IN, PIECES_OUT = 1, 2
-PIECES_FWD, PIECES_DGRAD, PIECES_U8FWD = 0, 1, 2
-
-
-def conv_pieces_supported(geom, op):
-    """Bit mask (PIECES_IN | PIECES_OUT) of what the route of (geom, op) can do with bf16 pieces (arl_conv_pieces)."""
-    caps = load().arl_conv_pieces_supported(C.byref(geom), op)
-    if caps < 0:
-        _check(caps, "arl_conv_pieces_supported")
-    return caps
-
-
-def pieces_like(t):
-    """An (uninitialised) bf16 pieces tensor of the fp32 tensor t: [3, numel] (see arl_conv_pieces)."""
-    assert t.numel() % 8 == 0
-    return torch.empty((3, t.numel()), dtype=torch.bfloat16, device=t.device)
-
-
-def conv_pieces(in_pieces=None, out_pieces=None):
-    """Hand bf16 pieces to the NEXT forward / data-gradient call (which consumes them)."""
-    for p in (in_pieces, out_pieces):
-        if p is not None:
-            _want(p, torch.bfloat16, "pieces")
-    _check(load().arl_conv_pieces(ptr(in_pieces), ptr(out_pieces)), "arl_conv_pieces")
 
 
 def conv2d_fwd(x, w, bias, y, geom, relu, workspace, stream=None):
@@ -509,13 +509,17 @@ def conv2d_u8_fwd(obs, idx, scale, w, bias, y, geom, relu, stream=None):
            "arl_conv2d_u8_fwd")
 
 
-def conv2d_bwd_data(dy, w, mask, dx, geom, stream=None):
+def conv2d_bwd_data(dy, w, mask, dx, geom, stream=None, corun=None):
+    """corun: an ArlCorunJob the launch may carry; returns True if it did (else the caller runs it: corun_job_run)."""
     ho, wo = conv_out_hw(geom)
     assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
     assert dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "dx size"
     assert mask is None or mask.numel() == dx.numel()
+    taken = _i32(0)
     _check(load().arl_conv2d_bwd_data(dy.data_ptr(), w.data_ptr(), None if mask is None else mask.data_ptr(),
-                                      dx.data_ptr(), C.byref(geom), stream_ptr(stream)), "arl_conv2d_bwd_data")
+                                      dx.data_ptr(), C.byref(geom), None if corun is None else C.byref(corun),
+                                      C.byref(taken), stream_ptr(stream)), "arl_conv2d_bwd_data")
+    return bool(taken.value)
 
 
 def conv2d_bwd_weight(dy, x, dw, geom, workspace, stream=None):
@@ -535,6 +539,7 @@ class FoldList(object):
         self._items = (ArlFoldItem * FOLD_MAX_ITEMS)()
         self._n = 0
         self.last_dw_in_place = False
+        self.corun_taken = False
 
     def _next(self):
         assert self._n < FOLD_MAX_ITEMS, "too many pending folds"
@@ -584,8 +589,9 @@ class FoldList(object):
                                                      stream_ptr(stream)), "arl_conv2d_u8_bwd_weight_parts")
         return self._bias_done(dbias)
 
-    def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, dbias=None, stream=None):
-        """dx (times mask > 0 if given) and (deferred) dw [+ dbias] of one layer in a single launch."""
+    def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, dbias=None, stream=None, corun=None):
+        """dx (times mask > 0 if given) and (deferred) dw [+ dbias] of one layer in a single launch.
+        corun: an ArlCorunJob the data-gradient launch may carry; `self.corun_taken` says whether it did."""
         ho, wo = conv_out_hw(geom)
         assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
         assert x.numel() == dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x / dx size"
@@ -593,10 +599,13 @@ class FoldList(object):
         item = self._next()
         slot = self._n - 1
         pb, ib = self._bias_slot(dbias)
+        taken = _i32(0)
         _check(load().arl_conv2d_bwd_pair(dy.data_ptr(), w.data_ptr(), ptr(mask), dx.data_ptr(), x.data_ptr(),
                                           dw.data_ptr(), C.byref(geom), ptr(workspace),
                                           workspace.numel() * workspace.element_size(), item, pb, ib,
+                                          None if corun is None else C.byref(corun), C.byref(taken),
                                           stream_ptr(stream)), "arl_conv2d_bwd_pair")
+        self.corun_taken = bool(taken.value)
         self.last_dw_in_place = self._items[slot].splits == 0      # no split partials: dw is final as written
         return self._bias_done(dbias)
 

@@ -13,6 +13,7 @@ import torch
 from accel_rl_amd import _lib
 from accel_rl_amd.algos.base import RLAlgorithm
 from accel_rl_amd.buffers import buffer_with_segs_view
+from accel_rl_amd.util.misc import graph_capture_mode
 from accel_rl_amd.util.quick_args import save_args
 import numpy as np
 
@@ -103,8 +104,9 @@ class AdvActorCriticBase(RLAlgorithm):
         return out
 
     def _enqueue_optimize(self, itr, samples_data):
-        graphable = self.use_graph and hasattr(self.optimizer, "device_updates") and \
-            self.optimizer.parallelism_tag == "single"
+        tag = self.optimizer.parallelism_tag
+        sync = tag == "synchronous" and getattr(self.optimizer, "graph_ready", lambda: False)()
+        graphable = self.use_graph and hasattr(self.optimizer, "device_updates") and (tag == "single" or sync)
         if not graphable:
             return self._device_optimize(itr, samples_data)
         if self._graph is None:
@@ -113,7 +115,7 @@ class AdvActorCriticBase(RLAlgorithm):
                 return self._device_optimize(itr, samples_data)
             torch.cuda.synchronize(self.policy.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
                 self._graph_out = self._device_optimize(itr, samples_data)
             self._graph, self._graph_samples = graph, samples_data
         assert samples_data is self._graph_samples, "the sampler must hand over the same buffer"

@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "accel_rl_hip.h"
+#include "accel_rl_hip_dev.h"
 
 #define ARL_WAVE 64
 

@@ -1,2296 +1,16 @@
-// The policy network's dense contractions on the gfx950 matrix cores, fp32 in / fp32
-// accumulate (v_mfma_f32_32x32x2_f32: bit-for-bit a k-ordered fmaf chain, so results do
-// not depend on launch timing; every split reduction below is folded in a fixed order).
-//
-// The reference expresses these as Theano conv2d / dot nodes and their gradients
-// (accel_rl/policies/pg/networks/pg_cnn.py:45-86, policies/layers.py:22-41,
-//  optimizers/single/ppo_optimizer.py:38-56); this file is the MI355X-native form:
-//
-//   arl_conv2d_fwd         y = relu(conv(x, w) + b)          implicit GEMM, rows gathered on the fly
-//   arl_conv2d_bwd_data    dx = conv^T(dy, w) [* (act > 0)]  implicit GEMM per stride-parity class
-//   arl_conv2d_bwd_weight  dw = sum_m dy[m]^T im2col(x)[m]   split over m, fixed-order fold
-//
-// A dense layer is the 1x1 convolution on a 1x1 image (H = W = kh = kw = 1, C = fan_in).
-// Layouts: activations NHWC fp32, weights (K, kh, kw, C) ("OHWI", correlation kernels),
-// gradients in the same layouts.  All channel counts are multiples of 4 so that every
-// gathered fragment is one aligned 16-byte load.
-//
-// Tiling: 256-thread workgroups = 4 waves; a wave owns TM x TN MFMA tiles of 32 x 32.
-// Operand tiles are double-buffered in LDS; global loads for tile k+1 are issued before
-// the MFMAs of tile k and written to LDS after them (one barrier per k-tile).  LDS tiles
-// whose reduction index is contiguous are padded to BK+4 floats per row so that the
-// ds_read_b128 fragment reads (4 consecutive k per lane -> 4 MFMAs) are conflict-free.
+// Entry points of the MFMA contraction kernels (kernels and launchers: mfma_conv_impl.h; their instantiations are
+// built in mfma_conv_p1 .. p7.hip so that the translation units compile side by side).
+#include "mfma_conv_impl.h"
 
-#include "arl_optim_dev.h"
+using namespace arlc;
 
-#include <stdlib.h>
-#include <type_traits>
+namespace arlc {
+thread_local CallCtx t_ctx = {9, nullptr, false};
+unsigned long long* g_trace = nullptr;
+bool g_force_generic = false;
+}  // namespace arlc
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// GEMM rows gathered from an NHWC tensor: row m = (b, oy, ox); reduction index
-// r = (ty * taps_x + tx) * Cs + ch reads src[b][y0 + step*ty][x0 + step*tx][ch],
-// (y0, x0) = (oy*mul + add_y, ox*mul + add_x); out-of-image taps read 0.
-struct GatherDesc {
-    const float* src;
-    unsigned src_bytes;
-    int Hs, Ws, Cs;
-    int out_h, out_w;
-    int mul, add_y, add_x;
-    int taps_x, step;
-    // fast path only: taps_y; rmin = smallest tap-origin element offset of a valid row,
-    // dmin = smallest tap displacement; origin = rmin + dmin (descriptor base shift, <= 0);
-    // src_bytes is then the descriptor size measured from src + origin
-    int taps_y, rmin, dmin, origin;
-    // fast path only: ceil(2^32 / out_w), ceil(2^32 / out_h) when rows * divisor < 2^32 (then
-    // __umulhi(n, magic) == n / divisor exactly for every row index n), else 0 = divide
-    unsigned mg_w, mg_h;
-    // U8 kernels only (conv 1 straight from the sampler's observations, no f32 copy): planar u8 images,
-    // element (b, ch, y, x) = src8[row(b) * img_bytes + ch * plane + y * Ws + x], row(b) = idx ? idx[b] : b;
-    // reduction index r = (ch * kh8 + ty) * kw8 + tx (the weights are then (K, C, kh, kw));
-    // operand value = float(byte) * scale, converted between the global load and the LDS store
-    const unsigned char* src8;
-    const int* idx;
-    float scale;
-    int plane, img_bytes, kh8, kw8;
-    // bf16-split kernels only (arl_conv_pieces): the three bf16 pieces of src, written by the launch that produced src
-    // -- piece q of element e at pieces + q * piece_bytes + 2 e -- or null: split in the kernel
-    const char* pieces;
-    long long piece_bytes;
-};
-
-// The weight operand.  B_KC:  element (n, r) at w[n*ld + r]                (r contiguous)
-//                      !B_KC: element (r, n) at w[(r % kc)*ld + tap(r / kc) + n], with
-// tap(t) = ((i0 + si*(t / taps_x))*kw + (j0 + si*(t % taps_x)))*c          (n contiguous)
-struct WeightDesc {
-    const float* w;
-    unsigned w_bytes;
-    int ld, kc, taps_x, i0, j0, si, kw, c;
-};
-
-struct OutDesc {
-    float* out;
-    const float* bias;      // [N] or null
-    const float* mask;      // same layout as out; out = 0 where mask <= 0 (relu backward), or null
-    unsigned out_bytes;     // size of the whole output tensor (strided epilogue's buffer descriptor)
-    int relu, dense;        // dense: out[m*N + n]
-    int OH, OW, omul, oadd_y, oadd_x;   // else out[((b*OH + oy*omul + oadd_y)*OW + ox*omul + oadd_x)*N + n]
-    // bf16-split kernels only (arl_conv_pieces): where to leave the three bf16 pieces of out (same element order,
-    // piece q at pieces + q * piece_bytes), for the launch that gathers out next; or null
-    char* pieces;
-    long long piece_bytes;
-};
-
-struct GemmArgs {
-    GatherDesc g;
-    WeightDesc b;
-    OutDesc o;
-    int M, N, K;
-    int k_per_split;        // multiple of BK; gridDim.z splits
-    int64_t split_stride;   // elements between split outputs (dense M*N)
-    unsigned long long* trace;  // tuning aid: per-workgroup timestamps (arl_conv_trace_buffer), or null
-    // stride-s data gradient: the s*s input-pixel parity classes are independent implicit GEMMs that
-    // differ only in the fields below; one launch runs them all, blockIdx.z = class (igemm_kernel only)
-    // persistent launches (igemm_persist_kernel): p_tiles row tiles in all, class c owns [p_first[c], p_first[c + 1])
-    int p_tiles, p_first[5];
-    int n_par;
-    int xcd;                // split kernels: tiles dealt to the XCDs in contiguous ranges (xcd_chunk)
-    struct Parity {
-        int M, out_h, out_w, add_y, add_x, rmin, dmin, origin, i0, j0, oadd_y, oadd_x;
-        unsigned src_bytes, mg_w, mg_h;
-    } par[4];
-};
-
-// XCD-aware placement.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own
-// 4 MB L2: tiles that share an operand panel (the column tiles of one weight-gradient split, the 64 tiles of one
-// forward split of a dense layer, the row tiles over one weight panel) and therefore have neighbouring ids end up on
-// eight different L2s, and every one of them pulls the panel over the fabric again -- measured 6-7 TB/s of L1 <- L2
-// requests, almost all L2 misses, in kernels whose unique operands are 28-45 MB.  Workgroup `id` of `n` takes tile
-// xcd_chunk(id, n): XCD x gets a CONTIGUOUS range of tile ids (bijective for any n).
-__device__ __forceinline__ int xcd_chunk(int id, int n) {
-    const int q = n >> 3, r = n & 7, x = id & 7, j = id >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-}
-
-// Hardware-bounds-checked 16-byte loads: a raw buffer load whose byte offset lies outside
-// the descriptor's range returns 0 and touches no memory, so padding taps, ragged rows and
-// the tail of the reduction need neither branches nor selects (the k-loop stays one basic
-// block and the scheduler can interleave address math and loads with the MFMAs).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned OOB = 0x7ffffff0u;       // > any supported tensor size (checked on the host)
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-// Row-major epilogue of one wave's TM x TN accumulator tiles: D[row][col] with col = lane & 31,
-// row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5).  Each store instruction writes two 128-byte row
-// segments; the row part of the address is a compile-time multiple of the row pitch and rides
-// in the scalar offset, so the epilogue costs no address arithmetic on the vector unit.
-template <int TM, int TN>
-__device__ __forceinline__ void store_tiles_rowmajor(const f32x16 (&acc)[TM][TN], float* out, int rows_total,
-                                                     int N, int row_base, int col_base, int lane,
-                                                     const float* bias, int relu) {
-    const int l31 = lane & 31, half = lane >> 5;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(out, (unsigned)rows_total * (unsigned)N * 4u);
-    const int row0 = row_base + 4 * half;
-    const bool full = row_base + TM * 32 <= rows_total;                 // uniform per wave
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = col_base + j * 32 + l31;
-        const float bj = (bias && n < N) ? bias[n] : 0.f;
-        const unsigned voff = n < N ? (unsigned)(row0 * N + n) << 2 : OOB;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int rc = i * 32 + (v & 3) + 8 * (v >> 2);
-                float val = acc[i][j][v] + bj;
-                if (relu) val = fmaxf(val, 0.f);
-                if (full || row0 + rc < rows_total)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(val), rs, voff, (unsigned)(rc * N) << 2, 0);
-            }
-    }
-}
-
-// bf16 pieces of fp32 numbers (see SPLIT below): x = h + m + l exactly, h = top 16 bits of x, m = top 16 bits of x - h
-constexpr unsigned HI16 = 0xffff0000u;
-// (bf16 of x0, bf16 of x1) truncated, x0 in the low half (k order = memory order)
-__device__ __forceinline__ unsigned hi_pair(float x0, float x1) {
-    return __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-}
-__device__ __forceinline__ float lo_part(float x) { return x - __uint_as_float(__float_as_uint(x) & HI16); }   // exact
-__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
-    h = hi_pair(x0, x1);
-    const float r0 = lo_part(x0), r1 = lo_part(x1);
-    m = hi_pair(r0, r1);
-    l = hi_pair(lo_part(r0), lo_part(r1));
-}
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// four consecutive elements' pieces to the three piece tensors (byte offset voff2 inside each)
-__device__ __forceinline__ void store_pieces4(const float4& v, const __amdgpu_buffer_rsrc_t (&rp)[3], unsigned voff2) {
-    unsigned h0, m0, l0, h1, m1, l1;
-    split_pair(v.x, v.y, h0, m0, l0);
-    split_pair(v.z, v.w, h1, m1, l1);
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{h0, h1}, rp[0], voff2, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{m0, m1}, rp[1], voff2, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{l0, l1}, rp[2], voff2, 0, 0);
-}
-
-// Epilogue of the operand-swapped kernels (acc = W-tile x X-tile^T): D'[row][col] with col = lane & 31
-// the GEMM row m and row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) the output channel n, so a lane holds
-// four consecutive channels of ONE output row per register quad and stores them as one b128 -- four
-// store instructions per 32x32 tile instead of sixteen, and one row decode per lane instead of
-// sixteen.  row_off[i] = element offset of the lane's row in tile i (or < 0: row out of range);
-// bias_q[j][q] = the lane's four bias values of quad q of column tile j (zeros without a bias);
-// N % 4 == 0 (checked on the host).  mask: same layout as out, out = 0 where mask <= 0.
-template <int TM, int TN, bool SCALED = false>
-__device__ __forceinline__ void store_tiles_quads(const f32x16 (&acc)[TM][TN], __amdgpu_buffer_rsrc_t rs,
-                                                  const long long (&row_off)[TM], int N, int col_base, int lane,
-                                                  const float4 (&bias_q)[TN][4], const float* mask, int relu,
-                                                  const float4 (*pre)[TM] = nullptr, float scale = 1.f,
-                                                  char* pieces = nullptr, long long piece_bytes = 0, unsigned out_bytes = 0) {
-    const int half = lane >> 5;
-    // the bf16 pieces of the stored values (arl_conv_pieces): same element offsets at two bytes per element
-    __amdgpu_buffer_rsrc_t rp[3];
-    if (pieces) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            rp[c] = make_rsrc(reinterpret_cast<const float*>(pieces + c * piece_bytes), out_bytes >> 1);
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        // the rectifier mask of a column tile: every load issued before the first one is consumed (one latency
-        // per column tile instead of one per store; per-workgroup timestamps had the epilogue of the stride-2
-        // data gradient at 10 k cycles of a 66 k lifetime)
-        float4 mk[4][TM];
-        if (mask && pre) {                              // (TN == 1: loaded in the prologue, see igemm_body)
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) mk[q][i] = pre[q][i];
-        } else if (mask) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int n = col_base + j * 32 + 8 * q + 4 * half;
-                    mk[q][i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (row_off[i] >= 0 && n < N) mk[q][i] = *reinterpret_cast<const float4*>(mask + row_off[i] + n);
-                }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = col_base + j * 32 + 8 * q + 4 * half;
-            const float4 bq = bias_q[j][q];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bool ok = row_off[i] >= 0 && n < N;
-                float4 val = SCALED     // (the u8 kernels: the pixel scale on the finished sum, see bytes_to_f4)
-                    ? make_float4(acc[i][j][4 * q] * scale + bq.x, acc[i][j][4 * q + 1] * scale + bq.y,
-                                  acc[i][j][4 * q + 2] * scale + bq.z, acc[i][j][4 * q + 3] * scale + bq.w)
-                    : make_float4(acc[i][j][4 * q] + bq.x, acc[i][j][4 * q + 1] + bq.y,
-                                  acc[i][j][4 * q + 2] + bq.z, acc[i][j][4 * q + 3] + bq.w);
-                if (relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
-                const unsigned voff = ok ? (unsigned)((row_off[i] + n) << 2) : OOB;
-                if (mask) {
-                    const float4 m = mk[q][i];
-                    if (!(m.x > 0.f)) val.x = 0.f;
-                    if (!(m.y > 0.f)) val.y = 0.f;
-                    if (!(m.z > 0.f)) val.z = 0.f;
-                    if (!(m.w > 0.f)) val.w = 0.f;
-                }
-                u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rs, voff, 0, 0);
-                if (pieces) store_pieces4(val, rp, voff >> 1);          // (OOB >> 1 is still beyond every tensor)
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// out[M][N] = rows(gather)[M][K] . W        (forward conv / dense forward: B_KC;
-//                                            data gradient / dense dx: !B_KC)
-// TAP_UNIFORM (!B_KC only): kc % BK == 0, so one k-tile lies inside one filter tap and the
-// weight-row decode is done once per tile instead of once per loaded row.
-// ------------------------------------------------------------------------------------------
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool TAP_UNIFORM>
-__global__ __launch_bounds__(256) void rowgather_gemm_kernel(const GemmArgs a) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32, CH = BK / 4;
-    constexpr int LDA = BK + 4;
-    constexpr int LDB = B_KC ? BK + 4 : BN;
-    constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
-    constexpr int ROWS_PER_PASS = 256 / CH;
-    constexpr int RA = BM / ROWS_PER_PASS;
-    constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
-    constexpr int RB = (NB4 + 255) / 256;
-    static_assert(WGM * WGN == 4 && BM % ROWS_PER_PASS == 0 && BK % 8 == 0, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sA = smem;
-    float* sB = smem + 2 * A_SZ;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * a.k_per_split;
-    const int kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.g.src, a.g.src_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
-
-    // ---- loop-invariant decode of this thread's A rows: tap origin (ry, rx) and element offset of it
-    const int a_chunk = tid % CH, a_row0 = tid / CH;
-    int ry[RA], rx[RA], rbase[RA];
-#pragma unroll
-    for (int p = 0; p < RA; ++p) {
-        const int m = m0 + a_row0 + p * ROWS_PER_PASS;
-        const int t = m / a.g.out_w, ox = m - t * a.g.out_w;
-        const int b = t / a.g.out_h, oy = t - b * a.g.out_h;
-        ry[p] = m < a.M ? oy * a.g.mul + a.g.add_y : -(1 << 28);
-        rx[p] = ox * a.g.mul + a.g.add_x;
-        rbase[p] = ((b * a.g.Hs + ry[p]) * a.g.Ws + rx[p]) * a.g.Cs;
-    }
-    float4 va[RA], vb[RB];
-    unsigned offA[RA], offB[RB];        // byte offsets of the NEXT tile's loads (OOB = reads as zero)
-
-    auto plan_tiles = [&](int kb) {
-        {
-            const int r = kb + a_chunk * 4;
-            const int tap = r / a.g.Cs, ch = r - tap * a.g.Cs;
-            const int ty = tap / a.g.taps_x, tx = tap - ty * a.g.taps_x;
-            const int dy = a.g.step * ty, dx = a.g.step * tx;
-            const int delta = (dy * a.g.Ws + dx) * a.g.Cs + ch;
-            const int kval = r < kend;
-#pragma unroll
-            for (int p = 0; p < RA; ++p) {
-                const int ok = kval & ((unsigned)(ry[p] + dy) < (unsigned)a.g.Hs) & ((unsigned)(rx[p] + dx) < (unsigned)a.g.Ws);
-                offA[p] = ok ? (unsigned)(rbase[p] + delta) << 2 : OOB;
-            }
-        }
-        if (B_KC) {
-#pragma unroll
-            for (int p = 0; p < RB; ++p) {
-                const int idx = tid + p * 256;
-                const int nl = idx / CH, chunk = idx - nl * CH;
-                const int n = n0 + nl, r = kb + chunk * 4;
-                const int ok = (NB4 % 256 == 0 || idx < NB4) & (n < a.N) & (r < kend);
-                offB[p] = ok ? (unsigned)(n * a.b.ld + r) << 2 : OOB;
-            }
-        } else {
-            constexpr int NC4 = BN / 4;
-            int tile_off = 0;
-            if (TAP_UNIFORM) {                  // (kb .. kb+BK) shares one tap
-                const int t = kb / a.b.kc, ko0 = kb - t * a.b.kc;
-                const int ti = t / a.b.taps_x, tj = t - ti * a.b.taps_x;
-                tile_off = ko0 * a.b.ld + ((a.b.i0 + a.b.si * ti) * a.b.kw + (a.b.j0 + a.b.si * tj)) * a.b.c;
-            }
-#pragma unroll
-            for (int p = 0; p < RB; ++p) {
-                const int idx = tid + p * 256;
-                const int kl = idx / NC4, nch = idx - kl * NC4;
-                const int r = kb + kl, n = n0 + nch * 4;
-                const int ok = (NB4 % 256 == 0 || idx < NB4) & (r < kend) & (n < a.N);
-                int row_off;
-                if (TAP_UNIFORM) {
-                    row_off = tile_off + kl * a.b.ld;
-                } else {
-                    const int t = r / a.b.kc, ko = r - t * a.b.kc;
-                    const int ti = t / a.b.taps_x, tj = t - ti * a.b.taps_x;
-                    row_off = ko * a.b.ld + ((a.b.i0 + a.b.si * ti) * a.b.kw + (a.b.j0 + a.b.si * tj)) * a.b.c;
-                }
-                offB[p] = ok ? (unsigned)(row_off + n) << 2 : OOB;
-            }
-        }
-    };
-    auto issue_loads = [&]() {
-#pragma unroll
-        for (int p = 0; p < RA; ++p) va[p] = buf_ld4(rsA, offA[p]);
-#pragma unroll
-        for (int p = 0; p < RB; ++p) vb[p] = buf_ld4(rsB, offB[p]);
-    };
-    auto store_tiles = [&](int buf) {
-        float* dA = sA + buf * A_SZ;
-        float* dB = sB + buf * B_SZ;
-#pragma unroll
-        for (int p = 0; p < RA; ++p)
-            *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) = va[p];
-#pragma unroll
-        for (int p = 0; p < RB; ++p) {
-            const int idx = tid + p * 256;
-            if (NB4 % 256 != 0 && idx >= NB4) continue;
-            if (B_KC) {
-                const int nl = idx / CH, chunk = idx - nl * CH;
-                *reinterpret_cast<float4*>(dB + nl * LDB + chunk * 4) = vb[p];
-            } else {
-                constexpr int NC4 = BN / 4;
-                const int kl = idx / NC4, nch = idx - kl * NC4;
-                *reinterpret_cast<float4*>(dB + kl * LDB + nch * 4) = vb[p];
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    // Software pipeline: the loads of tile kt+1 are issued first thing in iteration kt from
-    // offsets computed during iteration kt-1; the address math for tile kt+2 then runs in the
-    // shadow of tile kt's MFMAs, and the LDS stores (which wait for the loads) come last.
-    const int nk = (kend - kbeg + BK - 1) / BK;
-    plan_tiles(kbeg);
-    issue_loads();
-    plan_tiles(kbeg + BK);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        issue_loads();                          // tile kt+1 (past the end: all offsets out of range -> zeros, no traffic)
-        __builtin_amdgcn_sched_barrier(0);
-        plan_tiles(kbeg + (kt + 2) * BK);
-        const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
-        const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
-                               : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float fa[TM][4], fb[TN][4];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
-                fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                if (B_KC) {
-                    const float4 t = *reinterpret_cast<const float4*>(cB + j * 32 * LDB + ks * 8);
-                    fb[j][0] = t.x; fb[j][1] = t.y; fb[j][2] = t.z; fb[j][3] = t.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) fb[j][q] = cB[(ks * 8 + q) * LDB + j * 32];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: D[row][col], col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)
-    float* out = a.o.out + (int64_t)blockIdx.z * a.split_stride;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int m = m0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
-            if (m >= a.M) continue;
-            int64_t orow;
-            if (a.o.dense) {
-                orow = (int64_t)m * a.N;
-            } else {
-                const int t = m / a.g.out_w, ox = m - t * a.g.out_w;
-                const int b = t / a.g.out_h, oy = t - b * a.g.out_h;
-                orow = ((int64_t)(b * a.o.OH + oy * a.o.omul + a.o.oadd_y) * a.o.OW + ox * a.o.omul + a.o.oadd_x) * a.N;
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * TN * 32 + j * 32 + l31;
-                if (n >= a.N) continue;
-                float val = acc[i][j][v];
-                if (a.o.bias) val += a.o.bias[n];
-                if (a.o.relu) val = fmaxf(val, 0.f);
-                if (a.o.mask && !(a.o.mask[orow + n] > 0.f)) val = 0.f;
-                out[orow + n] = val;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// part[z][ko][r] = sum_{m in split z} dy[m][ko] * rows(gather)[m][r]    (weight gradient)
-// The reduction runs over the gathered rows, so their (b, oy, ox) decode changes every
-// k-tile: BK lanes decode one row each, one tile ahead, into a small LDS table that every
-// thread reads (two integer divisions per tile and workgroup instead of per load).
-// ------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* dy;        // [Mred][K_out]
-    GatherDesc g;
-    float* part;            // [splits][K_out][N]
-    unsigned dy_bytes;
-    int K_out, N, Mred;
-    int m_per_split;        // multiple of BK
-    int adv_b, adv_y, adv_x;    // fast path: 256 rows = adv_b images + adv_y output rows + adv_x pixels
-    float* bias_part;       // fast path: [splits][K_out] column sums of dy (the bias gradient's partials), or null
-    unsigned long long* trace;  // tuning aid (arl_conv_trace_buffer): per-workgroup timestamps as in GemmArgs, or null
-    int xcd;                    // split kernels: tiles dealt to the XCDs in contiguous ranges (xcd_chunk)
-};
-
-template <int WGM, int WGN, int TM, int TN, int BK>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
-    constexpr int NA4 = BK * BM / 4, RA = (NA4 + 255) / 256, MC4 = BM / 4;
-    constexpr int NC4 = BN / 4, KROWS = 256 / NC4, RB = BK / KROWS;
-    static_assert(WGM * WGN == 4 && 256 % NC4 == 0 && BK % KROWS == 0 && BK % 8 == 0 && BK <= 64, "tile shape");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ int4 s_row[3][BK];       // per gathered row: y0, x0, element offset of (b, y0, x0, 0); beyond the split: y0 << 0
-    float* sA = smem;
-    float* sB = smem + 2 * A_SZ;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int n0 = blockIdx.x * BN, i0 = blockIdx.y * BM;
-    const int mbeg = blockIdx.z * a.m_per_split;
-    const int mend = (mbeg + a.m_per_split < a.Mred) ? mbeg + a.m_per_split : a.Mred;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.dy, a.dy_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.g.src, a.g.src_bytes);
-
-    // ---- loop-invariant decode of this thread's gather column (4 consecutive r)
-    const int b_c4 = tid % NC4, b_k0 = tid / NC4;
-    const int r = n0 + b_c4 * 4;
-    const int rval = r < a.N;
-    const int tap = r / a.g.Cs, ch = r - tap * a.g.Cs;
-    const int ty = tap / a.g.taps_x, tx = tap - ty * a.g.taps_x;
-    const int cy = a.g.step * ty, cx = a.g.step * tx;
-    const int cdelta = (cy * a.g.Ws + cx) * a.g.Cs + ch;
-    float4 va[RA], vb[RB];
-    unsigned offA[RA], offB[RB];
-
-    auto decode_rows = [&](int kb, int slot) {      // lanes 0..BK-1 of wave 0
-        if (tid < BK) {
-            const int m = kb + tid;
-            const int t = m / a.g.out_w, ox = m - t * a.g.out_w;
-            const int b = t / a.g.out_h, oy = t - b * a.g.out_h;
-            const int y0 = m < mend ? oy * a.g.mul + a.g.add_y : -(1 << 28), x0 = ox * a.g.mul + a.g.add_x;
-            s_row[slot][tid] = make_int4(y0, x0, ((b * a.g.Hs + y0) * a.g.Ws + x0) * a.g.Cs, 0);
-        }
-    };
-    auto plan_tiles = [&](int kb, int slot) {
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            const int idx = tid + p * 256;
-            const int kl = idx / MC4, c4 = idx - kl * MC4;
-            const int m = kb + kl, ko = i0 + c4 * 4;
-            const int ok = (NA4 % 256 == 0 || idx < NA4) & (m < mend) & (ko < a.K_out);
-            offA[p] = ok ? (unsigned)(m * a.K_out + ko) << 2 : OOB;
-        }
-#pragma unroll
-        for (int p = 0; p < RB; ++p) {
-            const int4 e = s_row[slot][b_k0 + p * KROWS];
-            const int ok = rval & ((unsigned)(e.x + cy) < (unsigned)a.g.Hs) & ((unsigned)(e.y + cx) < (unsigned)a.g.Ws);
-            offB[p] = ok ? (unsigned)(e.z + cdelta) << 2 : OOB;
-        }
-    };
-    auto issue_loads = [&]() {
-#pragma unroll
-        for (int p = 0; p < RA; ++p) va[p] = buf_ld4(rsA, offA[p]);
-#pragma unroll
-        for (int p = 0; p < RB; ++p) vb[p] = buf_ld4(rsB, offB[p]);
-    };
-    auto store_tiles = [&](int buf) {
-        float* dA = sA + buf * A_SZ;
-        float* dB = sB + buf * B_SZ;
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            const int idx = tid + p * 256;
-            if (NA4 % 256 != 0 && idx >= NA4) continue;
-            *reinterpret_cast<float4*>(dA + idx * 4) = va[p];            // [kl][c4*4] row-major, ld = BM
-        }
-#pragma unroll
-        for (int p = 0; p < RB; ++p)
-            *reinterpret_cast<float4*>(dB + (b_k0 + p * KROWS) * BN + b_c4 * 4) = vb[p];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-
-    // Pipeline (see rowgather_gemm_kernel): loads of tile kt+1 first, then the offsets of tile
-    // kt+2 (from the row table written one iteration earlier) and the row decode of tile kt+3
-    // in the shadow of tile kt's MFMAs.  Row-table slot = tile % 3: the slot written in
-    // iteration kt (tile kt+3 = kt mod 3) was last read in iteration kt-1, before a barrier.
-    const int nk = (mend - mbeg + BK - 1) / BK;
-    decode_rows(mbeg, 0);
-    decode_rows(mbeg + BK, 1);
-    decode_rows(mbeg + 2 * BK, 2);
-    __syncthreads();
-    plan_tiles(mbeg, 0);
-    issue_loads();
-    plan_tiles(mbeg + BK, 1);
-    store_tiles(0);
-    __syncthreads();
-    int slot = 2;                                       // (kt + 2) % 3
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        issue_loads();                                  // tile kt+1
-        __builtin_amdgcn_sched_barrier(0);
-        plan_tiles(mbeg + (kt + 2) * BK, slot);
-        slot = slot == 2 ? 0 : slot + 1;                // (kt + 3) % 3: also the next iteration's plan slot
-        decode_rows(mbeg + (kt + 3) * BK, slot);
-        const float* cA = sA + buf * A_SZ + (half * 4) * BM + wm * TM * 32 + l31;
-        const float* cB = sB + buf * B_SZ + (half * 4) * BN + wn * TN * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float fa[TM][4], fb[TN][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i][q] = cA[(ks * 8 + q) * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j][q] = cB[(ks * 8 + q) * BN + j * 32];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        store_tiles(buf ^ 1);
-        __syncthreads();
-    }
-
-    float* out = a.part + (int64_t)blockIdx.z * a.K_out * a.N;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int ko = i0 + wm * TM * 32 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
-            if (ko >= a.K_out) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * TN * 32 + j * 32 + l31;
-                if (n < a.N) out[(int64_t)ko * a.N + n] = acc[i][j][v];
-            }
-        }
-    }
-}
-
-// ==========================================================================================
-// Scalar-addressed fast path.
-//
-// On gfx950 the fp32-input MFMA runs at the fp32 VECTOR rate and shares the SIMD's VALU issue:
-// every VALU instruction in the k-loop is time taken from the MFMAs (measured on MI355X,
-// tools/mfma_mix.hip: 6 v_add per MFMA drop 144 -> 93 TF/s; ds_read / buffer_load cost nothing).
-// The kernels below therefore keep the per-tile addressing entirely on the scalar unit: a k-tile
-// never straddles filter taps, so its address is   per-thread constant (voffset)  +  per-tile
-// uniform (soffset, SALU);  padding taps are switched off with one v_bfe_i32 + v_and_or per row
-// from a per-row bit mask built once in the prologue.  Requirements (else the generic kernels
-// above are used): K % BK == 0 and either Cs % BK == 0 (one tap per tile) or BK % Cs == 0 with
-// whole taps of one filter row per tile (MULTI_TAP: conv 1, 4 channels x 8 taps = 32).
-// ==========================================================================================
-__device__ __forceinline__ float4 buf_ld4s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-__device__ __forceinline__ u32x4 buf_ld4u(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
-}
-__device__ __forceinline__ u32x2 buf_ld2s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
-}
-__device__ __forceinline__ unsigned buf_ld1s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0);
-}
-// four packed bytes -> four floats (v_cvt_f32_ubyte0..3).  The pixel scale (1/255) is NOT applied here: a
-// convolution is linear in its input, so the u8 kernels accumulate sum(x * w) on the exact integers and multiply the
-// finished sum once -- conv(x * s, w) = s * conv(x, w) up to the rounding of one multiply per output instead of one
-// per operand element (two v_pk_mul_f32 per loaded dword, a third of the loader's vector work).
-__device__ __forceinline__ float4 bytes_to_f4(unsigned v) {
-    return make_float4((float)(v & 0xffu), (float)((v >> 8) & 0xffu), (float)((v >> 16) & 0xffu), (float)(v >> 24));
-}
-// n / d for a uniform runtime divisor: one v_mul_hi instead of the ~40-instruction division sequence
-// (vector instructions in these kernels are paid for in MFMA issue slots); magic == 0 -> plain division
-__device__ __forceinline__ int div_u(int n, int d, unsigned magic) {
-    if (magic) return (int)__umulhi((unsigned)n, magic);
-    return d == 1 ? n : n / d;                      // uniform branches
-}
-__device__ __forceinline__ unsigned mask_off(unsigned imask, int bit, unsigned voff) {
-    // imask bit set = tap invalid for this row -> force the offset out of range
-    return ((unsigned)__builtin_amdgcn_sbfe(imask, bit, 1) & OOB) | voff;
-}
-// Inverted tap mask of a gathered row whose tap (ty, tx) reads pixel (ry + step*ty, rx + step*tx): bit
-// ty*taps_x + tx is SET when that pixel lies outside the Hs x Ws image (taps_y * taps_x <= 32, step = +-1).
-// Closed form -- the valid taps of a row are a contiguous range in x and in y -- instead of a loop over the taps:
-// these kernels pay for every vector instruction in matrix-pipe issue slots (fp32 MFMA shares the VALU), and the
-// loops cost 28 instructions per tap row / column, per gathered row, in every workgroup's prologue and in the
-// weight gradient's row table refresh (conv 2 forward: 224 of ~400 non-MFMA vector instructions per workgroup).
-__device__ __forceinline__ unsigned low_bits(int n) { return n >= 32 ? ~0u : (1u << n) - 1u; }
-__device__ __forceinline__ unsigned tap_mask(int ry, int rx, int Hs, int Ws, int taps_y, int taps_x, int step) {
-    // x + step*t in [0, W)  <=>  t in [p, p + W) with p = -x (step = 1) or x - W + 1 (step = -1)
-    const int px = step > 0 ? -rx : rx - Ws + 1, py = step > 0 ? -ry : ry - Hs + 1;
-    const int xlo = min(max(px, 0), 31), xhi = min(px + Ws, taps_x), ylo = max(py, 0), yhi = min(py + Hs, taps_y);
-    const int xn = max(xhi - xlo, 0), yn = max(yhi - ylo, 0);
-    unsigned good = low_bits(xn) << xlo;                // one tap row's pattern ...
-    for (int sh = taps_x; sh < 32; sh *= 2) good |= good << sh;         // ... over every tap row (uniform trip count)
-    return ~(good & (low_bits(yn * taps_x) << min(ylo * taps_x, 31))); // rows [ylo, yhi) keep it, the others are out
-}
-
-// ==========================================================================================
-// SPLIT: fp32 contractions on the bf16 matrix pipe (arl_conv_precision).
-//
-// gfx950 has no fast fp32 matrix path: v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate (157 TF/s) and takes the
-// SIMD's vector issue with it, while v_mfma_f32_32x32x16_bf16 sustains 2.1-2.4 PF/s next to 4-6 vector instructions
-// per MFMA (tools/mfma_bf16_mix.hip).  An fp32 number is EXACTLY the sum of three bf16 numbers (24 significand bits =
-// 3 x 8: h = top 16 bits of x, m = top 16 bits of x - h, l = x - h - m, every step exact), so
-//     x * y = sum over the nine (or the six largest) products of their pieces,
-// each product exact in the fp32 accumulator (8 x 8 significand bits).  SPLIT = 9: all nine -- every product term of
-// the fp32 contraction enters the sum exactly, only the accumulation rounds (as it does in the fp32 MFMA chain);
-// SPLIT = 6: the terms below 2^-24 |x y| (m l, l m, l l) are dropped.  The split happens between the global load
-// and the LDS store (11 vector instructions per pair of elements, hidden under the MFMAs of the co-resident waves);
-// LDS holds three bf16 planes per operand tile.  u8 observations are exact in ONE bf16 plane (255 < 2^8): conv 1
-// needs three products, not nine.
-// LDS images per plane: k-contiguous operands [row][BK] bf16, 16-byte slots XOR-swizzled by the row so that the
-// ds_read_b128 fragment reads (lane = row, 8 consecutive k) are conflict-free without padding; k-major operands
-// (the data gradient's weights, both operands of the weight gradient) as [BK / 2][col] dwords of (k even, k odd)
-// pairs, a fragment = 4 ds_read_b32 -- the loader threads fetch two adjacent k rows and pack them.
-// ==========================================================================================
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-// acc += sum of the piece products, smallest terms first.  PA / PB = planes of the two operands (1: exact in bf16)
-// (the accumulators of a wave's TM x TN tiles take turns inside each piece pair: no back-to-back dependent MFMAs)
-template <int SPLIT, int PA, int PB, bool SWAP, int TM, int TN>
-__device__ __forceinline__ void split_products(const u32x4 (&fa)[TM][3], const u32x4 (&fb)[TN][3], f32x16 (&acc)[TM][TN]) {
-#pragma unroll
-    for (int s = 4; s >= 0; --s)
-#pragma unroll
-        for (int pa = 0; pa < PA; ++pa) {
-            const int pb = s - pa;
-            if (pb < 0 || pb >= PB) continue;
-            if (SPLIT == 6 && PA == 3 && PB == 3 && s > 2) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = SWAP ? mfma_bf16(fb[j][pb], fa[i][pa], acc[i][j]) : mfma_bf16(fa[i][pa], fb[j][pb], acc[i][j]);
-        }
-}
-// 16-byte slot swizzle of the k-contiguous LDS image: NS = BK / 8 slots per row
-template <int NS> __device__ __forceinline__ int kc_swz(int row) { return (row / (16 / NS)) % NS; }
-
-// N16: layers with <= 16 output columns (spec 0's 16-filter conv 1, the data gradient into 16 channels) use
-// v_mfma_f32_16x16x4_f32 -- a 32-wide tile would spend half of every MFMA on columns that do not exist.
-// A wave then owns TM groups of 16 rows x 16 columns; lane (l & 15, l >> 4) holds row l & 15 and the four
-// channels 4 (l >> 4) .. + 3 of each group, again one b128 store per group.
-// U8: the gathered operand is read from planar u8 images (GatherDesc::src8): a 4-wide k chunk is four
-// consecutive pixels of one filter row = one aligned dword (stride, width and plane size are multiples of 4,
-// no padding); a k-tile covers BK / kw8 whole filter rows of one plane, so the tile's address is again
-// per-thread constant + per-tile uniform.
-// PIPE3: three LDS stages and the k-tile's one barrier in the MIDDLE of its MFMAs.  A workgroup with one wave per
-// SIMD that stores tile t+1, waits at the barrier and only then reads its first fragments leaves the matrix pipe
-// idle once per k-tile (per-workgroup timestamps: two 112x64 workgroups on a CU keep the pipe 79 % busy, four 64x64
-// ones 90 %).  Here tile t+1 is stored and fenced halfway through tile t -- into the stage tile t-2 used, which every
-// wave has left since it passed the previous barrier --, so that nothing separates the last MFMA of a tile from the
-// first of the next; the loads of tile t+2 are issued right after the barrier (a full tile of latency cover).
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
-          bool U8 = false, bool PIPE3 = false, int SPLIT = 0, bool PIN = false, bool ADIR = false>
-__device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, const int by, const int bz, float* smem) {
-    constexpr bool SP = SPLIT != 0;                 // bf16-split products (see above): other LDS images, other MFMAs
-    // ADIR: the gathered operand never enters LDS.  With WGN == 1 a wave owns its 32-row tiles outright, and a lane's
-    // MFMA fragment -- row l31, eight consecutive k -- is 32 contiguous bytes of that row in memory: two 16-byte loads
-    // per 16 k land where the MFMA reads them (fp32, split in registers) or three (PIN: the pieces themselves).  The
-    // split kernels are otherwise LDS-bound: three planes written and read back per operand tile is more LDS time
-    // than the nine products take on the matrix pipe (128x32 tiles: ~1 400 LDS cycles against 1 152 per k-tile and CU).
-    static_assert(!ADIR || (SP && WGN == 1 && !MULTI_TAP && !(U8 && PIN)), "direct operand: split kernels, one wave per row tile");
-    // PIN: the gathered operand arrives as bf16 pieces (GatherDesc::pieces, left by the launch that produced it): the
-    // loader copies three 8-byte chunks per 4 k straight into the LDS planes -- no split, no vector work on this operand
-    static_assert(!PIN || (SP && !U8 && !MULTI_TAP), "pieces: split kernels, one tap per k-tile");
-    constexpr int MT = N16 ? 16 : 32;               // rows per MFMA tile
-    constexpr int BM = WGM * TM * MT, BN = N16 ? WGN * 16 : WGN * TN * 32, CH = BK / 4;
-    constexpr int LDA = BK + 4;
-    constexpr int LDB = B_KC ? BK + 4 : (N16 ? BN + 4 : BN);    // + 4: the four k-quads of a 16-wide read hit distinct banks
-    static_assert(!N16 || (TN == 1 && BK % 16 == 0), "16-wide tiles: one column tile per wave");
-    static_assert(!SP || (!N16 && !PIPE3 && BK % 16 == 0), "split products: 32-wide tiles, two LDS stages");
-    constexpr int ROWS_PER_PASS = 256 / CH;
-    constexpr int RA = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;        // BM need not be a multiple of a loader pass:
-    constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;   // the last pass's surplus rows load and store nothing
-    constexpr int NST = PIPE3 ? 3 : 2;                                  // LDS stages
-    constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
-    // split, k-major weights: a loader task = two adjacent k rows of four columns (packed into (k, k + 1) dwords)
-    constexpr int NPAIR = (BK / 2) * (BN / 4);
-    constexpr int RB = (SP && !B_KC) ? 2 * ((NPAIR + 255) / 256) : (NB4 + 255) / 256;
-    static_assert(WGM * WGN == 4 && BK % 8 == 0, "tile shape");
-    float* sA = smem;
-    float* sB = smem + NST * A_SZ;
-    // split images (bytes): PA planes of BM x BK bf16 + 3 planes of BK x BN bf16 per stage
-    constexpr int PA = U8 ? 1 : 3, ROWB = BK * 2, NS = BK / 8;
-    constexpr int LPA = ADIR ? 0 : PA;              // planes of the gathered operand that live in LDS
-    constexpr int SPA = BM * ROWB, SPB = BN * ROWB, STAGE = LPA * SPA + 3 * SPB;
-    char* const sS = reinterpret_cast<char*>(smem);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = bx * BM, n0 = by * BN;
-    GatherDesc g = a.g;
-    int M = a.M, w_i0 = a.b.i0, w_j0 = a.b.j0, oadd_y = a.o.oadd_y, oadd_x = a.o.oadd_x;
-    if (a.n_par) {                                  // uniform: this workgroup's parity class
-        const GemmArgs::Parity& q = a.par[bz];
-        M = q.M; g.out_h = q.out_h; g.out_w = q.out_w; g.add_y = q.add_y; g.add_x = q.add_x;
-        g.mg_w = q.mg_w; g.mg_h = q.mg_h;
-        g.rmin = q.rmin; g.dmin = q.dmin; g.origin = q.origin; g.src_bytes = q.src_bytes;
-        w_i0 = q.i0; w_j0 = q.j0; oadd_y = q.oadd_y; oadd_x = q.oadd_x;
-        if (m0 >= M) return;
-    }
-    const int kbeg = a.n_par ? 0 : bz * a.k_per_split;
-    const int kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
-    const int Cs = g.Cs, taps_x = g.taps_x, Ws = g.Ws, step = g.step;
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
-    if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    // descriptor origins: the smallest element offset a valid (row, tap) pair can produce
-    const __amdgpu_buffer_rsrc_t rsA = U8 ? make_rsrc(reinterpret_cast<const float*>(g.src8), g.src_bytes)
-                                          : make_rsrc(g.src + g.origin, g.src_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
-    __amdgpu_buffer_rsrc_t rsP[3];                  // PIN: the same window, two bytes per element, in every piece tensor
-    if constexpr (PIN) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            rsP[c] = make_rsrc(reinterpret_cast<const float*>(g.pieces + c * g.piece_bytes + 2 * (long long)g.origin),
-                               g.src_bytes >> 1);
-    }
-
-    // ---- per-thread constants -------------------------------------------------------------
-    const int a_chunk = tid % CH, a_row0 = tid / CH;
-    const int cpr8 = g.kw8 >> 2, rpt8 = U8 ? CH / cpr8 : 0;       // U8: chunks per filter row, filter rows per k-tile
-    int tpt = 0, chl = a_chunk * 4;                 // tap within the tile / channel within the tap
-    if (MULTI_TAP) { tpt = chl / Cs; chl -= tpt * Cs; }
-    unsigned voffA[RA], imask[RA], voffB[RB];
-    unsigned voffD[TM], imaskD[TM];                 // ADIR: the lane's own row of each of its wave's row tiles
-    unsigned voffD8[TM][BK / 16][2];                // ... U8: the two 4-pixel chunks of the lane's k octet of every 16-k step
-    if constexpr (ADIR) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * 32 + l31;
-            const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
-            const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
-            const int ry = oy * g.mul + g.add_y, rx = ox * g.mul + g.add_x;
-            const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
-            voffD[i] = m < M ? (unsigned)(rbase - g.rmin + half * 8) << 2 : OOB;        // k octet `half` of each 16 k
-            imaskD[i] = HAS_PAD ? tap_mask(ry, rx, g.Hs, Ws, g.taps_y, taps_x, step) : 0;
-            if constexpr (U8) {                     // chunk c of the k-tile = filter row c / cpr8 (of the tile), pixels 4 (c % cpr8) ..
-                const int row = (m < M && g.idx) ? g.idx[b] : b;
-#pragma unroll
-                for (int ks = 0; ks < BK / 16; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int c = 2 * (2 * ks + half) + j, tyl = c / cpr8, txq = c - tyl * cpr8;
-                        voffD8[i][ks][j] = m < M ? (unsigned)(row * g.img_bytes + (ry + tyl) * Ws + rx + 4 * txq) : OOB;
-                    }
-            }
-        }
-    }
-#pragma unroll
-    for (int p = 0; p < (ADIR ? 0 : RA); ++p) {
-        const int m = m0 + a_row0 + p * ROWS_PER_PASS;
-        const bool row_ok = m < M && (BM % ROWS_PER_PASS == 0 || a_row0 + p * ROWS_PER_PASS < BM);
-        const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
-        const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
-        const int ry = oy * g.mul + g.add_y, rx = ox * g.mul + g.add_x;
-        const int rbase = ((b * g.Hs + ry) * Ws + rx) * Cs;
-        voffA[p] = row_ok ? (unsigned)(rbase - g.rmin + tpt * Cs + chl) << 2 : OOB;
-        if constexpr (U8) {
-            const int tyl = a_chunk / cpr8, txq = a_chunk - tyl * cpr8;
-            voffA[p] = OOB;
-            if (row_ok) {
-                const int row = g.idx ? g.idx[b] : b;
-                voffA[p] = (unsigned)(row * g.img_bytes + (ry + tyl) * Ws + rx + 4 * txq);
-            }
-        }
-        imask[p] = 0;
-        // bit (ty*taps_x + tx) set <=> tap (ty, tx + tpt) is outside the image
-        if (HAS_PAD) imask[p] = tap_mask(ry, rx + step * tpt, g.Hs, Ws, g.taps_y, taps_x, step);
-    }
-#pragma unroll
-    for (int p = 0; p < RB; ++p) {
-        const int idx = tid + p * 256;
-        if (B_KC) {
-            const int nl = idx / CH, chunk = idx - nl * CH;
-            const int n = n0 + nl;
-            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && n < a.N) ? (unsigned)(n * a.b.ld + chunk * 4) << 2 : OOB;
-        } else if (SP) {                            // passes 2q, 2q + 1: rows 2 kl2, 2 kl2 + 1 of task tid + 256 q
-            constexpr int NC4 = BN / 4;
-            const int t = tid + (p >> 1) * 256;
-            const int kl2 = t / NC4, nch = t - kl2 * NC4;
-            const int n = n0 + nch * 4;
-            voffB[p] = (t < NPAIR && n < a.N) ? (unsigned)((2 * kl2 + (p & 1)) * a.b.ld + n) << 2 : OOB;
-        } else {
-            constexpr int NC4 = BN / 4;
-            const int kl = idx / NC4, nch = idx - kl * NC4;
-            const int n = n0 + nch * 4;
-            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && n < a.N) ? (unsigned)(kl * a.b.ld + n) << 2 : OOB;
-        }
-    }
-    // split: byte offset (inside a plane) of the 8 bytes this thread's 4-k chunk of a k-contiguous row lands on
-    auto kc_write_off = [&](int row, int chunk) { return row * ROWB + (((chunk >> 1) ^ kc_swz<NS>(row)) << 4) + ((chunk & 1) << 3); };
-
-    // ---- uniform per-tile state (scalar unit) ------------------------------------------------
-    int ty, tx, ch0;
-    {
-        const int tap = kbeg / Cs;
-        ch0 = kbeg - tap * Cs;
-        ty = tap / taps_x;
-        tx = tap - ty * taps_x;
-    }
-    if constexpr (U8) {                             // (plane ch0, first filter row ty of the tile); tx unused
-        const int khw = g.kh8 * g.kw8;
-        ch0 = kbeg / khw;
-        ty = (kbeg - ch0 * khw) / g.kw8;
-        tx = 0;
-    }
-    // split products: TWO register sets -- tile j rests in set j & 1 for a whole k-tile before it is split into LDS
-    // stage j & 1 under the MFMAs of tile j - 1 (the split is ~130 vector instructions per thread and k-tile: it has to
-    // run in the MFMAs' shadow, so its operands must have arrived long before)
-    constexpr int NR = SP ? 2 : 1;
-    float4 va_[NR][RA], vb_[NR][RB];
-    unsigned va8_[NR][RA];
-    u32x2 vp_[NR][RA][3];
-    // ADIR: the gathered operand runs ONE tile ahead of the MFMAs (tap state tyA / txA / ch0A), the weights two (through
-    // LDS, as above).  fd_[s]: the pieces of tile j, j = s (mod 2) counted so that the last tile is set 1, in fragment
-    // layout [row tile][16-k step][piece]; rd_: the fp32 tile in flight, split into fd_ at the end of the tile before.
-    constexpr int DST = BK / 16;
-    int tyA = ty, txA = tx, ch0A = ch0;
-    float4 rd_[TM][DST][2];
-    unsigned rd8_[TM][DST][2];
-    u32x4 fd_[2][TM][DST][3];
-    auto issue_A = [&](auto rs_c) {
-        constexpr int rs = decltype(rs_c)::value;
-        if constexpr (U8) {
-            const unsigned soff8 = (unsigned)(ch0A * g.plane + tyA * Ws);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int ks = 0; ks < DST; ++ks) {
-                    rd8_[i][ks][0] = buf_ld1s(rsA, voffD8[i][ks][0], soff8);
-                    rd8_[i][ks][1] = buf_ld1s(rsA, voffD8[i][ks][1], soff8);
-                }
-            return;
-        }
-        const unsigned soffA = (unsigned)(step * (tyA * Ws + txA) * Cs + ch0A - g.dmin) << 2;
-        const int bit = tyA * taps_x + txA;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned off = HAS_PAD ? mask_off(imaskD[i], bit, voffD[i]) : voffD[i];
-#pragma unroll
-            for (int ks = 0; ks < DST; ++ks) {
-                if constexpr (PIN) {                // (every out-of-range marker stays out of range: OOB / 2 + 32 > any tensor)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) fd_[rs][i][ks][c] = buf_ld4u(rsP[c], (off >> 1) + ks * 32, soffA >> 1);
-                } else {
-                    rd_[i][ks][0] = buf_ld4s(rsA, off + ks * 64, soffA);
-                    rd_[i][ks][1] = buf_ld4s(rsA, off + ks * 64 + 16, soffA);
-                }
-            }
-        }
-    };
-    auto next_tile_A = [&]() {
-        if constexpr (U8) {
-            tyA += rpt8;
-            if (tyA >= g.kh8) { tyA = 0; ++ch0A; }
-            return;
-        }
-        ch0A += BK;
-        if (ch0A >= Cs) {
-            ch0A = 0;
-            if (++txA >= taps_x) { txA = 0; ++tyA; }
-        }
-    };
-    auto split_A = [&](auto rs_c) {                 // rd_ -> fd_[rs] (nothing to do when the pieces were loaded)
-        constexpr int rs = decltype(rs_c)::value;
-        if constexpr (U8) {                         // 0 .. 255 is exact in bf16: one piece
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int ks = 0; ks < DST; ++ks) {
-                    const float4 f0 = bytes_to_f4(rd8_[i][ks][0]), f1 = bytes_to_f4(rd8_[i][ks][1]);
-                    fd_[rs][i][ks][0] = u32x4{hi_pair(f0.x, f0.y), hi_pair(f0.z, f0.w), hi_pair(f1.x, f1.y), hi_pair(f1.z, f1.w)};
-                }
-        } else if constexpr (!PIN) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int ks = 0; ks < DST; ++ks) {
-                    const float4 q0 = rd_[i][ks][0], q1 = rd_[i][ks][1];
-                    unsigned h[4], m[4], l[4];
-                    split_pair(q0.x, q0.y, h[0], m[0], l[0]);
-                    split_pair(q0.z, q0.w, h[1], m[1], l[1]);
-                    split_pair(q1.x, q1.y, h[2], m[2], l[2]);
-                    split_pair(q1.z, q1.w, h[3], m[3], l[3]);
-                    fd_[rs][i][ks][0] = u32x4{h[0], h[1], h[2], h[3]};
-                    fd_[rs][i][ks][1] = u32x4{m[0], m[1], m[2], m[3]};
-                    fd_[rs][i][ks][2] = u32x4{l[0], l[1], l[2], l[3]};
-                }
-        }
-    };
-    auto issue_loads = [&](int kk, int rs = 0) {    // tile starting at reduction index kk, tap state (ty, tx, ch0)
-        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs]; auto& vp = vp_[rs];
-        if constexpr (U8) {
-            const unsigned soffA = (unsigned)(ch0 * g.plane + ty * Ws);
-#pragma unroll
-            for (int p = 0; p < (ADIR ? 0 : RA); ++p) va8[p] = buf_ld1s(rsA, voffA[p], soffA);
-#pragma unroll
-            for (int p = 0; p < RB; ++p) vb[p] = buf_ld4s(rsB, voffB[p], (unsigned)kk << 2);
-            return;
-        }
-        const unsigned soffA = (unsigned)(step * (ty * Ws + tx) * Cs + ch0 - g.dmin) << 2;
-        unsigned soffB;
-        if (B_KC) soffB = (unsigned)kk << 2;
-        else soffB = (unsigned)(ch0 * a.b.ld + ((w_i0 + a.b.si * ty) * a.b.kw + (w_j0 + a.b.si * tx)) * a.b.c) << 2;
-        const int bit = ty * taps_x + tx;
-#pragma unroll
-        for (int p = 0; p < (ADIR ? 0 : RA); ++p) {
-            const unsigned off = HAS_PAD ? mask_off(imask[p], bit, voffA[p]) : voffA[p];
-            if constexpr (PIN) {                    // (OOB >> 1 is still beyond every tensor)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) vp[p][c] = buf_ld2s(rsP[c], off >> 1, soffA >> 1);
-            } else {
-                va[p] = buf_ld4s(rsA, off, soffA);
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < RB; ++p) vb[p] = buf_ld4s(rsB, voffB[p], soffB);
-    };
-    auto next_tile = [&]() {
-        if constexpr (U8) {
-            ty += rpt8;
-            if (ty >= g.kh8) { ty = 0; ++ch0; }
-            return;
-        }
-        if (MULTI_TAP) {
-            tx += BK / Cs;
-            if (tx >= taps_x) { tx = 0; ++ty; }
-        } else {
-            ch0 += BK;
-            if (ch0 >= Cs) {
-                ch0 = 0;
-                if (++tx >= taps_x) { tx = 0; ++ty; }
-            }
-        }
-    };
-    auto store_tiles = [&](int buf, int rs = 0) {
-        auto& va = va_[rs]; auto& vb = vb_[rs]; auto& va8 = va8_[rs]; auto& vp = vp_[rs];
-        if constexpr (SP) {
-            char* dS = sS + buf * STAGE;
-#pragma unroll
-            for (int p = 0; p < (ADIR ? 0 : RA); ++p) {
-                if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
-                char* d = dS + kc_write_off(a_row0 + p * ROWS_PER_PASS, a_chunk);
-                if constexpr (PIN) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) *reinterpret_cast<u32x2*>(d + c * SPA) = vp[p][c];
-                } else if constexpr (U8) {                 // 0 .. 255 is exact in bf16: one plane
-                    const float4 f = bytes_to_f4(va8[p]);
-                    *reinterpret_cast<uint2*>(d) = make_uint2(hi_pair(f.x, f.y), hi_pair(f.z, f.w));
-                } else {
-                    uint2 h, m, l;
-                    split_pair(va[p].x, va[p].y, h.x, m.x, l.x);
-                    split_pair(va[p].z, va[p].w, h.y, m.y, l.y);
-                    *reinterpret_cast<uint2*>(d) = h;
-                    *reinterpret_cast<uint2*>(d + SPA) = m;
-                    *reinterpret_cast<uint2*>(d + 2 * SPA) = l;
-                }
-            }
-            char* dB = dS + LPA * SPA;
-            if constexpr (B_KC) {
-#pragma unroll
-                for (int p = 0; p < RB; ++p) {
-                    const int idx = tid + p * 256;
-                    if (NB4 % 256 != 0 && idx >= NB4) continue;
-                    const int nl = idx / CH, chunk = idx - nl * CH;
-                    char* d = dB + kc_write_off(nl, chunk);
-                    uint2 h, m, l;
-                    split_pair(vb[p].x, vb[p].y, h.x, m.x, l.x);
-                    split_pair(vb[p].z, vb[p].w, h.y, m.y, l.y);
-                    *reinterpret_cast<uint2*>(d) = h;
-                    *reinterpret_cast<uint2*>(d + SPB) = m;
-                    *reinterpret_cast<uint2*>(d + 2 * SPB) = l;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < RB / 2; ++q) {
-                    constexpr int NC4 = BN / 4;
-                    const int t = tid + q * 256;
-                    if (NPAIR % 256 != 0 && t >= NPAIR) continue;
-                    const int kl2 = t / NC4, nch = t - kl2 * NC4;
-                    char* d = dB + (kl2 * BN + nch * 4) * 4;
-                    const float4 v0 = vb[2 * q], v1 = vb[2 * q + 1];
-                    uint4 h, m, l;
-                    split_pair(v0.x, v1.x, h.x, m.x, l.x);
-                    split_pair(v0.y, v1.y, h.y, m.y, l.y);
-                    split_pair(v0.z, v1.z, h.z, m.z, l.z);
-                    split_pair(v0.w, v1.w, h.w, m.w, l.w);
-                    *reinterpret_cast<uint4*>(d) = h;
-                    *reinterpret_cast<uint4*>(d + SPB) = m;
-                    *reinterpret_cast<uint4*>(d + 2 * SPB) = l;
-                }
-            }
-            return;
-        }
-        float* dA = sA + buf * A_SZ;
-        float* dB = sB + buf * B_SZ;
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
-            *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) =
-                U8 ? bytes_to_f4(va8[p]) : va[p];
-        }
-#pragma unroll
-        for (int p = 0; p < RB; ++p) {
-            const int idx = tid + p * 256;
-            if (NB4 % 256 != 0 && idx >= NB4) continue;
-            if (B_KC) {
-                const int nl = idx / CH, chunk = idx - nl * CH;
-                *reinterpret_cast<float4*>(dB + nl * LDB + chunk * 4) = vb[p];
-            } else {
-                constexpr int NC4 = BN / 4;
-                const int kl = idx / NC4, nch = idx - kl * NC4;
-                *reinterpret_cast<float4*>(dB + kl * LDB + nch * 4) = vb[p];
-            }
-        }
-    };
-
-    const int l15 = lane & 15, quad = lane >> 4;    // N16 lane coordinates
-    f32x16 acc[TM][TN];
-    f32x4 acc16[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc16[i][v] = 0.f;
-    }
-
-    // The epilogue's bias: loaded here, consumed after the loop (no loop-carried copies, latency long gone).
-    float4 bias_q[TN][4];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = N16 ? n0 + wn * 16 + 4 * quad : n0 + wn * TN * 32 + j * 32 + 8 * q + 4 * half;
-            bias_q[j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.o.bias && n < a.N && (!N16 || q == 0)) bias_q[j][q] = *reinterpret_cast<const float4*>(a.o.bias + n);
-        }
-    // The epilogue's output rows -- and, for the one-tile-per-wave shapes, the rectifier mask of the layer below
-    // (a data gradient's epilogue otherwise starts with a dependent global load per store: 8-10 k cycles of a 65 k
-    // workgroup lifetime in the stride-2 data gradient) -- are fetched here, a whole main loop ahead of their use.
-    long long row_off[TM];
-    auto decode_out_rows = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
-            if (a.o.dense) {
-                row_off[i] = m < M ? (long long)m * a.N : -1;
-            } else {                                    // stride-parity data gradient: rows map to scattered pixels
-                const int t = div_u(m, g.out_w, g.mg_w), ox = m - t * g.out_w;
-                const int b = div_u(t, g.out_h, g.mg_h), oy = t - b * g.out_h;
-                row_off[i] = m < M ? ((long long)(b * a.o.OH + oy * a.o.omul + oadd_y) * a.o.OW + ox * a.o.omul + oadd_x) * a.N
-                                   : -1;
-            }
-        }
-    };
-    constexpr bool PRE_MASK = TN == 1 && TM <= 2;       // (larger register tiles keep their registers for the main loop)
-    if (PRE_MASK) decode_out_rows();
-    float4 mk_pre[4][TM];
-    // issued at the start of the LAST k-tile: behind every operand load (an earlier issue would sit in front of the
-    // tile loads in the in-order vmcnt queue and stall the first LDS store on scattered, cache-cold addresses)
-    auto issue_mask_loads = [&]() {
-        if (!(PRE_MASK && a.o.mask)) return;
-#pragma unroll
-        for (int q = 0; q < (N16 ? 1 : 4); ++q)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int n = N16 ? n0 + wn * 16 + 4 * quad : n0 + wn * TN * 32 + 8 * q + 4 * half;
-                mk_pre[q][i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (row_off[i] >= 0 && n < a.N) mk_pre[q][i] = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
-            }
-    };
-    const int nk = (kend - kbeg) / BK;
-    // The MFMAs of sub-steps [LO, HI) of the k-tile in LDS stage BUF (16 k per sub-step with the 16-wide tiles, 8
-    // otherwise).  Compile-time stage: every LDS address is then a per-thread constant plus an immediate (with a
-    // run-time buffer index the compiler re-derived four base addresses per tile with vector adds, and every vector
-    // instruction here is taken from the MFMAs' issue slots).
-    constexpr int STEPS = (N16 || SP) ? BK / 16 : BK / 8;
-    auto mfma_steps = [&](auto buf_c, auto lo_c, auto hi_c) {
-        constexpr int buf = decltype(buf_c)::value, LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-        if constexpr (SP) {
-            // a lane's fragment = row l31 (of its 32-row tile), k octet 2 ks + half: one 16-byte slot per plane
-            const char* cA = sS + buf * STAGE + (wm * TM * 32) * ROWB + l31 * ROWB;
-            const char* cB = sS + buf * STAGE + LPA * SPA + (B_KC ? (wn * TN * 32) * ROWB + l31 * ROWB
-                                                                  : (half * 4 * BN + wn * TN * 32 + l31) * 4);
-            const int swz = kc_swz<NS>(l31);
-#pragma unroll
-            for (int ks = LO; ks < HI; ++ks) {
-                const int slot = ((2 * ks + half) ^ swz) << 4;
-                u32x4 fa[TM][3], fb[TN][3];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < PA; ++pl) {
-                        if constexpr (ADIR) fa[i][pl] = fd_[buf][i][ks][pl];
-                        else fa[i][pl] = *reinterpret_cast<const u32x4*>(cA + pl * SPA + i * 32 * ROWB + slot);
-                    }
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        if constexpr (B_KC) {
-                            fb[j][pl] = *reinterpret_cast<const u32x4*>(cB + pl * SPB + j * 32 * ROWB + slot);
-                        } else {
-                            const unsigned* q = reinterpret_cast<const unsigned*>(cB + pl * SPB + (ks * 8 * BN + j * 32) * 4);
-                            fb[j][pl] = u32x4{q[0], q[BN], q[2 * BN], q[3 * BN]};
-                        }
-                    }
-                split_products<SPLIT, PA, 3, true, TM, TN>(fa, fb, acc);
-            }
-        } else if constexpr (N16) {
-            const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
-            const float* cB = B_KC ? sB + buf * B_SZ + (wn * 16 + l15) * LDB + quad * 4
-                                   : sB + buf * B_SZ + (quad * 4) * LDB + wn * 16 + l15;
-#pragma unroll
-            for (int ks = LO; ks < HI; ++ks) {
-                float fa[TM][4], fb[4];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 16 * LDA + ks * 16);
-                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
-                }
-                if (B_KC) {
-                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 16);
-                    fb[0] = t.x; fb[1] = t.y; fb[2] = t.z; fb[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) fb[q] = cB[(ks * 16 + q) * LDB];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[q], fa[i][q], acc16[i], 0, 0, 0);
-            }
-        } else {
-            const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
-            const float* cB = B_KC ? sB + buf * B_SZ + (wn * TN * 32 + l31) * LDB + half * 4
-                                   : sB + buf * B_SZ + (half * 4) * LDB + wn * TN * 32 + l31;
-#pragma unroll
-            for (int ks = LO; ks < HI; ++ks) {
-                float fa[TM][4], fb[TN][4];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
-                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (B_KC) {
-                        const float4 t = *reinterpret_cast<const float4*>(cB + j * 32 * LDB + ks * 8);
-                        fb[j][0] = t.x; fb[j][1] = t.y; fb[j][2] = t.z; fb[j][3] = t.w;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) fb[j][q] = cB[(ks * 8 + q) * LDB + j * 32];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[j][q], fa[i][q], acc[i][j], 0, 0, 0);
-            }
-        }
-    };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    using C2 = std::integral_constant<int, 2>;
-    using CH_ = std::integral_constant<int, STEPS / 2>;
-    using CS_ = std::integral_constant<int, STEPS>;
-    if constexpr (PIPE3) {
-        static_assert(STEPS >= 2, "PIPE3 splits a k-tile's MFMAs in two");
-        // (Register double-buffering of the fragments on top of this -- the next sub-step's LDS reads issued before the
-        //  current MFMAs -- was measured too: 206-221 registers, one workgroup per CU for some shapes, slower.)
-        const int r3 = nk % 3;                          // stage of tile kt = (kt + 3 - r3) % 3: the last tile ends on stage 2
-        issue_loads(kbeg);
-        store_tiles((3 - r3) % 3);
-        __syncthreads();
-        if (nk > 1) { next_tile(); issue_loads(kbeg + BK); }
-        if (a.trace) tr1 = __builtin_readcyclecounter();
-        auto tile3 = [&](auto st_c, int kt) {
-            constexpr int st = decltype(st_c)::value;
-            mfma_steps(st_c, C0{}, CH_{});
-            if (kt + 1 < nk) {                          // uniform
-                store_tiles((st + 1) % 3);              // tile kt+1: loaded since the middle of tile kt-1
-                __syncthreads();
-                if (kt + 2 < nk) { next_tile(); issue_loads(kbeg + (kt + 2) * BK); }
-            } else {
-                issue_mask_loads();
-            }
-            mfma_steps(st_c, CH_{}, CS_{});
-        };
-        int kt = 0;
-        if (r3 == 1) { tile3(C2{}, 0); kt = 1; }
-        else if (r3 == 2) { tile3(C1{}, 0); tile3(C2{}, 1); kt = 2; }
-        for (; kt < nk; kt += 3) {
-            tile3(C0{}, kt);
-            tile3(C1{}, kt + 1);
-            tile3(C2{}, kt + 2);
-        }
-    } else if constexpr (SP) {
-        // tile j: register set and LDS stage (j + nk) & 1 (the loop ends on stage 1)
-        if (nk & 1) {                                   // uniform
-            if constexpr (ADIR) issue_A(C1{});
-            issue_loads(kbeg, 1);
-            if (nk > 1) { next_tile(); issue_loads(kbeg + BK, 0); }
-            store_tiles(1, 1);
-            if constexpr (ADIR) split_A(C1{});
-        } else {
-            if constexpr (ADIR) issue_A(C0{});
-            issue_loads(kbeg, 0);
-            next_tile(); issue_loads(kbeg + BK, 1);
-            store_tiles(0, 0);
-            if constexpr (ADIR) split_A(C0{});
-        }
-        __syncthreads();
-        if (a.trace) tr1 = __builtin_readcyclecounter();
-        // One basic block per steady-state k-tile: the MFMAs of tile kt (LDS stage buf) and the split + LDS stores of
-        // tile kt + 1 (register set and stage buf ^ 1) -- left to itself the scheduler issues the MFMAs in one clump
-        // and the ~130 vector instructions of the split after them; the group barriers below deal the vector work and
-        // the LDS stores out between the MFMAs, where they cost nothing (tools/mfma_bf16_mix.hip: 4-6 per MFMA are free).
-        constexpr int NPROD = PA == 1 ? 3 : SPLIT;
-        constexpr int NM = TM * TN * NPROD * STEPS;                                     // MFMAs per k-tile and wave
-        constexpr int NV = RA * (PIN ? 0 : U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44);   // the split's vector instructions
-        constexpr int NW = RA * PA + (B_KC ? RB * 3 : (RB / 2) * 3);                    // its LDS stores
-        constexpr int VPM = (NV + NM - 1) / NM < 6 ? (NV + NM - 1) / NM : 6;
-        constexpr int WEV = NM / NW > 0 ? NM / NW : 1;
-        auto mid_tile = [&](auto buf_c, int kt) {       // tiles 0 .. nk - 2
-            constexpr int buf = decltype(buf_c)::value;
-            if (kt + 2 < nk) {                          // uniform: tile kt + 2 -> the set tile kt has left
-                next_tile();
-                issue_loads(kbeg + (kt + 2) * BK, buf);
-            }
-            if constexpr (ADIR) {                       // tile kt + 1 of the direct operand
-                next_tile_A();
-                issue_A(std::integral_constant<int, (buf ^ 1)>{});
-                __builtin_amdgcn_sched_barrier(0);
-                mfma_steps(buf_c, C0{}, CS_{});
-                store_tiles(buf ^ 1, buf ^ 1);
-                split_A(std::integral_constant<int, (buf ^ 1)>{});
-                __syncthreads();
-                return;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_steps(buf_c, C0{}, CS_{});
-            store_tiles(buf ^ 1, buf ^ 1);
-            // (every fragment read first: the LDS stores of the other stage cannot be proven not to alias them and would
-            //  otherwise queue up behind the last read, at the end of the tile)
-            __builtin_amdgcn_sched_group_barrier(0x100, STEPS * (TM * PA + TN * 3 * (B_KC ? 1 : 4)), 0);
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
-                if (m % WEV == WEV - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            }
-            __syncthreads();
-        };
-        int kt = 0;
-        if (!(nk & 1)) { mid_tile(C0{}, 0); kt = 1; }
-        for (; kt + 1 < nk; kt += 2) {
-            mid_tile(C1{}, kt);
-            mid_tile(C0{}, kt + 1);
-        }
-        issue_mask_loads();
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_steps(C1{}, C0{}, CS_{});                  // the last tile
-    } else {
-    issue_loads(kbeg);
-    store_tiles(nk & 1);                            // first tile's buffer chosen so that the loop ends on buffer 1
-    __syncthreads();
-    if (a.trace) tr1 = __builtin_readcyclecounter();
-    // One k-tile with a COMPILE-TIME buffer index (see mfma_steps).
-    auto k_tile = [&](auto buf_c, int kt) {
-        constexpr int buf = decltype(buf_c)::value;
-        if (kt + 1 < nk) {                          // uniform branch
-            next_tile();
-            issue_loads(kbeg + (kt + 1) * BK);
-        } else {
-            issue_mask_loads();
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_steps(buf_c, C0{}, CS_{});
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            store_tiles(buf ^ 1);
-            __syncthreads();
-        }
-    };
-    {   // an odd tile count peels its FIRST tile (from buffer 1); the rest is whole (buffer 0, buffer 1) pairs
-        int kt = 0;
-        if (nk & 1) { k_tile(C1{}, 0); kt = 1; }
-        for (; kt < nk; kt += 2) {
-            k_tile(C0{}, kt);
-            k_tile(C1{}, kt + 1);
-        }
-    }
-    }
-
-    if (a.trace) tr2 = __builtin_readcyclecounter();
-    float* out = a.o.out + (a.n_par ? 0 : (int64_t)bz * a.split_stride);
-    {
-        // operands are swapped (acc = W-tile x X-tile^T): every lane owns ONE output row per 32-row tile
-        const __amdgpu_buffer_rsrc_t rsO = make_rsrc(out, a.o.out_bytes);
-        if (!PRE_MASK) decode_out_rows();
-        if constexpr (N16) {
-            const int n = n0 + wn * 16 + 4 * quad;
-            const float4 bq = bias_q[0][0];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bool ok = row_off[i] >= 0 && n < a.N;
-                float4 val = U8 ? make_float4(acc16[i][0] * g.scale + bq.x, acc16[i][1] * g.scale + bq.y,
-                                              acc16[i][2] * g.scale + bq.z, acc16[i][3] * g.scale + bq.w)
-                                : make_float4(acc16[i][0] + bq.x, acc16[i][1] + bq.y, acc16[i][2] + bq.z, acc16[i][3] + bq.w);
-                if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
-                if (a.o.mask) {
-                    float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (PRE_MASK) mk = mk_pre[0][i < TM ? i : 0];
-                    else if (ok) mk = *reinterpret_cast<const float4*>(a.o.mask + row_off[i] + n);
-                    if (!(mk.x > 0.f)) val.x = 0.f;
-                    if (!(mk.y > 0.f)) val.y = 0.f;
-                    if (!(mk.z > 0.f)) val.z = 0.f;
-                    if (!(mk.w > 0.f)) val.w = 0.f;
-                }
-                u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rsO, ok ? (unsigned)((row_off[i] + n) << 2) : OOB, 0, 0);
-            }
-        } else {
-            store_tiles_quads<TM, TN, U8>(acc, rsO, row_off, a.N, n0 + wn * TN * 32, lane, bias_q, a.o.mask, a.o.relu,
-                                          PRE_MASK ? mk_pre : nullptr, g.scale, SP ? a.o.pieces : nullptr,
-                                          a.o.piece_bytes, a.o.out_bytes);
-        }
-    }
-    if (a.trace && tid == 0) {
-        unsigned long long* t = a.trace + ((size_t)(bz * gridDim.y + by) * gridDim.x + bx) * 8;     // plain launches only
-        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_readcyclecounter();
-        t[4] = rt0; t[5] = __builtin_amdgcn_s_memrealtime();
-        t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-        t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
-    }
-}
-
-// (Register allocation: the 128-row x 32-column, 16-deep shape takes 100-106 registers = FOUR workgroups per CU.  Capping
-// it at 96 for a fifth (__launch_bounds__(256, 5): 4-9 spilled registers) was measured inside the learner: the fifth
-// workgroup is resident, the CU's timeline stays at ~105 k cycles for 8 x 8 192 matrix-pipe cycles of work -- with five
-// waves per SIMD in their main loops the pipe is still only ~2/3 busy, so residency is not what holds these two kernels
-// (conv 1 forward, stride-2 data gradient) back; tools/context_trace.py prints the timelines.)
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16 = false,
-          bool PIPE3 = false>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, false, PIPE3>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
-}
-
-// bf16-split products (igemm_body, SPLIT): MINW waves per SIMD; the co-run of arl_conv_corun_update as in igemm_occ_kernel
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool U8, int SPLIT, int MINW,
-          bool CORUN = false, bool PIN = false, bool ADIR = false>
-__global__ __launch_bounds__(256, MINW) void igemm_split_kernel(const GemmArgs a, const arl::OptSeg c) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int bx = blockIdx.x;
-    if constexpr (CORUN) {
-        if (bx < c.co_blocks) {
-            __shared__ double lds[8];
-            if (blockIdx.y || blockIdx.z) return;
-            if (c.method == ARL_OPT_ADAM) arl::opt_update_block<ARL_OPT_ADAM>(c, bx, c.co_blocks, lds);
-            else arl::opt_update_block<ARL_OPT_RMSPROP>(c, bx, c.co_blocks, lds);
-            return;
-        }
-        bx -= c.co_blocks;
-    }
-    int by = blockIdx.y, bz = blockIdx.z;
-    if (!CORUN && a.xcd) {                          // uniform
-        const int gx = gridDim.x, gy = gridDim.y;
-        const int t = xcd_chunk((bz * gy + by) * gx + bx, gx * gy * (int)gridDim.z);
-        bx = t % gx;
-        const int u = t / gx;
-        by = u % gy; bz = u / gy;
-    }
-    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, false, U8, false, SPLIT, PIN, ADIR>(a, bx, by, bz, smem);
-}
-
-// ==========================================================================================
-// Persistent variant of igemm_body for launches of MANY row tiles (conv 1 forward: 1 900 tiles of 128 rows, the
-// stride-2 data gradient: 4 x 475): gridDim.x resident workgroups walk the tiles t = blockIdx.x, + gridDim.x, ...
-// Per-workgroup timestamps of the one-tile-per-workgroup launch showed what a second wave of workgroups costs:
-// a workgroup that starts while its CU mates are in their main loops spends 10-16 k cycles in its prologue (the
-// address arithmetic competes with their MFMAs, the first tile's loads are cold), the CU drops to 0-2 workgroups
-// inside a main loop between the waves and again at the end -- 108 k cycles for 65 k of matrix-pipe work.  Here the
-// NEXT tile's rows are decoded and its first k-tile's loads issued at the start of the current tile's LAST k-tile
-// (under its MFMAs), the epilogue's stores are left in flight, and the main loop continues with one barrier between
-// tiles: the pipeline never drains.  One column tile (N <= BN), no reduction split, TN == 1.
-// ==========================================================================================
-template <int WGM, int WGN, int TM, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, bool U8>
-__device__ __forceinline__ void igemm_persist_body(const GemmArgs& a, float* smem) {
-    constexpr int TN = 1;
-    constexpr int MT = N16 ? 16 : 32;
-    constexpr int BM = WGM * TM * MT, BN = N16 ? WGN * 16 : WGN * TN * 32, CH = BK / 4;
-    constexpr int LDA = BK + 4;
-    constexpr int LDB = B_KC ? BK + 4 : (N16 ? BN + 4 : BN);
-    constexpr int ROWS_PER_PASS = 256 / CH;
-    constexpr int RA = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-    constexpr int A_SZ = BM * LDA, B_SZ = B_KC ? BN * LDB : BK * LDB;
-    constexpr int NB4 = B_KC ? BN * CH : BK * BN / 4;
-    constexpr int RB = (NB4 + 255) / 256;
-    static_assert(WGM * WGN == 4 && BK % 8 == 0 && (!N16 || BK % 16 == 0), "tile shape");
-    float* sA = smem;
-    float* sB = smem + 2 * A_SZ;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, half = lane >> 5, l15 = lane & 15, quad = lane >> 4;
-    const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
-    if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
-    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(a.o.out, a.o.out_bytes);
-
-    // ---- what a tile's class decides (uniform: scalar registers) ---------------------------------
-    struct Cls {
-        int M, out_h, out_w, add_y, add_x, rmin, dmin, i0, j0, oadd_y, oadd_x;
-        unsigned mg_w, mg_h;
-        __amdgpu_buffer_rsrc_t rsA;
-    };
-    auto load_cls = [&](int c) {
-        Cls k;
-        if (a.n_par) {
-            const GemmArgs::Parity& q = a.par[c];
-            k.M = q.M; k.out_h = q.out_h; k.out_w = q.out_w; k.add_y = q.add_y; k.add_x = q.add_x;
-            k.rmin = q.rmin; k.dmin = q.dmin; k.i0 = q.i0; k.j0 = q.j0; k.oadd_y = q.oadd_y; k.oadd_x = q.oadd_x;
-            k.mg_w = q.mg_w; k.mg_h = q.mg_h;
-            k.rsA = make_rsrc(a.g.src + q.origin, q.src_bytes);
-        } else {
-            k.M = a.M; k.out_h = a.g.out_h; k.out_w = a.g.out_w; k.add_y = a.g.add_y; k.add_x = a.g.add_x;
-            k.rmin = a.g.rmin; k.dmin = a.g.dmin; k.i0 = a.b.i0; k.j0 = a.b.j0; k.oadd_y = a.o.oadd_y; k.oadd_x = a.o.oadd_x;
-            k.mg_w = a.g.mg_w; k.mg_h = a.g.mg_h;
-            k.rsA = U8 ? make_rsrc(reinterpret_cast<const float*>(a.g.src8), a.g.src_bytes)
-                       : make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
-        }
-        return k;
-    };
-    // ---- what a tile decides per thread ------------------------------------------------------------
-    struct Tile { unsigned voffA[RA], imask[RA]; long long row_off[TM]; };
-    const int a_chunk = tid % CH, a_row0 = tid / CH;
-    const int cpr8 = a.g.kw8 >> 2, rpt8 = U8 ? CH / cpr8 : 0;
-    int tpt = 0, chl = a_chunk * 4;
-    if (MULTI_TAP) { tpt = chl / Cs; chl -= tpt * Cs; }
-    auto setup = [&](int t, Cls& k, Tile& T) {
-        int c = 0;
-        if (a.n_par) c = (t >= a.p_first[1]) + (t >= a.p_first[2]) + (t >= a.p_first[3]);
-        k = load_cls(c);
-        const int m0 = (t - a.p_first[c]) * BM;
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            const int m = m0 + a_row0 + p * ROWS_PER_PASS;
-            const bool row_ok = m < k.M && (BM % ROWS_PER_PASS == 0 || a_row0 + p * ROWS_PER_PASS < BM);
-            const int q = div_u(m, k.out_w, k.mg_w), ox = m - q * k.out_w;
-            const int b = div_u(q, k.out_h, k.mg_h), oy = q - b * k.out_h;
-            const int ry = oy * a.g.mul + k.add_y, rx = ox * a.g.mul + k.add_x;
-            const int rbase = ((b * a.g.Hs + ry) * Ws + rx) * Cs;
-            T.voffA[p] = row_ok ? (unsigned)(rbase - k.rmin + tpt * Cs + chl) << 2 : OOB;
-            if constexpr (U8) {
-                const int tyl = a_chunk / cpr8, txq = a_chunk - tyl * cpr8;
-                T.voffA[p] = OOB;
-                if (row_ok) {
-                    const int row = a.g.idx ? a.g.idx[b] : b;
-                    T.voffA[p] = (unsigned)(row * a.g.img_bytes + (ry + tyl) * Ws + rx + 4 * txq);
-                }
-            }
-            T.imask[p] = 0;
-            if (HAS_PAD) T.imask[p] = tap_mask(ry, rx + step * tpt, a.g.Hs, Ws, a.g.taps_y, taps_x, step);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * MT + (N16 ? l15 : l31);
-            if (a.o.dense) {
-                T.row_off[i] = m < k.M ? (long long)m * a.N : -1;
-            } else {
-                const int q = div_u(m, k.out_w, k.mg_w), ox = m - q * k.out_w;
-                const int b = div_u(q, k.out_h, k.mg_h), oy = q - b * k.out_h;
-                T.row_off[i] = m < k.M ? ((long long)(b * a.o.OH + oy * a.o.omul + k.oadd_y) * a.o.OW + ox * a.o.omul + k.oadd_x) * a.N
-                                       : -1;
-            }
-        }
-    };
-    unsigned voffB[RB];
-#pragma unroll
-    for (int p = 0; p < RB; ++p) {
-        const int idx = tid + p * 256;
-        if (B_KC) {
-            const int nl = idx / CH, chunk = idx - nl * CH;
-            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && nl < a.N) ? (unsigned)(nl * a.b.ld + chunk * 4) << 2 : OOB;
-        } else {
-            constexpr int NC4 = BN / 4;
-            const int kl = idx / NC4, nch = idx - kl * NC4;
-            voffB[p] = ((NB4 % 256 == 0 || idx < NB4) && nch * 4 < a.N) ? (unsigned)(kl * a.b.ld + nch * 4) << 2 : OOB;
-        }
-    }
-    // the lane's bias values (one column tile: the same for every row tile)
-    float4 bias_q[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int n = N16 ? wn * 16 + 4 * quad : wn * 32 + 8 * q + 4 * half;
-        bias_q[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.o.bias && n < a.N && (!N16 || q == 0)) bias_q[q] = *reinterpret_cast<const float4*>(a.o.bias + n);
-    }
-
-    // ---- k-tile machinery (as igemm_body) ----------------------------------------------------------
-    // Two k-tiles are in flight: k-tile j of a row tile lands in register set j & 1 while k-tile j - 1 waits in the
-    // other set for its turn in LDS (a whole k-tile of extra latency cover: with 16-deep k-tiles and four workgroups
-    // sharing the matrix pipe one k-tile lasts ~1 us, less than a load that misses the L2 takes).
-    struct Regs { float4 va[RA], vb[RB]; unsigned va8[RA]; };
-    Regs R0, R1;
-    int ty = 0, tx = 0, ch0 = 0, kk = 0;            // tap state / reduction index of the NEXT k-tile to be issued
-    auto issue_loads = [&](Regs& R, const Cls& k, const Tile& T) {
-        if constexpr (U8) {
-            const unsigned soffA = (unsigned)(ch0 * a.g.plane + ty * Ws);
-#pragma unroll
-            for (int p = 0; p < RA; ++p) R.va8[p] = buf_ld1s(k.rsA, T.voffA[p], soffA);
-#pragma unroll
-            for (int p = 0; p < RB; ++p) R.vb[p] = buf_ld4s(rsB, voffB[p], (unsigned)kk << 2);
-        } else {
-            const unsigned soffA = (unsigned)(step * (ty * Ws + tx) * Cs + ch0 - k.dmin) << 2;
-            unsigned soffB;
-            if (B_KC) soffB = (unsigned)kk << 2;
-            else soffB = (unsigned)(ch0 * a.b.ld + ((k.i0 + a.b.si * ty) * a.b.kw + (k.j0 + a.b.si * tx)) * a.b.c) << 2;
-            const int bit = ty * taps_x + tx;
-#pragma unroll
-            for (int p = 0; p < RA; ++p)
-                R.va[p] = buf_ld4s(k.rsA, HAS_PAD ? mask_off(T.imask[p], bit, T.voffA[p]) : T.voffA[p], soffA);
-#pragma unroll
-            for (int p = 0; p < RB; ++p) R.vb[p] = buf_ld4s(rsB, voffB[p], soffB);
-        }
-        // advance to the following k-tile
-        kk += BK;
-        if constexpr (U8) {
-            ty += rpt8;
-            if (ty >= a.g.kh8) { ty = 0; ++ch0; }
-        } else if (MULTI_TAP) {
-            tx += BK / Cs;
-            if (tx >= taps_x) { tx = 0; ++ty; }
-        } else {
-            ch0 += BK;
-            if (ch0 >= Cs) {
-                ch0 = 0;
-                if (++tx >= taps_x) { tx = 0; ++ty; }
-            }
-        }
-    };
-    auto first_tap = [&]() { ty = 0; tx = 0; ch0 = 0; kk = 0; };
-    auto store_tiles = [&](int buf, const Regs& R) {
-        float* dA = sA + buf * A_SZ;
-        float* dB = sB + buf * B_SZ;
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            if (BM % ROWS_PER_PASS != 0 && a_row0 + p * ROWS_PER_PASS >= BM) continue;
-            *reinterpret_cast<float4*>(dA + (a_row0 + p * ROWS_PER_PASS) * LDA + a_chunk * 4) =
-                U8 ? bytes_to_f4(R.va8[p]) : R.va[p];
-        }
-#pragma unroll
-        for (int p = 0; p < RB; ++p) {
-            const int idx = tid + p * 256;
-            if (NB4 % 256 != 0 && idx >= NB4) continue;
-            if (B_KC) {
-                const int nl = idx / CH, chunk = idx - nl * CH;
-                *reinterpret_cast<float4*>(dB + nl * LDB + chunk * 4) = R.vb[p];
-            } else {
-                constexpr int NC4 = BN / 4;
-                const int kl = idx / NC4, nch = idx - kl * NC4;
-                *reinterpret_cast<float4*>(dB + kl * LDB + nch * 4) = R.vb[p];
-            }
-        }
-    };
-    f32x16 acc[TM];
-    f32x4 acc16[TM];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) acc16[i][v] = 0.f;
-        }
-    };
-    auto mfma_tile = [&](auto buf_c) {
-        constexpr int buf = decltype(buf_c)::value;
-        if constexpr (N16) {
-            const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
-            const float* cB = B_KC ? sB + buf * B_SZ + (wn * 16 + l15) * LDB + quad * 4
-                                   : sB + buf * B_SZ + (quad * 4) * LDB + wn * 16 + l15;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                float fa[TM][4], fb[4];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 16 * LDA + ks * 16);
-                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
-                }
-                if (B_KC) {
-                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 16);
-                    fb[0] = t.x; fb[1] = t.y; fb[2] = t.z; fb[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) fb[q] = cB[(ks * 16 + q) * LDB];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc16[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[q], fa[i][q], acc16[i], 0, 0, 0);
-            }
-        } else {
-            const float* cA = sA + buf * A_SZ + (wm * TM * 32 + l31) * LDA + half * 4;
-            const float* cB = B_KC ? sB + buf * B_SZ + (wn * 32 + l31) * LDB + half * 4
-                                   : sB + buf * B_SZ + (half * 4) * LDB + wn * 32 + l31;
-#pragma unroll
-            for (int ks = 0; ks < BK / 8; ++ks) {
-                float fa[TM][4], fb[4];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const float4 t = *reinterpret_cast<const float4*>(cA + i * 32 * LDA + ks * 8);
-                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
-                }
-                if (B_KC) {
-                    const float4 t = *reinterpret_cast<const float4*>(cB + ks * 8);
-                    fb[0] = t.x; fb[1] = t.y; fb[2] = t.z; fb[3] = t.w;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) fb[q] = cB[(ks * 8 + q) * LDB];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[q], fa[i][q], acc[i], 0, 0, 0);
-            }
-        }
-    };
-    // the rectifier mask of the layer below (data gradients), fetched during the last k-tile
-    constexpr int NQ = N16 ? 1 : 4;
-    float4 mk_pre[NQ][TM];
-    auto issue_mask_loads = [&](const Tile& T) {
-        if (!a.o.mask) return;
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int n = N16 ? wn * 16 + 4 * quad : wn * 32 + 8 * q + 4 * half;
-                mk_pre[q][i] = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (T.row_off[i] >= 0 && n < a.N) mk_pre[q][i] = *reinterpret_cast<const float4*>(a.o.mask + T.row_off[i] + n);
-            }
-    };
-    auto epilogue = [&](const Tile& T) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int n = N16 ? wn * 16 + 4 * quad : wn * 32 + 8 * q + 4 * half;
-            const float4 bq = bias_q[q];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bool ok = T.row_off[i] >= 0 && n < a.N;
-                float4 val;
-                if constexpr (N16) val = make_float4(acc16[i][0], acc16[i][1], acc16[i][2], acc16[i][3]);
-                else val = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
-                if constexpr (U8) { val.x *= a.g.scale; val.y *= a.g.scale; val.z *= a.g.scale; val.w *= a.g.scale; }
-                val.x += bq.x; val.y += bq.y; val.z += bq.z; val.w += bq.w;
-                if (a.o.relu) { val.x = fmaxf(val.x, 0.f); val.y = fmaxf(val.y, 0.f); val.z = fmaxf(val.z, 0.f); val.w = fmaxf(val.w, 0.f); }
-                if (a.o.mask) {
-                    const float4 m = mk_pre[q][i];
-                    if (!(m.x > 0.f)) val.x = 0.f;
-                    if (!(m.y > 0.f)) val.y = 0.f;
-                    if (!(m.z > 0.f)) val.z = 0.f;
-                    if (!(m.w > 0.f)) val.w = 0.f;
-                }
-                u32x4 raw = {__float_as_uint(val.x), __float_as_uint(val.y), __float_as_uint(val.z), __float_as_uint(val.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(raw, rsO, ok ? (unsigned)((T.row_off[i] + n) << 2) : OOB, 0, 0);
-            }
-        }
-    };
-
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    const int nk = a.K / BK;                        // even, >= 2 (checked on the host): k-tile j sits in LDS buffer j & 1
-    int t = blockIdx.x;
-    if (t >= a.p_tiles) return;
-    Cls kc, kn;
-    Tile T, Tn;
-    setup(t, kc, T);
-    first_tap();
-    issue_loads(R0, kc, T);
-    issue_loads(R1, kc, T);
-    store_tiles(0, R0);
-    __syncthreads();
-    if (a.trace) tr1 = __builtin_readcyclecounter();
-    for (;;) {
-        const int tn = t + (int)gridDim.x;
-        const bool more = tn < a.p_tiles;           // uniform
-        zero_acc();
-        // k-tile kt (LDS buffer kt & 1): k-tile kt + 2 leaves for register set kt & 1, k-tile kt + 1 moves from the
-        // other set into the other buffer once this tile's MFMAs are issued
-        for (int kt = 0; kt + 2 < nk; kt += 2) {
-            issue_loads(R0, kc, T);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_tile(C0{});
-            __builtin_amdgcn_sched_barrier(0);
-            store_tiles(1, R1);
-            __syncthreads();
-            issue_loads(R1, kc, T);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_tile(C1{});
-            __builtin_amdgcn_sched_barrier(0);
-            store_tiles(0, R0);
-            __syncthreads();
-        }
-        // second-to-last k-tile: the NEXT row tile is decoded and its first k-tile requested
-        if (more) {
-            setup(tn, kn, Tn);
-            first_tap();
-            issue_loads(R0, kn, Tn);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(C0{});
-        __builtin_amdgcn_sched_barrier(0);
-        store_tiles(1, R1);
-        __syncthreads();
-        // last k-tile: the epilogue's mask and the next row tile's second k-tile
-        issue_mask_loads(T);
-        if (more) issue_loads(R1, kn, Tn);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_tile(C1{});
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue(T);
-        if (!more) break;
-        store_tiles(0, R0);                         // buffer 0 was last read before the previous barrier
-        __syncthreads();
-        t = tn; kc = kn; T = Tn;
-    }
-    if (a.trace && tid == 0) {
-        tr2 = __builtin_readcyclecounter();
-        unsigned long long* tp = a.trace + (size_t)blockIdx.x * 8;
-        tp[0] = tr0; tp[1] = tr1; tp[2] = tr2; tp[3] = tr2;
-        tp[4] = rt0; tp[5] = __builtin_amdgcn_s_memrealtime();
-        tp[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-        tp[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
-    }
-}
-
-template <int WGM, int WGN, int TM, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, bool U8, int MINW>
-__global__ __launch_bounds__(256, MINW) void igemm_persist_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    igemm_persist_body<WGM, WGN, TM, BK, B_KC, MULTI_TAP, HAS_PAD, N16, U8>(a, smem);
-}
-
-// the same body compiled for at least MINW waves per SIMD (small tiles, many resident workgroups)
-// CORUN: the grid's first c.co_blocks workgroups do not compute tiles but stream an optimiser update of a finished
-// gradient range (arl_conv_corun_update): HBM-bound work inside an MFMA-bound launch.  PPO step, spec 1: conv 3's data
-// gradient 42.6 -> ~48 us with the first dense layer's 99 MB adam update riding along, the update launch at the end of
-// the step 19.9 -> 4.9 us (a second stream inside the learner's hipGraph costs ~50 us per dependency instead).
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, bool HAS_PAD, bool N16, int MINW, bool CORUN = false,
-          bool U8 = false>
-__global__ __launch_bounds__(256, MINW) void igemm_occ_kernel(const GemmArgs a, const arl::OptSeg c) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if constexpr (CORUN) {
-        // The update's workgroups come FIRST in the grid -- one per CU, streaming from the start of the launch, while
-        // the tile workgroups fill the other four slots of every CU (appended behind the tiles they ran in the tail
-        // and lengthened it: +8.8 us inside the learner instead of +1).
-        if ((int)blockIdx.x < c.co_blocks) {
-            __shared__ double lds[8];
-            if (blockIdx.y || blockIdx.z) return;
-            if (c.method == ARL_OPT_ADAM) arl::opt_update_block<ARL_OPT_ADAM>(c, (int)blockIdx.x, c.co_blocks, lds);
-            else arl::opt_update_block<ARL_OPT_RMSPROP>(c, (int)blockIdx.x, c.co_blocks, lds);
-            return;
-        }
-        igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, U8, false>(a, blockIdx.x - c.co_blocks, blockIdx.y, blockIdx.z, smem);
-        return;
-    }
-    igemm_body<WGM, WGN, TM, TN, BK, B_KC, MULTI_TAP, HAS_PAD, N16, U8, false>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
-}
-
-// forward convolution straight from planar u8 observations (see igemm_body, U8)
-template <int WGM, int WGN, int TM, int TN, int BK, bool N16>
-__global__ __launch_bounds__(256) void igemm_u8_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    igemm_body<WGM, WGN, TM, TN, BK, true, false, false, N16, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
-}
-
-// Weight gradient, scalar-addressed: dy advances by a uniform stride per tile (soffset); the
-// gathered rows change every tile, so their element offsets and padding masks come from an LDS
-// table that all 256 threads refresh together, 256 rows (= 256 / BK tiles) at a time, each
-// thread walking its own row's (b, oy, ox) incrementally (no divisions in the loop).
-// Requirements: Mred % 256 == 0 is NOT needed, but Mred % BK == 0 and m_per_split % BK == 0.
-constexpr int WG_ROWS = 256;
-
-// M16: <= 16 output channels (spec 0's conv 1) -> v_mfma_f32_16x16x4_f32, 16 channel rows x 16-column groups
-// (a 32-row tile would spend half of every MFMA on channels that do not exist).
-// U8: the gathered rows come from planar u8 images (GatherDesc::src8; column r = (ch * kh8 + ty) * kw8 + tx,
-// so dw is (K, C, kh, kw)); the row count needs no rounding (the last tile's missing rows read as zeros).
-// SPLIT: bf16-split products (see igemm_body): both operands are k-major here, so both LDS images are pair-packed --
-// every loader task fetches two adjacent reduction rows of its four columns.
-template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false, bool U8 = false, int SPLIT = 0>
-__device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx, const int by, const int bz, float* smem) {
-    constexpr bool SP = SPLIT != 0;
-    constexpr int BM = M16 ? 16 : WGM * TM * 32, BN = WGN * TN * 32;
-    static_assert(!M16 || (WGM == 1 && TM == 1 && BK % 16 == 0), "16-row tiles: one row tile");
-    static_assert(!SP || (!M16 && BK % 16 == 0), "split products: 32-row tiles");
-    constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
-    constexpr int MC4 = BM / 4, NPA = (BK / 2) * MC4;        // split: pair tasks of the dy tile
-    constexpr int NA4 = BK * BM / 4, RA = SP ? 2 * ((NPA + 255) / 256) : (NA4 + 255) / 256;
-    constexpr int NC4 = BN / 4, KROWS = 256 / NC4, RB = BK / KROWS;
-    static_assert(!SP || RB % 2 == 0, "split products: an even number of gather passes (row pairs)");
-    constexpr int PB = U8 ? 1 : 3;
-    constexpr int SPA = BK * BM * 2, SPB = BK * BN * 2, STAGE = 3 * SPA + PB * SPB;   // bytes per plane / stage
-    char* const sS = reinterpret_cast<char*>(smem);
-    constexpr int TILES_PER_GROUP = WG_ROWS / BK;
-    static_assert(WGM * WGN == 4 && 256 % NC4 == 0 && BK % KROWS == 0 && BK % 8 == 0 && WG_ROWS % BK == 0, "tile shape");
-    __shared__ uint2 s_row[2][WG_ROWS];     // per gathered row: byte offset of its tap origin, inverted tap mask
-    float* sA = smem;
-    float* sB = smem + 2 * A_SZ;
-    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
-    if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int n0 = bx * BN, i0 = by * BM;
-    const int mbeg = bz * a.m_per_split;
-    const int mend = (mbeg + a.m_per_split < a.Mred) ? mbeg + a.m_per_split : a.Mred;
-    const int Cs = a.g.Cs, taps_x = a.g.taps_x, Ws = a.g.Ws, step = a.g.step;
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(a.dy, a.dy_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = U8 ? make_rsrc(reinterpret_cast<const float*>(a.g.src8), a.g.src_bytes)
-                                          : make_rsrc(a.g.src + a.g.origin, a.g.src_bytes);
-
-    // ---- per-thread constants: dy fragment offsets, gather column
-    unsigned voffA[RA];
-#pragma unroll
-    for (int p = 0; p < RA; ++p) {
-        int idx = tid + p * 256;
-        int kl = idx / MC4, c4 = idx - kl * MC4;
-        bool in_tile = NA4 % 256 == 0 || idx < NA4;
-        if constexpr (SP) {                         // passes 2q, 2q + 1: rows 2 kl2, 2 kl2 + 1 of task tid + 256 q
-            idx = tid + (p >> 1) * 256;
-            const int kl2 = idx / MC4;
-            c4 = idx - kl2 * MC4;
-            kl = 2 * kl2 + (p & 1);
-            in_tile = NPA % 256 == 0 || idx < NPA;
-        }
-        const int ko = i0 + c4 * 4;
-        voffA[p] = (in_tile && ko < a.K_out) ? (unsigned)(kl * a.K_out + ko) << 2 : OOB;
-    }
-    // the reduction row (within a k-tile) that dy pass p of this thread covers
-    auto a_row_of = [&](int p) { return SP ? 2 * ((tid + (p >> 1) * 256) / MC4) + (p & 1) : (tid + p * 256) / MC4; };
-    const int b_c4 = tid % NC4, b_k0 = tid / NC4;
-    const int r = n0 + b_c4 * 4;
-    const int tap = r / Cs, ch = r - tap * Cs;
-    const int cty = tap / taps_x, ctx = tap - cty * taps_x;
-    unsigned cdelta = r < a.N ? (unsigned)(step * (cty * Ws + ctx) * Cs + ch - a.g.dmin) << 2 : OOB;
-    if constexpr (U8) {
-        const int khw = a.g.kh8 * a.g.kw8;
-        const int pl = r / khw, rem = r - pl * khw;
-        const int fy = rem / a.g.kw8, fx = rem - fy * a.g.kw8;
-        cdelta = r < a.N ? (unsigned)(pl * a.g.plane + fy * Ws + fx) : OOB;
-    }
-
-    // ---- row producer state: thread t owns row t of every 256-row group
-    int pm = mbeg + tid, pb, poy, pox;
-    {
-        const int t = pm / a.g.out_w;
-        pox = pm - t * a.g.out_w;
-        pb = t / a.g.out_h;
-        poy = t - pb * a.g.out_h;
-    }
-    auto produce_rows = [&](int slot) {
-        const int ry = poy * a.g.mul + a.g.add_y, rx = pox * a.g.mul + a.g.add_x;
-        unsigned off = OOB, im = ~0u;
-        if (U8 && pm < mend) {
-            const int row = a.g.idx ? a.g.idx[pb] : pb;
-            off = (unsigned)(row * a.g.img_bytes + ry * Ws + rx);
-            im = 0;
-        } else if (pm < mend) {
-            off = (unsigned)(((pb * a.g.Hs + ry) * Ws + rx) * Cs - a.g.rmin) << 2;
-            im = 0;
-            if (HAS_PAD) im = tap_mask(ry, rx, a.g.Hs, Ws, a.g.taps_y, taps_x, step);
-        }
-        s_row[slot][tid] = make_uint2(off, im);
-        // advance this thread's row by 256 (host-provided decomposition 256 = qb*out_h*out_w + qw*out_w + rw)
-        pm += WG_ROWS;
-        pb += a.adv_b; poy += a.adv_y; pox += a.adv_x;
-        if (pox >= a.g.out_w) { pox -= a.g.out_w; ++poy; }
-        if (poy >= a.g.out_h) { poy -= a.g.out_h; ++pb; }
-    };
-
-    // The workgroups of the first column tile also sum their dy rows per channel: the bias gradient's
-    // partials ride along (4 RA vector adds per k-tile in 1 / (N / BN) of the workgroups).
-    const bool do_bias = a.bias_part != nullptr && bx == 0;             // uniform
-    float4 bsum[RA];
-#pragma unroll
-    for (int p = 0; p < RA; ++p) bsum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 va[RA], vb[RB];
-    unsigned vb8[RB];
-    auto issue_loads = [&](int tile) {              // tile index within the split
-        const unsigned soffA = (unsigned)((mbeg + tile * BK) * a.K_out) << 2;
-        const int grp = tile / TILES_PER_GROUP, tin = tile - grp * TILES_PER_GROUP;
-        const uint2* rows = &s_row[grp & 1][tin * BK + (SP ? 2 * b_k0 : b_k0)];
-        // (the buffer range check does not see soffset: U8's ragged last tile switches its missing dy rows off here)
-        const int rows_left = mend - (mbeg + tile * BK);
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            const bool row_ok = !U8 || rows_left >= BK || a_row_of(p) < rows_left;
-            va[p] = buf_ld4s(rsA, row_ok ? voffA[p] : OOB, soffA);
-        }
-#pragma unroll
-        for (int p = 0; p < RB; ++p) {
-            // split: passes 2q, 2q + 1 gather rows 2 (b_k0 + q KROWS), + 1
-            const uint2 e = rows[SP ? (p >> 1) * 2 * KROWS + (p & 1) : p * KROWS];
-            const unsigned off = e.x + cdelta;      // either term may be the OOB marker (sum stays >= OOB, < 2^32)
-            if constexpr (U8) vb8[p] = buf_ld1s(rsB, off, 0);
-            else vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
-        }
-    };
-    auto pack4 = [&](const float4& v0, const float4& v1, char* d, int plane_bytes) {     // rows k, k + 1 -> three planes
-        uint4 h, m, l;
-        split_pair(v0.x, v1.x, h.x, m.x, l.x);
-        split_pair(v0.y, v1.y, h.y, m.y, l.y);
-        split_pair(v0.z, v1.z, h.z, m.z, l.z);
-        split_pair(v0.w, v1.w, h.w, m.w, l.w);
-        *reinterpret_cast<uint4*>(d) = h;
-        *reinterpret_cast<uint4*>(d + plane_bytes) = m;
-        *reinterpret_cast<uint4*>(d + 2 * plane_bytes) = l;
-    };
-    auto store_tiles = [&](int buf, bool fresh) {   // fresh: va holds a tile not stored before
-        if constexpr (SP) {
-            char* dS = sS + buf * STAGE;
-#pragma unroll
-            for (int q = 0; q < RA / 2; ++q) {
-                const int t = tid + q * 256;
-                if (NPA % 256 != 0 && t >= NPA) continue;
-                pack4(va[2 * q], va[2 * q + 1], dS + t * 16, SPA);             // [kl2][c4 * 4] dwords, ld = BM
-                if (do_bias && fresh) {
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int p = 2 * q + e;
-                        bsum[p].x += va[p].x; bsum[p].y += va[p].y; bsum[p].z += va[p].z; bsum[p].w += va[p].w;
-                    }
-                }
-            }
-            char* dB = dS + 3 * SPA;
-#pragma unroll
-            for (int q = 0; q < RB / 2; ++q) {
-                char* d = dB + ((b_k0 + q * KROWS) * BN + b_c4 * 4) * 4;
-                if constexpr (U8) {                 // 0 .. 255 is exact in bf16: one plane
-                    const float4 f0 = bytes_to_f4(vb8[2 * q]), f1 = bytes_to_f4(vb8[2 * q + 1]);
-                    *reinterpret_cast<uint4*>(d) = make_uint4(hi_pair(f0.x, f1.x), hi_pair(f0.y, f1.y), hi_pair(f0.z, f1.z),
-                                                              hi_pair(f0.w, f1.w));
-                } else {
-                    pack4(vb[2 * q], vb[2 * q + 1], d, SPB);
-                }
-            }
-            return;
-        }
-        float* dA = sA + buf * A_SZ;
-        float* dB = sB + buf * B_SZ;
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            const int idx = tid + p * 256;
-            if (NA4 % 256 != 0 && idx >= NA4) continue;
-            *reinterpret_cast<float4*>(dA + idx * 4) = va[p];
-            if (do_bias && fresh) { bsum[p].x += va[p].x; bsum[p].y += va[p].y; bsum[p].z += va[p].z; bsum[p].w += va[p].w; }
-        }
-#pragma unroll
-        for (int p = 0; p < RB; ++p)
-            *reinterpret_cast<float4*>(dB + (b_k0 + p * KROWS) * BN + b_c4 * 4) =
-                U8 ? bytes_to_f4(vb8[p]) : vb[p];
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
-    constexpr int G16 = TN * 2;                     // M16: 16-column groups per wave
-    const int l15 = lane & 15, quad = lane >> 4;
-    f32x4 acc16[G16];
-#pragma unroll
-    for (int gq = 0; gq < G16; ++gq)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) acc16[gq][v] = 0.f;
-
-    // Row groups: group g (tiles g*T .. g*T+T-1) lives in slot g & 1.  Groups 0 and 1 are produced
-    // up front; group g+2 is produced in the first iteration of group g+1's ... see loop.
-    const int nk = U8 ? (mend - mbeg + BK - 1) / BK : (mend - mbeg) / BK;
-    produce_rows(0);
-    produce_rows(1);
-    __syncthreads();
-    issue_loads(0);
-    store_tiles(nk & 1, true);                      // first tile's buffer chosen so that the loop ends on buffer 1
-    __syncthreads();
-    if (a.trace) tr1 = __builtin_readcyclecounter();
-    // one k-tile with a compile-time buffer index (as in igemm_body: no vector address math between MFMAs)
-    auto k_tile = [&](auto buf_c, int kt) {
-        constexpr int buf = decltype(buf_c)::value;
-        if (kt + 1 < nk) issue_loads(kt + 1);
-        // tile kt+1 was the last reader of group (kt+1)/T when it is that group's last tile; the
-        // slot is rewritten (group + 2) one iteration later, after this iteration's barrier.
-        if (kt % TILES_PER_GROUP == 0 && kt >= TILES_PER_GROUP) produce_rows(((kt / TILES_PER_GROUP) + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SP) {
-            // fragment = column l31 (of its 32-wide tile), k octet 2 ks + half = pair rows 8 ks + 4 half .. + 3
-            const unsigned* cA = reinterpret_cast<const unsigned*>(sS + buf * STAGE) + (half * 4) * BM + wm * TM * 32 + l31;
-            const unsigned* cB = reinterpret_cast<const unsigned*>(sS + buf * STAGE + 3 * SPA) + (half * 4) * BN + wn * TN * 32 + l31;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                u32x4 fa[TM][3], fb[TN][3];
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
-                        const unsigned* q = cA + pl * (SPA / 4) + ks * 8 * BM + i * 32;
-                        fa[i][pl] = u32x4{q[0], q[BM], q[2 * BM], q[3 * BM]};
-                    }
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int pl = 0; pl < PB; ++pl) {
-                        const unsigned* q = cB + pl * (SPB / 4) + ks * 8 * BN + j * 32;
-                        fb[j][pl] = u32x4{q[0], q[BN], q[2 * BN], q[3 * BN]};
-                    }
-                split_products<SPLIT, 3, PB, false, TM, TN>(fa, fb, acc);
-            }
-        } else if constexpr (M16) {
-            const float* cA = sA + buf * A_SZ + (quad * 4) * BM + l15;
-            const float* cB = sB + buf * B_SZ + (quad * 4) * BN + wn * TN * 32 + l15;
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                float fa[4], fb[G16][4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    fa[q] = cA[(ks * 16 + q) * BM];
-#pragma unroll
-                    for (int gq = 0; gq < G16; ++gq) fb[gq][q] = cB[(ks * 16 + q) * BN + gq * 16];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int gq = 0; gq < G16; ++gq)
-                        acc16[gq] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[q], fb[gq][q], acc16[gq], 0, 0, 0);
-            }
-        } else {
-        const float* cA = sA + buf * A_SZ + (half * 4) * BM + wm * TM * 32 + l31;
-        const float* cB = sB + buf * B_SZ + (half * 4) * BN + wn * TN * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < BK / 8; ++ks) {
-            float fa[TM][4], fb[TN][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[i][q] = cA[(ks * 8 + q) * BM + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[j][q] = cB[(ks * 8 + q) * BN + j * 32];
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
-        }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            store_tiles(buf ^ 1, true);
-            __syncthreads();
-        }
-    };
-    {   // an odd tile count peels its FIRST tile (from buffer 1); the rest is whole (buffer 0, buffer 1) pairs
-        int kt = 0;
-        if (nk & 1) { k_tile(std::integral_constant<int, 1>{}, 0); kt = 1; }
-        for (; kt < nk; kt += 2) {
-            k_tile(std::integral_constant<int, 0>{}, kt);
-            k_tile(std::integral_constant<int, 1>{}, kt + 1);
-        }
-    }
-    if (a.trace) tr2 = __builtin_readcyclecounter();
-    if (do_bias) __syncthreads();                   // every wave is done with the tile buffers
-    if (do_bias) {                                  // [BK][MC4] float4 in the (now idle) A buffer, summed in row order
-        float4* red = reinterpret_cast<float4*>(sA);
-#pragma unroll
-        for (int p = 0; p < RA; ++p) {
-            if constexpr (SP) {
-                const int t = tid + (p >> 1) * 256;
-                if (NPA % 256 == 0 || t < NPA) red[a_row_of(p) * MC4 + t % MC4] = bsum[p];
-                continue;
-            }
-            const int idx = tid + p * 256;
-            if (NA4 % 256 == 0 || idx < NA4) red[idx] = bsum[p];
-        }
-        __syncthreads();
-        if (tid < MC4) {
-            float4 t = red[tid];
-            for (int kl = 1; kl < BK; ++kl) {
-                const float4 v = red[kl * MC4 + tid];
-                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-            }
-            const int ko = i0 + tid * 4;
-            if (ko < a.K_out) *reinterpret_cast<float4*>(a.bias_part + (int64_t)bz * a.K_out + ko) = t;
-        }
-    }
-
-    float* out = a.part + (int64_t)bz * a.K_out * a.N;
-    if constexpr (M16) {                            // D[row = 4 quad + v][col = l15] per 16-column group
-#pragma unroll
-        for (int gq = 0; gq < G16; ++gq) {
-            const int col = n0 + wn * TN * 32 + gq * 16 + l15;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = i0 + 4 * quad + v;
-                if (row < a.K_out && col < a.N) out[(int64_t)row * a.N + col] = U8 ? acc16[gq][v] * a.g.scale : acc16[gq][v];
-            }
-        }
-    } else {
-        if constexpr (U8) {                         // the pixel scale on the finished sums (see bytes_to_f4)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) acc[i][j][v] *= a.g.scale;
-        }
-        store_tiles_rowmajor<TM, TN>(acc, out, a.K_out, a.N, i0 + wm * TM * 32, n0 + wn * TN * 32, lane, nullptr, 0);
-    }
-    if (a.trace && tid == 0) {                      // (plain launches only: the slot is the workgroup's grid index)
-        unsigned long long* t = a.trace + ((size_t)(bz * gridDim.y + by) * gridDim.x + bx) * 8;
-        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_readcyclecounter();
-        t[4] = rt0; t[5] = __builtin_amdgcn_s_memrealtime();
-        t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-        t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
-    }
-}
-
-template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool M16 = false>
-__global__ __launch_bounds__(256, (TM * TN > 1 ? 2 : 4)) void wgrad_fast_kernel(const WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, M16>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
-}
-
-// weight gradient of a convolution whose input is the planar u8 observations (see wgrad_fast_body, U8)
-template <int WGM, int WGN, int TM, int TN, int BK, bool M16>
-__global__ __launch_bounds__(256, 4) void wgrad_u8_kernel(const WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    wgrad_fast_body<WGM, WGN, TM, TN, BK, false, M16, true>(a, blockIdx.x, blockIdx.y, blockIdx.z, smem);
-}
-
-// bf16-split products (wgrad_fast_body, SPLIT), from f32 activations or (U8) the planar u8 observations
-template <int WGM, int WGN, int TM, int TN, int BK, bool HAS_PAD, bool U8, int SPLIT, int MINW>
-__global__ __launch_bounds__(256, MINW) void wgrad_split_kernel(const WgradArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (a.xcd) {                                    // uniform
-        const int gx = gridDim.x, gy = gridDim.y;
-        const int t = xcd_chunk((bz * gy + by) * gx + bx, gx * gy * (int)gridDim.z);
-        bx = t % gx;
-        const int u = t / gx;
-        by = u % gy; bz = u / gy;
-    }
-    wgrad_fast_body<WGM, WGN, TM, TN, BK, HAS_PAD, false, U8, SPLIT>(a, bx, by, bz, smem);
-}
-
-// One launch for a layer's data gradient AND weight gradient (independent of each other, both read dy):
-// workgroups [0, n_ig) run data-gradient tiles, the rest weight-gradient tiles.  One ramp-up and one
-// tail instead of two, and the dispatcher fills the CUs the first problem's last wave leaves idle.
-template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK, bool HAS_PAD, int SPLIT = 0,
-          bool PIN = false>
-__global__ __launch_bounds__(256) void bwd_pair_kernel(const GemmArgs a, const WgradArgs w, const int dgx, const int dgy,
-                                                       const int n_ig, const int wgx, const int wgy) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int id = blockIdx.x;
-    if (a.xcd) id = xcd_chunk(id, (int)gridDim.x);     // uniform
-    if (id < n_ig) {
-        const int bx = id % dgx, t = id / dgx;          // the row tiles over one weight panel are neighbours
-        igemm_body<DWGM, DWGN, DTM, DTN, BK, false, false, HAS_PAD, false, false, false, SPLIT, PIN>(a, bx, t % dgy, t / dgy, smem);
-    } else {
-        id -= n_ig;
-        if (a.xcd) {                                    // ... and so are the row tiles over one panel of the layer's input
-            const int by = id % wgy, t = id / wgy;
-            wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD, false, false, SPLIT>(w, t % wgx, by, t / wgx, smem);
-        } else {
-            const int bx = id % wgx, t = id / wgx;
-            wgrad_fast_body<WWGM, WWGN, WTM, WTN, BK, HAS_PAD, false, false, SPLIT>(w, bx, t % wgy, t / wgy, smem);
-        }
-    }
-}
-
 // out[i] = act(sum_z part[z][i] + bias[i % n_bias]), float4 lanes, fixed summation order:
 // 16 threads share one output float4 (thread zg sums splits zg, zg+16, ...), then the 16
 // partial sums are added in index order -- enough parallelism for the small, many-split
@@ -2376,270 +96,6 @@ __global__ __launch_bounds__(256) void fold_many_kernel(const FoldManyArgs a) {
     }
 }
 
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool TAP_UNIFORM = false>
-int launch_rowgather(const GemmArgs& a, int splits, hipStream_t s) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * BN;
-    const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, splits);
-    hipLaunchKernelGGL((rowgather_gemm_kernel<WGM, WGN, TM, TN, BK, B_KC, TAP_UNIFORM>), grid, dim3(256), lds, s, a);
-    return arl::check_launch("rowgather_gemm_kernel");
-}
-
-template <int WGM, int WGN, int TM, int TN, int BK>
-int launch_wgrad(const WgradArgs& a, int splits, hipStream_t s) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
-    dim3 grid((a.N + BN - 1) / BN, (a.K_out + BM - 1) / BM, splits);
-    hipLaunchKernelGGL((wgrad_kernel<WGM, WGN, TM, TN, BK>), grid, dim3(256), lds, s, a);
-    return arl::check_launch("wgrad_kernel");
-}
-
-constexpr bool lds_fits(int floats) { return floats * 4 <= 65536; }
-
-template <typename K>
-int allow_big_lds(K kernel, size_t lds) {           // > 64 KiB of dynamic LDS needs an explicit opt-in
-    if (lds <= 65536) return 0;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { arl::set_error("hipFuncSetAttribute(LDS %zu): %s", lds, hipGetErrorString(e)); return (int)e; }
-    return 0;
-}
-
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16 = false, bool PIPE3 = false>
-int launch_igemm(const GemmArgs& a, int splits, bool multi_tap, bool has_pad, hipStream_t s) {
-    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * TN * 32;
-    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
-    const size_t lds = (size_t)(PIPE3 ? 3 : 2) * (A_SZ + B_SZ) * sizeof(float);
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
-    int rc = 0;
-#define ARL_IGEMM(MT, HP)                                                                                  \
-    do {                                                                                                   \
-        auto k = igemm_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16, PIPE3>;                             \
-        rc = allow_big_lds(k, lds);                                                                        \
-        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
-    } while (0)
-    if (multi_tap && has_pad) ARL_IGEMM(true, true);
-    else if (multi_tap) ARL_IGEMM(true, false);
-    else if (has_pad) ARL_IGEMM(false, true);
-    else ARL_IGEMM(false, false);
-#undef ARL_IGEMM
-    return rc ? rc : arl::check_launch("igemm_kernel");
-}
-
-int g_tile_choice = 0;             // arl_conv_tile_choice (tuning aid): 0 / 3 = 32x64 tiles for 33 .. 64 columns, 1 = 64x64, 2 = 112x64
-// arl_conv_corun_update: an optimiser job waiting for a data-gradient launch to carry it
-arl::OptSeg g_corun_job = {};
-int g_corun_blocks = 0;
-int g_corun_host_blocks = 256;          // workgroups that run a co-run job inside its host launch (tuning: ARL_CORUN_BLOCKS)
-bool g_corun_pending = false;
-int g_persist = 0;                  // arl_conv_persistent: resident workgroups per CU of the persistent launches (0 = off)
-int g_cus = 0;
-int num_cus() {
-    if (!g_cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&g_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_cus <= 0)
-            g_cus = 256;
-    }
-    return g_cus;
-}
-
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool N16, int MINW>
-int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s, int splits = 1) {
-    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * TN * 32;
-    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
-    const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
-    static_assert(lds_fits(2 * (A_SZ + B_SZ)), "<= 64 KiB of LDS");
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
-    arl::OptSeg c = {};
-    if constexpr (!B_KC) {                          // a data gradient hosts the pending optimiser job, if any
-        if (g_corun_pending && !multi_tap) {
-            c = g_corun_job;
-            c.co_blocks = g_corun_blocks < g_corun_host_blocks ? g_corun_blocks : g_corun_host_blocks;
-            grid.x += (unsigned)c.co_blocks;
-            g_corun_pending = false;
-            if (has_pad) hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, true, N16, MINW, true>), grid, dim3(256), lds, s, a, c);
-            else hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, false, false, N16, MINW, true>), grid, dim3(256), lds, s, a, c);
-            return arl::check_launch("igemm_occ_kernel (co-run)");
-        }
-    }
-#define ARL_IGEMM_OCC(MT, HP) \
-    hipLaunchKernelGGL((igemm_occ_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, N16, MINW>), grid, dim3(256), lds, s, a, c)
-    if (multi_tap && has_pad) ARL_IGEMM_OCC(true, true);
-    else if (multi_tap) ARL_IGEMM_OCC(true, false);
-    else if (has_pad) ARL_IGEMM_OCC(false, true);
-    else ARL_IGEMM_OCC(false, false);
-#undef ARL_IGEMM_OCC
-    return arl::check_launch("igemm_occ_kernel");
-}
-
-// arl_conv_precision: 0 = fp32 MFMA chain, 6 / 9 = bf16-split products (see igemm_body, SPLIT)
-int g_split = 9;
-#ifdef ARL_NO_SPLIT6        // development builds: half the split kernels (mode 6 then runs the nine-product kernels)
-#define ARL_BY_MODE(X6, X9) do { X9; } while (0)
-#else
-#define ARL_BY_MODE(X6, X9) do { if (g_split == 6) { X6; } else { X9; } } while (0)
-#endif
-
-// arl_conv_pieces: the bf16 pieces the NEXT forward / data-gradient launch reads its gathered operand from, and leaves
-// of its output (consumed -- cleared -- by that launch)
-struct Pieces { const void* in; void* out; };
-Pieces g_pieces = {nullptr, nullptr};
-Pieces grab_pieces() { const Pieces p = g_pieces; g_pieces = {nullptr, nullptr}; return p; }
-// caps bits (arl_conv_pieces_supported)
-constexpr int PIECES_IN = 1, PIECES_OUT = 2;
-// hand the pending pieces to a launch whose route has the capabilities `caps`; anything pending beyond them is refused
-int put_pieces(GemmArgs& a, const Pieces& pc, int caps, int64_t in_elems, int64_t out_elems) {
-    ARL_REQUIRE(!pc.in || (caps & PIECES_IN), ARL_E_ARG, "bf16 pieces of the input pending on a route that cannot read them (arl_conv_pieces_supported)");
-    ARL_REQUIRE(!pc.out || (caps & PIECES_OUT), ARL_E_ARG, "bf16 pieces of the output requested on a route that cannot write them (arl_conv_pieces_supported)");
-    ARL_REQUIRE((!pc.in || in_elems % 8 == 0) && (!pc.out || out_elems % 8 == 0), ARL_E_ALIGN,
-                "bf16 pieces: element count not a multiple of 8");
-    a.g.pieces = (const char*)pc.in; a.g.piece_bytes = in_elems * 2;
-    a.o.pieces = (char*)pc.out; a.o.piece_bytes = out_elems * 2;
-    return 0;
-}
-
-// the launch of igemm_split_kernel: two LDS stages of (1 or 3) + 3 bf16 planes; a data gradient hosts the pending
-// optimiser job like launch_igemm_occ
-template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool U8, int MINW>
-int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s, int splits = 1) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    const size_t lds = (size_t)2 * ((U8 ? 1 : 3) * BM + 3 * BN) * BK * 2;
-    const size_t lds_dir = (size_t)2 * 3 * BN * BK * 2;         // direct gathered operand: only the weights live in LDS
-    (void)lds_dir;
-    dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
-    arl::OptSeg c = {};
-    int rc = 0;
-#define ARL_SPLIT_K(MT, HP, SPL, CO, PI, AD)                                                               \
-    do {                                                                                                   \
-        auto k = igemm_split_kernel<WGM, WGN, TM, TN, BK, B_KC, MT, HP, U8, SPL, MINW, CO, PI, AD>;        \
-        const size_t lds_k = (AD) ? lds_dir : lds;                                                         \
-        rc = allow_big_lds(k, lds_k + (CO ? 64 : 0));                                                      \
-        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds_k, s, a, c);                                   \
-    } while (0)
-#define ARL_SPLIT_PIN(MT, HP, SPL, CO)                                                                     \
-    do {                                                                                                   \
-        if constexpr (!(MT) && !U8 && WGN == 1) {           /* the gathered operand straight into registers */ \
-            if (g_tile_choice != 3) {                                                                      \
-                if (a.g.pieces) ARL_SPLIT_K(MT, HP, SPL, CO, true, true); else ARL_SPLIT_K(MT, HP, SPL, CO, false, true); \
-                break;                                                                                     \
-            }                                                                                              \
-        }                                                                                                  \
-        if constexpr (U8 && WGN == 1) {                                                                    \
-            if (g_tile_choice != 3) { ARL_SPLIT_K(MT, HP, SPL, CO, false, true); break; }                  \
-        }                                                                                                  \
-        if constexpr (!(MT) && !U8) {                                                                      \
-            if (a.g.pieces) { ARL_SPLIT_K(MT, HP, SPL, CO, true, false); break; }                          \
-        }                                                                                                  \
-        ARL_SPLIT_K(MT, HP, SPL, CO, false, false);                                                        \
-    } while (0)
-#define ARL_SPLIT_MODE(MT, HP, CO)                                                                         \
-    do {                                                                                                   \
-        ARL_BY_MODE(ARL_SPLIT_PIN(MT, HP, 6, CO), ARL_SPLIT_PIN(MT, HP, 9, CO));                           \
-    } while (0)
-    if ((multi_tap || U8) && a.g.pieces) { arl::set_error("bf16 pieces on a kernel that cannot read them"); return ARL_E_ARG; }
-    if constexpr (U8) {
-        ARL_SPLIT_MODE(false, false, false);
-    } else {
-        if constexpr (!B_KC) {
-            if (g_corun_pending && !multi_tap) {
-                c = g_corun_job;
-                c.co_blocks = g_corun_blocks < g_corun_host_blocks ? g_corun_blocks : g_corun_host_blocks;
-                grid.x += (unsigned)c.co_blocks;
-                g_corun_pending = false;
-                if (has_pad) ARL_SPLIT_MODE(false, true, true); else ARL_SPLIT_MODE(false, false, true);
-                return rc ? rc : arl::check_launch("igemm_split_kernel (co-run)");
-            }
-        }
-        if (multi_tap && has_pad) ARL_SPLIT_MODE(true, true, false);
-        else if (multi_tap) ARL_SPLIT_MODE(true, false, false);
-        else if (has_pad) ARL_SPLIT_MODE(false, true, false);
-        else ARL_SPLIT_MODE(false, false, false);
-    }
-#undef ARL_SPLIT_PIN
-#undef ARL_SPLIT_MODE
-#undef ARL_SPLIT_K
-    return rc ? rc : arl::check_launch("igemm_split_kernel");
-}
-
-// more row tiles than resident workgroups?  (g_persist < 0, tests: always, walked by -g_persist workgroups)
-// (the callers also check that the reduction is an even number of k-tiles: the two-deep load pipeline's invariant)
-bool persist_pays(int tiles) { return g_persist < 0 || (g_persist > 0 && tiles > num_cus() * g_persist); }
-
-// persistent launch of igemm_persist_body: the tile plan rides in the arguments
-template <int WGM, int WGN, int TM, int BK, bool B_KC, bool N16, bool U8, int MINW>
-int launch_igemm_persist(GemmArgs a, bool multi_tap, bool has_pad, hipStream_t s) {
-    constexpr int BM = WGM * TM * (N16 ? 16 : 32), BN = N16 ? WGN * 16 : WGN * 32;
-    constexpr int A_SZ = BM * (BK + 4), B_SZ = B_KC ? BN * (BK + 4) : BK * (N16 ? BN + 4 : BN);
-    const size_t lds = (size_t)2 * (A_SZ + B_SZ) * sizeof(float);
-    int n = 0;
-    for (int c = 0; c < 5; ++c) a.p_first[c] = 0x7fffffff;
-    if (a.n_par) {
-        for (int c = 0; c < a.n_par; ++c) { a.p_first[c] = n; n += (a.par[c].M + BM - 1) / BM; }
-    } else {
-        a.p_first[0] = 0; n = (a.M + BM - 1) / BM;
-    }
-    a.p_tiles = n;
-    const int resident = g_persist < 0 ? -g_persist : num_cus() * (g_persist > 0 ? g_persist : MINW);
-    const dim3 grid(n < resident ? n : resident);
-    int rc = 0;
-#define ARL_PERSIST(MT, HP)                                                                                \
-    do {                                                                                                   \
-        auto k = igemm_persist_kernel<WGM, WGN, TM, BK, B_KC, MT, HP, N16, U8, MINW>;                      \
-        rc = allow_big_lds(k, lds);                                                                        \
-        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
-    } while (0)
-    if constexpr (U8) ARL_PERSIST(false, false);
-    else if (multi_tap && has_pad) ARL_PERSIST(true, true);
-    else if (multi_tap) ARL_PERSIST(true, false);
-    else if (has_pad) ARL_PERSIST(false, true);
-    else ARL_PERSIST(false, false);
-#undef ARL_PERSIST
-    return rc ? rc : arl::check_launch("igemm_persist_kernel");
-}
-
-template <int WGM, int WGN, int TM, int TN, int BK, bool M16 = false>
-int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t s) {
-    constexpr int BM = M16 ? 16 : WGM * TM * 32, BN = WGN * TN * 32;
-    const size_t lds = (size_t)2 * BK * (BM + BN) * sizeof(float);
-    dim3 grid((a.N + BN - 1) / BN, (a.K_out + BM - 1) / BM, splits);
-    int rc;
-    if (has_pad) {
-        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, true, M16>;
-        rc = allow_big_lds(k, lds + 4096);
-        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
-    } else {
-        auto k = wgrad_fast_kernel<WGM, WGN, TM, TN, BK, false, M16>;
-        rc = allow_big_lds(k, lds + 4096);
-        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
-    }
-    return rc ? rc : arl::check_launch("wgrad_fast_kernel");
-}
-
-template <int WGM, int WGN, int TM, int TN, int BK, bool U8, int MINW>
-int launch_wgrad_split(const WgradArgs& a, int splits, bool has_pad, hipStream_t s) {
-    constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    const size_t lds = (size_t)2 * (3 * BM + (U8 ? 1 : 3) * BN) * BK * 2;
-    dim3 grid((a.N + BN - 1) / BN, (a.K_out + BM - 1) / BM, splits);
-    int rc = 0;
-#define ARL_WSPLIT(HP, SPL)                                                                                \
-    do {                                                                                                   \
-        auto k = wgrad_split_kernel<WGM, WGN, TM, TN, BK, HP, U8, SPL, MINW>;                              \
-        rc = allow_big_lds(k, lds + 4096);                                                                 \
-        if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
-    } while (0)
-    if constexpr (U8) {
-        ARL_BY_MODE(ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
-    } else if (has_pad) {
-        ARL_BY_MODE(ARL_WSPLIT(true, 6), ARL_WSPLIT(true, 9));
-    } else {
-        ARL_BY_MODE(ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
-    }
-#undef ARL_WSPLIT
-    return rc ? rc : arl::check_launch("wgrad_split_kernel");
-}
-
 int launch_fold(const float* part, int splits, int64_t total, const float* bias, int n_bias, int relu,
                 float* out, hipStream_t s, const float* mask = nullptr) {
     const int64_t total4 = total >> 2;
@@ -2649,131 +105,42 @@ int launch_fold(const float* part, int splits, int64_t total, const float* bias,
     return arl::check_launch("fold_splits_kernel");
 }
 
-constexpr int TARGET_WGS = 256;     // one workgroup per CU is already MFMA-bound (fp32 MFMA: 1 wave / SIMD)
-constexpr int BKT = 32;             // k-tile of the skinny configurations (host-side split granularity)
-
-unsigned long long* g_trace = nullptr;
-bool g_force_generic = false;       // arl_conv_force_generic: route every call to the generic kernels (tests)
-
-struct Geom {
-    int64_t batch;
-    int H, W, C, K, kh, kw, stride, pad_h, pad_w, Ho, Wo;
-};
-
-int check_geom(const arl_conv_geom* g, Geom* o) {
-    if (!g || g->batch <= 0 || g->in_h <= 0 || g->in_w <= 0 || g->in_c <= 0 || g->out_c <= 0 || g->kh <= 0 ||
-        g->kw <= 0 || g->stride <= 0 || g->pad_h < 0 || g->pad_w < 0) {
-        arl::set_error("conv: bad geometry");
-        return ARL_E_ARG;
-    }
-    if ((g->in_c & 3) || (g->out_c & 3)) {
-        arl::set_error("conv: channel counts must be multiples of 4 (in %d, out %d)", g->in_c, g->out_c);
-        return ARL_E_RANGE;
-    }
-    o->batch = g->batch; o->H = g->in_h; o->W = g->in_w; o->C = g->in_c; o->K = g->out_c;
-    o->kh = g->kh; o->kw = g->kw; o->stride = g->stride; o->pad_h = g->pad_h; o->pad_w = g->pad_w;
-    o->Ho = (g->in_h + 2 * g->pad_h - g->kh) / g->stride + 1;
-    o->Wo = (g->in_w + 2 * g->pad_w - g->kw) / g->stride + 1;
-    const int64_t lim = (int64_t)OOB / 4;       // elements: every tensor must stay below the OOB byte offset
-    if (o->Ho <= 0 || o->Wo <= 0 || g->batch * (int64_t)o->Ho * o->Wo * g->out_c >= lim ||
-        g->batch * (int64_t)g->in_h * g->in_w * g->in_c >= lim ||
-        (int64_t)g->out_c * g->kh * g->kw * g->in_c >= lim) {
-        arl::set_error("conv: tensor larger than the 2 GiB the 32-bit buffer offsets address");
-        return ARL_E_RANGE;
-    }
-    return 0;
-}
-
-int round_up(int x, int q) { return (x + q - 1) / q * q; }
-
-// ceil(2^32 / d) if floor(n * that / 2^32) == n / d for every 0 <= n < rows (needs rows * d < 2^32), else 0
-unsigned div_magic(int64_t rows, int d) {
-    if (d <= 1 || rows * (int64_t)d >= ((int64_t)1 << 32)) return 0;
-    return (unsigned)((((uint64_t)1 << 32) + (uint64_t)d - 1) / (uint64_t)d);
-}
-
-// 33 .. 64 output columns, the default: 32x64 tiles -- each wave two 16-row groups of one 16-column stripe
-// (v_mfma_f32_16x16x4_f32), 32-deep k-tiles, two LDS stages (28 KB), compiled for five waves per SIMD.  Small tiles
-// spread the rows evenly (1 728 tiles at the PPO minibatch: 7 on the busiest CU against 6.75 on average, where 864
-// tiles of 64 rows leave it 4 against 3.375) and five or six resident workgroups per CU cover each other's barriers,
-// prologues and epilogues.  Measured, 20 launches per hipGraph, conv 2 / conv 3 forward at 512 images: 36.6 / 40.1 us
-// (64x64: 44.7 / 47.9, 112x64: 40.6 / 42.0); at 256: 22.4 / 24.1 (25.0 / 27.6, 25.4 / 26.7); at 128: 14.2 / 15.7
-// (15.6 / 17.3, 22.9 / 25.2); 16-deep k-tiles at 6-8 waves per SIMD and 48-row tiles were slower everywhere
-// (tools/tile_probe.py).  arl_conv_tile_choice: 1 = 64x64, 2 = 112x64, 3 = 32x64.
-template <bool B_KC>
-int launch_n64(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s) {
-    if (g_tile_choice == 1) return launch_igemm<2, 2, 1, 1, 32, B_KC>(a, 1, multi_tap, has_pad, s);
-    if (g_tile_choice == 2) return launch_igemm<1, 4, 7, 1, 32, B_KC, true, true>(a, 1, multi_tap, has_pad, s);
-    return launch_igemm_occ<1, 4, 2, 1, 32, B_KC, true, 5>(a, multi_tap, has_pad, s);
-}
-
-// split the reduction so that tiles * splits ~ TARGET_WGS, each split a multiple of BKT
-void plan_split(int tiles, int red, int* splits, int* per, int want = TARGET_WGS) {
-    int s = tiles >= want ? 1 : want / tiles;
-    const int max_s = (red + 4 * BKT - 1) / (4 * BKT);          // at least 4 k-tiles per split
-    if (s > max_s) s = max_s;
-    if (s < 1) s = 1;
-    *per = round_up((red + s - 1) / s, BKT);
-    *splits = (red + *per - 1) / *per;
-}
-
 }  // namespace
 
 extern "C" int64_t arl_conv_workspace_bytes(void) { return (int64_t)64 << 20; }
 
-extern "C" void arl_conv_trace_buffer(void* device_u64_or_null) { g_trace = (unsigned long long*)device_u64_or_null; }
+extern "C" void arl_dev_conv_trace_buffer(void* device_u64_or_null) { g_trace = (unsigned long long*)device_u64_or_null; }
 
-extern "C" void arl_conv_force_generic(int32_t on) { g_force_generic = on != 0; }
+extern "C" void arl_dev_conv_force_generic(int32_t on) { g_force_generic = on != 0; }
 
-extern "C" void arl_conv_tile_choice(int32_t choice) { g_tile_choice = choice; }
-
-extern "C" void arl_conv_persistent(int32_t workgroups_per_cu) { g_persist = workgroups_per_cu; }
-
-extern "C" int arl_conv_precision_get(void) { return g_split; }
-
-extern "C" int arl_conv_precision(int32_t mode) {
-    ARL_REQUIRE(mode == 0 || mode == 6 || mode == 9, ARL_E_ARG, "conv precision: 0 (fp32 MFMA), 6 or 9 (bf16-split products)");
-    g_split = mode;
-    return 0;
-}
-
-extern "C" int arl_conv_pieces(const void* in_pieces_or_null, void* out_pieces_or_null) {
-    ARL_REQUIRE(arl::aligned16(in_pieces_or_null) && arl::aligned16(out_pieces_or_null), ARL_E_ALIGN, "16-byte alignment");
-    g_pieces = {in_pieces_or_null, out_pieces_or_null};
-    return 0;
-}
-
-extern "C" int arl_conv_corun_update(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
-                                     float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
-                                     double* norm_parts, int64_t hole_first, int64_t hole_count) {
-    ARL_REQUIRE(!g_corun_pending, ARL_E_ARG, "a job is already pending (arl_conv_corun_flush first)");
-    int rc = arl::make_opt_seg(&g_corun_job, opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k,
-                               step_pp, norm_parts, hole_first, hole_count, 1, &g_corun_blocks);
+extern "C" int arl_corun_job_init(arl_corun_job* job, const arl_opt_state* opt, int32_t method, float learning_rate,
+                                  float avg_factor, float beta1_or_rho, float beta2, float epsilon, int32_t k,
+                                  float* step_pp, double* norm_parts, int64_t hole_first, int64_t hole_count) {
+    ARL_REQUIRE(job, ARL_E_ARG, "null pointer");
+    CorunJob* j = reinterpret_cast<CorunJob*>(job);
+    int rc = arl::make_opt_seg(&j->seg, opt, method, learning_rate, avg_factor, beta1_or_rho, beta2, epsilon, k,
+                               step_pp, norm_parts, hole_first, hole_count, 1, &j->blocks);
     if (rc) return rc;
-    if (const char* e = getenv("ARL_CORUN_BLOCKS")) g_corun_host_blocks = atoi(e) > 0 ? atoi(e) : 256;
-    g_corun_pending = true;
+    j->host_blocks = 256;               // workgroups that run the job inside its host launch (tuning: ARL_CORUN_BLOCKS)
+    if (const char* e = getenv("ARL_CORUN_BLOCKS")) j->host_blocks = atoi(e) > 0 ? atoi(e) : 256;
     return 0;
 }
 
-extern "C" int arl_conv_corun_flush(void* stream) {
-    if (!g_corun_pending) return 0;
-    g_corun_pending = false;
-    const int rc = arl::launch_opt_seg(g_corun_job, g_corun_blocks, (hipStream_t)stream);
-    return rc ? (rc > 0 ? -rc : rc) : 1;
+extern "C" int arl_corun_job_run(const arl_corun_job* job, void* stream) {
+    ARL_REQUIRE(job, ARL_E_ARG, "null pointer");
+    const CorunJob* j = reinterpret_cast<const CorunJob*>(job);
+    return arl::launch_opt_seg(j->seg, j->blocks, (hipStream_t)stream);
 }
 
 namespace {
-// caps_only: report the route's arl_conv_pieces capabilities instead of launching
 int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom, int32_t relu,
-             void* workspace, void* stream, const Pieces& pc, int* caps_only) {
+             void* workspace, void* stream) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
-    if (!caps_only) {
-        ARL_REQUIRE(x && w && y && workspace, ARL_E_ARG, "null pointer");
-        ARL_REQUIRE(arl::aligned16(x) && arl::aligned16(w) && arl::aligned16(y) && arl::aligned16(workspace) &&
-                        (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN, "16-byte alignment");
-    }
+    ARL_REQUIRE(x && w && y && workspace, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(arl::aligned16(x) && arl::aligned16(w) && arl::aligned16(y) && arl::aligned16(workspace) &&
+                    (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN, "16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     GemmArgs a = {};
     a.g.src = x; a.g.Hs = g.H; a.g.Ws = g.W; a.g.Cs = g.C; a.g.out_h = g.Ho; a.g.out_w = g.Wo;
@@ -2781,18 +148,12 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
     a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.kh * g.kw * g.C;
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.b.w = w; a.b.ld = a.K; a.b.w_bytes = (unsigned)((int64_t)a.N * a.K * 4);
-    a.o.dense = 1; a.trace = g_trace; a.xcd = g_tile_choice != 9;
+    a.o.dense = 1; a.trace = g_trace; a.xcd = 1;
     int splits = 1, per = round_up(a.K, BKT);
     const bool small = a.N >= 128 && (int64_t)a.M * a.N <= (int64_t)1 << 20;     // dense layers: split K
     // (the bf16-split kernels have no 16-wide tiles: 64x64 there)
-    const bool small32 = small && g_tile_choice != 1 && !g_split;  // 32x64 tiles: half the splits (and partial bytes) for the same grid
-    // bf16-split routes, tile choice 5: 128x64 tiles of the one-wave-per-row-tile kernel (the gathered operand straight
-    // into the fragment registers, the weights' LDS image shared by 128 rows), two workgroups per CU.  Same-box A/B at
-    // the PPO shapes: the launch 38.4 -> 36.8 us at 512 rows, but 16 / 31 splits instead of 12 / 24 for the fold to read:
-    // learner 3.29 -> 3.32 ms, rollout 0.564 -> 0.569 ms -- not the default.
-    const bool small128 = small && g_split && g_tile_choice == 5 && g.C % 32 == 0 && g.pad_h == 0 && g.pad_w == 0;
-    if (small128) plan_split(((a.M + 127) / 128) * ((a.N + 63) / 64), a.K, &splits, &per, 2 * TARGET_WGS);
-    else if (small) plan_split(((a.M + (small32 ? 31 : 63)) / (small32 ? 32 : 64)) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
+    const bool small32 = small && !g_split;         // 32x64 tiles: half the splits (and partial bytes) for the same grid
+    if (small) plan_split(((a.M + (small32 ? 31 : 63)) / (small32 ? 32 : 64)) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
     // ... and wider ones whose 128x128 tiles still leave CUs idle (spec-0 dense at the A2C batch: 5120 x 256 =
     // 80 tiles walking 88 k-tiles each, 231 us)
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
@@ -2811,11 +172,6 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
     const bool has_pad = g.pad_h > 0 || g.pad_w > 0;
     const bool fast = !g_force_generic && a.K % FBK == 0 && per % FBK == 0 && (single_tap || multi_tap) &&
                       (!has_pad || g.kh * g.kw <= 32) && a.N % 4 == 0;
-    // bf16 pieces ride with the split kernels: read when a k-tile is one tap, written when the launch stores the output
-    const int caps = (fast && g_split && a.N > 16 && !g_trace) ? (multi_tap ? 0 : PIECES_IN) | (splits == 1 ? PIECES_OUT : 0) : 0;
-    if (caps_only) { *caps_only = caps; return 0; }
-    rc = put_pieces(a, pc, caps, g.batch * g.H * g.W * g.C, (int64_t)a.M * a.N);
-    if (rc) return rc;
     if (fast) {
         a.o.out_bytes = (unsigned)((int64_t)a.M * a.N * 4);     // one split's output
         a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
@@ -2831,7 +187,6 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
             rc = launch_igemm<4, 1, 2, 1, 16, true, true>(a, splits, multi_tap, has_pad, s);        // 16-wide MFMA tiles
         else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
         else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
-        else if (small128 && !multi_tap) rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
         else if (g_split && small) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
         else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, true, false, 1>(a, multi_tap, has_pad, s, splits);
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
@@ -2855,32 +210,25 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {
-    return fwd_impl(x, w, bias_or_null, y, geom, relu, workspace, stream, grab_pieces(), nullptr);
+    ARL_ROUTE_SCOPE(geom, nullptr);
+    return fwd_impl(x, w, bias_or_null, y, geom, relu, workspace, stream);
 }
 
 namespace {
-// Fast-path launch descriptions, so that a layer's data and weight gradient can share one launch
-// (arl_conv2d_bwd_pair).  cfg: data gradient 0 = <4,1,1,1>, 1 = <2,2,1,1>, 2 = <2,2,2,2>;
-// weight gradient 0 = <1,4,1,1>, 1 = <2,2,1,1>, 2 = <2,2,2,2>.
-struct DgradPlan { GemmArgs a; bool fast, has_pad; int cfg; };
-struct WgradPlan { WgradArgs a; bool fast, has_pad; int cfg, splits; int64_t total; };
-
 // plan_only: describe the fast launch instead of issuing it (fast == false: nothing was done)
 // workspace (optional): lets a dense layer whose output tiles cannot fill the chip split its reduction
 int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float* dx, const arl_conv_geom* geom,
-               DgradPlan* plan_only, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0,
-               const Pieces& pc = Pieces{nullptr, nullptr}, int* caps_only = nullptr) {
+               DgradPlan* plan_only, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
-    ARL_REQUIRE(caps_only || (dy && w && dx), ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(dy && w && dx, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(g.kh % g.stride == 0 && g.kw % g.stride == 0, ARL_E_RANGE,
                 "data gradient needs kernel size divisible by stride");
     ARL_REQUIRE(arl::aligned16(dy) && arl::aligned16(w) && arl::aligned16(dx) &&
                     (!mask_or_null || arl::aligned16(mask_or_null)), ARL_E_ALIGN, "16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     const int st = g.stride;
-    const int64_t in_elems = g.batch * g.Ho * g.Wo * g.K, out_elems = g.batch * g.H * g.W * g.C;
     constexpr int FBK = 32;
     const int taps_y = g.kh / st, taps_x = g.kw / st;
     const bool has_pad = !(g.kh == 1 && g.kw == 1 && g.pad_h == 0 && g.pad_w == 0);
@@ -2904,7 +252,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         a.o.out_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
         a.o.OH = g.H; a.o.OW = g.W; a.o.omul = st; a.o.oadd_y = ph; a.o.oadd_x = pw;
         a.k_per_split = round_up(a.K, BKT);
-        a.trace = g_trace; a.xcd = g_tile_choice != 9;
+        a.trace = g_trace; a.xcd = 1;
         if (fast) {
             a.g.rmin = (a.g.add_y * g.Wo + a.g.add_x) * g.K;
             a.g.dmin = -((taps_y - 1) * g.Wo + (taps_x - 1)) * g.K;
@@ -2941,16 +289,10 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             plan_only->cfg = a.N <= 32 ? 0 : a.N <= 64 ? 1 : small ? 3 : 2;
             return 0;
         }
-        // bf16 pieces ride with the split kernels (a k-tile never straddles taps here: K % 32 == 0)
-        int caps = (g_split && a.N > 16 && !g_trace) ? PIECES_IN | PIECES_OUT : 0;
         if (small) {
             int splits = 1, per = a.k_per_split;
             if (workspace) plan_split(((a.M + 63) / 64) * ((a.N + 63) / 64), a.K, &splits, &per, 3 * TARGET_WGS);
             if ((int64_t)splits * a.M * a.N * 4 > workspace_bytes) { splits = 1; per = round_up(a.K, BKT); }
-            if (splits > 1) caps &= ~PIECES_OUT;
-            if (caps_only) { *caps_only = caps; return 0; }
-            rc = put_pieces(a, pc, caps, in_elems, out_elems);
-            if (rc) return rc;
             a.k_per_split = per;
             if (splits > 1) {
                 a.o.out = (float*)workspace; a.o.mask = nullptr; a.split_stride = (int64_t)a.M * a.N;
@@ -2960,26 +302,19 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             if (rc || splits == 1) return rc;
             return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, nullptr, 4, 0, dx, s, mask_or_null);
         }
-        if (caps_only) { *caps_only = caps; return 0; }
-        rc = put_pieces(a, pc, caps, in_elems, out_elems);
-        if (rc) return rc;
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
         else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, false, false, 2>(a, false, has_pad, s);
         else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, false, false, 2>(a, false, has_pad, s);
         else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, false, false, 1>(a, false, has_pad, s);
-        else if (a.N <= 32 && a.K % 32 == 0 && persist_pays((a.n_par ? a.n_par : 1) * ((a.M + 127) / 128)))
-            rc = launch_igemm_persist<4, 1, 1, 16, false, false, false, 4>(a, false, has_pad, s);
         // 17 .. 32 columns: 64x32 tiles on 16-wide MFMAs at five waves per SIMD (3 800 tiles instead of 1 900 of 128 rows
         // for the stride-2 gradient of the PPO minibatch: 52.5 -> 49.5 us; 32- and 96-row tiles, six waves: no better)
-        else if (a.N <= 32 && a.N > 16 && g_tile_choice != 1) rc = launch_igemm_occ<2, 2, 2, 1, 32, false, true, 5>(a, false, has_pad, s);
+        else if (a.N <= 32 && a.N > 16) rc = launch_igemm_occ<2, 2, 2, 1, 32, false, true, 5>(a, false, has_pad, s);
         else if (a.N <= 32) rc = launch_igemm<4, 1, 1, 1, 16, false>(a, 1, false, has_pad, s);      // 16-wide k-tile: see forward
         else if (a.N <= 64) rc = launch_n64<false>(a, false, has_pad, s);
         else rc = launch_igemm<2, 2, 2, 2, FBK, false>(a, 1, false, has_pad, s);
         return rc;
     }
     if (plan_only) { plan_only->fast = false; return 0; }
-    if (caps_only) { *caps_only = 0; return 0; }
-    ARL_REQUIRE(!pc.in && !pc.out, ARL_E_ARG, "bf16 pieces pending on the generic data-gradient kernels (arl_conv_pieces_supported)");
     for (int ph = 0; ph < st && ph < g.H; ++ph) {
         for (int pw = 0; pw < st && pw < g.W; ++pw) {
             const GemmArgs a = describe(ph, pw);
@@ -3013,7 +348,7 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
     a.K_out = g.K; a.N = g.kh * g.kw * g.C; a.Mred = (int)(g.batch * g.Ho * g.Wo);
     a.g.src_bytes = (unsigned)(g.batch * g.H * g.W * g.C * 4);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
-    a.trace = g_trace; a.xcd = g_tile_choice != 9;
+    a.trace = g_trace; a.xcd = 1;
     int bm, bn;
     if (g.K <= 16) { bm = 16; bn = 128; }
     else if (g.K <= 32) { bm = 32; bn = 128; }
@@ -3078,12 +413,17 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
 }  // namespace
 
 extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
-                                   const arl_conv_geom* geom, void* stream) {
-    return dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, nullptr, 0, grab_pieces());
+                                   const arl_conv_geom* geom, const arl_corun_job* job_or_null, int32_t* job_taken_or_null,
+                                   void* stream) {
+    ARL_ROUTE_SCOPE(geom, job_or_null);
+    const int rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream);
+    if (job_taken_or_null) *job_taken_or_null = t_ctx.corun_taken ? 1 : 0;
+    return rc;
 }
 
 extern "C" int arl_conv2d_bwd_weight(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
                                      void* workspace, void* stream) {
+    ARL_ROUTE_SCOPE(geom, nullptr);
     int splits = 1;
     int64_t total = 0;
     int rc = wgrad_impl(dy, x, dw, geom, workspace, arl_conv_workspace_bytes(), &splits, &total, nullptr, nullptr, stream);
@@ -3097,11 +437,9 @@ void bias_item(arl_fold_item* item, const float* bias_part, float* dbias, int sp
     item->splits = bias_part ? splits : -1;             // -1: not produced (generic kernels ran)
     item->valid = 0;
 }
-}  // namespace
-
-extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
-                                           void* workspace, int64_t workspace_bytes, arl_fold_item* item,
-                                           float* dbias_or_null, arl_fold_item* bias_item_or_null, void* stream) {
+int wgrad_parts_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
+                     void* workspace, int64_t workspace_bytes, arl_fold_item* item,
+                     float* dbias_or_null, arl_fold_item* bias_item_or_null, void* stream) {
     ARL_REQUIRE(item && (!dbias_or_null || bias_item_or_null), ARL_E_ARG, "null pointer");
     ARL_REQUIRE(!dbias_or_null || arl::aligned16(dbias_or_null), ARL_E_ALIGN, "16-byte alignment");
     int splits = 1;
@@ -3114,6 +452,14 @@ extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, floa
     item->valid = 0;
     if (dbias_or_null) bias_item(bias_item_or_null, bias_part, dbias_or_null, splits, geom->out_c);
     return rc;
+}
+}  // namespace
+
+extern "C" int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, const arl_conv_geom* geom,
+                                           void* workspace, int64_t workspace_bytes, arl_fold_item* item,
+                                           float* dbias_or_null, arl_fold_item* bias_item_or_null, void* stream) {
+    ARL_ROUTE_SCOPE(geom, nullptr);
+    return wgrad_parts_impl(dy, x, dw, geom, workspace, workspace_bytes, item, dbias_or_null, bias_item_or_null, stream);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -3157,6 +503,7 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     U8Geom g;
     int rc = check_u8(obs, obs_rows, geom, &g);
     if (rc) return rc;
+    ARL_ROUTE_SCOPE(geom, nullptr);
     ARL_REQUIRE(arl::aligned16(w) && arl::aligned16(y) && (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN,
                 "16-byte alignment");
     GemmArgs a = {};
@@ -3167,10 +514,7 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     a.o.out_bytes = (unsigned)((int64_t)a.M * a.N * 4);
     a.k_per_split = a.K;                            // K % 16 == 0 by check_u8 (whole filter rows per k-tile)
     a.g.mg_w = div_magic((int64_t)a.M + 256, a.g.out_w); a.g.mg_h = div_magic((int64_t)a.M + 256, a.g.out_h);
-    a.trace = g_trace; a.xcd = g_tile_choice != 9;
-    const bool split_route = a.N > 16 && g_split && g.kh % (8 / (g.kw >> 2)) == 0;
-    rc = put_pieces(a, grab_pieces(), split_route ? PIECES_OUT : 0, 0, (int64_t)a.M * a.N);
-    if (rc) return rc;
+    a.trace = g_trace; a.xcd = 1;
     constexpr int BK = 16, BM = 128;
     const dim3 grid((a.M + BM - 1) / BM, 1, 1);
     if (a.N <= 16) {
@@ -3179,9 +523,7 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     } else if (g_split && g.kh % (8 / (g.kw >> 2)) == 0) {
         // bf16-split products: the pixels are exact in one bf16 plane (three products), 32-deep k-tiles = whole filter rows
         return launch_igemm_split<4, 1, 2, 1, 32, true, true, 2>(a, false, false, (hipStream_t)stream);
-    } else if (a.K % (2 * BK) == 0 && persist_pays((int)grid.x)) {
-        return launch_igemm_persist<4, 1, 1, BK, true, false, true, 4>(a, false, false, (hipStream_t)stream);
-    } else if (g_tile_choice != 1 && g.kh % (8 / (g.kw >> 2)) == 0) {
+    } else if (g.kh % (8 / (g.kw >> 2)) == 0) {
         // 17 .. 32 filters: 64x32 tiles on 16-wide MFMAs, 32-deep k-tiles (whole filter rows: kh % (32 / kw) == 0), five
         // waves per SIMD -- 3 800 tiles for the PPO minibatch instead of 1 900 of 128 rows: 52.1 -> 49.7 us
         constexpr int PBM = 64, PBK = 32;
@@ -3207,6 +549,7 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     U8Geom g;
     int rc = check_u8(obs, obs_rows, geom, &g);
     if (rc) return rc;
+    ARL_ROUTE_SCOPE(geom, nullptr);
     ARL_REQUIRE(arl::aligned16(dy) && arl::aligned16(dw) && arl::aligned16(workspace) &&
                     (!dbias_or_null || arl::aligned16(dbias_or_null)), ARL_E_ALIGN, "16-byte alignment");
     WgradArgs a = {};
@@ -3214,7 +557,7 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     fill_u8(&a.g, obs, obs_rows, idx_or_null, scale, g);
     a.K_out = g.K; a.N = g.C * g.kh * g.kw; a.Mred = (int)(g.batch * g.Ho * g.Wo);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
-    a.trace = g_trace; a.xcd = g_tile_choice != 9;
+    a.trace = g_trace; a.xcd = 1;
     const int bm = g.K <= 16 ? 16 : 32, bn = 128;
     const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     int splits, per;
@@ -3244,59 +587,21 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     return arl::check_launch("wgrad_u8_kernel");
 }
 
-namespace {
-template <int DWGM, int DWGN, int DTM, int DTN, int WWGM, int WWGN, int WTM, int WTN, int BK = 32>
-int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_t s) {
-    constexpr int DBM = DWGM * DTM * 32, DBN = DWGN * DTN * 32, WBM = WWGM * WTM * 32, WBN = WWGN * WTN * 32;
-    const size_t lds_d = (size_t)2 * (DBM * (BK + 4) + BK * DBN) * sizeof(float);
-    const size_t lds_w = (size_t)2 * BK * (WBM + WBN) * sizeof(float);
-    const size_t lds = lds_d > lds_w ? lds_d : lds_w;
-    const int dgx = (d.a.M + DBM - 1) / DBM, dgy = (d.a.N + DBN - 1) / DBN, dgz = d.a.n_par ? d.a.n_par : 1;
-    const int wgx = (w.a.N + WBN - 1) / WBN, wgy = (w.a.K_out + WBM - 1) / WBM, wgz = w.splits;
-    const int n_ig = dgx * dgy * dgz, n_wg = wgx * wgy * wgz;
-    int rc;
-    if (g_split) {
-        const size_t lds_s = (size_t)2 * 3 * ((DBM + DBN) > (WBM + WBN) ? (DBM + DBN) : (WBM + WBN)) * BK * 2;
-#define ARL_PSPLIT_K(HP, SPL, PI)                                                                          \
-    do {                                                                                                   \
-        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, HP, SPL, PI>;             \
-        rc = allow_big_lds(k, lds_s + 4096);                                                               \
-        if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds_s, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy); \
-    } while (0)
-#define ARL_PSPLIT(HP, SPL)                                                                                \
-    do {                                                                                                   \
-        if (d.a.g.pieces) ARL_PSPLIT_K(HP, SPL, true); else ARL_PSPLIT_K(HP, SPL, false);                  \
-    } while (0)
-        if (has_pad) ARL_BY_MODE(ARL_PSPLIT(true, 6), ARL_PSPLIT(true, 9));
-        else ARL_BY_MODE(ARL_PSPLIT(false, 6), ARL_PSPLIT(false, 9));
-#undef ARL_PSPLIT
-#undef ARL_PSPLIT_K
-    } else if (has_pad) {
-        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, true>;
-        rc = allow_big_lds(k, lds + 4096);
-        if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy);
-    } else {
-        auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, false>;
-        rc = allow_big_lds(k, lds + 4096);
-        if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy);
-    }
-    return rc ? rc : arl::check_launch("bwd_pair_kernel");
-}
-
-}  // namespace
 
 extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
                                    const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
                                    int64_t workspace_bytes, arl_fold_item* item, float* dbias_or_null,
-                                   arl_fold_item* bias_item_or_null, void* stream) {
+                                   arl_fold_item* bias_item_or_null, const arl_corun_job* job_or_null,
+                                   int32_t* job_taken_or_null, void* stream) {
     ARL_REQUIRE(item && geom && (!dbias_or_null || bias_item_or_null), ARL_E_ARG, "null pointer");
+    if (job_taken_or_null) *job_taken_or_null = 0;
+    ARL_ROUTE_SCOPE(geom, job_or_null);
     ARL_REQUIRE(!dbias_or_null || arl::aligned16(dbias_or_null), ARL_E_ALIGN, "16-byte alignment");
     DgradPlan dp = {};
     WgradPlan wp = {};
     int splits = 1;
     int64_t total = 0;
     float* bias_part = nullptr;
-    const Pieces pc = grab_pieces();
     int rc = dgrad_impl(dy, w, mask_or_null, dx, geom, &dp, stream);
     if (rc) return rc;
     rc = wgrad_impl(dy, x, dw, geom, workspace, workspace_bytes, &splits, &total,
@@ -3312,19 +617,16 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
         // the data gradient may split its reduction: it gets the upper half of the workspace (and is folded at
         // once), the weight gradient's deferred partials the lower half
         const int64_t half = (workspace_bytes / 2) & ~(int64_t)15;
-        rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, (char*)workspace + half, workspace_bytes - half, pc);
+        rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, (char*)workspace + half, workspace_bytes - half);
+        if (job_taken_or_null) *job_taken_or_null = t_ctx.corun_taken ? 1 : 0;
         if (rc) return rc;
-        return arl_conv2d_bwd_weight_parts(dy, x, dw, geom, workspace, half, item, dbias_or_null,
-                                           bias_item_or_null, stream);
+        return wgrad_parts_impl(dy, x, dw, geom, workspace, half, item, dbias_or_null, bias_item_or_null, stream);
     }
     hipStream_t s = (hipStream_t)stream;
-    rc = put_pieces(dp.a, pc, g_split ? PIECES_IN | PIECES_OUT : 0, (int64_t)geom->batch * dp.a.g.Hs * dp.a.g.Ws * dp.a.g.Cs,
-                    (int64_t)dp.a.M * dp.a.N);
-    if (rc) return rc;
     // split kernels: 16-deep k-tiles halve the LDS images (98 -> 49 KB), so that TWO workgroups share a CU and one's
     // loads / splits / LDS stores run under the other's MFMAs (one 128x128 workgroup alone keeps the matrix pipe ~50 %
     // busy): the dense pair of the PPO minibatch 89.4 -> 71.9 us, bit-identical
-    if (g_split && g_tile_choice != 6) rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2, 16>(dp, wp, has_pad, s);
+    if (g_split) rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2, 16>(dp, wp, has_pad, s);
     else rc = launch_pair<2, 2, 2, 2, 2, 2, 2, 2>(dp, wp, has_pad, s);
     item->part = (const float*)workspace; item->out = dw; item->total = wp.total;
     item->splits = wp.splits > 1 ? wp.splits : 0;
@@ -3352,22 +654,3 @@ extern "C" int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream
     hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return arl::check_launch("fold_many_kernel");
 }
-
-extern "C" int arl_conv_pieces_supported(const arl_conv_geom* geom, int32_t op) {
-    ARL_REQUIRE(geom && op >= 0 && op <= 2, ARL_E_ARG, "op: 0 forward, 1 data gradient, 2 forward from u8 rows");
-    int caps = 0, rc = 0;
-    const Pieces none = {nullptr, nullptr};
-    if (op == 0) rc = fwd_impl(nullptr, nullptr, nullptr, nullptr, geom, 0, nullptr, nullptr, none, &caps);
-    else if (op == 1) {
-        // (the paired dense launch -- the widest tiles of both gradients -- reads and writes pieces like the plain one;
-        //  a data gradient that would split its reduction when it runs apart is asked as it runs apart)
-        rc = dgrad_impl(nullptr, nullptr, nullptr, nullptr, geom, nullptr, nullptr, reinterpret_cast<void*>(16),
-                        arl_conv_workspace_bytes() / 2, none, &caps);
-    } else {
-        U8Geom g;
-        rc = check_u8(reinterpret_cast<const uint8_t*>(16), geom->batch, geom, &g);
-        if (!rc) caps = (g.K > 16 && g_split && g.kh % (8 / (g.kw >> 2)) == 0) ? PIECES_OUT : 0;
-    }
-    return rc ? (rc < 0 ? rc : -rc) : caps;
-}
-

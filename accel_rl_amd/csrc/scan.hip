@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) void scan_wave_kernel(
 }
 
 bool g_force_wave = false;
-int g_wave_nch = 0;             // arl_scan_wave_groups: groups per wave of the wave scan (0 = chosen by size)      // arl_scan_force_wave: tests run the wave scan at every horizon <= 512
+int g_wave_nch = 0;             // arl_dev_scan_wave_groups: groups per wave of the wave scan (0 = chosen by size)      // arl_dev_scan_force_wave: tests run the wave scan at every horizon <= 512
 
 // E steps per lane (1, 2, 4 or 8) x SEG lanes per segment (a power of two <= 64) for horizons T <= 512;
 // returns -1 beyond that (the caller falls back to the exact walk)
@@ -541,8 +541,8 @@ int check_scan_args(const void* a, const void* b, const void* c, const void* d, 
 
 }  // namespace
 
-extern "C" void arl_scan_force_wave(int32_t on) { g_force_wave = on != 0; }
-extern "C" void arl_scan_wave_groups(int32_t n) { g_wave_nch = (n == 1 || n == 2 || n == 4) ? n : 0; }
+extern "C" void arl_dev_scan_force_wave(int32_t on) { g_force_wave = on != 0; }
+extern "C" void arl_dev_scan_wave_groups(int32_t n) { g_wave_nch = (n == 1 || n == 2 || n == 4) ? n : 0; }
 
 extern "C" int arl_gae_scan(const float* rewards, const float* values, const uint8_t* dones,
                             const float* last_values, double discount, double gae_lambda,

@@ -70,8 +70,9 @@ class BaseOptimizer(object):
         self._norm_log = torch.zeros(NORM_LOG_LEN, dtype=torch.float32, device=dev)
         self._n_updates = 0
         self._step_pp = self._norm_parts = None      # the no-clip update's state (see _apply_update)
-        self._hole = None                            # (first, count): range whose update a conv launch carries
-        self._hole_count = 0                         # ... as used by this call's updates (0: plain updates)
+        self._hole = None                            # (first, count): range whose update this backward pass handed out
+        self._call_hole = None                       # ... as fixed by the call's first update
+        self._hole_count = 0                         # ... its length (0: plain updates)
         st = _lib.ArlOptState()
         st.n_params = n
         st.params, st.grads = target.flat_params.data_ptr(), target.flat_grads.data_ptr()
@@ -100,11 +101,16 @@ class BaseOptimizer(object):
             self._noclip_state()
             k = self._n_updates % self._opt_state.norm_log_len      # position inside the call
             hole, self._hole = self._hole, None
-            count = hole[1] if hole else 0
-            assert k == 0 or count == self._hole_count, "a call's updates must all be split the same way"
-            self._hole_count = count
-            if hole:
-                _lib.conv_corun_flush()              # no data-gradient launch took the job: it runs on its own now
+            if k == 0:                               # the first update decides how the whole call is split
+                self._call_hole = hole
+                self._hole_count = hole[1] if hole else 0
+            elif self._hole_count and hole is None:  # a later backward pass did not hand its hole over: run it here
+                hole = self._call_hole
+                _lib.corun_job_run(_lib.corun_job(self._opt_state, self._update_method.kernel_id, self._learning_rate,
+                                                  avg_factor, b1, b2, eps, k, self._step_pp, self._norm_parts,
+                                                  hole[0], hole[1]))
+            if self._hole_count:
+                hole = self._call_hole
                 _lib.opt_step_noclip_split(self._opt_state, self._update_method.kernel_id, self._learning_rate,
                                            avg_factor, b1, b2, eps, k, self._step_pp, self._norm_parts, hole[0],
                                            hole[1], 0)
@@ -124,6 +130,10 @@ class BaseOptimizer(object):
             dev = self._target.device
             self._step_pp = self._step_count.repeat(2).contiguous()
             self._norm_parts = torch.zeros(_lib.OPT_NORM_SLOTS * _lib.OPT_NORM_BLOCKS, dtype=torch.float64, device=dev)
+        elif self._n_updates % self._opt_state.norm_log_len == 0 and not self._hole:
+            # start of a call: Lasagne's t as it stands in step_count (an external write -- a restored checkpoint --
+            # since the last call must not be overwritten by this call's opt_finish)
+            self._step_pp.copy_(self._step_count.expand(2))
 
     def _corun_hook(self, avg_factor=1.0):
         """For the policy's `dense_w_hook`: without norm clipping nothing has to wait for the whole gradient, so the
@@ -135,11 +145,15 @@ class BaseOptimizer(object):
         b1, b2, eps = self._kernel_args
 
         def hook(first, count):
+            """-> the job (plain data: nothing is pending anywhere if the caller drops it), or None when this call's
+            updates are not split (its first backward pass offered no hole) or are split elsewhere."""
             self._noclip_state()
             k = self._n_updates % self._opt_state.norm_log_len
-            _lib.conv_corun_update(self._opt_state, self._update_method.kernel_id, self._learning_rate, avg_factor,
-                                   b1, b2, eps, k, self._step_pp, self._norm_parts, first, count)
+            if k and (self._hole_count == 0 or self._call_hole != (first, count)):
+                return None
             self._hole = (first, count)
+            return _lib.corun_job(self._opt_state, self._update_method.kernel_id, self._learning_rate, avg_factor,
+                                  b1, b2, eps, k, self._step_pp, self._norm_parts, first, count)
         return hook
 
     def _set_updates_per_call(self, count):

@@ -6,6 +6,7 @@ import numpy as np
 import torch
 
 from accel_rl_amd.optimizers.base import BaseOptimizer
+from accel_rl_amd.util.misc import graph_capture_mode
 
 
 class DqnOptimizer(BaseOptimizer):
@@ -40,7 +41,7 @@ class DqnOptimizer(BaseOptimizer):
                 return self._step(static)
             torch.cuda.synchronize(self._target.device)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
                 self._graph_out = self._step(static)
             self._graph = graph
         self._graph.replay()

@@ -98,13 +98,16 @@ class PpoOptimizer(BaseOptimizer):
             return self._overlapped_minibatches(data)
         losses = []
         corun = self._corun_hook() if self.parallelism_tag == "single" else None
-        for k in range(self._n_minibatches):
-            mb = self._minibatch(data, self._idx_dev[k])
-            if corun is not None:
-                mb["dense_w_hook"] = corun
-            losses.append(self._backward(self._losses, mb))
-            self._share_grad()
-            self._apply_update(self._avg_factor())
+        try:
+            for k in range(self._n_minibatches):
+                mb = self._minibatch(data, self._idx_dev[k])
+                if corun is not None:
+                    mb["dense_w_hook"] = corun
+                losses.append(self._backward(self._losses, mb))
+                self._share_grad()
+                self._apply_update(self._avg_factor())
+        finally:
+            self._hole = None           # (a backward pass that raised leaves no hole behind for the next call)
         return losses, self._recent_grad_norms(self._n_minibatches)
 
     def _minibatch(self, data, idx):

@@ -18,6 +18,18 @@ class _SyncMixin(object):
     _rank = 0
     _overlap_allreduce = True   # PpoOptimizer._overlapped_minibatches: bucket tail all-reduced under the conv backward
     _force_collective = False   # issue the all-reduce even with one rank (plumbing tests)
+    # One hipGraph for the whole optimize_policy call, RCCL's all-reduces captured inside (aac_base._enqueue_optimize):
+    # the eager path pays a compute -> RCCL stream -> compute hand-over per all-reduce on the host's launch path; inside a
+    # graph they are edges.  Only on the `nccl` backend (gloo copies through the host: not capturable).
+    graph_collectives = True
+
+    def graph_ready(self):
+        """True when this optimizer's collectives can be captured into a hipGraph."""
+        if not self.graph_collectives:
+            return False
+        if not (self._n_gpu > 1 or self._force_collective):
+            return True                     # no collective is issued at all
+        return dist.is_initialized() and dist.get_backend(self._comm) == "nccl"
 
     def init_comm(self, gpu_comm, rank, n_gpu):
         """`gpu_comm`: a torch.distributed process group (None = default group)."""

@@ -85,9 +85,6 @@ class AtariCnnPolicy(object):
         self.pixel_scale = pixel_scale
         self.initial_param_values = initial_param_values
         self._scratch = dict()
-        # bf16 pieces between the trunk's launches (arl_conv_pieces): bit-identical results, measured SLOWER on MI355X
-        # (the scattered 8-byte piece stores cost an epilogue 7-17 us; reading them saves at most 2 us) -- off
-        self.use_pieces = os.environ.get("ARL_CONV_PIECES") == "1"
 
     recurrent = property(lambda self: False)
     vectorized = property(lambda self: True)
@@ -292,8 +289,9 @@ class AtariCnnPolicy(object):
         return out
 
     def _layer_geoms(self, b):
-        """ctypes geometry records of every layer at batch size b (cached)."""
-        gs = self._geoms.get(b)
+        """ctypes geometry records of every layer at batch size b (cached per contraction route: _lib.default_route)."""
+        key = (b, _lib.default_route)
+        gs = self._geoms.get(key)
         if gs is None:
             c, h, w = self._obs_shape
             conv = []
@@ -301,28 +299,8 @@ class AtariCnnPolicy(object):
                 conv.append(_lib.conv_geom(b, h, w, ci, nf, sz, sz, st, pad[0], pad[1]))
                 h, w = ho, wo
             dense = [_lib.dense_geom(b, fan_in, hs) for hs, fan_in in self._hid_geom]
-            gs = self._geoms[b] = (conv, dense)
+            gs = self._geoms[key] = (conv, dense)
         return gs
-
-    def _pieces_caps(self, b, u8):
-        """arl_conv_pieces capabilities of every trunk layer's forward and data-gradient route at batch b: the bf16
-        pieces of an activation / activation gradient ride from the launch that writes it to the launch that gathers it
-        next, when both routes take them.  (Asked on every call: the answer follows arl_conv_precision and the other
-        route switches; host-side only.)"""
-        conv_g, dense_g = self._layer_geoms(b)
-        gs = list(conv_g) + list(dense_g)
-        if not self.use_pieces:
-            return [0] * len(gs), [0] * len(gs)
-        fwd = [_lib.conv_pieces_supported(g, _lib.PIECES_U8FWD if (u8 and i == 0) else _lib.PIECES_FWD)
-               for i, g in enumerate(gs)]
-        dgr = [0] + [_lib.conv_pieces_supported(g, _lib.PIECES_DGRAD) for g in gs[1:]]
-        return fwd, dgr
-
-    def _out_pieces(self, caps, i, nxt, key, t):
-        """Pieces tensor for the output of layer i's launch (None unless that route writes and layer nxt's reads them)."""
-        if 0 <= nxt < len(caps) and (caps[i] & _lib.PIECES_OUT) and (caps[nxt] & _lib.PIECES_IN) and t.numel() % 8 == 0:
-            return self._buffer(key, (3, t.numel()), dtype=torch.bfloat16)
-        return None
 
     def _trunk(self, x, w=None, tag=""):
         """Explicit conv/dense stack (no autograd) on NHWC memory.  Returns (conv activations
@@ -332,28 +310,21 @@ class AtariCnnPolicy(object):
         b = x.shape[0]
         w = self._w if w is None else w
         conv_g, dense_g = self._layer_geoms(b)
-        caps, _ = self._pieces_caps(b, isinstance(x, ObsRows))
-        acts, a, a_pc = [], x, None
+        acts, a = [], x
         for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom):
             z = self._buffer(("act" + tag, i, b), (b, ho, wo, nf))
-            z_pc = self._out_pieces(caps, i, i + 1, ("act_pc" + tag, i, b), z)
-            if a_pc is not None or z_pc is not None:
-                _lib.conv_pieces(a_pc, z_pc)
             if isinstance(a, ObsRows):
                 _lib.conv2d_u8_fwd(a.obs, a.idx, self._scale, w[0], w[1], z, conv_g[0], True)
             else:
                 _lib.conv2d_fwd(a, w[2 * i], w[2 * i + 1], z, conv_g[i], True, self._conv_ws)
             acts.append(z)
-            a, a_pc = z, z_pc
+            a = z
         hids, k = [], 2 * self._n_conv
         for j, (hs, fan_in) in enumerate(self._hid_geom):
             hcur = self._buffer(("hid" + tag, j, b), (b, hs))
-            h_pc = self._out_pieces(caps, self._n_conv + j, self._n_conv + j + 1, ("hid_pc" + tag, j, b), hcur)
-            if a_pc is not None or h_pc is not None:
-                _lib.conv_pieces(a_pc, h_pc)
             _lib.conv2d_fwd(a, w[k], w[k + 1], hcur, dense_g[j], True, self._conv_ws)
             hids.append(hcur)
-            a, a_pc = hcur, h_pc
+            a = hcur
             k += 2
         return acts, hids
 
@@ -401,52 +372,48 @@ class AtariCnnPolicy(object):
         """Gradients of every trunk layer into flat_grads, given dh = d loss / d (last hidden
         activation); masked: dh is already multiplied by that activation's rectifier mask.
         x, acts, hids as returned by _scaled / _trunk.
-        dense_w_hook(first, count): called once the FIRST dense layer's weight gradient -- by far the largest tensor
-        of the bucket, elements [first, first + count) -- is final in flat_grads (its kernel wrote it in place, no
-        fold pending), i.e. before the conv layers' backward: the optimizer can hand that range's update to the next
-        data-gradient launch (arl_conv_corun_update)."""
+        dense_w_hook(first, count) -> job or None: called once the FIRST dense layer's weight gradient -- by far the
+        largest tensor of the bucket, elements [first, first + count) -- is final in flat_grads (its kernel wrote it in
+        place, no fold pending), i.e. before the conv layers' backward: the optimizer may answer with that range's update
+        as a job (_lib.corun_job) which the next data-gradient launch that can carries in extra workgroups; if none
+        does, it runs as its own launch at the end of the pass."""
         b = x.shape[0]
         conv_g, dense_g = self._layer_geoms(b)
-        _, caps = self._pieces_caps(b, isinstance(x, ObsRows))
         # ---- dense layers, last to first; the split folds of the whole pass run once, at the end
-        d_cur, d_pc = dh, None
+        d_cur, job = dh, None
         for j in range(self._n_hid - 1, -1, -1):
             k = 2 * (self._n_conv + j)
             hs, fan_in = self._hid_geom[j]
             inp = hids[j - 1] if j > 0 else acts[-1]
             d_prev = self._buffer(("dx_hid", j, b), (b, fan_in))
-            li = self._n_conv + j
-            p_pc = self._out_pieces(caps, li, li - 1, ("dx_hid_pc", j, b), d_prev)
-            if d_pc is not None or p_pc is not None:
-                _lib.conv_pieces(d_pc, p_pc)
-            d_pc = p_pc
             self._layer_grads(d_cur, masked, hids[j], b, hs, k, dense_g[j], inp, d_prev)
             if j == 0 and dense_w_hook is not None and self._folds.last_dw_in_place:
-                dense_w_hook(self._offsets[k], (self._g[k].numel() + 3) // 4 * 4)
+                job = dense_w_hook(self._offsets[k], (self._g[k].numel() + 3) // 4 * 4)
             d_cur, masked = d_prev, True
         if split_hook is not None and self._n_hid:      # dense + head gradients are final from here on
             self._folds.run()
             split_hook()
-        self._backward_convs(x, acts, d_cur, masked, d_pc, caps)
+        self._backward_convs(x, acts, d_cur, masked, corun=job)
 
-    def _backward_convs(self, x, acts, d_act, masked=False, d_pc=None, caps=None):
+    def _backward_convs(self, x, acts, d_act, masked=False, corun=None):
         """Conv layers, last to first; d_act = NHWC gradient of the last conv output (masked: already
-        multiplied by its rectifier mask); d_pc: its bf16 pieces, if the launch that wrote it left them."""
+        multiplied by its rectifier mask); corun: an optimiser job (_lib.corun_job) for the first data-gradient launch
+        that can carry it."""
         b = x.shape[0]
         conv_g, _ = self._layer_geoms(b)
-        if caps is None:
-            _, caps = self._pieces_caps(b, isinstance(x, ObsRows))
         for i in range(self._n_conv - 1, -1, -1):
             nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
             d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape)) if i > 0 else None
-            p_pc = self._out_pieces(caps, i, i - 1, ("dx_conv_pc", i, b), d_in) if i > 0 else None
-            if i > 0 and (d_pc is not None or p_pc is not None):
-                _lib.conv_pieces(d_pc, p_pc)
-            self._layer_grads(d_act, masked, acts[i], b * ho * wo, nf, 2 * i, conv_g[i], acts[i - 1] if i > 0 else x, d_in)
-            d_act, masked, d_pc = d_in, True, p_pc
+            self._layer_grads(d_act, masked, acts[i], b * ho * wo, nf, 2 * i, conv_g[i], acts[i - 1] if i > 0 else x, d_in,
+                              corun=corun if i > 0 else None)
+            if corun is not None and i > 0 and self._folds.corun_taken:
+                corun = None
+            d_act, masked = d_in, True
+        if corun is not None:
+            _lib.corun_job_run(corun)           # no launch could carry it: on its own, ahead of the step's update
         self._folds.run()
 
-    def _layer_grads(self, d, masked, y, rows, channels, k, geom, inp, d_in):
+    def _layer_grads(self, d, masked, y, rows, channels, k, geom, inp, d_in, corun=None):
         """One layer's backward: bias and weight gradient (deferred folds) and, with d_in, the data gradient
         already multiplied by the rectifier mask of `inp` (the layer below's output), so that the layer below
         gets its pre-activation gradient without another pass.  Not `masked`: d still needs this layer's own
@@ -460,7 +427,7 @@ class AtariCnnPolicy(object):
                                               self._fold_ws(("dw", k)), dbias=dbias)
         elif d_in is not None:      # data + weight gradient share one launch where that pays (dense layers)
             done = folds.conv2d_bwd_pair(d, self._w[k], inp, d_in, inp, self._g[k], geom, self._fold_ws(("dw", k)),
-                                         dbias=dbias)
+                                         dbias=dbias, corun=corun)
         else:
             done = folds.conv2d_bwd_weight(d, inp, self._g[k], geom, self._fold_ws(("dw", k)), dbias=dbias)
         if not done:                # generic kernels leave the bias sums to the streaming kernel (its mask is idempotent)

@@ -32,7 +32,7 @@ from accel_rl_amd.envs import synthetic_atari as synth
 from accel_rl_amd.sampler.base import BaseMbSampler
 from accel_rl_amd.sampler.util import TrajInfo
 from accel_rl_amd.util import logger
-from accel_rl_amd.util.misc import nbytes_unit, struct
+from accel_rl_amd.util.misc import graph_capture_mode, nbytes_unit, struct
 
 NOOP_RING = 4096
 
@@ -344,10 +344,13 @@ class GpuVecSampler(BaseMbSampler):
         """The kernels end an episode when Length > limit (worker.py:42)."""
         return self.max_path_length
 
-    def _env_step(self, state, ro, prob, value, uniforms, step, mid_batch_reset, active=None, single_write=False):
+    def _env_step(self, state, ro, prob, value, uniforms, step, mid_batch_reset, active=None, single_write=False,
+                  limit=None):
         """The env side of one agent step: ONE launch (arl_env_step); the two-launch form only for a limit below
-        one step, which the fused kernel's reset forecast does not cover."""
-        limit = self._kernel_max_path_length()
+        one step, which the fused kernel's reset forecast does not cover.  limit: episodes end when Length > limit
+        (default: this sampler family's rule for served steps)."""
+        if limit is None:
+            limit = self._kernel_max_path_length()
         if limit >= 1:
             _lib.env_step(self._game, state, ro, prob, value, uniforms, step, mid_batch_reset, limit,
                           self.discount, self.env.max_start_noops, active=active, single_write=single_write)
@@ -368,7 +371,7 @@ class GpuVecSampler(BaseMbSampler):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
             self._enqueue_batch()
         # warm-up and capture-time work must not count: restore the state
         for k, v in snap.items():
@@ -441,7 +444,8 @@ class GpuVecSampler(BaseMbSampler):
         for k in range(int(counts.max().item()) if n else 0):
             active = (counts > k).to(torch.uint8)
             u = torch.rand(n, dtype=torch.float64, device=dev, generator=gen)
-            self._env_step(self._state, ro, prob, value, u, 0, True, active=active)
+            # (the start-up walk resets at Length > max_path_length in every sampler family: sampler/util.py:50)
+            self._env_step(self._state, ro, prob, value, u, 0, True, active=active, limit=self.max_path_length)
             if k % 256 == 255:
                 self._st.done_count.zero_()
                 self._refill_noop_ring(2 * self.n_parallel)

@@ -48,3 +48,11 @@ def make_seed():
     t2 = time.time()
     t2 = int((t2 - int(t2)) * span * 1e4) % span
     return (t2 - t1) % span
+
+
+def graph_capture_mode():
+    """capture_error_mode for torch.cuda.graph: once a torch.distributed process group exists, its watchdog thread may
+    query events at any time -- legal next to a capture only in thread_local mode (a global-mode capture is invalidated
+    by ANY other thread's HIP call; seen as 'operation failed due to a previous error during capture')."""
+    import torch.distributed as dist
+    return "thread_local" if dist.is_available() and dist.is_initialized() else "global"

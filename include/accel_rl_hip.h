@@ -54,14 +54,6 @@ const char* arl_last_error(void);
  * Return / advantage scans
  * ------------------------------------------------------------------------- */
 
-/* Test hook: with ARL_PROMO_ASSOC run the wave suffix scan at EVERY horizon <= 512 (not only where it is the faster
- * kernel).  Not thread-safe.                                                                                     */
-void arl_scan_force_wave(int32_t on);
-/* Tuning / test hook: segment groups (64 lanes x E steps each) a wave of the wave suffix scan owns -- 1, 2 or 4; every
- * value gives the same results bit for bit.  0 (default) = chosen by the launch's size (4 once the launch fills the
- * chip several times over: all of a wave's loads are issued before its first scan).  Not thread-safe.            */
-void arl_scan_wave_groups(int32_t n);
-
 /* GAE(lambda).  Replaces gen_adv_est, accel_rl/algos/pg/util.py:6-23, and the
  * per-env Python loop around it, accel_rl/algos/pg/aac_base.py:122-127.
  *   rewards, values  f32[n_env*horizon]   dones u8[n_env*horizon] (0/1)
@@ -357,74 +349,26 @@ typedef struct arl_conv_geom {
     int32_t out_c, kh, kw;        /* weight w  f32[out_c][kh][kw][in_c] (correlation)   */
     int32_t stride, pad_h, pad_w; /* output y  f32[batch][out_h][out_w][out_c],
                                      out_h = (in_h + 2 pad_h - kh) / stride + 1          */
+    int32_t route;                /* how the fp32 contractions of this call are computed: ARL_CONV_ROUTE_*  */
 } arl_conv_geom;
+
+/* arl_conv_geom::route (the reference's floatX is float32: accel_rl/policies/pg/networks/pg_cnn.py:45-86 through
+ * Theano).  Operands and results are fp32 on every route; only the way through the matrix cores differs:
+ *   ARL_CONV_ROUTE_SPLIT9 (0, the default of a zero-initialised struct): each fp32 operand is split EXACTLY into three
+ *      bf16 pieces (24 significand bits = 3 x 8) and all nine piece products -- each exact in fp32 -- are accumulated
+ *      in fp32 by v_mfma_f32_32x32x16_bf16: every product term of the fp32 contraction enters the sum exactly, only
+ *      the accumulation rounds;
+ *   ARL_CONV_ROUTE_FP32   v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain (157 TF/s peak on gfx950);
+ *   ARL_CONV_ROUTE_SPLIT6 as SPLIT9 without the three smallest piece products (each below 2^-24 of |x y|).
+ * u8 observations are exact in one bf16 piece (three products on both split routes).  Layers with <= 16 output
+ * columns and the generic (any channel count) kernels always take the fp32 chain.  Deterministic on every route;
+ * any other value: ARL_E_ARG.  The route is an argument of the call: the library keeps no mode.                     */
+#define ARL_CONV_ROUTE_SPLIT9 0
+#define ARL_CONV_ROUTE_FP32   1
+#define ARL_CONV_ROUTE_SPLIT6 6
 
 /* Scratch for the split reductions below (fixed; the caller allocates once). */
 int64_t arl_conv_workspace_bytes(void);
-
-/* Diagnostic hook (tools/conv_trace.py): while a device buffer of u64[workgroups][8] is set,
- * the forward / data-gradient / weight-gradient kernels record per-workgroup shader-clock timestamps
- * (start, main loop begin, main loop end, end), two 100 MHz wall-clock samples, HW_ID and XCC_ID.
- * NULL (the default) disables it.  Not thread-safe; not for production use.             */
-void arl_conv_trace_buffer(void* device_u64_or_null);
-
-/* Test hook: route every following call to the generic (any channel count / any K) kernels instead
- * of the scalar-addressed fast path, so that both are covered by the parity tests.  Not thread-safe. */
-void arl_conv_force_generic(int32_t on);
-
-/* Tuning / test hook.  Layers with 33 .. 64 output columns: 0 (default) and 3 = 32x64 tiles (16x16 MFMA, five
- * waves per SIMD), 1 = 64x64 tiles (32x32 MFMA), 2 = 112x64 tiles (16x16 MFMA, three LDS stages).  Layers with
- * 17 .. 32 columns (data gradient, u8 forward): 1 = the 128x32 tiles on 32x32 MFMAs, anything else (default) =
- * 64x32 tiles on 16x16 MFMAs at five waves per SIMD.
- * bf16-split routes (arl_conv_precision 6 / 9) -- every choice gives the same results bit for bit:
- * 3 = the gathered operand of the one-wave-per-row-tile shapes passes through LDS like the weights (default: straight
- * from memory into the MFMA fragment registers); 6 = 32-deep k-tiles for the paired dense data + weight gradient
- * (default 16-deep: two 128x128 workgroups per CU); 5 = split-K forward of the dense layers on 128x64 tiles, rows straight
- * into the fragment registers (default: 64x64 tiles, both operands through LDS; measured equal end to end); 9 = workgroups take tiles in launch order (default: XCD-aware,
- * each XCD a contiguous range of tile ids so that tiles sharing an operand panel share an L2).  Not thread-safe. */
-void arl_conv_tile_choice(int32_t choice);
-
-/* Tuning / test hook: launches of many row tiles (conv 1 forward, the stride-2 data gradient) as
- * `workgroups_per_cu` persistent workgroups per CU that walk the tiles with the next tile's first loads in
- * flight under the current tile's last MFMAs (0 = one workgroup per tile; < 0, tests: every eligible launch,
- * walked by -workgroups_per_cu workgroups in all).  Same results bit for bit.  Not thread-safe. */
-void arl_conv_persistent(int32_t workgroups_per_cu);
-
-/* How the fp32 contractions of every following conv / dense call are computed (the reference's floatX is
- * float32: accel_rl/policies/pg/networks/pg_cnn.py:45-86 through Theano).  Operands and results are fp32 in
- * every mode; only the route through the matrix cores differs:
- *   0  v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain (157 TF/s peak on gfx950);
- *   9  (default) each fp32 operand is split EXACTLY into three bf16 pieces (24 significand bits = 3 x 8) and all
- *      nine piece products -- each exact in fp32 -- are accumulated in fp32 by v_mfma_f32_32x32x16_bf16: every
- *      product term of the fp32 contraction enters the sum exactly, only the accumulation rounds;
- *   6  as 9 without the three smallest piece products (each below 2^-24 of |x y|).
- * u8 observations are exact in one bf16 piece (three products in both split modes).  Layers with <= 16 output
- * columns and the generic (any channel count) kernels always take route 0.  Deterministic in every mode.
- * Returns ARL_E_ARG for any other value.  Not thread-safe. */
-int arl_conv_precision(int32_t mode);
-/* The mode in force (0, 6 or 9). */
-int arl_conv_precision_get(void);
-
-/* bf16 pieces of activations travel between the bf16-split kernels (arl_conv_precision 6 / 9), so that a tensor is
- * split ONCE, by the launch that produces it, instead of by every workgroup and filter tap that gathers it
- * (a conv 3 input element is otherwise split nine times; the split is 5.5 vector instructions per element, taken
- * from the issue slots of the matrix instructions).  A pieces tensor of an fp32 tensor t of n elements is
- * 3 n bf16 = 6 n bytes: piece q of element e at byte q * 2 n + 2 e, with t[e] == piece0 + piece1 + piece2 exactly
- * (piece0 = the top 16 bits of t[e], piece1 = the top 16 bits of t[e] - piece0, piece2 the rest).
- * arl_conv_pieces hands two such tensors to the NEXT arl_conv2d_fwd / arl_conv2d_u8_fwd / arl_conv2d_bwd_data /
- * arl_conv2d_bwd_pair call on this thread's library state, which consumes (clears) them:
- *   in_pieces   pieces of that call's gathered operand (x of a forward call, dy of a data gradient), written by
- *               the call that produced that tensor; the fp32 tensor is then not read.  NULL: split in the kernel.
- *   out_pieces  where that call leaves the pieces of its output (y, dx) next to the fp32 output.  NULL: none.
- * Results are bit-identical with and without pieces (same pieces, same products, same order).
- * A call whose route cannot honour a pending pointer fails with ARL_E_ARG and launches nothing: ask
- * arl_conv_pieces_supported first.  n % 8 == 0; 16-byte aligned (else ARL_E_ALIGN).  Not thread-safe. */
-int arl_conv_pieces(const void* in_pieces_or_null, void* out_pieces_or_null);
-
-/* What the route of a geometry can do under the current arl_conv_precision / tile settings: bit 0 = read in_pieces,
- * bit 1 = write out_pieces (>= 0), or a negative ARL_E_* for a bad geometry.  op: 0 = arl_conv2d_fwd,
- * 1 = arl_conv2d_bwd_data / the data-gradient half of arl_conv2d_bwd_pair, 2 = arl_conv2d_u8_fwd. */
-int arl_conv_pieces_supported(const arl_conv_geom* geom, int32_t op);
 
 /* y = conv(x, w) + bias, then max(., 0) if relu.  Replaces the forward of Lasagne's
  * Conv2DLayer / DenseLayer as used by PgCnn (accel_rl/policies/pg/networks/pg_cnn.py:47-68,
@@ -437,8 +381,13 @@ int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, fl
  * If mask is given (same shape as dx): dx = 0 where mask <= 0 -- the rectifier
  * backward of the previous layer.  Requires kh % stride == 0 and kw % stride == 0.
  * Replaces the T.grad of the same layers (optimizers/single/ppo_optimizer.py:38-40). */
+/* job (optional): an optimiser job (arl_corun_job, below) that this call's launch may carry in extra workgroups;
+ * *job_taken = 1 if it did (only the scalar-addressed data-gradient launches of layers with > 16 input channels
+ * can), else 0 and the caller runs the job itself (arl_corun_job_run). */
+struct arl_corun_job;
 int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
-                        const arl_conv_geom* geom, void* stream);
+                        const arl_conv_geom* geom, const struct arl_corun_job* job_or_null,
+                        int32_t* job_taken_or_null, void* stream);
 
 /* dw f32[out_c][kh][kw][in_c] = gradient of the layer weights given dy and the layer
  * input x; the reduction over batch x out_h x out_w is split across workgroups and
@@ -464,7 +413,8 @@ int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream);
 int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
                         const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
                         int64_t workspace_bytes, arl_fold_item* item, float* dbias_or_null,
-                        arl_fold_item* bias_item_or_null, void* stream);
+                        arl_fold_item* bias_item_or_null, const struct arl_corun_job* job_or_null,
+                        int32_t* job_taken_or_null, void* stream);
 
 /* Convolution 1 read straight from the sampler's observations (no f32 copy of the input):
  * obs u8[obs_rows][in_c][in_h][in_w] (the layout of samples_buf.observations,
@@ -708,7 +658,7 @@ int arl_opt_finish(const arl_opt_state* opt, int32_t n_updates, float avg_factor
  * range [hole_first, hole_first + hole_count) of the bucket is final (spec 1: the first dense layer's 3.5 M weights,
  * written by its weight-gradient kernel long before the conv layers' backward ends), that range's update -- HBM-bound
  * streaming -- can run INSIDE the launch of a later MFMA-bound data-gradient kernel, in extra workgroups
- * (arl_conv_corun_update below; inside the PPO step: the host launch 42.6 -> ~48 us, the step's own update launch
+ * (arl_corun_job below; inside the PPO step: the host launch 42.6 -> ~48 us, the step's own update launch
  * 19.9 -> 4.9 us), and the step ends with the update of the small rest.  part 0 = everything but the hole (advances t; hole_count = 0: the
  * plain arl_opt_step_noclip), part 1 = the hole as a launch of its own.  hole_first, hole_count multiples of 4.
  * Per element the arithmetic is arl_opt_step_noclip's; a call that used a hole ends with arl_opt_finish_split.       */
@@ -717,16 +667,17 @@ int arl_opt_step_noclip_split(const arl_opt_state* opt, int32_t method, float le
                               double* norm_parts, int64_t hole_first, int64_t hole_count, int32_t part, void* stream);
 int arl_opt_finish_split(const arl_opt_state* opt, int32_t n_updates, float avg_factor, float* step_pp,
                          const double* norm_parts, int64_t hole_count, void* stream);
-/* Hand part 1 of update k to the NEXT data-gradient launch of a 33 .. 64-column layer (arl_conv2d_bwd_data /
- * arl_conv2d_bwd_pair on the scalar-addressed fast path): its grid gets one extra workgroup per CU (the first of the
- * grid; ARL_CORUN_BLOCKS overrides the count, a tuning aid) that streams the update while the others keep the matrix
- * pipe busy.  arl_conv_corun_flush: if no launch has taken the job yet, run it as its own
- * launch on `stream` (returns 1 then, 0 if nothing was pending, < 0 on error) -- call it before part 0.
- * One pending job at a time; not thread-safe.                                                                        */
-int arl_conv_corun_update(const arl_opt_state* opt, int32_t method, float learning_rate, float avg_factor,
-                          float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
-                          double* norm_parts, int64_t hole_first, int64_t hole_count);
-int arl_conv_corun_flush(void* stream);
+/* Part 1 of update k as a job that a data-gradient launch carries: arl_corun_job_init describes it (same arguments
+ * as part 1 above; nothing is launched), arl_conv2d_bwd_data / arl_conv2d_bwd_pair take it as an argument -- the
+ * launch's grid gets one extra workgroup per CU (the first of the grid; ARL_CORUN_BLOCKS overrides the count, a tuning
+ * aid) that streams the update while the others keep the matrix pipe busy -- and report whether they ran it;
+ * arl_corun_job_run runs it as its own launch (what the caller does when no launch took it), before part 0.
+ * The job is plain data owned by the caller: nothing is pending inside the library, an abandoned job costs nothing. */
+typedef struct arl_corun_job { int64_t opaque[40]; } arl_corun_job;
+int arl_corun_job_init(arl_corun_job* job, const arl_opt_state* opt, int32_t method, float learning_rate,
+                       float avg_factor, float beta1_or_rho, float beta2, float epsilon, int32_t k, float* step_pp,
+                       double* norm_parts, int64_t hole_first, int64_t hole_count);
+int arl_corun_job_run(const arl_corun_job* job, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,32 @@
+/* Development hooks of libaccel_rl_hip.so: process-global switches for the parity tests and the measurement tools
+ * (tests/, tools/).  NOT part of the drop-in boundary -- include/accel_rl_hip.h, which keeps no state between calls --
+ * and not thread-safe: set them from the one thread that drives the device, around the calls they are meant for.     */
+#ifndef ACCEL_RL_HIP_DEV_H
+#define ACCEL_RL_HIP_DEV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Diagnostic (tools/conv_trace.py): while a device buffer of u64[workgroups][8] is set, the forward / data-gradient /
+ * weight-gradient kernels record per-workgroup shader-clock timestamps (start, main loop begin, main loop end, end),
+ * two 100 MHz wall-clock samples, HW_ID and XCC_ID.  NULL (the default) disables it.                                */
+void arl_dev_conv_trace_buffer(void* device_u64_or_null);
+
+/* Tests: route every following conv / dense call to the generic (any channel count / any K) kernels instead of the
+ * scalar-addressed fast path, so that both are covered by the parity tests.                                        */
+void arl_dev_conv_force_generic(int32_t on);
+
+/* Tests: with ARL_PROMO_ASSOC run the wave suffix scan at EVERY horizon <= 512 (not only where it is the faster
+ * kernel).                                                                                                          */
+void arl_dev_scan_force_wave(int32_t on);
+/* Tuning / tests: segment groups (64 lanes x E steps each) a wave of the wave suffix scan owns -- 1, 2 or 4; every
+ * value gives the same results bit for bit.  0 (default) = chosen by the launch's size.                             */
+void arl_dev_scan_wave_groups(int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACCEL_RL_HIP_DEV_H */

@@ -1,5 +1,6 @@
 """CPU-only: the C-ABI library builds, loads, and exports exactly what
-include/accel_rl_hip.h declares; argument errors are reported without a GPU."""
+include/accel_rl_hip.h (the drop-in boundary: stateless) and include/accel_rl_hip_dev.h (development hooks) declare;
+argument errors are reported without a GPU."""
 import ctypes
 import os
 import re
@@ -16,8 +17,8 @@ def lib():
     return _lib.load()
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "accel_rl_hip.h")).read()
+def _declared_functions(header="accel_rl_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(arl_[a-z0-9_]+)\s*\(", text)))
 
@@ -27,12 +28,27 @@ def test_header_and_binding_agree(lib):
     declared = _declared_functions()
     assert len(declared) >= 14
     assert sorted(_lib.EXPORTED_SYMBOLS) == declared
+    dev = _declared_functions("accel_rl_hip_dev.h")
+    assert sorted(_lib.DEV_SYMBOLS) == dev and all(n.startswith("arl_dev_") for n in dev)
+    assert not set(dev) & set(declared)
 
 
 def test_every_declared_symbol_is_exported(lib):
     raw = ctypes.CDLL(os.path.join(ROOT, "accel_rl_amd", "libaccel_rl_hip.so"))
-    for name in _declared_functions():
+    for name in _declared_functions() + _declared_functions("accel_rl_hip_dev.h"):
         assert getattr(raw, name) is not None, name
+
+
+def test_the_boundary_header_keeps_no_state():
+    """'no global state besides the error string'.  Every process-global switch lives in
+    accel_rl_hip_dev.h; the boundary header declares none (no 'Not thread-safe' function, no mode setters), and the
+    library's conv / dense entry points take their route and their co-run job as arguments."""
+    text = open(os.path.join(ROOT, "include", "accel_rl_hip.h")).read()
+    assert "not thread-safe" not in text.lower()
+    names = _declared_functions()
+    assert not [n for n in names if n.startswith("arl_dev_") or n.endswith(("_precision", "_tile_choice", "_persistent",
+                                                                             "_force_generic", "_force_wave"))]
+    assert "int32_t route;" in text and "arl_corun_job" in text
 
 
 def test_abi_version_and_arg_errors(lib):
@@ -52,9 +68,10 @@ def test_struct_layouts_match_header(lib):
     import subprocess
     import tempfile
     from accel_rl_amd import _lib
-    src = ('#include <stdio.h>\n#include "accel_rl_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    src = ('#include <stdio.h>\n#include "accel_rl_hip.h"\n#include "accel_rl_hip_dev.h"\n'
+           'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
            'sizeof(arl_game),sizeof(arl_env_state),sizeof(arl_rollout),sizeof(arl_opt_state),'
-           'sizeof(arl_conv_geom),sizeof(arl_replay),sizeof(arl_fold_item));return 0;}')
+           'sizeof(arl_conv_geom),sizeof(arl_replay),sizeof(arl_fold_item),sizeof(arl_corun_job));return 0;}')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -63,7 +80,8 @@ def test_struct_layouts_match_header(lib):
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(_lib.ArlGame), ctypes.sizeof(_lib.ArlEnvState),
                      ctypes.sizeof(_lib.ArlRollout), ctypes.sizeof(_lib.ArlOptState),
-                     ctypes.sizeof(_lib.ArlConvGeom), ctypes.sizeof(_lib.ArlReplay), ctypes.sizeof(_lib.ArlFoldItem)]
+                     ctypes.sizeof(_lib.ArlConvGeom), ctypes.sizeof(_lib.ArlReplay), ctypes.sizeof(_lib.ArlFoldItem),
+                     ctypes.sizeof(_lib.ArlCorunJob)]
 
 
 def test_no_cpu_fallback():

@@ -25,12 +25,12 @@ CASES = [(700, 512, 4, 104, 80, 32, 8, 8, 4),      # spec-1 conv 1 at the PPO mi
 
 @pytest.fixture(autouse=True, params=[9, 6, 0], ids=["split9", "split6", "fp32chain"])
 def precision(request):
-    """Every test under the three routes of arl_conv_precision (u8 pixels are exact in ONE bf16 piece: three piece
+    """Every test under the three routes of arl_conv_geom.route (u8 pixels are exact in ONE bf16 piece: three piece
     products per k in both split routes; layers of <= 16 filters take the fp32 chain in every mode)."""
     from accel_rl_amd import _lib
-    assert _lib.load().arl_conv_precision(request.param) == 0
+    _lib.set_conv_precision(request.param)          # (the geometries built below take this module default)
     yield request.param
-    _lib.load().arl_conv_precision(9)
+    _lib.set_conv_precision(9)
 
 
 def _mk(case, seed=0):

@@ -110,17 +110,17 @@ def test_wave_suffix_scan_within_tolerance(L, n, t):
     shape: T <= 64 one step per lane, 2 / 4 / 8 steps per lane with vector accesses when T divides, scalar otherwise;
     T > 512 falls back to the exact walk).  Tolerance: BASELINE.json's 1e-5 for returns / advantages, relative to
     max(1, |x|), against BOTH exact modes of the oracle; identical results run to run."""
-    L.load().arl_scan_force_wave(1)                  # (by default horizons below 96 take the exact walk: it is faster there)
+    L.load().arl_dev_scan_force_wave(1)                  # (by default horizons below 96 take the exact walk: it is faster there)
     try:
         ref = _wave_scan_checks(L, n, t)
         for groups in (1, 2, 4):                     # segment groups per wave (chosen by size otherwise): same bits
-            L.load().arl_scan_wave_groups(groups)
+            L.load().arl_dev_scan_wave_groups(groups)
             got = _wave_scan_checks(L, n, t)
             for a, b in zip(ref, got):
                 np.testing.assert_array_equal(a, b)
     finally:
-        L.load().arl_scan_force_wave(0)
-        L.load().arl_scan_wave_groups(0)
+        L.load().arl_dev_scan_force_wave(0)
+        L.load().arl_dev_scan_wave_groups(0)
 
 
 def _wave_scan_checks(L, n, t):
@@ -417,7 +417,7 @@ def test_noclip_single_launch_update_vs_oracle(L, n, method):
 @pytest.mark.parametrize("method", ["adam", "rmsprop"])
 @pytest.mark.parametrize("carrier", ["own launch", "data gradient"])
 def test_split_update_is_the_plain_update(L, method, carrier):
-    """arl_opt_step_noclip_split / arl_conv_corun_update: the update of a hole of the bucket as its own launch, or in
+    """arl_opt_step_noclip_split / arl_corun_job: the update of a hole of the bucket as its own launch, or in
     extra workgroups of a data-gradient launch (whose own result must not change), plus the update of the rest ==
     the one-launch update bit for bit: parameters, slots, t, and the call's logged norms (same f64 partial sums up to
     their grouping)."""
@@ -451,11 +451,10 @@ def test_split_update_is_the_plain_update(L, method, carrier):
             if carrier == "own launch":
                 L.opt_step_noclip_split(st, mid, *args, k, step_pp, parts, first, count, 1)
             else:
-                L.conv_corun_update(st, mid, *args, k, step_pp, parts, first, count)
+                job = L.corun_job(st, mid, *args, k, step_pp, parts, first, count)
                 dx = torch.full_like(dx_ref, float("nan"))
-                L.conv2d_bwd_data(dy, wt, None, dx, geom)
+                assert L.conv2d_bwd_data(dy, wt, None, dx, geom, corun=job)     # the launch took the job
                 assert torch.equal(dx, dx_ref)
-                assert not L.conv_corun_flush()                 # the launch took the job
             L.opt_step_noclip_split(st, mid, *args, k, step_pp, parts, first, count, 0)
             for key in ("p", "m") + (("v",) if adam else ()):
                 assert torch.equal(twins[0][1][key], twins[1][1][key]), (call, k, key)
@@ -465,11 +464,18 @@ def test_split_update_is_the_plain_update(L, method, carrier):
         a, b = twins[0][1]["log"][:n_upd].cpu().numpy(), twins[1][1]["log"][:n_upd].cpu().numpy()
         assert np.allclose(a, b, rtol=1e-6), (a, b)
         assert twins[0][4].cpu().tolist() == twins[1][4].cpu().tolist()
-    # a job nobody carries runs on its own when flushed
+    # a launch that cannot carry a job says so (channel counts 12 / 20: the generic kernels) and leaves the bucket
+    # alone; the job then runs on its own; a job that is never run costs nothing (plain data, nothing pending)
     st, keep, p, g, step_pp, parts = twins[1]
     before = keep["p"].clone()
-    L.conv_corun_update(st, mid, *args, 0, step_pp, parts, first, count)
-    assert L.conv_corun_flush() and not L.conv_corun_flush()
+    job = L.corun_job(st, mid, *args, 0, step_pp, parts, first, count)
+    ogeom = L.conv_geom(9, 20, 14, 12, 20, 3, 3, 1, 1, 1)
+    odx = torch.empty(9, 20, 14, 12, device=DEV)
+    assert not L.conv2d_bwd_data(torch.randn(9, 20, 14, 20, device=DEV), torch.randn(20, 3, 3, 12, device=DEV), None, odx,
+                                 ogeom, corun=job)
+    torch.cuda.synchronize()
+    assert torch.equal(before, keep["p"])
+    L.corun_job_run(job)
     torch.cuda.synchronize()
     assert not torch.equal(before[first:first + count], keep["p"][first:first + count])
     assert torch.equal(before[:first], keep["p"][:first]) and torch.equal(before[first + count:], keep["p"][first + count:])

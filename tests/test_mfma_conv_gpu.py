@@ -1,4 +1,4 @@
-"""MFMA implicit-GEMM convolution / dense kernels (csrc/mfma_conv.hip; every route of arl_conv_precision) against
+"""MFMA implicit-GEMM convolution / dense kernels (csrc/mfma_conv*.hip; every route of arl_conv_geom.route) against
 plain PyTorch fp32 on the same inputs.  Floating point, so a tolerance: the kernels
 accumulate in fp32 in k order (bitwise an fmaf chain); torch's reference reduces in a
 different order, so results agree to fp32 round-off of the reduction:
@@ -46,26 +46,18 @@ def _tol(want, k_red):
     return 2e-5 * np.sqrt(k_red) * max(want.abs().max().item(), 1e-6)
 
 
-@pytest.fixture(params=["fast", "fast_split6", "fast_fp32", "generic", "fast_tiles64", "fast_tiles112", "fast_persistent",
-                        "fast_dense128"])
+@pytest.fixture(params=["fast", "fast_split6", "fast_fp32", "generic"])
 def path(request):
     """Both kernel families: the scalar-addressed fast path (taken whenever a k-tile of 32 stays inside
     one filter row) and the generic fallback (any multiple-of-4 channel count, any K); on the fast path the three
-    routes of arl_conv_precision (default: nine bf16-split products; six; the fp32 MFMA chain) and, on the fp32 chain,
-    the other two tile shapes of the 33 .. 64-column layers (the default is 32x64) and the persistent launches of
-    the many-tile layers walked by three workgroups; on the nine-product route the 128x64 tiles of the dense layers' split-K
-    forward (tile choice 5)."""
+    routes of arl_conv_geom.route (default: nine bf16-split products; six; the fp32 MFMA chain)."""
     from accel_rl_amd import _lib
     lib = _lib.load()
-    lib.arl_conv_force_generic(1 if request.param == "generic" else 0)
-    assert lib.arl_conv_precision({"fast": 9, "fast_split6": 6, "fast_dense128": 9}.get(request.param, 0)) == 0
-    lib.arl_conv_tile_choice({"fast_tiles64": 1, "fast_tiles112": 2, "fast_dense128": 5}.get(request.param, 0))
-    lib.arl_conv_persistent(-3 if request.param == "fast_persistent" else 0)    # 3 workgroups walk every tile
+    lib.arl_dev_conv_force_generic(1 if request.param == "generic" else 0)
+    _lib.set_conv_precision({"fast": 9, "fast_split6": 6}.get(request.param, 0))
     yield request.param
-    lib.arl_conv_force_generic(0)
-    lib.arl_conv_tile_choice(0)
-    lib.arl_conv_persistent(0)
-    lib.arl_conv_precision(9)
+    lib.arl_dev_conv_force_generic(0)
+    _lib.set_conv_precision(9)
 
 
 ODD_CASES = [(9, 20, 14, 12, 20, 3, 1, 1),      # channels 12 / 20: no power-of-two anywhere -> generic kernels
@@ -231,7 +223,7 @@ def test_argument_errors():
         _lib.load().arl_conv2d_fwd(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), _lib.C.byref(bad), 0,
                                    ws.data_ptr(), None) and (_ for _ in ()).throw(RuntimeError("rc"))
     odd = _lib.conv_geom(2, 13, 9, 64, 64, 3, 3, 2, 1, 1)       # kernel 3, stride 2: unsupported data gradient
-    rc = _lib.load().arl_conv2d_bwd_data(y.data_ptr(), wt.data_ptr(), None, x.data_ptr(), _lib.C.byref(odd), None)
+    rc = _lib.load().arl_conv2d_bwd_data(y.data_ptr(), wt.data_ptr(), None, x.data_ptr(), _lib.C.byref(odd), None, None, None)
     assert rc == -2 and b"stride" in _lib.load().arl_last_error()
     with pytest.raises(RuntimeError):
         _lib.conv2d_fwd(x.cpu(), wt, None, y, geom, False, ws) if False else _lib.ptr(x.cpu())
@@ -313,7 +305,7 @@ def test_random_geometries_against_torch_and_the_generic_kernels(case):
     gx, gw = gx.permute(0, 2, 3, 1), gw.permute(0, 2, 3, 1)
     res = {}
     for generic in (0, 1):
-        _lib.load().arl_conv_force_generic(generic)
+        _lib.load().arl_dev_conv_force_generic(generic)
         try:
             y = torch.full((b, ho, wo, k), float("nan"), device=DEV)
             _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
@@ -322,7 +314,7 @@ def test_random_geometries_against_torch_and_the_generic_kernels(case):
             dw = torch.full((k, ks, ks, c), float("nan"), device=DEV)
             _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
         finally:
-            _lib.load().arl_conv_force_generic(0)
+            _lib.load().arl_dev_conv_force_generic(0)
         assert (y - want_y).abs().max().item() <= _tol(want_y, ks * ks * c), (case, generic)
         want_dx = torch.where(x > 0, gx, torch.zeros_like(gx))
         assert (dx - want_dx).abs().max().item() <= _tol(gx, (ks // st) ** 2 * k), (case, generic)
@@ -332,78 +324,18 @@ def test_random_geometries_against_torch_and_the_generic_kernels(case):
         assert torch.allclose(a, g_, rtol=1e-4, atol=1e-4 * max(g_.abs().max().item(), 1e-6))
 
 
-@pytest.mark.parametrize("walkers", [-1, -3, -7, 1])
-def test_persistent_launches_are_bit_identical(walkers):
-    """arl_conv_persistent: the same tiles, walked by a few resident workgroups with the next tile's loads in flight,
-    must give the one-workgroup-per-tile results bit for bit -- conv 1 forward from u8 rows picked by index (ragged last
-    tile), the stride-2 data gradient into 32 channels with and without the rectifier mask (four parity classes of
-    different sizes), and a stride-1 data gradient into 32 channels (dense rows)."""
-    from accel_rl_amd import _lib
-    lib = _lib.load()
-    gen = torch.Generator(device=DEV).manual_seed(11)
-    rnd = lambda *s: torch.randn(*s, device=DEV, generator=gen)                 # noqa: E731
-
-    def both(fn):
-        outs = []
-        lib.arl_conv_tile_choice(1)                 # the persistent kernels walk the classic 128-row tiles (32x32 MFMAs)
-        lib.arl_conv_precision(0)                   # ... of the fp32 MFMA chain
-        for w in (0, walkers):
-            lib.arl_conv_persistent(w)
-            try:
-                outs.append(fn())
-            finally:
-                lib.arl_conv_persistent(0)
-        lib.arl_conv_tile_choice(0)
-        lib.arl_conv_precision(9)
-        return outs
-    # conv 1 forward, u8 rows by index: 37 images of 104 x 80 -> 37 * 475 rows = 138 tiles of 128 and a ragged one
-    obs = torch.randint(0, 256, (50, 4, 104, 80), device=DEV, dtype=torch.int32, generator=gen).to(torch.uint8)
-    idx = torch.randperm(50, device=DEV, generator=gen)[:37].to(torch.int32)
-    g1 = _lib.conv_geom(37, 104, 80, 4, 32, 8, 8, 4, 0, 0)
-    w1, b1 = rnd(32, 4, 8, 8) * 0.05, rnd(32)
-
-    def fwd_u8():
-        y = torch.full((37, 25, 19, 32), float("nan"), device=DEV)
-        _lib.conv2d_u8_fwd(obs, idx, 1. / 255, w1, b1, y, g1, True)
-        return y
-    a, b = both(fwd_u8)
-    assert torch.isfinite(a).all() and torch.equal(a, b)
-    # stride-2 data gradient into 32 channels (conv 2 of spec 1), classes of 13x10, 13x9, 12x10, 12x9 pixels per image
-    g2 = _lib.conv_geom(9, 25, 19, 32, 64, 4, 4, 2, 1, 1)
-    ho, wo = _lib.conv_out_hw(g2)
-    dy, w2, x2 = rnd(9, ho, wo, 64), rnd(64, 4, 4, 32) * 0.05, rnd(9, 25, 19, 32)
-    for mask in (None, x2):
-        def dgrad():
-            dx = torch.full((9, 25, 19, 32), float("nan"), device=DEV)
-            _lib.conv2d_bwd_data(dy, w2, mask, dx, g2)
-            return dx
-        a, b = both(dgrad)
-        assert torch.isfinite(a).all() and torch.equal(a, b)
-    # stride-1 data gradient into 32 channels
-    g3 = _lib.conv_geom(5, 12, 9, 32, 64, 3, 3, 1, 1, 1)
-    dy3, w3 = rnd(5, 12, 9, 64), rnd(64, 3, 3, 32) * 0.05
-
-    def dgrad1():
-        dx = torch.full((5, 12, 9, 32), float("nan"), device=DEV)
-        _lib.conv2d_bwd_data(dy3, w3, None, dx, g3)
-        return dx
-    a, b = both(dgrad1)
-    assert torch.isfinite(a).all() and torch.equal(a, b)
-
-
 SPEC1 = [("conv1", 104, 80, 4, 32, 8, 4, 0), ("conv2", 25, 19, 32, 64, 4, 2, 1), ("conv3", 12, 9, 64, 64, 3, 1, 1),
          ("dense", 1, 1, 3456, 512, 1, 1, 0)]
 
 
 @pytest.mark.parametrize("layer", SPEC1, ids=[c[0] for c in SPEC1])
 def test_every_precision_route_is_fp32_accurate_against_float64(layer):
-    """arl_conv_precision: the bf16-split routes (nine / six piece products accumulated in fp32 by the bf16 MFMAs) must be
+    """arl_conv_geom.route: the bf16-split routes (nine / six piece products accumulated in fp32 by the bf16 MFMAs) must be
     as close to the EXACT (float64) contraction as the fp32 MFMA chain is -- at the spec-1 layer shapes, forward, data and
     weight gradient, and conv 1 from u8 rows.  Bar: rms error <= 6e-7 of the rms of the exact result for every route
     (observed 0.7e-7 .. 4.1e-7, the fp32 chain the largest), and a split route at most 1.5x the fp32 chain's error + 3e-8.
-    Also: every route is run-to-run bit-identical, and an unknown mode is refused."""
+    Also: every route is run-to-run bit-identical, and an unknown route is refused."""
     from accel_rl_amd import _lib
-    lib = _lib.load()
     name, h, w, c, k, ks, st, p = layer
     b = 48
     gen = torch.Generator(device=DEV).manual_seed(3)
@@ -429,39 +361,135 @@ def test_every_precision_route_is_fp32_accurate_against_float64(layer):
         ref["u8fwd"] = (out8 + bias.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).detach()
         ref["u8wgrad"] = torch.autograd.grad(out8, w8r, nchw(dy))[0]
 
-    def run_all():
+    def run_all(g):
         y, dx, dw = torch.empty(b, ho, wo, k, device=DEV), torch.empty_like(x), torch.empty_like(wt)
-        _lib.conv2d_fwd(x, wt, bias, y, geom, False, ws)
-        _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
-        _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+        _lib.conv2d_fwd(x, wt, bias, y, g, False, ws)
+        _lib.conv2d_bwd_data(dy, wt, None, dx, g)
+        _lib.conv2d_bwd_weight(dy, x, dw, g, ws)
         got = dict(fwd=y, dgrad=dx, wgrad=dw)
         if obs is not None:
             y8, dw8, db = torch.empty_like(y), torch.empty_like(w8), torch.empty(k, device=DEV)
-            _lib.conv2d_u8_fwd(obs, None, 1.0 / 255.0, w8, bias, y8, geom, False)
+            _lib.conv2d_u8_fwd(obs, None, 1.0 / 255.0, w8, bias, y8, g, False)
             folds = _lib.FoldList()
-            folds.conv2d_u8_bwd_weight(dy, obs, None, 1.0 / 255.0, dw8, geom, ws, dbias=db)
+            folds.conv2d_u8_bwd_weight(dy, obs, None, 1.0 / 255.0, dw8, g, ws, dbias=db)
             folds.run()
             got.update(u8fwd=y8, u8wgrad=dw8)
         torch.cuda.synchronize()
         return got
-
-    def rel_rms(got, want):
-        return ((got.double() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
     errs = {}
-    try:
-        for mode in (0, 6, 9):
-            assert lib.arl_conv_precision(mode) == 0
-            got, again = run_all(), run_all()
-            for op in got:
-                assert torch.equal(got[op], again[op]), (mode, op)
-                errs[mode, op] = rel_rms(got[op], ref[op])
-                assert errs[mode, op] <= 6e-7, (mode, op, errs[mode, op])
-        for mode in (6, 9):
-            for op in ref:
-                assert errs[mode, op] <= 1.5 * errs[0, op] + 3e-8, (mode, op, errs[mode, op], errs[0, op])
-        assert lib.arl_conv_precision(7) != 0 and b"conv precision" in lib.arl_last_error()
-    finally:
-        lib.arl_conv_precision(9)
+    for mode, route in ((0, _lib.ROUTE_FP32), (6, _lib.ROUTE_SPLIT6), (9, _lib.ROUTE_SPLIT9)):
+        g = _lib.with_route(geom, route)
+        got, again = run_all(g), run_all(g)
+        for op in got:
+            assert torch.equal(got[op], again[op]), (mode, op)
+            errs[mode, op] = _rel_rms(got[op], ref[op])
+            assert errs[mode, op] <= 6e-7, (mode, op, errs[mode, op])
+    for mode in (6, 9):
+        for op in ref:
+            assert errs[mode, op] <= 1.5 * errs[0, op] + 3e-8, (mode, op, errs[mode, op], errs[0, op])
+    y = torch.empty(b, ho, wo, k, device=DEV)
+    with pytest.raises(RuntimeError, match="conv route"):
+        _lib.conv2d_fwd(x, wt, bias, y, _lib.with_route(geom, 7), False, ws)
+    with pytest.raises(ValueError):
+        _lib.set_conv_precision(7)
+
+
+def _rel_rms(got, want):
+    return ((got.double() - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item()
+
+
+PAIRED = [("conv2", 25, 19, 32, 64, 4, 2, 1), ("dense", 1, 1, 6912, 512, 1, 1, 0)]
+
+
+@pytest.mark.parametrize("layer", PAIRED, ids=[c[0] for c in PAIRED])
+def test_learner_batch_backward_is_fp32_accurate_against_float64(layer):
+    """The float64 comparison at the LEARNER's batch (512 rows), where the routes take their own kernels (at 48 rows the
+    small launches of conv 1 / the dense layers fall to one kernel whatever the route), through the call the learner makes:
+    arl_conv2d_bwd_pair -- for the dense layer the one launch that holds data and weight gradient (bwd_pair_kernel, 12 % of
+    a PPO step), for conv 2 its split kernels launched apart.  Same bars as above ('weak': float64 test does
+    not reach every B = 512 kernel)."""
+    from accel_rl_amd import _lib
+    name, h, w, c, k, ks, st, p = layer
+    b = 512
+    gen = torch.Generator(device=DEV).manual_seed(17)
+    geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p)
+    ho, wo = _lib.conv_out_hw(geom)
+    x = torch.randn(b, h, w, c, device=DEV, generator=gen).relu()
+    wt = torch.randn(k, ks, ks, c, device=DEV, generator=gen) / np.sqrt(ks * ks * c)
+    dy = torch.randn(b, ho, wo, k, device=DEV, generator=gen)
+    mask = torch.randn(x.shape, device=DEV, generator=gen)
+    nchw = lambda t: t.double().permute(0, 3, 1, 2)                              # noqa: E731
+    xr, wr = nchw(x).detach().requires_grad_(), nchw(wt).detach().requires_grad_()
+    gx, gw = torch.autograd.grad(F.conv2d(xr, wr, None, stride=st, padding=p), (xr, wr), nchw(dy))
+    want = dict(dgrad=torch.where(mask > 0, gx.permute(0, 2, 3, 1), torch.zeros((), dtype=torch.float64, device=DEV)),
+                wgrad=gw.permute(0, 2, 3, 1), dbias=dy.double().sum((0, 1, 2)))
+    errs = {}
+    for mode, route in ((0, _lib.ROUTE_FP32), (6, _lib.ROUTE_SPLIT6), (9, _lib.ROUTE_SPLIT9)):
+        g = _lib.with_route(geom, route)
+        runs = []
+        for _ in range(2):
+            dx, dw, db = torch.full_like(x, float("nan")), torch.full_like(wt, float("nan")), torch.empty(k, device=DEV)
+            folds, ws = _lib.FoldList(), _lib.conv_workspace(DEV)
+            assert folds.conv2d_bwd_pair(dy, wt, mask, dx, x, dw, g, ws, dbias=db)
+            folds.run()
+            torch.cuda.synchronize()
+            runs.append(dict(dgrad=dx, wgrad=dw, dbias=db))
+        for op in want:
+            assert torch.equal(runs[0][op], runs[1][op]), (mode, op)
+            errs[mode, op] = _rel_rms(runs[0][op], want[op])
+            assert errs[mode, op] <= 6e-7, (mode, op, errs[mode, op])
+    for mode in (6, 9):
+        for op in ("dgrad", "wgrad"):
+            assert errs[mode, op] <= 1.5 * errs[0, op] + 3e-8, (mode, op, errs[mode, op], errs[0, op])
+
+
+@pytest.mark.parametrize("mode", [9, 6])
+def test_split_routes_on_tiny_operands(mode):
+    """Operands of 2^-120 .. 2^-100: the third bf16 piece of such a number lies below 2^-126 -- a bf16 SUBNORMAL.
+    Documented expectation: v_mfma_f32_32x32x16_bf16 takes subnormal bf16 inputs as they are (no flush), and the
+    products here (>= 2^-240 in exact arithmetic) underflow fp32 anyway, so what this pins is (a) no NaN / Inf / garbage
+    from subnormal pieces, (b) tiny x normal operands: x in 2^-120 .. 2^-100 against weights of magnitude 2^60 .. 2^90
+    gives results of normal size that must carry the fp32 chain's accuracy (the pieces of x below 2^-126 contribute
+    exactly or are lost at the 2^-24 level, never more).  Forward and weight gradient of conv 3's shape."""
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = 8, 12, 9, 64, 64, 3, 1, 1
+    gen = torch.Generator(device=DEV).manual_seed(29)
+    geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p, route=_lib.ROUTE_SPLIT9 if mode == 9 else _lib.ROUTE_SPLIT6)
+    ws = _lib.conv_workspace(DEV)
+    tiny = lambda shape: torch.randn(shape, device=DEV, generator=gen) * \
+        torch.exp2(torch.randint(-120, -99, shape, device=DEV, generator=gen).float())     # noqa: E731
+    big = lambda shape: torch.randn(shape, device=DEV, generator=gen) * \
+        torch.exp2(torch.randint(60, 91, shape, device=DEV, generator=gen).float())        # noqa: E731
+    x, wt = tiny((b, h, w, c)), big((k, ks, ks, c))
+    assert (x != 0).all() and x.abs().max() < 2.0 ** -96
+    y, yc = torch.empty(b, h, w, k, device=DEV), torch.empty(b, h, w, k, device=DEV)
+    _lib.conv2d_fwd(x, wt, None, y, geom, False, ws)
+    _lib.conv2d_fwd(x, wt, None, yc, _lib.with_route(geom, _lib.ROUTE_FP32), False, ws)       # the fp32 MFMA chain
+    want = F.conv2d(x.double().permute(0, 3, 1, 2), wt.double().permute(0, 3, 1, 2), None, stride=1, padding=1).permute(0, 2, 3, 1)
+    assert torch.isfinite(y).all()
+    # operands spread over 2^20 x 2^30: the sums are carried by a few large products and every route rounds at the
+    # size of its running sums -- the bar is the fp32 chain's own error on the same data, element by element against
+    # the magnitude sum, and in rms
+    scale = F.conv2d(x.double().abs().permute(0, 3, 1, 2), wt.double().abs().permute(0, 3, 1, 2), None, stride=1,
+                     padding=1).permute(0, 2, 3, 1)
+    e_split, e_chain = ((y.double() - want).abs() / scale).max().item(), ((yc.double() - want).abs() / scale).max().item()
+    assert e_split <= max(2.0 * e_chain, 2.0 ** -22), (e_split, e_chain)
+    assert _rel_rms(y, want) <= 1.5 * _rel_rms(yc, want) + 3e-8, (_rel_rms(y, want), _rel_rms(yc, want))
+    # tiny x tiny: every product underflows; the result must be exactly +-0 or a denormal-size number, never garbage
+    y2 = torch.full_like(y, float("nan"))
+    _lib.conv2d_fwd(x, tiny((k, ks, ks, c)), None, y2, geom, False, ws)
+    assert torch.isfinite(y2).all() and y2.abs().max() < 2.0 ** -126
+    # weight gradient: dy big, x tiny
+    dy = big((b, h, w, k))
+    dw = torch.empty_like(wt)
+    _lib.conv2d_bwd_weight(dy, x, dw, geom, ws)
+    xr, wr = x.double().permute(0, 3, 1, 2).requires_grad_(), wt.double().permute(0, 3, 1, 2).requires_grad_()
+    gw, = torch.autograd.grad(F.conv2d(xr, wr, None, stride=1, padding=1), wr, dy.double().permute(0, 3, 1, 2))
+    dwc = torch.empty_like(wt)
+    _lib.conv2d_bwd_weight(dy, x, dwc, _lib.with_route(geom, _lib.ROUTE_FP32), ws)
+    assert torch.isfinite(dw).all()
+    e_split, e_chain = _rel_rms(dw, gw.permute(0, 2, 3, 1)), _rel_rms(dwc, gw.permute(0, 2, 3, 1))
+    assert e_split <= 1.5 * e_chain + 3e-8, (e_split, e_chain)
 
 
 EXACT = [("conv2", 33, 25, 19, 32, 64, 4, 2, 1), ("conv3", 20, 12, 9, 64, 64, 3, 1, 1), ("dense", 512, 1, 1, 3456, 512, 1, 1, 0)]
@@ -507,15 +535,12 @@ def test_split_routes_carry_full_fp32_significands_exactly(layer, mode):
     want = dict(fwd=out.permute(0, 2, 3, 1).detach(), dgrad=gx.permute(0, 2, 3, 1), wgrad=gw.permute(0, 2, 3, 1))
     for t in want.values():
         assert torch.equal(t.float().double(), t)                                            # the references are fp32 numbers
-    assert lib.arl_conv_precision(mode) == 0
-    try:
-        y, dx, dw = torch.empty(b, ho, wo, k, device=DEV), torch.empty_like(x), torch.empty_like(wt)
-        _lib.conv2d_fwd(x, wt, None, y, geom, False, ws)
-        _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
-        _lib.conv2d_bwd_weight(dy1, x, dw, geom, ws)
-        torch.cuda.synchronize()
-        for op, got in (("fwd", y), ("dgrad", dx), ("wgrad", dw)):
-            assert want[op].abs().max() > 0
-            assert torch.equal(got.double(), want[op]), (op, (got.double() - want[op]).abs().max().item())
-    finally:
-        lib.arl_conv_precision(9)
+    geom = _lib.with_route(geom, _lib.ROUTE_SPLIT9 if mode == 9 else _lib.ROUTE_SPLIT6)
+    y, dx, dw = torch.empty(b, ho, wo, k, device=DEV), torch.empty_like(x), torch.empty_like(wt)
+    _lib.conv2d_fwd(x, wt, None, y, geom, False, ws)
+    _lib.conv2d_bwd_data(dy, wt, None, dx, geom)
+    _lib.conv2d_bwd_weight(dy1, x, dw, geom, ws)
+    torch.cuda.synchronize()
+    for op, got in (("fwd", y), ("dgrad", dx), ("wgrad", dw)):
+        assert want[op].abs().max() > 0
+        assert torch.equal(got.double(), want[op]), (op, (got.double() - want[op]).abs().max().item())

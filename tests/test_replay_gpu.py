@@ -247,3 +247,81 @@ def test_prioritized_device_path_tracks_the_reference_path():
                 np.testing.assert_allclose(dev.priority_tree.tree.cpu().numpy(), host.priority_tree.tree.cpu().numpy(),
                                            rtol=2e-7, atol=1e-12)
     assert fast > 0 and slow > 0, (fast, slow)
+
+
+def test_config5_store_at_its_stated_size():
+    """BASELINE config 5 as stated: the 1 000 448-transition store of 256 environments -- 8.33 GB of
+    frames, i.e. byte offsets past 2^32 from environment 131 on -- appended to until every environment's ring has wrapped,
+    then `extract_batch` against the oracle port at states on both sides of the 2^32-byte boundary and of the wrap, and
+    one sampling round of the 21-level sum tree through the device path against the host path.
+    The port mirrors four of the 256 environments (every environment is independent of the others:
+    accel_rl/algos/dqn/replay_buffers/frame.py:23-90 keeps one object per environment; sum tree: sum_tree.py:12-98)."""
+    from accel_rl_amd.algos.dqn.replay_buffers.prioritized import PrioritizedReplayBuffer
+    free, _ = torch.cuda.mem_get_info()
+    if free < 12 << 30:
+        pytest.skip("needs 12 GB of free HBM")
+    n_env, t, f, h_r, size = 256, 4, 4, 3, 1000448
+    mk = lambda: PrioritizedReplayBuffer(alpha=0.6, beta_initial=0.4, default_priority=1., env_spec=_Spec((f, 104, 80)),   # noqa: E731
+                                         size=size, reward_horizon=h_r, sampling_horizon=t, n_environments=n_env,
+                                         discount=0.99, device=DEV)
+    buf = mk()
+    S = buf.env_replay_size
+    assert S == 3908 and buf.frames.numel() == n_env * (S + f - 1) * 8320 and buf.frames.numel() > 2 ** 33 - 2 ** 30
+    frame_bytes = (S + f - 1) * 8320
+    e_lo = (2 ** 32) // frame_bytes                          # the environment whose ring the 2^32-byte boundary cuts
+    assert e_lo == 131
+    s_cut = (2 ** 32 - e_lo * frame_bytes) // 8320           # ... and the ring slot it falls into
+    envs = [0, e_lo, e_lo + 1, n_env - 1]
+    port = R.ReplayPort(len(envs), f, (104, 80), S * len(envs), h_r, t, 0.99)
+    assert port.S == S
+    g = torch.Generator(device=DEV).manual_seed(7)
+    sel = torch.tensor(envs, device=DEV)
+    n_app = S // t + 23                                      # every ring wraps; the cursor ends at 92
+    for b in range(n_app):
+        obs = torch.randint(0, 256, (n_env, t, f, 104, 80), dtype=torch.uint8, device=DEV, generator=g)
+        acts = torch.randint(0, 18, (n_env, t), dtype=torch.uint8, device=DEV, generator=g)
+        rews = torch.randn((n_env, t), device=DEV, generator=g)
+        dones = torch.rand((n_env, t), device=DEV, generator=g) < 0.02
+        buf.append_data(dict(observations=obs.reshape(n_env * t, f, 104, 80), actions=acts.reshape(-1),
+                             rewards=rews.reshape(-1), dones=dones.reshape(-1)))
+        port.append(obs[sel].cpu().numpy(), acts[sel].cpu().numpy(), rews[sel].cpu().numpy(), dones[sel].cpu().numpy())
+    assert buf.idx == port.idx == (n_app * t) % S and port.full
+    for k in ("n_blanks", "acts", "rewards", "returns"):
+        np.testing.assert_array_equal(getattr(buf, k)[sel].cpu().numpy(), getattr(port, k), err_msg=k)
+    np.testing.assert_array_equal(buf.terminals[sel].cpu().numpy().astype(bool), port.terminals)
+    # states around the wrap of the ring, around the write cursor, and around the 2^32-byte boundary (environment e_lo)
+    steps = list(range(0, 12)) + list(range(S - 12, S)) + list(range(port.idx - 8, port.idx + 8)) + \
+        list(range(s_cut - 10, s_cut + 6)) + [1000, 2000, 3000]
+    pe = np.repeat(np.arange(len(envs)), len(steps))
+    ps = np.tile(np.array(steps), len(envs))
+    got = buf.extract_batch(np.array(envs)[pe], ps)
+    want = port.extract_batch(pe, ps)
+    for gg, ww in zip(got, want):
+        np.testing.assert_array_equal(gg.cpu().numpy(), ww)
+    cut_rows = (pe == 1) & (ps + f - 1 >= s_cut) & (ps <= s_cut)
+    assert cut_rows.sum() >= f                               # observations that straddle the 2^32-byte boundary
+    assert got[0].cpu().numpy()[cut_rows].any()
+    # ---- the 21-level tree: one sampling round, device path against the host path from the same state and seed
+    tree = buf.priority_tree
+    assert tree.tree_level == 21 and tree.tree.numel() == 2 ** 21 - 1 and tree.t_l_shift == 2 ** 20 - 1
+    pri = torch.rand(size, dtype=torch.float64, device=DEV, generator=g) + 0.01
+    leaves = tree.tree[tree.t_l_shift:tree.t_l_shift + size]
+    live = leaves > 0                                        # the zeroed window around the cursor stays zero
+    leaves[live] = pri[live]                                 # random priorities on every live state, then the sums above them
+    for lvl in range(19, -1, -1):
+        lo, hi = 2 ** lvl - 1, 2 ** (lvl + 1) - 1
+        tree.tree[lo:hi] = tree.tree[2 * lo + 1:2 * hi + 1:2] + tree.tree[2 * lo + 2:2 * hi + 2:2]
+    np.random.seed(11)
+    want = buf.sample_batch(512)
+    want = [w.clone() if isinstance(w, torch.Tensor) else np.array(w) for w in want]   # (outputs may be reused buffers)
+    after = np.random.randint(0, 2 ** 31 - 1)
+    want_idx = tree.last_tree_idxs.cpu().numpy().copy()
+    np.random.seed(11)
+    got = buf.sample_batch(512, device_weights=True)
+    assert np.random.randint(0, 2 ** 31 - 1) == after        # same consumption of the host RNG
+    np.testing.assert_array_equal(tree.last_tree_idxs.cpu().numpy(), want_idx)
+    for w, gg in zip(want[:5], got[:5]):
+        assert torch.equal(w, gg)
+    np.testing.assert_allclose(got[5].cpu().numpy(), np.asarray(want[5]).astype(np.float32), rtol=3e-7, atol=0)
+    e_s = np.divmod(want_idx - tree.t_l_shift, S)
+    assert (e_s[0] >= e_lo).any() and (e_s[0] < e_lo).any()  # the batch drew from both sides of the boundary

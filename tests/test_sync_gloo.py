@@ -62,6 +62,62 @@ def test_sync_optimizer_allreduce_world2():
     assert sorted(out.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
 
 
+def _overlap_worker(rank, world, port, out):
+    """The path mPPO ships for N > 1 (optimizers/single.py `_overlapped_minibatches`): the bucket's tail is all-reduced
+    from the policy's split hook while the backward pass still writes the head, the head after it; the update must see
+    every element summed over the ranks exactly once.  Backward pass and update kernel are stand-ins (CPU tensors)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from accel_rl_amd.optimizers import update_methods
+    from accel_rl_amd.optimizers.sync import SyncPpoOptimizer
+    opt = SyncPpoOptimizer(learning_rate=1e-3, update_method=update_methods.adam, update_method_args=None, epochs=1,
+                           minibatch_size=4)
+    n, split = 10, 4
+    tgt = opt._target = _Target(n)
+    tgt.grad_split_offset = split
+    opt.init_comm(None, rank, world)
+    assert opt._overlap_allreduce and not opt.graph_ready()      # gloo: eager, never captured
+    opt._n_minibatches, opt._idx_dev, opt._losses = 3, [None] * 3, None
+    opt._grad_tap = taps = []
+    seen = []
+
+    def local(k, r):
+        return torch.arange(float(n)) * (r + 1) + 100. * k
+
+    def backward(losses, mb):
+        k = len(seen)
+        tgt.flat_grads[split:] = local(k, rank)[split:]         # dense + heads first ...
+        mb["split_hook"]()                                      # ... their all-reduce starts here
+        tgt.flat_grads[:split] = local(k, rank)[:split]         # ... while the conv layers' gradients are written
+        return torch.zeros(4)
+    opt._backward = backward
+    opt._apply_update = lambda avg: seen.append((tgt.flat_grads.clone(), avg))
+    opt._recent_grad_norms = lambda count: torch.zeros(count)
+    opt._overlapped_minibatches(dict())
+    assert len(seen) == 3 and len(taps) == 6                    # two slices per minibatch, each reduced once
+    for k, (g, avg) in enumerate(seen):
+        want = sum(local(k, r) for r in range(world))
+        assert torch.equal(g, want), (k, g, want)
+        assert avg == 1.0 / world
+    firsts = sorted(set(f for f, _ in taps))
+    assert firsts == [0, split]
+    out.put((rank, "ok"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_tail_head_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    out, port = ctx.Queue(), _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(out.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+
+
 # ----------------------------------------------------------------------------- runner
 
 class _FakePolicy(object):

@@ -76,7 +76,7 @@ def test_two_ranks_stay_bit_identical(tmp_path):
     assert np.isfinite(a["final"]).all() and not np.array_equal(a["final"], a["init"])
 
 
-def _rccl_world1(port, out_dir):
+def _rccl_world1(port, out_dir, capture=True):
     """One rank on the `nccl` backend (= RCCL on ROCm) with the collective forced: mPPO's eager minibatches with
     the asynchronous tail / head all-reduce of the gradient bucket on RCCL's stream (optimizers/sync.py
     _share_grad_async, optimizers/single.py _overlapped_minibatches), then PPO's single-graph learner from the
@@ -107,6 +107,7 @@ def _rccl_world1(port, out_dir):
                         affinities=dict(gpu=0), log_interval_steps=320, **kw)
         if tag == "sync":
             algo.optimizer._force_collective = True
+            algo.optimizer.graph_collectives = capture
         n_itr = runner.startup()
         assert algo.optimizer.parallelism_tag == ("synchronous" if tag == "sync" else "single")
         norms = []
@@ -118,23 +119,27 @@ def _rccl_world1(port, out_dir):
         results[tag + "_final"] = policy.get_param_values()
         results[tag + "_norms"] = np.stack(norms)
         results[tag + "_split"] = np.int64(policy.grad_split_offset)
+        results[tag + "_captured"] = np.int64(algo._graph is not None)
         runner.shutdown()
     np.savez(os.path.join(out_dir, "rccl.npz"), **results)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_rccl_backend_forced_collective_matches_single_gpu(tmp_path):
-    """the path that ships for N > 1 (backend `nccl` = RCCL, asynchronous all-reduce of the
-    two bucket slices, optimiser step waiting on RCCL's stream) exercised on the device; reference:
-    accel_rl/optimizers/sync/base.py:22-24, sync_ppo_optimizer.py:27-34."""
+@pytest.mark.parametrize("capture", [True, False], ids=["one hipGraph", "eager"])
+def test_rccl_backend_forced_collective_matches_single_gpu(tmp_path, capture):
+    """the path that ships for N > 1 (backend `nccl` = RCCL, asynchronous all-reduce of
+    the two bucket slices, optimiser step waiting on RCCL's stream) exercised on the device -- as eager minibatches, and
+    with the WHOLE optimize_policy call, RCCL's all-reduces included, captured in one hipGraph (the default on `nccl`);
+    reference: accel_rl/optimizers/sync/base.py:22-24, sync_ppo_optimizer.py:27-34,56-78."""
     ctx = mp.get_context("spawn")
-    p = ctx.Process(target=_rccl_world1, args=(_free_port(), str(tmp_path)))
+    p = ctx.Process(target=_rccl_world1, args=(_free_port(), str(tmp_path), capture))
     p.start()
     p.join(600)
     assert p.exitcode == 0, p.exitcode
     r = np.load(os.path.join(str(tmp_path), "rccl.npz"))
     assert 0 < int(r["sync_split"]) < r["sync_final"].size            # both bucket slices are non-empty
+    assert int(r["sync_captured"]) == int(capture) and int(r["single_captured"]) == 1
     assert r["sync_norms"].shape == (6, 4) and np.isfinite(r["sync_norms"]).all()
     np.testing.assert_array_equal(r["sync_norms"], r["single_norms"])
     np.testing.assert_array_equal(r["sync_final"], r["single_final"])
@@ -228,7 +233,7 @@ def test_two_rank_update_is_the_oracle_step_on_the_mean_gradient(tmp_path, kind)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     a, b = (np.load(os.path.join(str(tmp_path), "mean_%s_rank%d.npz" % (kind, r))) for r in range(2))
     n = int(a["n"])
-    assert n == int(b["n"]) == (8 if kind == "ppo" else 2)          # 2 iterations x (2 epochs x 2 minibatches | 1 step)
+    assert n == int(b["n"]) == (20 if kind == "ppo" else 2)         # 2 iterations x (2 epochs x 5 minibatches of 160 samples | 1 step)
     if kind == "ppo":
         assert 0 < int(a["split"]) < a["p_0"].size                  # both slices of the bucket exist
     lr, args, clip = np.float32(a["lr"]), a["args"], float(a["clip"])

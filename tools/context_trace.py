@@ -1,4 +1,4 @@
-"""Per-workgroup timeline (arl_conv_trace_buffer) of ONE conv kernel launch as the learner runs it: inside an eager
+"""Per-workgroup timeline (arl_dev_conv_trace_buffer) of ONE conv kernel launch as the learner runs it: inside an eager
 PPO minibatch (B = 512, spec 1), i.e. on activations the previous layer has just written, after a long busy stretch.
 usage: python tools/context_trace.py [c1f | c2f | c3f | df | c3d | c2d]   (forward conv 1..3 / dense, data gradient
 of conv 3 / conv 2)"""
@@ -34,10 +34,10 @@ def wrap(fn, k):
         hit = state["armed"] and kind == k and state["calls"][k] == nth
         state["calls"][k] += 1
         if hit:
-            lib.arl_conv_trace_buffer(tr.data_ptr())
+            lib.arl_dev_conv_trace_buffer(tr.data_ptr())
         out = fn(*a, **kw)
         if hit:
-            lib.arl_conv_trace_buffer(None)
+            lib.arl_dev_conv_trace_buffer(None)
         return out
     return wrapped
 
@@ -89,11 +89,7 @@ def report(tag):
                                                       np.median(epi), np.median(t[:, 3] - t[:, 0]), np.median(rs), rs.max(), hist))
 
 
-lib.arl_conv_persistent(int(os.environ.get("ARL_PERSIST", "0")))      # persistent launches: lifetimes span all of a workgroup's tiles
-TILES = {1: "64x64", 2: "112x64", 3: "32x64 (default)"}
-for choice in ((3, 1, 2) if which in ('c2f', 'c3f', 'c3d') else (3,)):
-    lib.arl_conv_tile_choice(choice)
-    policy._scratch.clear()
+for choice in (0,):
     for rep in range(3):                       # two warm passes over the 8 minibatches, then the traced one
         for j, ix in enumerate(idxs):
             state["calls"] = dict(u8=0, fwd=0, pair=0)
@@ -102,5 +98,4 @@ for choice in ((3, 1, 2) if which in ('c2f', 'c3f', 'c3d') else (3,)):
                 tr.zero_()
             policy.loss_and_grads(dict(mb, idx=ix), 1, 0.2, 1.0, 0.01, lr)
     torch.cuda.synchronize()
-    report("%s, 64-column tiles %s" % (which, TILES[choice]))
-lib.arl_conv_tile_choice(0)
+    report(which)

@@ -1,4 +1,4 @@
-"""Per-workgroup timeline of one fp32-MFMA conv kernel launch (arl_conv_trace_buffer):
+"""Per-workgroup timeline of one fp32-MFMA conv kernel launch (arl_dev_conv_trace_buffer):
 how long prologue / main loop / epilogue take in shader clocks, the effective clock,
 how the dispatcher spread the workgroups over CUs.  usage: python tools/conv_trace.py [batch]"""
 import os
@@ -41,10 +41,10 @@ def main():
             launch()
         torch.cuda.synchronize()
         tr = torch.zeros(8192 * 8, dtype=torch.int64, device=DEV)
-        lib.arl_conv_trace_buffer(tr.data_ptr())
+        lib.arl_dev_conv_trace_buffer(tr.data_ptr())
         launch()
         torch.cuda.synchronize()
-        lib.arl_conv_trace_buffer(None)
+        lib.arl_dev_conv_trace_buffer(None)
         t = tr.cpu().numpy().reshape(-1, 8)
         t = t[t[:, 0] != 0]
         hw0, xcc0 = t[:, 6], t[:, 7] & 0xf

@@ -1,4 +1,4 @@
-"""One PPO minibatch (forward, heads + losses, backward, update) of the spec-1 policy at B = 512 under tuning knobs,
+"""One PPO minibatch (forward, heads + losses, backward, update) of the spec-1 policy at B = 512 
 timed as 8 minibatches per hipGraph (the learner's shape).  usage: python tools/learner_probe.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,6 @@ from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
 from accel_rl_amd.spaces import Discrete, UintBox, EnvSpec
 DEV = "cuda:0"
 lib = _lib.load()
-lib.arl_conv_persistent(int(os.environ.get("ARL_PERSIST", "0")))
 policy = AtariCnnPolicy(**cnn_specs[1])
 policy.initialize(EnvSpec(UintBox((4, 104, 80)), Discrete(4)), device=DEV)
 n = 1280
@@ -41,8 +40,5 @@ def gt(rep=10):
     return a.elapsed_time(b) / (8 * rep) * 1e3
 
 
-for choice in [int(x) for x in sys.argv[1:]] or (1, 2, 3, 1, 2, 3):
-    lib.arl_conv_tile_choice(choice)
-    policy._scratch.clear()
-    print("tile choice %d: %.1f us per minibatch (forward + backward, no update)" % (choice, gt()))
-lib.arl_conv_tile_choice(0)
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
+    print("%.1f us per minibatch (forward + backward, no update)" % gt())

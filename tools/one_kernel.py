@@ -17,7 +17,6 @@ def main():
     b = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
     lib = _lib.load()
-    lib.arl_conv_tile_choice(int(os.environ.get("ARL_TILE_CHOICE", "0")))
     h, w, c, k, ks, st, p = LAYERS[name]
     geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p)
     ho, wo = _lib.conv_out_hw(geom)

@@ -22,14 +22,11 @@ python tools/gae_sweep.py > $O/gae_sweep.txt 2>&1
 # the bf16-split routes: accuracy of every kernel against float64 and launch times per route; the bench line per route
 python tools/split_check.py 512 48 2>&1 | grep -v amdgpu.ids > $O/split_check.txt
 for m in 0 6; do ARL_CONV_PRECISION=$m timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_precision_$m.json; done
-# tile / persistence / timeline probes of the fp32 MFMA chain (arl_conv_precision 0), whose tile choices they label
+# tile / persistence / timeline probes of the fp32 MFMA chain (ARL_CONV_PRECISION=0: arl_conv_geom.route = ARL_CONV_ROUTE_FP32), whose tile choices they label
 export ARL_CONV_PRECISION=0
 (for w in c1f c2f c3f df c3d c2d; do python tools/context_trace.py $w 2>&1 | grep -v amdgpu.ids; done) > $O/context_trace.txt
 python tools/conv_trace.py 512 2>&1 | grep -v amdgpu.ids > $O/conv_trace.txt
-python tools/learner_probe.py 2>&1 | grep tile > $O/learner_probe.txt
-python tools/tile_probe.py 512 256 128 2>&1 | grep "B=\|dev" > $O/tile_probe.txt
-python tools/persist_probe.py 0 3 4 5 0 2>&1 | grep persistent > $O/persist_probe.txt
-(for w in c1f c2d; do ARL_PERSIST=4 python tools/context_trace.py $w 2>&1 | grep -v amdgpu.ids; done) > $O/context_trace_persistent.txt
+python tools/learner_probe.py 2>&1 | grep minibatch > $O/learner_probe.txt
 unset ARL_CONV_PRECISION
 python tools/env_step_probe.py 256 2>&1 | grep dbg > $O/env_step_probe.txt; python tools/env_step_probe.py 2048 2>&1 | grep dbg >> $O/env_step_probe.txt
 timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/null | tail -n 1 > $O/bench_a2c1024.json

@@ -1,4 +1,4 @@
-"""arl_conv_precision: the three routes of the fp32 contractions (0 = fp32 MFMA chain, 6 / 9 = bf16-split products)
+"""arl_conv_geom.route: the three routes of the fp32 contractions (0 = fp32 MFMA chain, 6 / 9 = bf16-split products)
 at the spec-1 layer shapes -- error of every kernel against a float64 reference on the same inputs, and event-timed
 launch durations at the PPO minibatch.  usage: python tools/split_check.py [timing batch] [accuracy batch]"""
 import os
@@ -35,7 +35,6 @@ def err(got, want):
 
 def run(b, timing):
     lib = _lib.load()
-    lib.arl_conv_tile_choice(int(os.environ.get("ARL_TILE_CHOICE", "0")))
     ws = _lib.conv_workspace(DEV)
     gen = torch.Generator(device=DEV).manual_seed(3)
     for name, h, w, c, k, ks, st, p in LAYERS:
@@ -62,7 +61,8 @@ def run(b, timing):
                 ref["u8fwd"] = (out8 + bias.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).detach()
                 ref["u8wgrad"] = torch.autograd.grad(out8, w8r, dyd)[0]
         for mode in MODES:
-            assert lib.arl_conv_precision(mode) == 0
+            _lib.set_conv_precision(mode)
+            geom = _lib.with_route(geom)
             ops = dict(fwd=lambda: _lib.conv2d_fwd(x, wt, bias, y, geom, False, ws),
                        dgrad=lambda: _lib.conv2d_bwd_data(dy, wt, None, dx, geom),
                        wgrad=lambda: _lib.conv2d_bwd_weight(dy, x, dw, geom, ws))
@@ -86,7 +86,7 @@ def run(b, timing):
                     torch.cuda.synchronize()
                     mx, rms = err(outs[op], ref[op])
                     print("%-6s %-8s mode %d  max err / max|ref| %.3e   rms err / rms ref %.3e" % (name, op, mode, mx, rms), flush=True)
-    lib.arl_conv_precision(9)
+    _lib.set_conv_precision(9)
 
 
 if __name__ == "__main__":

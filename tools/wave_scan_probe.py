@@ -1,4 +1,4 @@
-"""The wave suffix scan (ARL_PROMO_ASSOC) at 2^26 elements by segment groups per wave (arl_scan_wave_groups) next to the
+"""The wave suffix scan (ARL_PROMO_ASSOC) at 2^26 elements by segment groups per wave (arl_dev_scan_wave_groups) next to the
 exact walk, fraction of the 8 TB/s HBM peak.  usage: python tools/wave_scan_probe.py [log2 elements]"""
 import os
 import sys
@@ -26,7 +26,7 @@ def main():
     lg = int(sys.argv[1]) if len(sys.argv) > 1 else 26
     lib = _lib.load()
     gen = torch.Generator(device=DEV).manual_seed(1)
-    lib.arl_scan_force_wave(1)
+    lib.arl_dev_scan_force_wave(1)
     for t in (5, 16, 32, 64, 128, 256, 512):
         n = (1 << lg) // t
         r = torch.randn(n * t, device=DEV, generator=gen)
@@ -38,12 +38,12 @@ def main():
         us = ev(lambda: _lib.gae_scan(r, v, d, lv, 0.99, 0.95, n, t, adv, ret))
         line = "T = %3d  exact walk %7.1f us %.3f |" % (t, us, nbytes / us / 1e3 / 8000.)
         for g in (1, 2, 4, 0):
-            lib.arl_scan_wave_groups(g)
+            lib.arl_dev_scan_wave_groups(g)
             us = ev(lambda: _lib.gae_scan(r, v, d, lv, 0.99, 0.95, n, t, adv, ret, promo=_lib.PROMO_ASSOC))
             line += "  groups %d: %7.1f us %.3f" % (g, us, nbytes / us / 1e3 / 8000.)
         print(line)
         del r, v, d, lv, adv, ret
-    lib.arl_scan_force_wave(0)
+    lib.arl_dev_scan_force_wave(0)
 
 
 if __name__ == "__main__":
