@@ -91,8 +91,9 @@ def graph_time_ms(fn, per_graph=20, replays=5):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    from accel_rl_amd.util.misc import graph_capture_mode
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode=graph_capture_mode()):
         for _ in range(per_graph):
             fn()
     g.replay()
@@ -160,6 +161,57 @@ def pmc_traffic(log2_elems):
         return rec["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         return None
+
+
+ENV_SWEEP_ENVS = 16384          # environments of the bandwidth-bound env_step measurement (2.7 GB of rollout rows)
+
+
+def env_step_sweep(device, n_env=ENV_SWEEP_ENVS):
+    """arl_env_step (the whole env side of a rollout step: sample, emulate, max / crop / 2x2 box, stack, store) at a
+    bandwidth-bound size.  Algorithmic bytes per env-step: preprocess + stack 75 520 (two raw frames in, one
+    preprocessed frame out) + rollout store 33 295 + 4 A; `achieved` is computed from that figure, not from what the
+    kernel moves (it also reads the three older frames of the stack, 24 960 B: the reference's stacked-observation layout
+    -- the PMC traffic, tools/env_step_pmc.sh, is in `traffic`)."""
+    from accel_rl_amd import _lib
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
+    smp = GpuVecSampler(EnvCls=SynthAtariEnv, env_args=dict(game=GAME), horizon=HORIZON, n_parallel=16,
+                        envs_per=n_env // 32, max_path_length=int(27e3), max_decorrelation_steps=0, device=device)
+    state = np.random.get_state()
+    smp.initialize(seed=1, discount=0.99, need_extra_obs=True)
+
+    class Served(object):
+        recurrent = False
+        serves_rows = True
+        def reset(self, n_batch): pass                                   # noqa: E301,E704
+        def get_action(self, ob): return None, None                      # noqa: E301,E704
+    pol = Served()
+    smp.policy_init(pol)
+    np.random.set_state(state)
+    a = smp.env_spec.action_space.n
+    prob = torch.full((n_env, a), 1.0 / a, device=device)
+    val = torch.zeros(n_env, device=device)
+    u = torch.rand(n_env, dtype=torch.float64, device=device)
+    per_graph = 20
+    ms = graph_time_ms(lambda: _lib.env_step(smp._game, smp._state, smp._rollout, prob, val, u, 1, True, 27000, 0.99,
+                                             smp.env.max_start_noops, single_write=True), per_graph=per_graph, replays=5)
+    nbytes = n_env * (75520 + 33295 + 4 * a)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "env_step_pmc.json")) as f:
+            rec = json.load(f)
+        import hashlib
+        with open(os.path.join(ROOT, "accel_rl_amd", "csrc", "env.hip"), "rb") as f:
+            if rec.get("env_hip_sha1") == hashlib.sha1(f.read()).hexdigest():
+                traffic = int(rec["hbm_bytes_per_env_step"] * n_env)
+    except (OSError, ValueError, KeyError):
+        pass
+    smp.shutdown()
+    return dict(kernel="env_step@sweep (env_step_kernel, %d envs, rollout rows written once)" % n_env, bound="hbm",
+                avg_launch_us=round(ms * 1e3, 2), bytes_per_launch=nbytes, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
+                unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                timing="%d launches per hipGraph, 5 replays" % per_graph)
 
 
 def kernel_table(device, sampler, algo, policy, reps=20):
@@ -683,6 +735,7 @@ def main():
         if not args.no_roofline:
             line["roofline"] = roofline_gae(device, args.roofline_log2, 30)
             line["kernels"] = kernel_table(device, sampler, algo, policy)
+            line["kernels"].append(env_step_sweep(device))
             line["mfma"] = mfma_table(device, policy)
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cb = cpu_baseline(device, policy, cpu_pool, sampler, algo, itr + 2 * reps)

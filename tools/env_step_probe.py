@@ -1,6 +1,6 @@
 """Time arl_env_step (the env side of one rollout step, one launch) inside a hipGraph of 40 chained launches, with the
 stacked observation written twice (step_obs kept current) and once (policies that serve rows of the rollout buffer).
-usage: python tools/env_step_probe.py [n_envs]"""
+usage: python tools/env_step_probe.py [n_envs] [0 | 1: only that single_write mode]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,7 @@ class P(object):
 pol = P(); pol.p = torch.full((n_env, 4), 0.25, device=dev); pol.v = torch.zeros(n_env, device=dev)
 smp.policy_init(pol)
 u = torch.rand(n_env, dtype=torch.float64, device=dev)
-for single in (0, 1):
+for single in ((int(sys.argv[2]),) if len(sys.argv) > 2 else (0, 1)):
     def go():
         for s in range(40):
             _lib.env_step(smp._game, smp._state, smp._rollout, pol.p, pol.v, u, s % 4, True, 27000, 0.99, 30, single_write=single)
