@@ -351,6 +351,11 @@ class AtariCnnPolicy(object):
         (pi_loss, v_loss, ent_loss, pi+v+ent) as a device tensor."""
         with torch.no_grad():
             idx = mb.get("idx")
+            rows = mb["observations"].shape[0] if idx is None else idx.shape[0]
+            limit = self.rows_per_pass()
+            if limit and rows >= 3 * limit:
+                return self._loss_and_grads_in_passes(mb, rows, limit, kind, clip_param, v_loss_coeff, ent_loss_coeff,
+                                                      lr_mult, inv_count)
             x = self._scaled(mb["observations"], idx)
             b = x.shape[0]
             acts, hids = self._trunk(x)
@@ -367,6 +372,59 @@ class AtariCnnPolicy(object):
             self._backward_trunk(x, acts, hids, dh, masked=True, split_hook=mb.get("split_hook"),
                                  dense_w_hook=mb.get("dense_w_hook"))
             return loss4
+
+    # Rows of a minibatch per forward + backward pass.  The activations of a pass and their gradients (fp32, every conv
+    # layer's output twice) plus the u8 rows it reads want to stay in the 256 MiB Infinity Cache between the launch
+    # that writes them and the launches that read them: measured (tools/batch_sweep.py, profiles/r03/batch_sweep.txt)
+    # the cost per row is lowest at 1024 rows for spec 1 (232 KB + 33 KB per row) and at 2048 for spec 0 (88 + 33 KB)
+    # and, for spec 1, 15-25 % higher at 4096-5120 rows in one pass (spec 0: 2 %).  A minibatch of three or more such
+    # passes (the strong-scaling bench's 4096 rows of spec 1 on one GPU) is therefore walked in passes of that size
+    # whose gradients are added in a fixed order -- the same mean-loss gradient, other summation order
+    # (accel_rl/optimizers/single/a2c_optimizer.py:37-43 takes one step on the whole batch; so does this); the
+    # accumulation costs ~3 % of a pass, so smaller multiples stay in one pass.  None = one pass whatever the size.
+    max_rows_per_pass = "auto"
+    CACHE_BYTES = 256 << 20
+
+    def rows_per_pass(self):
+        if self.max_rows_per_pass != "auto":
+            return self.max_rows_per_pass
+        per_row = int(np.prod(self._obs_shape)) + 8 * sum(nf * ho * wo for nf, ci, sz, st, pad, ho, wo in self._conv_geom)
+        return max(256, (self.CACHE_BYTES // per_row + 128) // 256 * 256)
+
+    def _loss_and_grads_in_passes(self, mb, rows, limit, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult,
+                                  inv_count):
+        """loss_and_grads of a minibatch larger than rows_per_pass(): passes over consecutive slices of its index list,
+        every pass normalised by the WHOLE minibatch's count; gradients and the four loss sums accumulate in pass
+        order (deterministic).  The co-run / split hooks of the one-pass learner do not apply (nothing is final before
+        the last pass)."""
+        idx = mb.get("idx")
+        if idx is None:
+            idx = self._buffer(("all_rows", rows), (rows,), dtype=torch.int32)
+            idx.copy_(torch.arange(rows, dtype=torch.int32, device=self.device))
+        if inv_count is None:
+            inv_count = self._buffer(("inv_rows", rows), (1,))
+            inv_count.fill_(1.0 / rows)
+        acc = self._buffer(("grad_acc",), tuple(self.flat_grads.shape))
+        loss_acc = self._buffer(("loss_acc",), (4,))
+        one = dict((k, v) for k, v in mb.items() if k not in ("split_hook", "dense_w_hook"))
+        saved, self.max_rows_per_pass = self.max_rows_per_pass, None
+        try:
+            for k, lo in enumerate(range(0, rows, limit)):
+                one["idx"] = idx[lo:min(lo + limit, rows)]
+                loss4 = self.loss_and_grads(one, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult, inv_count)
+                if k == 0:
+                    acc.copy_(self.flat_grads)
+                    loss_acc.copy_(loss4)
+                else:
+                    acc.add_(self.flat_grads)
+                    loss_acc.add_(loss4)
+        finally:
+            self.max_rows_per_pass = saved
+        self.flat_grads.copy_(acc)
+        hook = mb.get("split_hook")
+        if hook is not None:
+            hook()                              # the whole bucket is final from here on
+        return loss_acc
 
     def _backward_trunk(self, x, acts, hids, dh, masked=False, split_hook=None, dense_w_hook=None):
         """Gradients of every trunk layer into flat_grads, given dh = d loss / d (last hidden
