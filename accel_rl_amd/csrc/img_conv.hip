@@ -1,0 +1,161 @@
+// "Image-stationary" kernels (round 3): a persistent workgroup keeps what a whole IMAGE's outputs need in LDS instead of
+// gathering it tap by tap from global memory.
+//
+// conv1_img_kernel: the first convolution straight from the sampler's u8 observations (arl_conv2d_u8_fwd; the
+// reference's network input is obs * (1 / 255): accel_rl/policies/pg/atari_cnn_policy.py:88-91, first layer
+// pg_cnn.py:47-52) for 32 filters of 8 x 8 pixels:
+//   * the layer's weights are split ONCE per workgroup -- exactly, into three bf16 planes (mfma_conv_impl.h, SPLIT) --
+//     and stay in LDS in MFMA-fragment order for the workgroup's whole life (48 KB at 4 planes);
+//   * an image (33 KB of u8) arrives with coalesced 16-byte loads into one of two LDS buffers while the previous image
+//     is being computed; one barrier per image;
+//   * an MFMA A fragment -- eight consecutive pixels of one filter row -- is two dwords of LDS, converted to bf16
+//     (0 .. 255 is exact in one piece) between the read and the MFMA: three products per multiply, as in igemm_body's
+//     U8 path, in the same order (weight planes l, m, h per 16-k step; steps in (plane, filter row) order), so the
+//     results are bit-identical to it;
+//   * 16 waves per workgroup, a wave owns one 32-pixel row tile of an image at a time.
+// The kernel it replaces gathers one dword per lane and instruction from global memory (64 cache lines per load
+// instruction: bound by the texture addresser, 24.5 us at the PPO minibatch); this one runs 19 us there and 10.9 us
+// instead of 15.6 us at the rollout's 256 rows (tools/proto/conv1_img_proto.hip, profiles/r03/conv1_img_proto.txt).
+#include "mfma_conv_impl.h"
+
+namespace arlc {
+
+struct Conv1ImgArgs {
+    const unsigned char* obs;   // u8 [rows][C][H][W]
+    const int* idx;             // row of image b, or null
+    const float* w;             // f32 [32][C][8][8]
+    const float* bias;          // f32 [32] or null
+    float* y;                   // f32 [B][OH][OW][32]
+    float scale;
+    int n_img, C, H, W, OH, OW, stride, relu;
+};
+
+__device__ __forceinline__ u32x2 bytes_to_bf16x4(unsigned v) {     // four packed bytes -> four bf16, exact
+    const float4 f = bytes_to_f4(v);
+    return u32x2{hi_pair(f.x, f.y), hi_pair(f.z, f.w)};
+}
+
+constexpr int C1_NW = 16, C1_NT = C1_NW * 64, C1_MAX_IMG = 40960;
+
+__global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int N = 32, KH = 8, MAXLD = (C1_MAX_IMG / 16 + C1_NT - 1) / C1_NT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int C = a.C, H = a.H, W = a.W, npix = C * H * W, K = C * 64, nsteps = K / 16;
+    char* const sW = lds;                                   // [nsteps][3 planes][64 lanes] 16-byte fragments
+    char* const sI = lds + nsteps * 3072;                   // two u8 images [C][H][W]
+    const int n16 = npix / 16;
+    u32x4 ireg[MAXLD];
+    auto img_issue = [&](int img) {
+        const int row = a.idx ? a.idx[img] : img;
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.obs + (size_t)row * npix);
+#pragma unroll
+        for (int i = 0; i < MAXLD; ++i)
+            if (tid + C1_NT * i < n16) ireg[i] = src[tid + C1_NT * i];
+    };
+    auto img_store = [&](int buf) {
+        char* d = sI + buf * npix;
+#pragma unroll
+        for (int i = 0; i < MAXLD; ++i)
+            if (tid + C1_NT * i < n16) *reinterpret_cast<u32x4*>(d + (tid + C1_NT * i) * 16) = ireg[i];
+    };
+    img_issue(blockIdx.x);
+    // weights: fragment (step s, lane) = filter l31, reduction indices 16 s + 8 half + 0..7 (index (c * 8 + ty) * 8 + tx)
+    for (int f = tid; f < nsteps * 64; f += C1_NT) {
+        const int s = f >> 6, fl = f & 63;
+        const float* src = a.w + (size_t)(fl & 31) * K + s * 16 + (fl >> 5) * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
+        unsigned h[4], m[4], l[4];
+        split_pair(v0.x, v0.y, h[0], m[0], l[0]);
+        split_pair(v0.z, v0.w, h[1], m[1], l[1]);
+        split_pair(v1.x, v1.y, h[2], m[2], l[2]);
+        split_pair(v1.z, v1.w, h[3], m[3], l[3]);
+        char* d = sW + s * 3072 + fl * 16;
+        *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
+        *reinterpret_cast<u32x4*>(d + 1024) = u32x4{m[0], m[1], m[2], m[3]};
+        *reinterpret_cast<u32x4*>(d + 2048) = u32x4{l[0], l[1], l[2], l[3]};
+    }
+    const int rows = a.OH * a.OW, tiles = (rows + 31) / 32;
+    float4 bq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) bq[q] = *reinterpret_cast<const float4*>(a.bias + 8 * q + 4 * half);
+    }
+    img_store(0);
+    if (blockIdx.x + gridDim.x < (unsigned)a.n_img) img_issue(blockIdx.x + gridDim.x);
+    __syncthreads();
+    int buf = 0;
+    for (int img = blockIdx.x; img < a.n_img; img += gridDim.x, buf ^= 1) {
+        const char* im = sI + buf * npix;
+        for (int tp = wave; tp < tiles; tp += C1_NW) {
+            const int m = tp * 32 + l31;
+            const int mm = m < rows ? m : 0;
+            const int oy = mm / a.OW, ox = mm - oy * a.OW;
+            const unsigned off = (unsigned)((oy * a.stride + half) * W + ox * a.stride);     // filter row `half` of a step
+            f32x16 acc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+            const char* wl = sW + lane * 16;
+#pragma unroll 2
+            for (int s = 0; s < nsteps; ++s) {              // step s = plane s / 4, filter rows 2 (s % 4) + half
+                const unsigned po = (unsigned)(((s / (KH / 2)) * H + 2 * (s % (KH / 2))) * W);
+                u32x4 fb[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const u32x4*>(wl + s * 3072 + pl * 1024);
+                const unsigned* q = reinterpret_cast<const unsigned*>(im + po + off);
+                const u32x2 lo = bytes_to_bf16x4(q[0]), hi = bytes_to_bf16x4(q[1]);
+                const u32x4 fa = u32x4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int pl = 2; pl >= 0; --pl) acc = mfma_bf16(fb[pl], fa, acc);   // (split_products<.., 1, 3, true>: l, m, h)
+            }
+            if (m < rows) {                                 // lane = pixel m, channels 8 q + 4 half + 0..3
+                float* dst = a.y + ((size_t)img * rows + m) * N + 4 * half;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float4 v = make_float4(acc[4 * q] * a.scale + bq[q].x, acc[4 * q + 1] * a.scale + bq[q].y,
+                                           acc[4 * q + 2] * a.scale + bq[q].z, acc[4 * q + 3] * a.scale + bq[q].w);
+                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    *reinterpret_cast<float4*>(dst + 8 * q) = v;
+                }
+            }
+        }
+        // the next image's bytes (in flight while this one was computed) -> the other buffer, which every wave left at
+        // the last barrier; the image after that starts its way from memory
+        if (img + (int)gridDim.x < a.n_img) {
+            img_store(buf ^ 1);
+            if (img + 2 * (int)gridDim.x < a.n_img) img_issue(img + 2 * gridDim.x);
+        }
+        __syncthreads();
+    }
+}
+
+bool g_no_img_kernels = false;          // arl_dev_conv_variant(1): the tap-gathering kernels everywhere (A/B, parity tests)
+
+// arl_conv2d_u8_fwd's geometries that take the image-stationary kernel; < 0: not one of them (nothing launched)
+int launch_conv1_img(const unsigned char* obs, const int32_t* idx, float scale, const float* w, const float* bias, float* y,
+                     int64_t batch, int C, int H, int W, int K, int kh, int kw, int stride, int Ho, int Wo, int relu,
+                     hipStream_t s) {
+    const int npix = C * H * W;
+    const size_t lds = (size_t)(C * 64 / 16) * 3072 + 2 * (size_t)npix;
+    if (g_no_img_kernels || !t_ctx.split || K != 32 || kh != 8 || kw != 8 || npix % 16 != 0 || npix > C1_MAX_IMG ||
+        lds > 160 * 1024 || ((uintptr_t)obs & 15) || (W & 3) || (stride & 3) || batch > 0x7fffffff)
+        return -1;
+    Conv1ImgArgs a = {obs, idx, w, bias, y, scale, (int)batch, C, H, W, Ho, Wo, stride, relu};
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_img_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { arl::set_error("hipFuncSetAttribute(conv1_img_kernel): %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int cus = 256;
+    hipLaunchKernelGGL(conv1_img_kernel, dim3((unsigned)(batch < cus ? batch : cus)), dim3(C1_NT), lds, s, a);
+    return arl::check_launch("conv1_img_kernel");
+}
+
+}  // namespace arlc
+
+extern "C" void arl_dev_conv_variant(int32_t v) { arlc::g_no_img_kernels = (v & 1) != 0; }

@@ -506,6 +506,11 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     ARL_ROUTE_SCOPE(geom, nullptr);
     ARL_REQUIRE(arl::aligned16(w) && arl::aligned16(y) && (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN,
                 "16-byte alignment");
+    if (!g_trace) {                                 // 32 filters of 8 x 8: the whole image in LDS (img_conv.hip)
+        rc = launch_conv1_img(obs, idx_or_null, scale, w, bias_or_null, y, g.batch, g.C, g.H, g.W, g.K, g.kh, g.kw, g.stride,
+                              g.Ho, g.Wo, relu, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     GemmArgs a = {};
     fill_u8(&a.g, obs, obs_rows, idx_or_null, scale, g);
     a.M = (int)(g.batch * g.Ho * g.Wo); a.N = g.K; a.K = g.C * g.kh * g.kw;

@@ -19,6 +19,10 @@ void arl_dev_conv_trace_buffer(void* device_u64_or_null);
  * scalar-addressed fast path, so that both are covered by the parity tests.                                        */
 void arl_dev_conv_force_generic(int32_t on);
 
+/* Tests / A-B measurements: bit 0 set = the image-stationary kernels (csrc/img_conv.hip) are not used; the tap-gathering
+ * kernels they replace run instead (same results bit for bit).                                                      */
+void arl_dev_conv_variant(int32_t v);
+
 /* Tests: with ARL_PROMO_ASSOC run the wave suffix scan at EVERY horizon <= 512 (not only where it is the faster
  * kernel).                                                                                                          */
 void arl_dev_scan_force_wave(int32_t on);

@@ -178,3 +178,37 @@ def test_random_geometries(seed):
     assert (dw - w_ref.grad).abs().max().item() <= _tol(w_ref.grad, k_red), case
     want_b = dy.sum(dim=(0, 1, 2))
     assert (db - want_b).abs().max().item() <= _tol(want_b, k_red), case
+
+
+IMG_CASES = [(600, 512, 4, 104, 80, 32, 8, 8, 4),      # the PPO minibatch: two images per workgroup, rows by index
+             (256, None, 4, 104, 80, 32, 8, 8, 4),     # the rollout: one image per workgroup
+             (300, 259, 4, 104, 80, 32, 8, 8, 4),      # three more images than CUs
+             (40, 37, 1, 104, 80, 32, 8, 8, 4),        # one plane (four k-steps), fewer images than CUs
+             (9, 7, 3, 48, 64, 32, 8, 8, 8),           # three planes, stride 8
+             (5, None, 2, 200, 96, 32, 8, 8, 4)]       # a larger image (38 400 bytes, 1 128 output pixels: 36 row tiles)
+
+
+@pytest.mark.parametrize("case", IMG_CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_image_stationary_kernel_is_bit_identical_to_the_tap_gather_kernel(case, relu, precision):
+    """csrc/img_conv.hip (32 filters of 8 x 8: the image in LDS, the weights split once per workgroup) against the kernel
+    it replaces (igemm_body's U8 path, arl_dev_conv_variant(1)): the same piece products in the same order -- equal bit for
+    bit on both split routes; on the fp32 chain both calls take the one old kernel.  And against PyTorch fp32."""
+    from accel_rl_amd import _lib
+    obs, idx, wt, bias, geom = _mk(case, seed=5)
+    ho, wo = _lib.conv_out_hw(geom)
+    outs = []
+    for variant in (0, 1):
+        _lib.load().arl_dev_conv_variant(variant)
+        try:
+            y = torch.full((geom.batch, ho, wo, geom.out_c), float("nan"), device=DEV)
+            _lib.conv2d_u8_fwd(obs, idx, SCALE, wt, bias if relu else None, y, geom, relu)
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().arl_dev_conv_variant(0)
+        outs.append(y)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1])
+    want = F.conv2d(_x(obs, idx), wt, bias if relu else None, stride=case[8])
+    want = (F.relu(want) if relu else want).permute(0, 2, 3, 1)
+    assert (outs[0] - want).abs().max().item() <= _tol(want, wt[0].numel())
