@@ -76,6 +76,12 @@ __device__ __forceinline__ unsigned swz(unsigned L) {
     const unsigned row = L >> 3, col = L & 7;
     return ((row ^ ((row >> 3) & 1)) << 7) + ((col ^ (row & 7)) << 4);
 }
+// V5 layout: blocks of 16 pixels, chunk-major inside a block -- byte offset of 16-byte chunk c of pixel p (CH chunks per
+// pixel): 16 lanes at consecutive pixels (any alignment) read 16 different bank groups; lanes whose tap is outside the
+// image read slot (p & 15) of a ZERO block (p = the pixel index they would have had): the same bank group as inside
+template <int CH> __device__ __forceinline__ unsigned blk16(unsigned p, unsigned c) {
+    return (p >> 4) * (CH * 256) + c * 256 + (p & 15) * 16;
+}
 
 // V3: flattened block schedule (the fragment-ordered weights hold the blocks in consumption order), a THREE-stage weight
 // ring filled two blocks ahead by LDS-DMA, the fragments of block j + 1 (image AND weights) read into registers during
@@ -104,9 +110,10 @@ __global__ __launch_bounds__(512, 2 * WPC) void img_conv_kernel(const ImgConvArg
     const unsigned sW = 3 * plane_bytes;            // LDS byte offset of the ring
     unsigned long long t0 = 0, t1 = 0, t2 = 0, tk0 = 0, tk1 = 0, tk2 = 0;
     if (a.trace) t0 = __builtin_readcyclecounter();
-    if (tid < 3 * CH) {                             // the zero pixel (index npix)
-        const int pl = tid / CH, c = tid % CH;
-        *reinterpret_cast<u32x4*>(sA + pl * plane_bytes + swz(npix * CH + c)) = u32x4{0, 0, 0, 0};
+    const int zero_base = (npix + 15) & ~15;        // the zero block: 16 pixel slots behind the image
+    if (tid < 3 * CH * 16) {
+        const int pl = tid / (CH * 16), c = (tid / 16) % CH;
+        *reinterpret_cast<u32x4*>(sA + pl * plane_bytes + blk16<CH>(zero_base + (tid & 15), c)) = u32x4{0, 0, 0, 0};
     }
     // ---- weight ring: block G of this workgroup's stream is block G % T of the schedule, stage G % 3
     auto w_issue = [&](int blk, unsigned stage_off) {       // role-1 waves: PIECES / 4 pieces each
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(512, 2 * WPC) void img_conv_kernel(const ImgConvArg
                 unsigned h0, m0, l0, h1, m1, l1;
                 split_pair(v.x, v.y, h0, m0, l0);
                 split_pair(v.z, v.w, h1, m1, l1);
-                const unsigned off = swz((unsigned)idx >> 1) + ((idx & 1) << 3);
+                const unsigned off = blk16<CH>((unsigned)idx / (C / 4), ((unsigned)idx % (C / 4)) >> 1) + ((idx & 1) << 3);
                 *reinterpret_cast<u32x2*>(sA + off) = u32x2{h0, h1};
                 *reinterpret_cast<u32x2*>(sA + plane_bytes + off) = u32x2{m0, m1};
                 *reinterpret_cast<u32x2*>(sA + 2 * plane_bytes + off) = u32x2{l0, l1};
@@ -178,14 +185,15 @@ __global__ __launch_bounds__(512, 2 * WPC) void img_conv_kernel(const ImgConvArg
                 int tap = 0, tx = 0, toff = 0, rowoff = 0, cb = 0;
                 Frag F[2];
                 auto read_frags = [&](Frag& f, unsigned stage_off) {
-                    const int pix = ((bad >> tap) & 1) ? npix : pbase + toff;
-                    const unsigned o0 = swz((unsigned)(pix * CH + cb * 4 + half));
+                    const int lin = pbase + toff;
+                    const int pix = ((bad >> tap) & 1) ? zero_base + (lin & 15) : lin;
+                    const unsigned o0 = blk16<CH>((unsigned)pix, (unsigned)(cb * 4 + half));
                     const char* wS = lds + stage_off + (nh * 2) * 3072 + lane * 16;
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
                         for (int pl = 0; pl < 3; ++pl) {
-                            f.a[s][pl] = *reinterpret_cast<const u32x4*>(sA + pl * plane_bytes + (o0 ^ (s << 5)));
+                            f.a[s][pl] = *reinterpret_cast<const u32x4*>(sA + pl * plane_bytes + o0 + s * 512);
                             f.w[s][pl] = *reinterpret_cast<const u32x4*>(wS + s * 3072 + pl * 1024);
                         }
                     if (++cb == CB) {
@@ -341,8 +349,7 @@ int main(int argc, char** argv) {
         ImgConvArgs a = {};
         a.x = dx; a.y = dy; a.bias = db; a.mask = nullptr; a.wf = dwf;
         a.n_img = n_img; a.H = L.H; a.W = L.W; a.OH = OH; a.OW = OW; a.N = L.N; a.relu = 1; a.n_prob = 1;
-        const int chunks = (L.H * L.W + 1) * (L.C / 8);
-        a.plane_bytes = ((chunks + 127) / 128) * 128 * 16;
+        a.plane_bytes = ((L.H * L.W + 15) / 16 + 1) * 16 * (L.C / 8) * 16;
         a.p[0] = ImgProblem{OH * OW, OW, L.stride, -L.pad, -L.pad, L.k, L.k, 1, 1, 0, 0, 0};
         a.n_blocks = K / 32;
         const size_t lds_bytes = 3 * (size_t)a.plane_bytes + 3 * (L.N / 32) * 2 * 3 * 1024;

@@ -1,4 +1,5 @@
-# Regenerates profiles/r02 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root; ~6 GPU-minutes)
+# Regenerates the one-box part of profiles/r03 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
+# ~7 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r03
 set -x
 R=$(pwd); O=$R/gpurun_out/fin; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
@@ -28,7 +29,10 @@ export ARL_CONV_PRECISION=0
 python tools/conv_trace.py 512 2>&1 | grep -v amdgpu.ids > $O/conv_trace.txt
 python tools/learner_probe.py 2>&1 | grep minibatch > $O/learner_probe.txt
 unset ARL_CONV_PRECISION
-python tools/env_step_probe.py 256 2>&1 | grep dbg > $O/env_step_probe.txt; python tools/env_step_probe.py 2048 2>&1 | grep dbg >> $O/env_step_probe.txt
+(for n in 256 1024 4096 16384 32768; do python tools/env_step_probe.py $n 2>&1 | grep dbg; done) > $O/env_step_probe.txt
+bash tools/env_step_pmc.sh 32768 gpurun_out/fin > /dev/null 2>&1
+python tools/batch_sweep.py 2>&1 | grep "^spec" > $O/batch_sweep_passes.txt
+bash tools/sync_ab.sh gpurun_out/fin > /dev/null 2>&1
 timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/null | tail -n 1 > $O/bench_a2c1024.json
 timeout 300 python bench.py --scaling strong --total-envs 2048 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > $O/bench_strong_2048_n1.json
 timeout 300 python bench.py --workload catdqn --steps 30 --warmup 5 --dqn-batch 512 2>/dev/null | tail -n 1 > $O/bench_catdqn_batch512.json

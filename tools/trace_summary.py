@@ -23,9 +23,13 @@ rows = [r for r in rows if r[0] >= a and r[1] <= b]
 span = rows[-1][1] - rows[0][0]
 busy, last_end = 0, rows[0][0]
 agg = collections.defaultdict(lambda: [0, 0])
+gap = collections.defaultdict(lambda: [0, 0])       # idle time in front of a kernel's launches (nothing else running)
 for s, e, n in rows:
     agg[n][0] += e - s
     agg[n][1] += 1
+    if s > last_end:
+        gap[n][0] += s - last_end
+        gap[n][1] += 1
     if e > last_end:
         busy += e - max(s, last_end)
         last_end = e
@@ -33,3 +37,6 @@ print("window %.1f ms, busy %.1f ms (%.1f%%), %d launches" % (span / 1e6, busy /
 tot = sum(v[0] for v in agg.values())
 for n, (d, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:top]:
     print("%6.2f%% %9.3f ms %7d calls %9.1f us/call  %s" % (100. * d / tot, d / 1e6, c, d / c / 1e3, n[:120]))
+print("idle in front of (top 8):")
+for n, (d, c) in sorted(gap.items(), key=lambda kv: -kv[1][0])[:8]:
+    print("        %9.3f ms over %5d gaps = %6.1f us each, %d launches  %s" % (d / 1e6, c, d / c / 1e3, agg[n][1], n[:100]))
