@@ -13,6 +13,7 @@ import torch
 from accel_rl_amd import _lib
 from accel_rl_amd.algos.base import RLAlgorithm
 from accel_rl_amd.buffers import buffer_with_segs_view
+from accel_rl_amd.util import logger
 from accel_rl_amd.util.misc import graph_capture_mode
 from accel_rl_amd.util.quick_args import save_args
 import numpy as np
@@ -114,9 +115,22 @@ class AdvActorCriticBase(RLAlgorithm):
             if self._warm_calls <= 2:
                 return self._device_optimize(itr, samples_data)
             torch.cuda.synchronize(self.policy.device)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
-                self._graph_out = self._device_optimize(itr, samples_data)
+            graph, failure = torch.cuda.CUDAGraph(), None
+            try:
+                with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
+                    self._graph_out = self._device_optimize(itr, samples_data)
+            except Exception as e:          # single GPU: a bug, raise.  N > 1: every rank must take the same road
+                if not sync:
+                    raise
+                failure = e
+            if sync and not self.optimizer.ranks_agree(failure is None):
+                # a rank could not capture its collectives: ALL ranks run the minibatches eagerly from here on (the
+                # structure of round 2, same sums in the same order; tests/test_sync_gpu.py runs both)
+                logger.log("WARNING: hipGraph capture of the synchronous learner failed on a rank (%r): eager "
+                           "minibatches from here on" % (failure,))
+                self.optimizer.graph_collectives = False
+                torch.cuda.synchronize(self.policy.device)
+                return self._device_optimize(itr, samples_data)
             self._graph, self._graph_samples = graph, samples_data
         assert samples_data is self._graph_samples, "the sampler must hand over the same buffer"
         self._graph.replay()

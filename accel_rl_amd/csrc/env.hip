@@ -538,6 +538,11 @@ __global__ __launch_bounds__(256) void env_step_kernel(
         // this env's flag for the next launch: recomputed if it stepped, carried over if it sat this one out
         st.next_reset[(int64_t)(fpar ^ 1) * st.n_env + e] = is_active ? (uint8_t)will_reset(g, o.s, max_path_length)
                                                                      : carried;
+        // the ranks above came from the PREVIOUS launch's forecast, the reset itself from this launch's rules: they
+        // agree as long as termination does not depend on the action and consecutive launches use one length limit.
+        // A disagreement would misorder the streams' no-op draws silently -- count it instead (epoch[2], sticky; the
+        // sampler raises when its mirror of the block shows a non-zero count)
+        if (mid_batch_reset && is_active && (o.reset_flag != 0) != (carried != 0)) atomicAdd(st.epoch + 2, 1);
     }
     if (o.mode != MODE_SKIP) {
         if (fast) fp.store(g, out0, out1, tid);

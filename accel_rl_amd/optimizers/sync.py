@@ -7,6 +7,7 @@ sync/sync_a2c_optimizer.py:13-59, sync/sync_ppo_optimizer.py:13-78; order
 "avg, then norm/clip" from sync_ppo_optimizer.py:27-34 / optimizers/util.py:63-67.
 The collective is torch.distributed (backend "nccl" == RCCL on ROCm; "gloo" for
 the CPU tests of the protocol)."""
+import torch
 import torch.distributed as dist
 
 from accel_rl_amd.optimizers.single import A2cOptimizer, PpoOptimizer
@@ -30,6 +31,14 @@ class _SyncMixin(object):
         if not (self._n_gpu > 1 or self._force_collective):
             return True                     # no collective is issued at all
         return dist.is_initialized() and dist.get_backend(self._comm) == "nccl"
+
+    def ranks_agree(self, ok):
+        """True iff `ok` holds on every rank (one tiny eager all-reduce; no collective when there is one rank)."""
+        if not (self._n_gpu > 1 and dist.is_initialized()):
+            return bool(ok)
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=self._target.flat_grads.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._comm)
+        return int(flag.item()) == 0
 
     def init_comm(self, gpu_comm, rank, n_gpu):
         """`gpu_comm`: a torch.distributed process group (None = default group)."""

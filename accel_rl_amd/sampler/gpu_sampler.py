@@ -38,11 +38,11 @@ NOOP_RING = 4096
 
 
 def _packed_block(spec, device, pinned=False):
-    """One zeroed byte block holding every (name, shape, dtype) of `spec` at 16-byte-aligned offsets;
-    returns (block, {name: typed view})."""
+    """One zeroed byte block holding every (name, shape, dtype) of `spec` at 128-byte-aligned offsets (the arrival
+    tickets of arl_env_step sit on a cache line each only if `epoch` starts on one); returns (block, {name: typed view})."""
     offsets, total = [], 0
     for _, shape, dtype in spec:
-        total = (total + 15) // 16 * 16
+        total = (total + 127) // 128 * 128
         offsets.append(total)
         total += int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
     block = torch.zeros(total, dtype=torch.uint8, device=device)
@@ -387,6 +387,11 @@ class GpuVecSampler(BaseMbSampler):
         read from the pinned mirrors; tops the no-op ring up from the same snapshot."""
         self._batch_event.synchronize()
         h = self._host
+        if int(h.epoch[2]):
+            raise RuntimeError("arl_env_step: %d mid-batch resets were not announced by the previous launch's forecast "
+                               "(st.next_reset): the start no-op draws of their RNG streams are misordered.  The length "
+                               "limit changed between launches, or the emulator's termination depends on the action"
+                               % int(h.epoch[2]))
         count = min(int(h.done_count[0]), self._state.done_capacity)
         infos = []
         if count:

@@ -156,7 +156,10 @@ typedef struct arl_env_state {
     const uint8_t* noop_ring;   /* u8[n_streams][noop_ring_len] pre-drawn counts */
     int64_t* noop_cursor;       /* i64[2][n_streams], ping-pong by epoch parity  */
     int32_t* epoch;             /* i32[ARL_EPOCH_WORDS], zero-initialised: [0] number of env launches so far;
-                                 * the rest are arl_env_step's arrival tickets ([1] top, [32 (s + 1)] shard s) */
+                                 * [2] arl_env_step's count of resets its one-launch-ahead forecast (next_reset) did
+                                 * not announce -- must stay 0, a caller should check it once per batch;
+                                 * the rest are arl_env_step's arrival tickets ([1] top, [32 (s + 1)] shard s: one
+                                 * 128-byte line each when the array is 128-byte aligned) */
     int32_t  noop_ring_len;
     int32_t  envs_per_stream;
     /* completed-trajectory records (the reference's traj_infos_queue,

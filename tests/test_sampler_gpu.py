@@ -252,6 +252,25 @@ def test_decorrelation_runs_and_desynchronises():
     assert buf.observations.shape == (64 * 5, 4, 104, 80)
 
 
+def test_unannounced_mid_batch_reset_is_reported():
+    """arl_env_step ranks a stream's resets from the previous launch's forecast; a reset the forecast did not announce
+    (here: the length limit drops between two eager batches) would misorder the stream's no-op draws -- the kernel
+    counts it (epoch[2]) and the sampler refuses the batch."""
+    rs = np.random.RandomState(2)
+    p = np.full((64, 4), 0.25, np.float32)
+    smp = make_gpu_sampler("breakout", 5, 4, 4, 5, True, 1000, dict(), (p, rs.randn(64).astype(np.float32)), 0.99, False)
+    buf, infos = smp.obtain_samples(0)
+    list(infos)                                                   # resolves the batch: nothing to report
+    assert int(smp._st.epoch[2].item()) == 0
+    smp.max_path_length = 3                                       # every env is already longer: all reset at once
+    buf, infos = smp.obtain_samples(1)
+    assert int(smp._st.epoch[2].item()) > 0
+    with pytest.raises(RuntimeError, match="not announced"):
+        len(infos)
+    smp._pending = None
+    smp.shutdown()
+
+
 # ---- SURVEY 8(f2): evaluation sampler + AccelRLEval ------------------------------------------
 
 @pytest.mark.parametrize("use_graph", [False, True])

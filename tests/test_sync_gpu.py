@@ -107,7 +107,15 @@ def _rccl_world1(port, out_dir, capture=True):
                         affinities=dict(gpu=0), log_interval_steps=320, **kw)
         if tag == "sync":
             algo.optimizer._force_collective = True
-            algo.optimizer.graph_collectives = capture
+            algo.optimizer.graph_collectives = bool(capture)
+            if capture == "fails":                     # a rank whose collective cannot be captured
+                issue = algo.optimizer._share_grad_async
+
+                def refusing(*a, **k):
+                    if torch.cuda.is_current_stream_capturing():
+                        raise RuntimeError("injected: no collectives under capture")
+                    return issue(*a, **k)
+                algo.optimizer._share_grad_async = refusing
         n_itr = runner.startup()
         assert algo.optimizer.parallelism_tag == ("synchronous" if tag == "sync" else "single")
         norms = []
@@ -126,11 +134,12 @@ def _rccl_world1(port, out_dir, capture=True):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("capture", [True, False], ids=["one hipGraph", "eager"])
+@pytest.mark.parametrize("capture", [True, False, "fails"], ids=["one hipGraph", "eager", "capture fails"])
 def test_rccl_backend_forced_collective_matches_single_gpu(tmp_path, capture):
     """the path that ships for N > 1 (backend `nccl` = RCCL, asynchronous all-reduce of
     the two bucket slices, optimiser step waiting on RCCL's stream) exercised on the device -- as eager minibatches, and
     with the WHOLE optimize_policy call, RCCL's all-reduces included, captured in one hipGraph (the default on `nccl`);
+    "capture fails": a collective that refuses to be captured must leave the learner on the eager road with the same bits;
     reference: accel_rl/optimizers/sync/base.py:22-24, sync_ppo_optimizer.py:27-34,56-78."""
     ctx = mp.get_context("spawn")
     p = ctx.Process(target=_rccl_world1, args=(_free_port(), str(tmp_path), capture))
@@ -139,7 +148,7 @@ def test_rccl_backend_forced_collective_matches_single_gpu(tmp_path, capture):
     assert p.exitcode == 0, p.exitcode
     r = np.load(os.path.join(str(tmp_path), "rccl.npz"))
     assert 0 < int(r["sync_split"]) < r["sync_final"].size            # both bucket slices are non-empty
-    assert int(r["sync_captured"]) == int(capture) and int(r["single_captured"]) == 1
+    assert int(r["sync_captured"]) == int(capture is True) and int(r["single_captured"]) == 1
     assert r["sync_norms"].shape == (6, 4) and np.isfinite(r["sync_norms"]).all()
     np.testing.assert_array_equal(r["sync_norms"], r["single_norms"])
     np.testing.assert_array_equal(r["sync_final"], r["single_final"])
