@@ -45,6 +45,9 @@ def _optimizer_worker(rank, world, port, out):
         want = torch.arange(10.) * sum(r + 1 for r in range(world))
         assert torch.equal(opt._target.flat_grads, want)
         assert opt._avg_factor() == 1.0 / world             # applied AFTER the sum (sync/base.py:14-16)
+        # the consensus the learner takes before it commits to a captured graph: one rank's failure is everybody's
+        assert opt.ranks_agree(True) is True
+        assert opt.ranks_agree(rank != 1) is False
     out.put((rank, "ok"))
     dist.barrier()
     dist.destroy_process_group()
