@@ -13,7 +13,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define VSUBF(x) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(x) : "v"(fy))
 #define VPERM(x) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x) : "v"(y), "v"(sel))
 template <int MODE>
-__global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, float fb, int y) {
+__global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, float fb, int y, const float4* src) {
     __shared__ float4 lds[2048];
     f32x16 c0, c1, c2, c3;
     for (int v = 0; v < 16; ++v) { c0[v] = 0.f; c1[v] = 0.f; c2[v] = 0.f; c3[v] = 0.f; }
@@ -23,6 +23,9 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
     lds[threadIdx.x] = make_float4(fa, fb, fa, fb);
     __syncthreads();
     float4 f0 = make_float4(0, 0, 0, 0), f1 = f0, f2 = f0;
+    // vector-memory modes: a wave's load is 1 KB contiguous (14, 15: every 4 / 8 MFMAs), one 128-byte line per lane (16), or an
+    // LDS-DMA of 1 KB (17); the source is a 1 MB buffer that stays in L2
+    const float4* gsrc = src + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255) * 256 + (MODE == 16 ? (threadIdx.x & 63) * 8 : (threadIdx.x & 63));
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -46,6 +49,13 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
             if (MODE == 4 || MODE == 5) {
                 asm volatile("ds_read_b128 %0, %1" : "=v"(f0) : "v"((threadIdx.x & 63) * 16 + r * 1024));
             }
+            if (MODE == 14 || (MODE == 15 && r == 0) || MODE == 16) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f0) : "v"(gsrc + (MODE == 16 ? 0 : 64 * r)) : "memory");
+            }
+            if (MODE == 17) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + 64 * r),
+                                                 (__attribute__((address_space(3))) void*)(lds + (threadIdx.x >> 6) * 64 + 1024), 16, 0, 0);
+            }
             MFB(c2);
             if (MODE == 1) { VADD(x0); VADD(x1); VADD(x2); VADD(x3); }
             if (MODE == 2) { VADD(x0); VADD(x1); VADD(x2); VADD(x3); VADD(x0); VADD(x1); VADD(x2); VADD(x3); }
@@ -62,6 +72,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
             }
         }
         if (MODE == 4 || MODE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (MODE >= 14 && MODE <= 17) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float s = x0 + x1 + x2 + x3 + f0.x + f1.y + f2.z + fx0 + fx1;
     for (int v = 0; v < 16; ++v) s += c0[v] + c1[v] + c2[v] + c3[v];
@@ -70,10 +81,12 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
 template <int MODE> void run(const char* what, int blocks, int iters) {
     float* out; (void)hipMalloc(&out, blocks * 256 * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    probe<MODE><<<blocks, 256>>>(out, iters, 1.f, 1.f, 7);
+    static float4* src = nullptr;
+    if (!src) { (void)hipMalloc(&src, 2 << 20); (void)hipMemset(src, 0, 2 << 20); }
+    probe<MODE><<<blocks, 256>>>(out, iters, 1.f, 1.f, 7, src);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
-    probe<MODE><<<blocks, 256>>>(out, iters, 1.f, 1.f, 7);
+    probe<MODE><<<blocks, 256>>>(out, iters, 1.f, 1.f, 7, src);
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     double macs_per_mfma = MODE == 9 ? 2048.0 : 16384.0;
@@ -98,6 +111,10 @@ int main() {
         run<11>("bf16 mfma, two accumulators taking turns", blocks, 2000);
         run<12>("one accumulator + 4 vector instructions per mfma", blocks, 2000);
         run<13>("two accumulators + 4 vector instructions per mfma", blocks, 2000);
+        run<14>("bf16 mfma + 1 global_load_dwordx4 (1 KB row) per 4 mfma", blocks, 2000);
+        run<15>("bf16 mfma + 1 global_load_dwordx4 (1 KB row) per 8 mfma", blocks, 2000);
+        run<16>("bf16 mfma + 1 global_load_dwordx4 (line per lane) per 4", blocks, 2000);
+        run<17>("bf16 mfma + 1 LDS-DMA of 1 KB per 4 mfma", blocks, 2000);
     }
     return 0;
 }

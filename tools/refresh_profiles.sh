@@ -15,6 +15,8 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pD -o w -- py
 cp $(find /tmp/pD -name "*counter_collection.csv" | head -n 1) $O/gae_pmc_WRITE_SIZE.csv
 python $R/tools/gae_pmc_traffic.py $O/gae_pmc_FETCH_SIZE.csv $O/gae_pmc_WRITE_SIZE.csv > $O/gae_pmc_traffic.json
 cp $O/gae_pmc_traffic.json $R/profiles/gae_pmc_traffic.json     # bench.py reads it (roofline.traffic; keyed by scan.hip's sha1)
+cd $R; bash tools/env_step_pmc.sh 32768 gpurun_out/fin > /dev/null 2>&1
+cp $O/env_step_pmc.json $R/profiles/env_step_pmc.json     # bench.py reads it (env_step@sweep traffic; keyed by env.hip's sha1)
 cd $R; timeout 900 python bench.py > $O/bench.log 2>$O/bench.err; tail -n 1 $O/bench.log > $O/bench.json
 cd /tmp
 cd $R; timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d /tmp/pE -o m -- python tools/conv_bench.py 512 o > $O/mfma.log 2>&1
@@ -30,7 +32,6 @@ python tools/conv_trace.py 512 2>&1 | grep -v amdgpu.ids > $O/conv_trace.txt
 python tools/learner_probe.py 2>&1 | grep minibatch > $O/learner_probe.txt
 unset ARL_CONV_PRECISION
 (for n in 256 1024 4096 16384 32768; do python tools/env_step_probe.py $n 2>&1 | grep dbg; done) > $O/env_step_probe.txt
-bash tools/env_step_pmc.sh 32768 gpurun_out/fin > /dev/null 2>&1
 python tools/batch_sweep.py 2>&1 | grep "^spec" > $O/batch_sweep_passes.txt
 bash tools/sync_ab.sh gpurun_out/fin > /dev/null 2>&1
 timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/null | tail -n 1 > $O/bench_a2c1024.json
