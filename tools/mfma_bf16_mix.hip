@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
     float4 f0 = make_float4(0, 0, 0, 0), f1 = f0, f2 = f0;
     // vector-memory modes: a wave's load is 1 KB contiguous (14, 15: every 4 / 8 MFMAs), one 128-byte line per lane (16), or an
     // LDS-DMA of 1 KB (17); the source is a 1 MB buffer that stays in L2
-    const float4* gsrc = src + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255) * 256 + (MODE == 16 ? (threadIdx.x & 63) * 8 : (threadIdx.x & 63));
+    const float4* gsrc = src + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & 255) * 256 + (MODE == 16 ? (threadIdx.x & 63) * 8 : (MODE == 18 || MODE == 19) ? (threadIdx.x & 31) * 8 + ((threadIdx.x >> 5) & 1) : (threadIdx.x & 63));
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
             if (MODE == 4 || MODE == 5) {
                 asm volatile("ds_read_b128 %0, %1" : "=v"(f0) : "v"((threadIdx.x & 63) * 16 + r * 1024));
             }
-            if (MODE == 14 || (MODE == 15 && r == 0) || MODE == 16) {
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f0) : "v"(gsrc + (MODE == 16 ? 0 : 64 * r)) : "memory");
+            if (MODE == 14 || (MODE == 15 && r == 0) || MODE == 16 || MODE == 18 || (MODE == 19 && r == 0)) {
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f0) : "v"(gsrc + (MODE == 16 || MODE == 18 || MODE == 19 ? 2 * r : 64 * r)) : "memory");
             }
             if (MODE == 17) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + 64 * r),
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float fa, fl
             }
         }
         if (MODE == 4 || MODE == 5) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (MODE >= 14 && MODE <= 17) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MODE >= 14 && MODE <= 19) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     float s = x0 + x1 + x2 + x3 + f0.x + f1.y + f2.z + fx0 + fx1;
     for (int v = 0; v < 16; ++v) s += c0[v] + c1[v] + c2[v] + c3[v];
@@ -115,6 +115,8 @@ int main() {
         run<15>("bf16 mfma + 1 global_load_dwordx4 (1 KB row) per 8 mfma", blocks, 2000);
         run<16>("bf16 mfma + 1 global_load_dwordx4 (line per lane) per 4", blocks, 2000);
         run<17>("bf16 mfma + 1 LDS-DMA of 1 KB per 4 mfma", blocks, 2000);
+        run<18>("bf16 mfma + 1 load, lane = (row, half) (32 lines) per 4", blocks, 2000);
+        run<19>("bf16 mfma + 1 load, lane = (row, half) (32 lines) per 8", blocks, 2000);
     }
     return 0;
 }
