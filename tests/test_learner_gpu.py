@@ -385,6 +385,48 @@ def test_explicit_backward_matches_autograd(kind):
             (kind, use_valids, (got - want).abs().max().item(), scale)
 
 
+@pytest.mark.parametrize("kind,use_valids", [("ppo", False), ("a2c", True)])
+def test_minibatch_walked_in_passes_is_the_one_pass_gradient(kind, use_valids):
+    """A minibatch of three or more cache-sized passes (the strong-scaling bench's 4096 rows, config 3's 5120-row batch) is
+    walked in passes whose gradients and loss sums add up in a fixed order (AtariCnnPolicy.rows_per_pass): the same mean
+    gradient as ONE pass over all rows -- every pass normalised by the WHOLE minibatch's count, also with valids --, the
+    split hook called once at the end, and the same bits from call to call."""
+    n_env, horizon = 32, 5
+    policy, algo, buf, spec = make(kind, n_env, horizon, False)
+    rs = np.random.RandomState(9)
+    fill(buf, policy, rs, n_env, horizon)
+    n = n_env * horizon
+    adv, ret = torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    idx = torch.from_numpy(rs.permutation(n)[:112].astype(np.int32)).to(DEV)          # 3.5 passes of 32 rows
+    valids = torch.from_numpy((rs.rand(n) < 0.8).astype(np.int8)).to(DEV)
+    lr_mult = torch.full((1,), 0.7, device=DEV)
+    inv = (1. / valids[idx.long()].sum(dtype=torch.float32)).reshape(1) if use_valids else None
+    calls = []
+    mb = dict(observations=buf.observations, idx=idx, actions=buf.actions, advantages=adv, returns=ret,
+              old_prob=buf.agent_infos["prob"] * 0.9 + 0.1 / 6, valids=valids if use_valids else None,
+              split_hook=lambda: calls.append(policy.flat_grads.clone()))
+    kid, v_c = (1, 1.0) if kind == "ppo" else (0, 0.25)
+    policy.max_rows_per_pass = None                                    # one pass whatever the size
+    loss_one = policy.loss_and_grads(mb, kid, 0.2, v_c, 0.01, lr_mult, inv).clone()
+    grad_one = policy.flat_grads.clone()
+    del calls[:]
+    policy.max_rows_per_pass = 32
+    assert policy.rows_per_pass() == 32
+    loss_p = policy.loss_and_grads(mb, kid, 0.2, v_c, 0.01, lr_mult, inv).clone()
+    grad_p = policy.flat_grads.clone()
+    assert len(calls) == 1 and torch.equal(calls[0], grad_p)           # the hook saw the finished bucket, once
+    scale = grad_one.abs().max().item()
+    assert torch.allclose(loss_p, loss_one, rtol=1e-5, atol=1e-6), (loss_p, loss_one)
+    assert torch.allclose(grad_p, grad_one, rtol=1e-4, atol=1e-6 * max(scale, 1e-3)), (grad_p - grad_one).abs().max().item()
+    loss_q = policy.loss_and_grads(mb, kid, 0.2, v_c, 0.01, lr_mult, inv)
+    assert torch.equal(loss_q, loss_p) and torch.equal(policy.flat_grads, grad_p)      # fixed order: deterministic
+    policy.max_rows_per_pass = 64                                      # 112 rows < 3 x 64: one pass again
+    policy.loss_and_grads(mb, kid, 0.2, v_c, 0.01, lr_mult, inv)
+    assert torch.equal(policy.flat_grads, grad_one)
+    policy.max_rows_per_pass = "auto"
+    assert policy.rows_per_pass() == 2304 and policy.rows_per_pass() % 256 == 0        # spec 0 at 4 x 104 x 80
+
+
 @pytest.mark.parametrize("kind", ["ppo", "a2c"])
 def test_fused_losses_match_the_algorithm_formulas(kind):
     """The algorithm's `_losses` (HIP forward + fused head kernel + HIP backward, selected by `loss_kind`) against
