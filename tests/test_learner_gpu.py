@@ -259,13 +259,25 @@ def test_graph_learner_is_bit_identical_to_eager(case):
     assert twins[1][1]._graph is not None and twins[0][1]._graph is None
 
 
-def test_corun_update_is_bit_identical_to_the_plain_update():
+@pytest.mark.parametrize("hooks", ["every minibatch", "not from every minibatch"])
+def test_corun_update_is_bit_identical_to_the_plain_update(hooks):
     """PPO at the headline shape: the first dense layer's update riding inside conv 3's data-gradient launch (the
     default) against the one-launch update at the end of the step -- parameters and optimiser slots bit-identical after
-    every call, logged gradient norms equal to f32 round-off."""
+    every call, logged gradient norms equal to f32 round-off.  "not from every minibatch": a backward pass that does not
+    hand the range over (every second one here, never the call's first, which decides the split) gets the range's update
+    as a launch of its own (optimizers/base.py `_apply_update`) -- the call stays consistent, same bits."""
     kind, n_env, kw = LEARNER_CASES["ppo_config2"]
     twins = [make(kind, n_env, 5, False, **kw) for _ in range(2)]
     twins[1][1].optimizer.corun_update = False
+    if hooks != "every minibatch":
+        inner, seen = twins[0][0].loss_and_grads, [0]
+
+        def forgetful(mb, *a, **k):
+            seen[0] += 1
+            if seen[0] % 8 not in (1, 3, 6):            # 8 minibatches per call; the first always hands over
+                mb = dict((key, v) for key, v in mb.items() if key != "dense_w_hook")
+            return inner(mb, *a, **k)
+        twins[0][0].loss_and_grads = forgetful
     rs = np.random.RandomState(2)
     for itr in range(2):
         fill(twins[0][2], twins[0][0], rs, n_env, 5)
