@@ -300,6 +300,39 @@ def test_corun_update_is_bit_identical_to_the_plain_update(hooks):
     assert twins[0][1].optimizer._hole_count == 6912 * 512 and twins[1][1].optimizer._hole_count == 0
 
 
+@pytest.mark.parametrize("use_graph", [False, True], ids=["eager", "hipGraph"])
+def test_step_counter_written_between_calls_is_honoured(use_graph):
+    """Lasagne's t lives in the optimiser's step_count; the one-pass update keeps a ping-pong copy of it during a call.
+    A write from outside between two calls (a restored checkpoint) must be what the next call starts from -- and what
+    its bias correction uses -- not the copy the previous call left behind (optimizers/base.py)."""
+    policy, algo, buf, _ = make("ppo", 16, 5, use_graph)
+    opt = algo.optimizer
+    rs = np.random.RandomState(4)
+    per_call = None
+    for itr in range(4):                                    # the graph is captured in the third call
+        fill(buf, policy, rs, 16, 5)
+        algo.optimize_policy(itr, buf)
+        torch.cuda.synchronize()
+        t = int(opt._step_count.item())
+        per_call = per_call or t
+        assert t == per_call * (itr + 1)
+    twin_params = policy.flat_params.clone()
+    slots = (opt._slot0.clone(), opt._slot1.clone())
+    fill(buf, policy, rs, 16, 5)
+    state = np.random.get_state()
+    outs = []
+    for start in (1000., float(4 * per_call)):              # a restored counter / the counter as the calls left it
+        policy.flat_params.copy_(twin_params)
+        opt._slot0.copy_(slots[0]); opt._slot1.copy_(slots[1])
+        opt._step_count.fill_(start)
+        np.random.set_state(state)
+        algo.optimize_policy(4, buf)
+        torch.cuda.synchronize()
+        assert opt._step_count.item() == start + per_call
+        outs.append(policy.flat_params.clone())
+    assert not torch.equal(outs[0], outs[1])                # adam's bias correction saw the other t
+
+
 def test_param_vector_roundtrip_and_reference_layout():
     policy, algo, buf, spec = make("ppo", 4, 5, False, spec_id=1)
     flat = policy.get_param_values()
