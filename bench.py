@@ -752,13 +752,21 @@ def main():
     runner.shutdown()
     if dist.is_initialized():
         dist.barrier()
-        dist.destroy_process_group()
     if rank == 0:
         # RCCL writes its version banner to C stdout (block-buffered when piped): flush it first so that
         # the JSON line is the LAST line this process prints
         import ctypes
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
+    if dist.is_initialized():
+        # The line is out; the teardown of the process group (communicators that captured graphs still refer to, a
+        # watchdog thread) gets a deadline so that it can neither hold the line back nor hang the launcher
+        import threading
+        t = threading.Timer(30.0, lambda: os._exit(0))
+        t.daemon = True
+        t.start()
+        dist.destroy_process_group()
+        t.cancel()
 
 
 if __name__ == "__main__":

@@ -12,6 +12,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from mp_util import leave_group, run_ranks
+
 
 def _free_port():
     s = socket.socket()
@@ -49,20 +51,15 @@ def _optimizer_worker(rank, world, port, out):
         assert opt.ranks_agree(True) is True
         assert opt.ranks_agree(rank != 1) is False
     out.put((rank, "ok"))
-    dist.barrier()
-    dist.destroy_process_group()
+    leave_group(dist)
 
 
 def test_sync_optimizer_allreduce_world2():
     ctx = mp.get_context("spawn")
     out, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_optimizer_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert sorted(out.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+    codes, got = run_ranks(ctx, _optimizer_worker, [(r, 2, port, out) for r in range(2)], 120,
+                           before_join=lambda: sorted(out.get(timeout=110) for _ in range(2)))
+    assert codes == [0, 0] and got == [(0, "ok"), (1, "ok")], (codes, got)
 
 
 def _overlap_worker(rank, world, port, out):
@@ -105,20 +102,15 @@ def _overlap_worker(rank, world, port, out):
     firsts = sorted(set(f for f, _ in taps))
     assert firsts == [0, split]
     out.put((rank, "ok"))
-    dist.barrier()
-    dist.destroy_process_group()
+    leave_group(dist)
 
 
 def test_overlapped_tail_head_allreduce_world2():
     ctx = mp.get_context("spawn")
     out, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert sorted(out.get(timeout=5) for _ in range(2)) == [(0, "ok"), (1, "ok")]
+    codes, got = run_ranks(ctx, _overlap_worker, [(r, 2, port, out) for r in range(2)], 120,
+                           before_join=lambda: sorted(out.get(timeout=110) for _ in range(2)))
+    assert codes == [0, 0] and got == [(0, "ok"), (1, "ok")], (codes, got)
 
 
 # ----------------------------------------------------------------------------- runner
@@ -211,20 +203,15 @@ def _runner_worker(rank, world, port, out):
                  calls=algo.calls, params=policy.flat_params.numpy().copy(),
                  trajs=runner._cum_completed_trajs,
                  tab=getattr(runner, "last_tabular", None) and dict(runner.last_tabular)))
-    dist.barrier()
-    dist.destroy_process_group()
+    leave_group(dist)
 
 
 def test_sync_runner_world2():
     ctx = mp.get_context("spawn")
     out, port = ctx.Queue(), _free_port()
-    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted((out.get(timeout=180) for _ in range(2)), key=lambda d: d["rank"])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    codes, res = run_ranks(ctx, _runner_worker, [(r, 2, port, out) for r in range(2)], 240,
+                           before_join=lambda: sorted((out.get(timeout=180) for _ in range(2)), key=lambda d: d["rank"]))
+    assert codes == [0, 0], codes
     r0, r1 = res
     assert (r0["seed"], r1["seed"]) == (7, 107)                  # seed + 100*rank (multigpu_rl_base.py:28)
     assert (r0["sampler_seed"], r1["sampler_seed"]) == (8, 108)  # sampler gets seed + 1

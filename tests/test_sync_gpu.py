@@ -11,6 +11,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
+from mp_util import leave_group, run_ranks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -55,19 +57,14 @@ def _rank(rank, world, port, out_dir):
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), init=init, final=policy.get_param_values(), obs0=obs0,
              n_itr=n_itr, tag=np.array(algo.optimizer.parallelism_tag))
     runner.shutdown()
-    dist.barrier()
-    dist.destroy_process_group()
+    leave_group(dist)
 
 
 def test_two_ranks_stay_bit_identical(tmp_path):
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes, _ = run_ranks(ctx, _rank, [(r, 2, port, str(tmp_path)) for r in range(2)], 300)
+    assert codes == [0, 0], codes
     a, b = (np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(2))
     assert str(a["tag"]) == "synchronous" and int(a["n_itr"]) == int(b["n_itr"]) == 5      # 1280 / (160 x 2 ranks) + 1
     np.testing.assert_array_equal(a["init"], b["init"])                   # rank 0's parameters were broadcast
@@ -130,8 +127,7 @@ def _rccl_world1(port, out_dir, capture=True):
         results[tag + "_captured"] = np.int64(algo._graph is not None)
         runner.shutdown()
     np.savez(os.path.join(out_dir, "rccl.npz"), **results)
-    dist.barrier()
-    dist.destroy_process_group()
+    leave_group(dist)
 
 
 @pytest.mark.parametrize("capture", [True, False, "fails"], ids=["one hipGraph", "eager", "capture fails"])
@@ -142,10 +138,8 @@ def test_rccl_backend_forced_collective_matches_single_gpu(tmp_path, capture):
     "capture fails": a collective that refuses to be captured must leave the learner on the eager road with the same bits;
     reference: accel_rl/optimizers/sync/base.py:22-24, sync_ppo_optimizer.py:27-34,56-78."""
     ctx = mp.get_context("spawn")
-    p = ctx.Process(target=_rccl_world1, args=(_free_port(), str(tmp_path), capture))
-    p.start()
-    p.join(600)
-    assert p.exitcode == 0, p.exitcode
+    codes, _ = run_ranks(ctx, _rccl_world1, [(_free_port(), str(tmp_path), capture)], 600)
+    assert codes == [0], codes
     r = np.load(os.path.join(str(tmp_path), "rccl.npz"))
     assert 0 < int(r["sync_split"]) < r["sync_final"].size            # both bucket slices are non-empty
     assert int(r["sync_captured"]) == int(capture is True) and int(r["single_captured"]) == 1
@@ -220,8 +214,7 @@ def _rank_mean_grad(rank, world, port, out_dir, kind):
                 out["%s_%d" % (key, k)] = val
     np.savez(os.path.join(out_dir, "mean_%s_rank%d.npz" % (kind, rank)), **out)
     runner.shutdown()
-    dist.barrier()
-    dist.destroy_process_group()
+    leave_group(dist)
 
 
 @pytest.mark.parametrize("kind", ["ppo", "a2c"])
@@ -234,12 +227,8 @@ def test_two_rank_update_is_the_oracle_step_on_the_mean_gradient(tmp_path, kind)
     from oracle import ref_port as P
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_rank_mean_grad, args=(r, 2, port, str(tmp_path), kind)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    codes, _ = run_ranks(ctx, _rank_mean_grad, [(r, 2, port, str(tmp_path), kind) for r in range(2)], 300)
+    assert codes == [0, 0], codes
     a, b = (np.load(os.path.join(str(tmp_path), "mean_%s_rank%d.npz" % (kind, r))) for r in range(2))
     n = int(a["n"])
     assert n == int(b["n"]) == (20 if kind == "ppo" else 2)         # 2 iterations x (2 epochs x 5 minibatches of 160 samples | 1 step)
