@@ -767,6 +767,12 @@ def main():
         t.start()
         dist.destroy_process_group()
         t.cancel()
+    # Nothing is left to do: skip interpreter finalisation (hipGraphs, the ctypes-loaded library and RCCL's communicators
+    # would be destroyed in whatever order it picks, against a HIP runtime that shuts itself down through its own exit
+    # handlers -- a crash there would turn a finished measurement into a failed run)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":
