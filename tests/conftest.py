@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The plain-PyTorch references of the kernel tests (F.conv2d and its autograd) run on ATen's own convolution
+    # (im2col + rocBLAS), NOT on MIOpen: on a fresh box MIOpen has no tuning database and compiles / searches kernels
+    # on first use, and that search aborted the interpreter (SIGABRT inside torch.autograd.grad, conv backward of a
+    # random geometry) in two of three first runs on fresh boxes.  The product never calls MIOpen.
+    try:
+        import torch
+        torch.backends.cudnn.enabled = False
+    except ImportError:
+        pass
 
 
 def pytest_sessionfinish(session, exitstatus):
