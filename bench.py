@@ -767,12 +767,13 @@ def main():
         t.start()
         dist.destroy_process_group()
         t.cancel()
-    # Nothing is left to do: skip interpreter finalisation (hipGraphs, the ctypes-loaded library and RCCL's communicators
-    # would be destroyed in whatever order it picks, against a HIP runtime that shuts itself down through its own exit
-    # handlers -- a crash there would turn a finished measurement into a failed run)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    # Leave nothing for interpreter finalisation to destroy against a HIP runtime that is shutting itself down: the
+    # captured graphs go now, while the device is alive (a normal exit follows -- profilers flush their output there)
+    algo._graph = algo._graph_out = None
+    sampler._graph = None
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 if __name__ == "__main__":
