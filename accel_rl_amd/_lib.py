@@ -12,8 +12,9 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libaccel_rl_hip.so")
 
-ARL_ABI_VERSION = 1
+ARL_ABI_VERSION = 2
 PROMO_NEP50, PROMO_LEGACY, PROMO_ASSOC = 0, 1, 2
+PPO_TIE_THEANO, PPO_TIE_MATH = 0, 1      # ARL_PPO_TIE_*: whose gradient min() / clip() hand on (accel_rl_hip.h)
 OPT_ADAM, OPT_RMSPROP = 0, 1
 MAX_ACTIONS = 18
 REPLAY_MAX_HORIZON = 16
@@ -104,8 +105,8 @@ _SIGNATURES = {
     "arl_relu_bwd_bias_grad": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp]),
     "arl_pg_head_workspace_bytes": (_i64, []),
     "arl_pg_head_infer": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 7),
-    "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
+    "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 7),
+    "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), C.POINTER(ArlCorunJob), C.POINTER(_i32), _vp]),
@@ -431,13 +432,14 @@ def pg_head_infer(h, w_head, b_head, prob, value, stream=None):
 
 def pg_head_loss(h, w_head, b_head, actions, advantages, returns, old_prob, valids, idx, lr_mult,
                  inv_count, n_actions, kind, clip_param, v_loss_coeff, ent_loss_coeff,
-                 dout, dh, dw_head, db_head, loss4, workspace, stream=None, relu_mask_dh=False):
+                 dout, dh, dw_head, db_head, loss4, workspace, stream=None, relu_mask_dh=False,
+                 tie_rule=PPO_TIE_THEANO):
     """relu_mask_dh: h is a rectifier's output; return dh already multiplied by (h > 0)."""
     batch, hid = h.shape
     _check(load().arl_pg_head_loss(
         ptr(h), w_head.data_ptr(), b_head.data_ptr(), ptr(actions), ptr(advantages), ptr(returns),
         ptr(old_prob), ptr(valids), ptr(idx), ptr(lr_mult), ptr(inv_count), batch, hid, n_actions,
-        kind, float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), int(bool(relu_mask_dh)), ptr(dout), ptr(dh),
+        kind, int(tie_rule), float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), int(bool(relu_mask_dh)), ptr(dout), ptr(dh),
         dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), stream_ptr(stream)),
         "arl_pg_head_loss")
 
@@ -617,7 +619,8 @@ class FoldList(object):
 
     def pg_head_loss(self, h, w_head, b_head, actions, advantages, returns, old_prob, valids, idx, lr_mult,
                      inv_count, n_actions, kind, clip_param, v_loss_coeff, ent_loss_coeff,
-                     dout, dh, dw_head, db_head, loss4, workspace, stream=None, relu_mask_dh=False):
+                     dout, dh, dw_head, db_head, loss4, workspace, stream=None, relu_mask_dh=False,
+                 tie_rule=PPO_TIE_THEANO):
         """pg_head_loss with its three small folds (dw_head, db_head, loss4) left to run()."""
         batch, hid = h.shape
         assert self._n + 3 <= FOLD_MAX_ITEMS, "too many pending folds"
@@ -626,7 +629,7 @@ class FoldList(object):
         _check(load().arl_pg_head_loss_parts(
             ptr(h), w_head.data_ptr(), b_head.data_ptr(), ptr(actions), ptr(advantages), ptr(returns),
             ptr(old_prob), ptr(valids), ptr(idx), ptr(lr_mult), ptr(inv_count), batch, hid, n_actions,
-            kind, float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), int(bool(relu_mask_dh)), ptr(dout),
+            kind, int(tie_rule), float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), int(bool(relu_mask_dh)), ptr(dout),
             ptr(dh), dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), first, stream_ptr(stream)),
             "arl_pg_head_loss_parts")
 

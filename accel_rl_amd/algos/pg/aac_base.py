@@ -198,10 +198,11 @@ class AdvActorCriticBase(RLAlgorithm):
             mb = dict(mb, horizon=self._horizon)
         loss4 = self.policy.loss_and_grads(mb, self.loss_kind, getattr(self, "clip_param", 0.),
                                            self.v_loss_coeff, self.ent_loss_coeff, self._lr_mult,
-                                           inv_count)
+                                           inv_count, tie_rule=self.loss_tie_rule)
         return loss4            # (pi_loss, v_loss, ent_loss, their sum): the optimizer reads [3]
 
     loss_kind = None        # 0 = A2C, 1 = PPO (selects the fused kernel's pi_loss)
+    loss_tie_rule = 0       # ARL_PPO_TIE_THEANO; only PPO's surrogate has a tie to break (BasePPO.ppo_tie_rule)
 
     def pi_loss(self, policy, act, adv, old_dist_info, new_dist_info, valids):
         """The subclass's policy loss as a formula on tensors (a2c.py:43-46 / ppo.py:42-51).  The learner does

@@ -160,7 +160,7 @@ struct HeadLossArgs {
     float* loss_partials;    // [gridDim][4] = pi, v, ent, their sum
     float* wpart;            // [gridDim][K][hid] this workgroup's share of dW_head = sum_b dout[b] x h[b], or null
     float* bpart;            // [gridDim][Kp]     ... of db_head = sum_b dout[b]                (with wpart)
-    int batch, hid, n_act, kind;
+    int batch, hid, n_act, kind, tie_rule;
     float clip_param, v_coeff, ent_coeff;
     int mask_dh;             // dh *= (h > 0): h is a rectifier's output and the caller wants the gradient before it
 };
@@ -278,7 +278,14 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
             const float s1 = ratio * adv, s2 = rc * adv;
             pi_term = fminf(s1, s2);
             const bool in_range = (ratio >= lo) && (ratio <= hi);
-            const float g_ratio = in_range ? adv : (s1 < s2 ? adv : 0.f);
+            float g_ratio;
+            if (a.tie_rule == ARL_PPO_TIE_THEANO) {
+                // the reference's graph: Minimum.L_op hands eq(min, x) g to BOTH arguments, Clip.L_op passes g
+                // for lo <= r <= hi -- inside the range s1 and s2 are the same number and the sample counts twice
+                g_ratio = ((pi_term == s1) ? adv : 0.f) + ((pi_term == s2 && in_range) ? adv : 0.f);
+            } else {
+                g_ratio = in_range ? adv : (s1 < s2 ? adv : 0.f);
+            }
             g_act = -w * g_ratio / (old_pa + TINY);
         } else {                                                         // A2C, a2c.py:43-46
             pi_term = logf(pa + TINY) * adv;
@@ -496,13 +503,15 @@ extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const
                                 const float* old_prob, const int8_t* valids_or_null,
                                 const int32_t* idx_or_null, const float* lr_mult,
                                 const float* inv_count_or_null, int64_t batch, int32_t hid,
-                                int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
+                                int32_t n_actions, int32_t kind, int32_t tie_rule, float clip_param, float v_loss_coeff,
                                 float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
                                 float* dw_head, float* db_head, float* loss4, void* workspace, arl_fold_item* items3,
                                       void* stream) {
     ARL_REQUIRE(h && w_head && b_head && actions && advantages && returns && lr_mult && dout && dh &&
                     dw_head && db_head && loss4 && workspace && items3, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(kind == 0 || (kind == 1 && old_prob), ARL_E_ARG, "kind must be 0 (A2C) or 1 (PPO, needs old_prob)");
+    ARL_REQUIRE(tie_rule == ARL_PPO_TIE_THEANO || tie_rule == ARL_PPO_TIE_MATH, ARL_E_ARG,
+                "tie_rule must be ARL_PPO_TIE_THEANO or ARL_PPO_TIE_MATH");
     int rc = check_head(batch, hid, n_actions);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
@@ -511,7 +520,7 @@ extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const
     a.ret = returns; a.old_prob = old_prob; a.valids = valids_or_null; a.idx = idx_or_null;
     a.lr_mult = lr_mult; a.inv_count = inv_count_or_null; a.dout = dout; a.dh = dh;
     a.loss_partials = (float*)workspace;
-    a.batch = (int)batch; a.hid = hid; a.n_act = n_actions; a.kind = kind;
+    a.batch = (int)batch; a.hid = hid; a.n_act = n_actions; a.kind = kind; a.tie_rule = tie_rule;
     a.clip_param = clip_param; a.v_coeff = v_loss_coeff; a.ent_coeff = ent_loss_coeff; a.mask_dh = relu_mask_dh;
     const int grid = (int)((batch + 3) / 4 < 256 ? (batch + 3) / 4 : 256);
     const int K = n_actions + 1;
@@ -554,12 +563,12 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
                                 const float* old_prob, const int8_t* valids_or_null,
                                 const int32_t* idx_or_null, const float* lr_mult,
                                 const float* inv_count_or_null, int64_t batch, int32_t hid,
-                                int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
+                                int32_t n_actions, int32_t kind, int32_t tie_rule, float clip_param, float v_loss_coeff,
                                 float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
                                 float* dw_head, float* db_head, float* loss4, void* workspace, void* stream) {
     arl_fold_item items[3];
     int rc = arl_pg_head_loss_parts(h, w_head, b_head, actions, advantages, returns, old_prob, valids_or_null,
-                                    idx_or_null, lr_mult, inv_count_or_null, batch, hid, n_actions, kind, clip_param,
+                                    idx_or_null, lr_mult, inv_count_or_null, batch, hid, n_actions, kind, tie_rule, clip_param,
                                     v_loss_coeff, ent_loss_coeff, relu_mask_dh, dout, dh, dw_head, db_head, loss4,
                                     workspace, items, stream);
     if (rc) return rc;

@@ -343,19 +343,21 @@ class AtariCnnPolicy(object):
 
     # ------------------------------------------------------------- training
     def loss_and_grads(self, mb, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult,
-                       inv_count=None):
+                       inv_count=None, tie_rule=_lib.PPO_TIE_THEANO):
         """One minibatch: forward, losses (a2c.py:43-46 / ppo.py:42-51 + aac_base.py:60-66)
         and the full backward pass into `flat_grads` (overwritten, not accumulated).
         mb: observations u8[n,...], idx i32[B] or None, actions, advantages, returns,
         old_prob, valids (full-batch arrays, rows selected by idx).  Returns loss4 =
-        (pi_loss, v_loss, ent_loss, pi+v+ent) as a device tensor."""
+        (pi_loss, v_loss, ent_loss, pi+v+ent) as a device tensor.  tie_rule (PPO): whose gradient the surrogate's
+        min() / clip() hand on -- the reference's Theano graph (default) or the mathematical derivative
+        (ARL_PPO_TIE_*, accel_rl_hip.h)."""
         with torch.no_grad():
             idx = mb.get("idx")
             rows = mb["observations"].shape[0] if idx is None else idx.shape[0]
             limit = self.rows_per_pass()
             if limit and rows >= 3 * limit:
                 return self._loss_and_grads_in_passes(mb, rows, limit, kind, clip_param, v_loss_coeff, ent_loss_coeff,
-                                                      lr_mult, inv_count)
+                                                      lr_mult, inv_count, tie_rule)
             x = self._scaled(mb["observations"], idx)
             b = x.shape[0]
             acts, hids = self._trunk(x)
@@ -368,7 +370,7 @@ class AtariCnnPolicy(object):
                               mb["advantages"], mb["returns"], mb.get("old_prob"), mb.get("valids"),
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
                               ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws,
-                              relu_mask_dh=True)
+                              relu_mask_dh=True, tie_rule=tie_rule)
             self._backward_trunk(x, acts, hids, dh, masked=True, split_hook=mb.get("split_hook"),
                                  dense_w_hook=mb.get("dense_w_hook"))
             return loss4
@@ -392,7 +394,7 @@ class AtariCnnPolicy(object):
         return max(256, (self.CACHE_BYTES // per_row + 128) // 256 * 256)
 
     def _loss_and_grads_in_passes(self, mb, rows, limit, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult,
-                                  inv_count):
+                                  inv_count, tie_rule=_lib.PPO_TIE_THEANO):
         """loss_and_grads of a minibatch larger than rows_per_pass(): passes over consecutive slices of its index list,
         every pass normalised by the WHOLE minibatch's count; gradients and the four loss sums accumulate in pass
         order (deterministic).  The co-run / split hooks of the one-pass learner do not apply (nothing is final before
@@ -411,7 +413,8 @@ class AtariCnnPolicy(object):
         try:
             for k, lo in enumerate(range(0, rows, limit)):
                 one["idx"] = idx[lo:min(lo + limit, rows)]
-                loss4 = self.loss_and_grads(one, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult, inv_count)
+                loss4 = self.loss_and_grads(one, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult, inv_count,
+                                            tie_rule)
                 if k == 0:
                     acc.copy_(self.flat_grads)
                     loss_acc.copy_(loss4)

@@ -145,7 +145,8 @@ class RecurrentCnnPolicy(AtariCnnPolicy):
         return action, infos
 
     # ---- training: BPTT over each environment's segment ----------------------------
-    def loss_and_grads(self, mb, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult, inv_count=None):
+    def loss_and_grads(self, mb, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult, inv_count=None,
+                       tie_rule=_lib.PPO_TIE_THEANO):
         """Whole-batch update (rows env-major = [trajectory][time]); mb additionally carries
         `horizon` and the stored previous states (only the rows of t = 0 are used)."""
         if mb.get("idx") is not None:
@@ -185,7 +186,7 @@ class RecurrentCnnPolicy(AtariCnnPolicy):
             _lib.pg_head_loss(st_all[0], self.params[kh], self.params[kh + 1], mb["actions"], mb["advantages"],
                               mb["returns"], mb.get("old_prob"), mb.get("valids"), None, lr_mult, inv_count,
                               self.n_act, kind, clip_param, v_loss_coeff, ent_loss_coeff, dout, dh_all, g[kh],
-                              g[kh + 1], loss4, self._loss_ws)
+                              g[kh + 1], loss4, self._loss_ws, tie_rule=tie_rule)
             # ---- backward scan
             carry = self._buffer(("carry", nb), (nb, hh))
             dh_rec = self._buffer(("dh_rec", nb), (nb, hh))

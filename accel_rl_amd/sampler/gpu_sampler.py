@@ -456,3 +456,11 @@ class GpuVecSampler(BaseMbSampler):
                 self._refill_noop_ring(2 * self.n_parallel)
         self._st.done_count.zero_()
         self._refill_noop_ring(2 * self.n_parallel)
+        served = self._kernel_max_path_length()
+        if served != self.max_path_length:
+            # The walk's last launch forecast each env's next reset under the walk's rule (Length > L); the served steps
+            # of this sampler family end an episode at Length >= L (worker_with_eval.py:48): an env that leaves the walk
+            # one step short of L resets in the FIRST served launch, and that launch ranks the stream's no-op draws
+            # from the forecast -- restate it under the served rule (only the over-length term can differ)
+            par = int(self._st.launch_count.item()) & 1
+            self._st.next_reset[par] |= (self._st.traj_len + 1 > served).to(torch.uint8)

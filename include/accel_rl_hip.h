@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ARL_ABI_VERSION 1
+#define ARL_ABI_VERSION 2
 
 #define ARL_E_ARG      (-1)   /* null pointer / non-positive size                 */
 #define ARL_E_RANGE    (-2)   /* size outside what the kernels support             */
@@ -311,19 +311,28 @@ int arl_pg_head_infer(const float* h, const float* w_head, const float* b_head, 
  * v_loss = c_v mean((V-R)^2); ent_loss = -c_e mean(-sum pi log(pi+1e-8))
  * (aac_base.py:60-66, categorical.py:66-78); means are valids_mean when valids
  * is given (algos/pg/util.py:49-53; inv_count = 1/sum(valids) over the minibatch).
- * Rows of the batch arrays are selected by idx (NULL = identity).  Where the
- * min() ties (ratio inside the clip range) the gradient is adv, as in any
- * autograd that splits ties to sum 1 (Theano's tie rule is unpinned).
+ * Rows of the batch arrays are selected by idx (NULL = identity).
+ * tie_rule (PPO only) = how min() and clip() hand their gradient on:
+ *   ARL_PPO_TIE_THEANO  the reference learner's graph: T.minimum gives eq(min, x) g to EVERY argument
+ *                       equal to the minimum, T.clip passes g for lo <= r <= hi (bounds included;
+ *                       theano/scalar/basic.py Minimum.L_op / Clip.L_op; Theano is a third-party
+ *                       dependency absent from /root/reference: restated, parity unpinned), so
+ *                       d surr / d r = adv ((surr == s1) + (surr == s2)(lo <= r <= hi)):
+ *                       2 adv inside the clip range, adv where s1 < s2 outside it, else 0;
+ *   ARL_PPO_TIE_MATH    the mathematical derivative (adv inside the range): what an autograd that
+ *                       splits a tie's gradient to sum 1 (torch.minimum) gives.
  *   out: dout f32[batch][A+1], dh f32[batch][hid] (before the hidden relu mask),
  *        dw_head f32[A+1][hid], db_head f32[A+1], loss4 f32[4] = pi, v, ent, pi+v+ent
  *   workspace >= arl_pg_head_workspace_bytes()                                  */
+#define ARL_PPO_TIE_THEANO 0
+#define ARL_PPO_TIE_MATH   1
 int64_t arl_pg_head_workspace_bytes(void);
 int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
                      const uint8_t* actions, const float* advantages, const float* returns,
                      const float* old_prob, const int8_t* valids_or_null,
                      const int32_t* idx_or_null, const float* lr_mult,
                      const float* inv_count_or_null, int64_t batch, int32_t hid, int32_t n_actions,
-                     int32_t kind, float clip_param, float v_loss_coeff, float ent_loss_coeff,
+                     int32_t kind, int32_t tie_rule, float clip_param, float v_loss_coeff, float ent_loss_coeff,
                      int32_t relu_mask_dh, float* dout, float* dh, float* dw_head, float* db_head,
                      float* loss4, void* workspace, void* stream);
 /* Same, stopping before the three small folds (dw_head, db_head, loss4): they are described in items3[0..2] for
@@ -335,8 +344,8 @@ int arl_pg_head_loss_parts(const float* h, const float* w_head, const float* b_h
                            const float* old_prob, const int8_t* valids_or_null,
                            const int32_t* idx_or_null, const float* lr_mult,
                            const float* inv_count_or_null, int64_t batch, int32_t hid,
-                           int32_t n_actions, int32_t kind, float clip_param, float v_loss_coeff,
-                           float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
+                           int32_t n_actions, int32_t kind, int32_t tie_rule, float clip_param,
+                           float v_loss_coeff, float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
                            float* dw_head, float* db_head, float* loss4, void* workspace,
                            struct arl_fold_item* items3, void* stream);
 

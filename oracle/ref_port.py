@@ -564,3 +564,35 @@ def clip_by_total_norm(grads_flat, clip):
         return g, norm
     scale = np.clip(norm, 0, F32(clip)) / (F32(1e-7) + norm)
     return (g * F32(scale)).astype(F32), norm
+
+
+# =============================================================================
+# PPO surrogate: value and gradient with respect to the likelihood ratio
+#   (accel_rl/algos/pg/ppo.py:42-51)
+# =============================================================================
+
+def ppo_surrogate(ratio, adv, clip, tie_rule="theano"):
+    """surr = minimum(ratio adv, clip(ratio, 1 - clip, 1 + clip) adv) (ppo.py:45-49) and d surr / d ratio, f32.
+
+    PARITY UNPINNED for the gradient: it is produced by Theano's symbolic differentiation, and Theano (unpinned
+    in the reference, absent from /root/reference and from this image) cannot be run here.  Restated from its
+    published scalar-op rules, theano/scalar/basic.py:
+        Minimum.L_op:  gx = eq(minimum(x, y), x) gz,  gy = eq(minimum(x, y), y) gz   (BOTH on a tie)
+        Clip.L_op:     gx = ((x >= min) & (x <= max)) gz                              (bounds included)
+    so with s1 = ratio adv, s2 = clip(ratio) adv:
+        d surr / d ratio = adv [surr == s1] + adv [surr == s2] [lo <= ratio <= hi]
+    = 2 adv inside the clip range (s1 and s2 are the same number there), adv where s1 < s2 outside it, 0 where
+    the clipped branch is the minimum.  tie_rule="math" is the mathematical derivative (adv inside the range)."""
+    ratio, adv = np.asarray(ratio, F32), np.asarray(adv, F32)
+    lo, hi = F32(1) - F32(clip), F32(1) + F32(clip)
+    s1 = ratio * adv
+    s2 = np.minimum(np.maximum(ratio, lo), hi) * adv
+    surr = np.minimum(s1, s2)
+    inside = (ratio >= lo) & (ratio <= hi)
+    if tie_rule == "theano":
+        grad = adv * (surr == s1).astype(F32) + adv * ((surr == s2) & inside).astype(F32)
+    elif tie_rule == "math":
+        grad = np.where(inside, adv, np.where(s1 < s2, adv, F32(0))).astype(F32)
+    else:
+        raise ValueError(tie_rule)
+    return surr.astype(F32), grad.astype(F32)

@@ -37,3 +37,32 @@ def losses(algo, mb):
     ent_loss = - algo.ent_loss_coeff * valids_mean(policy.distribution.entropy_sym(new_info), valids)
     pi_loss = algo.pi_loss(policy, pick(mb["actions"]), pick(mb["advantages"]), old_info, new_info, valids)
     return pi_loss, v_loss, ent_loss
+
+
+class _TheanoSurrogate(torch.autograd.Function):
+    """PPO's surrogate minimum(r A, clip(r, lo, hi) A) (accel_rl/algos/pg/ppo.py:45-49) with the gradient Theano's
+    symbolic differentiation produces (theano/scalar/basic.py Minimum.L_op: eq(out, x) g to BOTH arguments; Clip.L_op:
+    g for lo <= x <= hi) -- the closed form of oracle/ref_port.py::ppo_surrogate, written independently of
+    accel_rl_amd/util/theano_ops.py (which composes the two ops)."""
+
+    @staticmethod
+    def forward(ctx, ratio, adv, lo, hi):
+        s1 = ratio * adv
+        s2 = torch.minimum(torch.maximum(ratio, lo), hi) * adv
+        surr = torch.minimum(s1, s2)
+        ctx.save_for_backward(adv, (surr == s1), (surr == s2) & (ratio >= lo) & (ratio <= hi))
+        return surr
+
+    @staticmethod
+    def backward(ctx, g):
+        adv, first, second = ctx.saved_tensors
+        return g * adv * (first.to(g.dtype) + second.to(g.dtype)), None, None, None
+
+
+def ppo_surrogate(ratio, adv, clip, tie_rule="theano"):
+    """surr[B]; tie_rule "theano" = the reference's graph (default of the product), "math" = torch.minimum's."""
+    lo = torch.as_tensor(1. - clip, dtype=ratio.dtype, device=ratio.device)
+    hi = torch.as_tensor(1. + clip, dtype=ratio.dtype, device=ratio.device)
+    if tie_rule == "theano":
+        return _TheanoSurrogate.apply(ratio, adv, lo, hi)
+    return torch.minimum(ratio * adv, torch.clamp(ratio, float(lo), float(hi)) * adv)

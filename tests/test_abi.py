@@ -52,7 +52,7 @@ def test_the_boundary_header_keeps_no_state():
 
 
 def test_abi_version_and_arg_errors(lib):
-    assert lib.arl_abi_version() == 1
+    assert lib.arl_abi_version() == 2
     # null pointers / bad sizes are rejected before any HIP call is made
     assert lib.arl_gae_scan(None, None, None, None, 0.99, 0.95, 4, 5, 0, None, None, None) == -1
     assert b"null" in lib.arl_last_error()

@@ -212,3 +212,34 @@ def test_logger_context_files_and_snapshots(tmp_path, monkeypatch):
     np.testing.assert_array_equal(snap["policy_param_values"], np.arange(4, dtype=np.float32) + 4)
     logger.set_snapshot_mode("none")
     logger.set_snapshot_dir(None)
+
+
+def test_ppo_surrogate_gradient_rules():
+    """The three statements of Theano's min / clip gradient agree on the samples where the rules differ: the oracle's
+    closed form (oracle/ref_port.py::ppo_surrogate), the product's composed autograd ops (util/theano_ops.py, what
+    BasePPO.pi_loss is written with) and the tests' one-Function restatement (tests/autograd_ref.py).  Inside the
+    clip range -- bounds included -- the reference's graph yields 2 A (accel_rl/algos/pg/ppo.py:47-49)."""
+    import torch
+    import autograd_ref
+    from accel_rl_amd.util import theano_ops
+    from oracle import ref_port as P
+    clip = 0.25                                                    # 0.75 and 1.25 are exact in fp32
+    ratio = np.array([1.0, 0.75, 1.25, 0.7499999, 1.2500001, 0.5, 2.0, 0.5, 2.0, 1.0, 0.9, 1.1, 3.0], np.float32)
+    adv = np.array([1.5, -2.0, 0.5, 1.0, 1.0, 1.0, 1.0, -1.0, -1.0, 0.0, -0.25, 4.0, 0.0], np.float32)
+    surr, g = P.ppo_surrogate(ratio, adv, clip, "theano")
+    want = np.array([3.0, -4.0, 1.0, 1.0, 0.0, 1.0, 0.0, 0.0, -1.0, 0.0, -0.5, 8.0, 0.0], np.float32)
+    assert np.array_equal(g, want)
+    _, g_math = P.ppo_surrogate(ratio, adv, clip, "math")
+    assert np.array_equal(g_math, np.array([1.5, -2.0, 0.5, 1.0, 0.0, 1.0, 0.0, 0.0, -1.0, 0.0, -0.25, 4.0, 0.0], np.float32))
+    for build in (lambda r, a: theano_ops.minimum(r * a, theano_ops.clip(r, 1. - clip, 1. + clip) * a),
+                  lambda r, a: autograd_ref.ppo_surrogate(r, a, clip, "theano")):
+        r = torch.from_numpy(ratio).requires_grad_()
+        out = build(r, torch.from_numpy(adv))
+        out.sum().backward()
+        assert np.array_equal(out.detach().numpy(), surr)
+        assert np.array_equal(r.grad.numpy(), g)
+    from accel_rl_amd.algos.pg.ppo import PPO
+    assert PPO().ppo_tie_rule == "theano" and PPO().loss_tie_rule == 0
+    assert PPO(ppo_tie_rule="math").loss_tie_rule == 1
+    with pytest.raises(ValueError):
+        PPO(ppo_tie_rule="torch")

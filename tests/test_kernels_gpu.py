@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 
+import autograd_ref
 from conftest import load_golden
 from oracle import ref_port as P
 from oracle import synth_ale
@@ -538,11 +539,13 @@ def test_bias_relu_and_backward(L, rows, ch):
 
 
 @pytest.mark.parametrize("n_act,hid,batch", [(4, 512, 512), (6, 256, 100), (18, 512, 64), (4, 64, 5), (9, 1024, 33)])
-@pytest.mark.parametrize("kind", [0, 1])
+@pytest.mark.parametrize("kind,tie", [(0, "theano"), (1, "theano"), (1, "math")])
 @pytest.mark.parametrize("masked", [False, True])
-def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, masked):
+def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, tie, masked):
     """heads + softmax + A2C/PPO/value/entropy losses and all gradients vs PyTorch autograd
-    on the reference's formulas (aac_base.py:60-70, a2c.py:43-46, ppo.py:42-51)."""
+    on the reference's formulas (aac_base.py:60-70, a2c.py:43-46, ppo.py:42-51); PPO under both gradient rules
+    for the surrogate's min / clip: the reference's Theano graph (default: 2 A inside the clip range) and the
+    mathematical derivative."""
     gen = torch.Generator(device=DEV).manual_seed(n_act * 1000 + hid + batch)
     n_rows = batch * 3
     h = torch.relu(torch.randn(batch, hid, device=DEV, generator=gen)).requires_grad_()
@@ -573,7 +576,7 @@ def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, masked):
         old_sel = old[sel]
         ratio = (pa + 1e-8) / (old_sel[torch.arange(batch), a] + 1e-8)
         c = clip * 0.6
-        pi = -torch.sum(wgt * torch.minimum(ratio * adv[sel], torch.clamp(ratio, 1 - c, 1 + c) * adv[sel]))
+        pi = -torch.sum(wgt * autograd_ref.ppo_surrogate(ratio, adv[sel], c, tie))
     else:
         pi = -torch.sum(wgt * torch.log(pa + 1e-8) * adv[sel])
     vl = c_v * torch.sum(wgt * (value - ret[sel]) ** 2)
@@ -585,7 +588,8 @@ def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, masked):
     dw, db, loss4 = torch.empty_like(w), torch.empty_like(bh), torch.zeros(4, device=DEV)
     ws = L.pg_head_workspace(DEV)
     L.pg_head_loss(h.detach(), w.detach(), bh.detach(), act, adv, ret, old, valids, idx, lr_mult, inv,
-                   n_act, kind, clip, c_v, c_e, dout, dh, dw, db, loss4, ws)
+                   n_act, kind, clip, c_v, c_e, dout, dh, dw, db, loss4, ws,
+                   tie_rule=dict(theano=L.PPO_TIE_THEANO, math=L.PPO_TIE_MATH)[tie])
     assert torch.allclose(loss4[:3], torch.stack([pi, vl, el]).detach(), rtol=1e-4, atol=1e-6)
     for got, want, name in ((dh, gh, "dh"), (dw, gw, "dw"), (db, gb, "db")):
         scale = max(want.abs().max().item(), 1e-6)
@@ -595,3 +599,68 @@ def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, masked):
     v2 = torch.empty(batch, device=DEV)
     L.pg_head_infer(h.detach(), w.detach(), bh.detach(), p2, v2)
     assert torch.allclose(p2, prob.detach(), rtol=1e-5, atol=1e-7) and torch.allclose(v2, value.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tie", ["theano", "math"])
+def test_ppo_tie_rule_on_the_boundaries_at_the_config2_shape(L, tie):
+    """BASELINE config 2's minibatch (512 rows, 4 actions, 512 hidden units).  The samples the two gradient rules
+    differ on, placed deliberately: ratio == 1 exactly (old probability = the kernel's own), ratio exactly ON the
+    lower / upper bound (clip chosen as 1 - ratio, resp. ratio - 1, of a row: both exact in fp32), advantage == 0,
+    clip == 0 (both bounds coincide with ratio 1), and ordinary rows either side of the range.  Theano's rule
+    (ppo.py:47-49 through Minimum.L_op / Clip.L_op): 2 A wherever lo <= ratio <= hi, bounds INCLUDED; A where the
+    unclipped branch is the smaller outside; 0 otherwise.  The reference side is autograd on the same formulas with
+    the forward value of the ratio pinned to the kernel's own bits (straight-through), so that a last-bit difference
+    between torch's softmax and the kernel's cannot move a sample across a bound."""
+    batch, n_act, hid = 512, 4, 512
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    h0 = torch.relu(torch.randn(batch, hid, device=DEV, generator=gen))
+    w0 = torch.randn(n_act + 1, hid, device=DEV, generator=gen) * 0.05
+    b0 = torch.randn(n_act + 1, device=DEV, generator=gen) * 0.1
+    act = torch.randint(0, n_act, (batch,), device=DEV, generator=gen).to(torch.uint8)
+    adv = torch.randn(batch, device=DEV, generator=gen)
+    ret = torch.randn(batch, device=DEV, generator=gen)
+    p_k = torch.empty(batch, n_act, device=DEV)
+    v_k = torch.empty(batch, device=DEV)
+    L.pg_head_infer(h0, w0, b0, p_k, v_k)                     # the kernel's own probabilities
+    rows = torch.arange(batch, device=DEV)
+    a = act.long()
+    old = torch.softmax(torch.log(p_k) + 0.25 * torch.randn(batch, n_act, device=DEV, generator=gen), 1)
+    old[:128] = p_k[:128]                                     # ratio == 1 exactly
+    adv[64:96] = 0.                                           # ... some of them with a zero advantage
+    adv[200:232] = 0.                                         # and some ordinary rows too
+    tiny = np.float32(1e-8)
+    ratio_k = ((p_k[rows, a] + tiny) / (old[rows, a] + tiny))
+    assert torch.all(ratio_k[:128] == 1.)
+    lr_mult = torch.ones(1, device=DEV)
+    c_v, c_e = 1.0, 0.01
+    cases = [0.2, 0.0]
+    below = ratio_k[(ratio_k > 0.6) & (ratio_k < 1.)]
+    above = ratio_k[(ratio_k > 1.) & (ratio_k < 1.4)]
+    cases += [float(np.float32(1.) - np.float32(below[0].item())), float(np.float32(above[0].item()) - np.float32(1.))]
+    if tie == "math":
+        cases = [0.2]       # ON a bound the mathematical derivative does not exist (torch splits the tie of its
+        #                     max / min there; the kernel's "math" rule counts the bound as inside): not compared
+    for clip in cases:
+        lo, hi = np.float32(1.) - np.float32(clip), np.float32(1.) + np.float32(clip)
+        n_on = int(((ratio_k == float(lo)) | (ratio_k == float(hi))).sum())
+        assert n_on >= 1 or clip == 0.2, (clip, n_on)          # the constructed clips really put a row ON a bound
+        h, w, bh = h0.clone().requires_grad_(), w0.clone().requires_grad_(), b0.clone().requires_grad_()
+        out = h @ w.t() + bh
+        prob, value = torch.softmax(out[:, :n_act], 1), out[:, n_act]
+        ratio_t = (prob[rows, a] + 1e-8) / (old[rows, a] + 1e-8)
+        ratio = ratio_t + (ratio_k - ratio_t).detach()         # the kernel's value, torch's derivative
+        wgt = torch.full((batch,), 1. / batch, device=DEV)
+        pi = -torch.sum(wgt * autograd_ref.ppo_surrogate(ratio, adv, float(clip), tie))
+        vl = c_v * torch.sum(wgt * (value - ret) ** 2)
+        el = -c_e * torch.sum(wgt * -torch.sum(prob * torch.log(prob + 1e-8), dim=1))
+        gh, gw, gb = torch.autograd.grad(pi + vl + el, [h, w, bh])
+        dout = torch.empty(batch, n_act + 1, device=DEV)
+        dh = torch.empty(batch, hid, device=DEV)
+        dw, db, loss4 = torch.empty_like(w0), torch.empty_like(b0), torch.zeros(4, device=DEV)
+        L.pg_head_loss(h0, w0, b0, act, adv, ret, old, None, None, lr_mult, None, n_act, 1, clip, c_v, c_e,
+                       dout, dh, dw, db, loss4, L.pg_head_workspace(DEV),
+                       tie_rule=dict(theano=L.PPO_TIE_THEANO, math=L.PPO_TIE_MATH)[tie])
+        assert torch.allclose(loss4[:3], torch.stack([pi, vl, el]).detach(), rtol=1e-4, atol=1e-6), clip
+        for got, want, name in ((dh, gh, "dh"), (dw, gw, "dw"), (db, gb, "db")):
+            scale = max(want.abs().max().item(), 1e-6)
+            assert torch.allclose(got, want, rtol=1e-3, atol=1e-5 * scale), (clip, name, (got - want).abs().max().item())

@@ -53,7 +53,7 @@ def ref_params_from(policy):
     return out
 
 
-def ref_loss(kind, params, spec, mb, clip, v_coeff, ent_coeff=0.01):
+def ref_loss(kind, params, spec, mb, clip, v_coeff, ent_coeff=0.01, tie="theano"):
     prob, value = ref_forward(params, spec, mb["obs"].float() * np.float32(1. / 255))
     act = mb["act"].long()
     pa = prob[torch.arange(len(act)), act]
@@ -61,7 +61,9 @@ def ref_loss(kind, params, spec, mb, clip, v_coeff, ent_coeff=0.01):
     mean = torch.mean if valids is None else (lambda x: torch.sum(valids * x) * (1. / torch.sum(valids)))
     if kind == "ppo":
         ratio = (pa + TINY) / (mb["old_prob"][torch.arange(len(act)), act] + TINY)
-        pi = -mean(torch.minimum(ratio * mb["adv"], torch.clamp(ratio, 1 - clip, 1 + clip) * mb["adv"]))
+        # the reference's graph differentiated as Theano does (ppo.py:47-49; tests/autograd_ref.py): an unclipped
+        # sample's gradient is 2 adv; tie="math" = torch.minimum's own rule, the product's PPO(ppo_tie_rule="math")
+        pi = -mean(autograd_ref.ppo_surrogate(ratio, mb["adv"], float(clip), tie))
     else:
         pi = -mean(torch.log(pa + TINY) * mb["adv"])
     v = v_coeff * mean((value - mb["ret"]) ** 2)
@@ -70,7 +72,7 @@ def ref_loss(kind, params, spec, mb, clip, v_coeff, ent_coeff=0.01):
 
 
 def make(kind, n_env, horizon, use_graph, spec_id=0, n_frames=4, n_act=6, minibatch=32, epochs=2,
-         mid_batch_reset=True):
+         mid_batch_reset=True, tie="theano"):
     from accel_rl_amd.algos.pg.a2c import A2C
     from accel_rl_amd.algos.pg.ppo import PPO
     from accel_rl_amd.buffers import buffer_with_segs_view, batch_buffer
@@ -83,7 +85,8 @@ def make(kind, n_env, horizon, use_graph, spec_id=0, n_frames=4, n_act=6, miniba
     policy = AtariCnnPolicy(**cnn_specs[spec_id])
     policy.initialize(env_spec, device=DEV)
     if kind == "ppo":
-        algo = PPO(optimizer_args=dict(minibatch_size=minibatch, epochs=epochs), use_graph=use_graph, lr_schedule="linear")
+        algo = PPO(optimizer_args=dict(minibatch_size=minibatch, epochs=epochs), use_graph=use_graph, lr_schedule="linear",
+                   ppo_tie_rule=tie)
     else:
         algo = A2C(use_graph=use_graph)
     algo.initialize(policy, env_spec, n_env * horizon, horizon, mid_batch_reset=mid_batch_reset)
@@ -118,6 +121,7 @@ def fill(buf, policy, rs, n_env, horizon):
 # frame, mid_batch_reset=False -> the valids-weighted losses).
 LEARNER_CASES = {
     "ppo_tiny": ("ppo", 16, dict()),
+    "ppo_tiny_math_tie": ("ppo", 16, dict(tie="math")),
     "a2c_tiny": ("a2c", 16, dict()),
     "ppo_config2": ("ppo", 256, dict(spec_id=1, n_act=4, minibatch=512, epochs=4)),
     "a2c_config3": ("a2c", 1024, dict(spec_id=0, n_act=4)),
@@ -205,7 +209,7 @@ def test_learner_matches_plain_torch(case):
             mb = dict(obs=buf.observations[ix], act=buf.actions[ix], adv=adv[ix], ret=ret[ix],
                       old_prob=buf.agent_infos["prob"][ix], valids=val[ix] if use_valids else None)
             loss = ref_loss(kind, ref_params, spec, mb, np.float32(0.2) * np.float32(lr_mult),
-                            1.0 if kind == "ppo" else 0.25)
+                            1.0 if kind == "ppo" else 0.25, tie=kw.get("tie", "theano"))
             g = np.concatenate([host(x).reshape(-1) for x in torch.autograd.grad(loss, ref_params)])
             if adam:
                 g, norm = P.clip_by_total_norm(g, None)

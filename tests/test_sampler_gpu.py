@@ -322,6 +322,41 @@ def test_gpu_eval_sampler_matches_reference(tag, use_graph):
     smp.shutdown()
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_eval_sampler_with_a_length_limit_below_the_decorrelation_walk(use_graph):
+    """The start-up walk resets at Length > L (sampler/util.py:50), the served steps of the eval sampler family at
+    Length >= L (worker_with_eval.py:48): with L = 25 and up to 1000 decorrelation steps about one env in 26 leaves
+    the walk at Length L - 1 and must reset in the first served launch.  That reset is announced (the forecast is
+    restated under the served rule after the walk), so no batch is refused, no trajectory outlives L, and every
+    completed trajectory of the first batches that hit the limit has Length == L exactly."""
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.sampler.gpu_sampler_with_eval import GpuVecEvalSampler
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    L = 25
+    smp = GpuVecEvalSampler(eval_steps=64 * 30, eval_envs_per=1, EnvCls=SynthAtariEnv, env_args=dict(game="pong"),
+                            horizon=5, n_parallel=8, envs_per=16, mid_batch_reset=True, max_path_length=L,
+                            max_decorrelation_steps=1000, device=DEV, use_graph=use_graph)
+    np.random.seed(5)
+    smp.initialize(seed=9, affinities=dict(), discount=0.99, need_extra_obs=True)
+    n = smp.total_n_envs
+    lens = smp._st.traj_len.cpu().numpy()
+    assert lens.max() <= L and (lens == L - 1).sum() >= 1, "the case under test: an env one step short of the limit"
+    rs = np.random.RandomState(0)
+    smp.policy_init(DeviceTablePolicy(np.full((64, 6), 1. / 6, np.float32), rs.randn(64).astype(np.float32)))
+    seen = []
+    for b in range(8):
+        if b == 3:
+            ev = smp.evaluate_policy(b)
+            assert all(ti.Length <= L for ti in ev)
+        buf, infos = smp.obtain_samples(b)
+        seen += [ti.Length for ti in infos]                        # raises if a reset was not announced
+        assert int(smp._st.traj_len.max().item()) < L
+    assert int(smp._st.epoch[2].item()) == 0
+    assert len(seen) >= n and max(seen) == L
+    smp.shutdown()
+
+
 def test_eval_runner_trains_and_logs():
     """AccelRLEval (accel_rl/runners/accel_rl.py:108-180): evaluation every log interval, its tabular keys."""
     from accel_rl_amd.algos.pg.ppo import PPO
