@@ -116,6 +116,10 @@ class AdvActorCriticBase(RLAlgorithm):
                 return self._device_optimize(itr, samples_data)
             torch.cuda.synchronize(self.policy.device)
             graph, failure = torch.cuda.CUDAGraph(), None
+            # a capture that fails part-way leaves the optimiser's host-side call counters advanced by a partial call
+            # (no kernel ran): the eager re-run below must start from the state the capture started from
+            opt_host = {k: getattr(self.optimizer, k) for k in
+                        ("_n_updates", "_hole", "_call_hole", "_hole_count", "_pending_avg") if hasattr(self.optimizer, k)}
             try:
                 with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
                     self._graph_out = self._device_optimize(itr, samples_data)
@@ -129,6 +133,8 @@ class AdvActorCriticBase(RLAlgorithm):
                 logger.log("WARNING: hipGraph capture of the synchronous learner failed on a rank (%r): eager "
                            "minibatches from here on" % (failure,))
                 self.optimizer.graph_collectives = False
+                for k, v in opt_host.items():
+                    setattr(self.optimizer, k, v)
                 torch.cuda.synchronize(self.policy.device)
                 return self._device_optimize(itr, samples_data)
             self._graph, self._graph_samples = graph, samples_data

@@ -28,6 +28,7 @@ struct Conv1ImgArgs {
     float* y;                   // f32 [B][OH][OW][32]
     float scale;
     int n_img, C, H, W, OH, OW, stride, relu;
+    int obs_rows;               // rows of obs: an index outside [0, obs_rows) reads row 0 instead of faulting
 };
 
 __device__ __forceinline__ u32x2 bytes_to_bf16x4(unsigned v) {     // four packed bytes -> four bf16, exact
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) 
     const int n16 = npix / 16;
     u32x4 ireg[MAXLD];
     auto img_issue = [&](int img) {
-        const int row = a.idx ? a.idx[img] : img;
+        int row = a.idx ? a.idx[img] : img;
+        row = (unsigned)row < (unsigned)a.obs_rows ? row : 0;
         const u32x4* src = reinterpret_cast<const u32x4*>(a.obs + (size_t)row * npix);
 #pragma unroll
         for (int i = 0; i < MAXLD; ++i)
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) 
 bool g_no_img_kernels = false;          // arl_dev_conv_variant(1): the tap-gathering kernels everywhere (A/B, parity tests)
 
 // arl_conv2d_u8_fwd's geometries that take the image-stationary kernel; < 0: not one of them (nothing launched)
-int launch_conv1_img(const unsigned char* obs, const int32_t* idx, float scale, const float* w, const float* bias, float* y,
+int launch_conv1_img(const unsigned char* obs, int64_t obs_rows, const int32_t* idx, float scale, const float* w, const float* bias, float* y,
                      int64_t batch, int C, int H, int W, int K, int kh, int kw, int stride, int Ho, int Wo, int relu,
                      hipStream_t s) {
     const int npix = C * H * W;
@@ -143,13 +145,12 @@ int launch_conv1_img(const unsigned char* obs, const int32_t* idx, float scale, 
     if (g_no_img_kernels || !t_ctx.split || K != 32 || kh != 8 || kw != 8 || npix % 16 != 0 || npix > C1_MAX_IMG ||
         lds > 160 * 1024 || ((uintptr_t)obs & 15) || (W & 3) || (stride & 3) || batch > 0x7fffffff)
         return -1;
-    Conv1ImgArgs a = {obs, idx, w, bias, y, scale, (int)batch, C, H, W, Ho, Wo, stride, relu};
-    static bool attr_set = false;
-    if (!attr_set) {
+    Conv1ImgArgs a = {obs, idx, w, bias, y, scale, (int)batch, C, H, W, Ho, Wo, stride, relu,
+                      (int)(obs_rows < 0x7fffffff ? obs_rows : 0x7fffffff)};
+    {   // per launch: the attribute belongs to the CURRENT device's copy of the kernel (no process-wide flag)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_img_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { arl::set_error("hipFuncSetAttribute(conv1_img_kernel): %s", hipGetErrorString(e)); return (int)e; }
-        attr_set = true;
     }
     const int cus = 256;
     hipLaunchKernelGGL(conv1_img_kernel, dim3((unsigned)(batch < cus ? batch : cus)), dim3(C1_NT), lds, s, a);

@@ -507,7 +507,7 @@ extern "C" int arl_conv2d_u8_fwd(const uint8_t* obs, int64_t obs_rows, const int
     ARL_REQUIRE(arl::aligned16(w) && arl::aligned16(y) && (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN,
                 "16-byte alignment");
     if (!g_trace) {                                 // 32 filters of 8 x 8: the whole image in LDS (img_conv.hip)
-        rc = launch_conv1_img(obs, idx_or_null, scale, w, bias_or_null, y, g.batch, g.C, g.H, g.W, g.K, g.kh, g.kw, g.stride,
+        rc = launch_conv1_img(obs, obs_rows, idx_or_null, scale, w, bias_or_null, y, g.batch, g.C, g.H, g.W, g.K, g.kh, g.kw, g.stride,
                               g.Ho, g.Wo, relu, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }

@@ -23,6 +23,10 @@ class _SyncMixin(object):
     # the eager path pays a compute -> RCCL stream -> compute hand-over per all-reduce on the host's launch path; inside a
     # graph they are edges.  Only on the `nccl` backend (gloo copies through the host: not capturable).
     graph_collectives = True
+    # measurement hook (bench.py, N > 1, AFTER the timed region): the same learner with its collectives left out, so
+    # that the line can state how much of the step the all-reduces add (`allreduce_exposed_ms`).  Every rank's
+    # parameters then follow its own gradient: never set on a run whose result is used.
+    _elide_collective = False
 
     def graph_ready(self):
         """True when this optimizer's collectives can be captured into a hipGraph."""
@@ -55,14 +59,14 @@ class _SyncMixin(object):
             self._grad_tap.append((int(first), g.detach().clone()))
 
     def _share_grad(self):
-        if self._n_gpu > 1 or self._force_collective:
+        if (self._n_gpu > 1 or self._force_collective) and not self._elide_collective:
             self._tap(self._target.flat_grads, 0)
             dist.all_reduce(self._target.flat_grads, op=dist.ReduceOp.SUM, group=self._comm)
 
     def _share_grad_async(self, tail):
         """The same all-reduce, asynchronous, of the bucket's tail / head / whole (the split point is the
         policy's `grad_split_offset`: everything behind it is final when the policy calls the split hook)."""
-        if not (self._n_gpu > 1 or self._force_collective):
+        if not (self._n_gpu > 1 or self._force_collective) or self._elide_collective:
             return None
         g, first = self._target.flat_grads, 0
         if tail is not None:

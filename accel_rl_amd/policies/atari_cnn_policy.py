@@ -378,7 +378,8 @@ class AtariCnnPolicy(object):
     # Rows of a minibatch per forward + backward pass.  The activations of a pass and their gradients (fp32, every conv
     # layer's output twice) plus the u8 rows it reads want to stay in the 256 MiB Infinity Cache between the launch
     # that writes them and the launches that read them: measured (tools/batch_sweep.py, profiles/r03/batch_sweep.txt)
-    # the cost per row is lowest at 1024 rows for spec 1 (232 KB + 33 KB per row) and at 2048 for spec 0 (88 + 33 KB)
+    # the cost per row is lowest at 1024 rows for spec 1 (232 KB + 33 KB per row; the formula below gives 1024) and around
+    # 2048 for spec 0 (88 + 33 KB; the formula gives 2304 = (2218 + 128) // 256 * 256, i.e. passes start at 6912 rows)
     # and, for spec 1, 15-25 % higher at 4096-5120 rows in one pass (spec 0: 2 %).  A minibatch of three or more such
     # passes (the strong-scaling bench's 4096 rows of spec 1 on one GPU) is therefore walked in passes of that size
     # whose gradients are added in a fixed order -- the same mean-loss gradient, other summation order
@@ -406,6 +407,11 @@ class AtariCnnPolicy(object):
         if inv_count is None:
             inv_count = self._buffer(("inv_rows", rows), (1,))
             inv_count.fill_(1.0 / rows)
+        if not getattr(self, "_passes_logged", False):
+            self._passes_logged = True
+            from accel_rl_amd.util import logger
+            logger.log("AtariCnnPolicy: minibatches of %d rows are walked in passes of %d (gradients accumulated in a fixed "
+                       "order; max_rows_per_pass = None keeps one pass)" % (rows, limit))
         acc = self._buffer(("grad_acc",), tuple(self.flat_grads.shape))
         loss_acc = self._buffer(("loss_acc",), (4,))
         one = dict((k, v) for k, v in mb.items() if k not in ("split_hook", "dense_w_hook"))

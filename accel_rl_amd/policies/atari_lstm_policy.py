@@ -79,7 +79,7 @@ class RecurrentCnnPolicy(AtariCnnPolicy):
 
     # ---- forward ---------------------------------------------------------------
     def _geom(self, rows, fan_in, units):
-        key = ("rec", rows, fan_in, units)
+        key = ("rec", rows, fan_in, units, _lib.default_route)      # the route is a field of the geometry
         if key not in self._geoms:
             self._geoms[key] = _lib.dense_geom(rows, fan_in, units)
         return self._geoms[key]

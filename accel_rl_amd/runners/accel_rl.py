@@ -58,6 +58,24 @@ class AccelRLBase(Runner):
         self.policy.initialize(env_spec, device=self.sampler.device)
         logger.log("Policy trainable params -- number: {:,}   size: {:,.1f} {}".format(
             self.policy.n_params, *nbytes_unit(self.policy.n_params * 4)))
+        self.pin_master()
+
+    def pin_master(self):
+        """accel_rl_base.py:71-72: the runner's process (here: the thread that replays the rank's graphs) is pinned to
+        affinities["gpu_cpus"]; no key = untouched.  CPUs the process may not use (a cgroup narrower than the launcher's
+        table) are dropped, and an empty remainder leaves the affinity as it is instead of failing the run."""
+        import os
+        want = self.affinities.get("gpu_cpus") if hasattr(self.affinities, "get") else None
+        if not want:
+            return None
+        allowed = os.sched_getaffinity(0)
+        cpus = sorted(set(int(c) for c in want) & allowed)
+        if not cpus:
+            logger.log("WARNING: gpu_cpus %s not among this process's CPUs %s: affinity unchanged" % (list(want), sorted(allowed)))
+            return None
+        os.sched_setaffinity(0, cpus)
+        logger.log("Runner CPU affinity: %s" % cpus)
+        return cpus
 
     def get_n_itr(self, sample_size):
         """reference: accel_rl_base.py:74-87"""

@@ -211,6 +211,9 @@ def env_step_sweep(device, n_env=ENV_SWEEP_ENVS):
     return dict(kernel="env_step@sweep (env_step_kernel, %d envs, rollout rows written once)" % n_env, bound="hbm",
                 avg_launch_us=round(ms * 1e3, 2), bytes_per_launch=nbytes, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                # what the DRAM really moves (PMC bytes / launch time): the 2 MB raw-frame bank is served from L2 / MALL,
+                # so this is BELOW the algorithmic fraction -- the kernel is not HBM-bound
+                frac_dram=(round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                 timing="%d launches per hipGraph, 5 replays" % per_graph)
 
 
@@ -315,27 +318,40 @@ def mfma_table(device, policy, batch=512, reps=20):
             iso_ms, _ = event_time_ms(fn, reps)
             mean_ms = graph_time_ms(fn)
             tfs = flops / (mean_ms * 1e-3) / 1e12
+            # What bounds the launch is the pipe its MFMAs are issued on: the fp32 MFMA chain (157.3 TF/s) for route 0
+            # and for the <= 16-column layers, the bf16 pipe for the split routes -- where one fp32 multiply is
+            # `products` bf16 MFMA products, i.e. a ceiling of 2 500 / products TF/s of fp32 flops (278 at nine, 833
+            # for u8 pixels).  `frac` is against THAT ceiling; the fp32-MFMA fraction stays as a secondary key.
+            products = (3 if "u8" in name else mode) if (mode and g.out_c > 16) else 0
+            route_peak = MFMA_BF16_PEAK_TFS / products if products else MFMA_F32_PEAK_TFS
             row = dict(kernel="%s %s" % (name, tag), avg_launch_us=round(mean_ms * 1e3, 2),
                        isolated_launch_us=round(iso_ms * 1e3, 2),
-                       flops_per_launch=int(flops), achieved_TFs=round(tfs, 1),
+                       flops_per_launch=int(flops), achieved_TFs=round(tfs, 1), route_peak_TFs=round(route_peak, 1),
+                       frac=round(tfs / route_peak, 4),
                        frac_mfma_f32=round(tfs / MFMA_F32_PEAK_TFS, 4), launches_per_step=8)
-            if mode and g.out_c > 16:
-                products = 3 if "u8" in name else mode
+            if products:
                 row.update(products_per_multiply=products, matrix_pipe_TFs=round(tfs * products, 1),
                            frac_mfma_bf16=round(tfs * products / MFMA_BF16_PEAK_TFS, 4))
+            row["_pipe_us_at_peak"] = flops / route_peak / 1e6
             rows.append(row)
         k += 2
     total_us = sum(r["avg_launch_us"] for r in rows)
     total_fl = sum(r["flops_per_launch"] for r in rows)
-    out = dict(bound="mfma", dtype="f32", peak=MFMA_F32_PEAK_TFS, unit="TFLOP/s", batch=batch,
+    # the ceiling of the whole set on the route it runs: total flops / the time its MFMAs take at their pipes' peaks
+    route_peak = total_fl / sum(r.pop("_pipe_us_at_peak") for r in rows) / 1e6
+    out = dict(bound="mfma", dtype="f32", peak=round(route_peak, 1), unit="TFLOP/s", batch=batch,
+               route_peak=round(route_peak, 1), fp32_mfma_peak=MFMA_F32_PEAK_TFS, bf16_mfma_peak=MFMA_BF16_PEAK_TFS,
                route=("fp32 MFMA chain (v_mfma_f32_32x32x2_f32)" if not mode else
                       "fp32 operands split exactly into three bf16 pieces, %d piece products per multiply accumulated in fp32 "
-                      "(v_mfma_f32_32x32x16_bf16); achieved / frac count fp32 flops (2 x MACs) against the fp32 MFMA peak, "
-                      "matrix_pipe_TFs / frac_mfma_bf16 the bf16 MFMA flops actually issued against the dense bf16 peak" % mode),
+                      "(v_mfma_f32_32x32x16_bf16; u8 pixels are one piece: three products); achieved counts fp32 flops (2 x MACs); "
+                      "peak = route_peak = those flops / the time the issued bf16 MFMA products take at the dense bf16 peak "
+                      "(2 500 TF/s / products per multiply, flop-weighted over the kernels), frac = achieved / route_peak; "
+                      "frac_vs_fp32_mfma = the same flops against the fp32 MFMA peak this route does not use" % mode),
                timing="avg_launch_us: 20 launches back to back in one hipGraph (as the learner runs them); "
                       "isolated_launch_us: one launch between its own pair of events",
                achieved=round(total_fl / total_us / 1e6, 1),
-               frac=round(total_fl / total_us / 1e6 / MFMA_F32_PEAK_TFS, 4), kernels=rows)
+               frac=round(total_fl / total_us / 1e6 / route_peak, 4),
+               frac_vs_fp32_mfma=round(total_fl / total_us / 1e6 / MFMA_F32_PEAK_TFS, 4), kernels=rows)
     # The peak above assumes 2.4 GHz.  The clock these kernels actually sustain: per workgroup, shader-cycle
     # counter against the 100 MHz wall clock over a traced conv-2 forward launch that follows 40 untraced ones
     # (arl_dev_conv_trace_buffer, as tools/conv_trace.py).
@@ -360,7 +376,7 @@ def mfma_table(device, policy, batch=512, reps=20):
             if len(t):          # per workgroup: shader cycles / (100 MHz ticks * 10 ns)
                 clocks.append(float(np.median((t[:, 3] - t[:, 0]) / np.maximum(t[:, 5] - t[:, 4], 1) / 10.0)))
         clk = float(np.median(clocks))
-        peak_clk = MFMA_F32_PEAK_TFS * clk / 2.4
+        peak_clk = route_peak * clk / 2.4
         out.update(sustained_clock_ghz=round(clk, 3), peak_at_sustained_clock=round(peak_clk, 1),
                    frac_at_sustained_clock=round(out["achieved"] / peak_clk, 4))
     finally:
@@ -583,6 +599,52 @@ def catdqn_main(args):
     print(json.dumps(line), flush=True)
 
 
+def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, timed, reps, itr, t_step, t_roll, t_learn):
+    """What the N > 1 line says about itself (every rank computes, rank 0 prints):
+      per_rank_ms                         min / max over the ranks of each rank's own step, rollout and learner time
+                                          (a straggler shows as max >> min; the headline takes the max);
+      params_bit_identical_across_ranks   all-reduce(MIN) == all-reduce(MAX) of a 64-bit checksum of the parameter
+                                          bucket after the timed region: the synchronous update's invariant
+                                          (sync_ppo_optimizer.py:27-34: same averaged gradient, same local update);
+      graph_captured                      the learner of the timed region ran as ONE hipGraph with the collectives
+                                          inside (False: every rank fell back to eager minibatches together --
+                                          SyncPpoOptimizer.ranks_agree -- or --no-graph);
+      allreduce_exposed_ms                learner time with the collectives minus the SAME learner with them left out
+                                          (re-captured; measured last, the ranks' parameters diverge from there on):
+                                          what the all-reduces add to a step after the overlap with the conv backward.
+    All collectives below are issued by every rank in the same order."""
+    opt = algo.optimizer
+    f64 = lambda *x: torch.tensor(list(x), dtype=torch.float64, device=device)          # noqa: E731
+    mine = f64(t_step, t_roll, t_learn) * 1e3
+    lo, hi = mine.clone(), mine.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    words = policy.flat_params.view(torch.int32).to(torch.int64)
+    pos = torch.arange(1, words.numel() + 1, device=device, dtype=torch.int64)
+    check = torch.stack([words.sum(), (words * (pos % 65521)).sum()])                     # position-sensitive
+    cmin, cmax = check.clone(), check.clone()
+    dist.all_reduce(cmin, op=dist.ReduceOp.MIN)
+    dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
+    out = {"per_rank_ms": {k: [round(float(lo[i]), 4), round(float(hi[i]), 4)]
+                           for i, k in enumerate(("step", "rollout", "learner"))},
+           "params_bit_identical_across_ranks": bool(torch.equal(cmin, cmax)),
+           "param_checksum": [int(x) for x in cmin.tolist()],
+           "graph_captured": bool(getattr(algo, "_graph", None) is not None and opt.graph_ready()),
+           "overlapped_allreduce": bool(getattr(opt, "_overlap_allreduce", False)),
+           "allreduce_bytes_per_update": int(policy.flat_grads.numel() * 4)}
+    # the same learner without its collectives: drop the captured graph, two eager calls, re-capture, time
+    opt._elide_collective = True
+    algo._graph, algo._graph_out, algo._warm_calls = None, None, 0
+    for i in range(3):
+        algo.optimize_policy(itr + i, samples)
+    t_quiet = timed(lambda i: algo.optimize_policy(itr + 3 + i, samples), reps)
+    quiet = f64(t_quiet * 1e3)
+    dist.all_reduce(quiet, op=dist.ReduceOp.MAX)
+    out["learner_without_collectives_ms"] = round(float(quiet[0]), 4)
+    out["allreduce_exposed_ms"] = round(float(hi[2]) - float(quiet[0]), 4)
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, as the
     reference's runner forks its n-1 workers from one process (accel_rl/runners/multigpu_rl_base.py:20-45).
@@ -695,7 +757,7 @@ def main():
         one_step(itr, sampler, algo)
         itr += 1
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = elapsed_local = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -722,7 +784,8 @@ def main():
                                 ("hipGraph rollout" if not args.no_graph else "eager",)),
                    "total_envs": N_ENVS * world, "global_minibatch": MINIBATCH * world,
                    "env_steps_per_step_per_gpu": N_ENVS * HORIZON,
-                   "parallelism": "dp%d sync all-reduce (RCCL)" % world if world > 1 else "single"},
+                   "parallelism": ("dp%d sync all-reduce (%s)" % (world, "RCCL" if backend == "nccl" else backend))
+                                  if world > 1 else "single"},
     }
     # phase split of the same workload (after the timed region): rollout only / learner only
     def timed(fn, reps):
@@ -738,6 +801,9 @@ def main():
     t_learn = timed(lambda i: algo.optimize_policy(itr + i, samples), reps)
     line["phases"] = {"rollout_ms": round(t_roll * 1e3, 4), "learner_ms": round(t_learn * 1e3, 4),
                       "rollout_only_env_steps_per_s": round(N_ENVS * HORIZON / t_roll, 1)}
+    if world > 1:
+        line["multi_gpu"] = multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, timed, reps,
+                                                  itr + 2 * reps, elapsed_local / args.steps, t_roll, t_learn)
     if rank == 0 and world == 1:
         if not args.no_roofline:
             line["roofline"] = roofline_gae(device, args.roofline_log2, 30)

@@ -84,6 +84,30 @@ def test_struct_layouts_match_header(lib):
                      ctypes.sizeof(_lib.ArlCorunJob)]
 
 
+def test_struct_field_offsets_match_header(lib):
+    """Every field of every ctypes mirror sits at the header's offsetof (a field that moves into former padding
+    keeps sizeof unchanged -- arl_conv_geom.route did exactly that in round 3)."""
+    import subprocess
+    import tempfile
+    from accel_rl_amd import _lib
+    pairs = [("arl_game", _lib.ArlGame), ("arl_env_state", _lib.ArlEnvState), ("arl_rollout", _lib.ArlRollout),
+             ("arl_opt_state", _lib.ArlOptState), ("arl_conv_geom", _lib.ArlConvGeom), ("arl_replay", _lib.ArlReplay),
+             ("arl_fold_item", _lib.ArlFoldItem)]
+    lines = ['printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (c, f[0], c, f[0]) for c, cls in pairs for f in cls._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "accel_rl_hip.h"\nint main(){%s return 0;}' % "\n".join(lines)
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "o.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "o")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    classes = dict(pairs)
+    assert len(out) == 2 * len(lines) and len(lines) > 80
+    for name, off in zip(out[0::2], out[1::2]):
+        c, f = name.split(".")
+        assert getattr(classes[c], f).offset == int(off), name
+
+
 def test_no_cpu_fallback():
     """Host tensors are refused: the product has no CPU path."""
     import torch

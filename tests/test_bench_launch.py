@@ -45,6 +45,33 @@ def test_two_ranks_spawned_in_development_mode():
     d = _line(out)
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["scaling"] == "weak"
     assert d["steps"] == 2 and d["config"]["total_envs"] == 512 and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2 sync all-reduce (gloo)"          # the label names the backend that ran
+    _check_multi_gpu_keys(d, 2)
+
+
+def _check_multi_gpu_keys(d, world):
+    """The N > 1 line describes itself (bench.py::multi_gpu_diagnostics)."""
+    m = d["multi_gpu"]
+    for k in ("step", "rollout", "learner"):
+        lo, hi = m["per_rank_ms"][k]
+        assert 0 < lo <= hi
+    assert m["params_bit_identical_across_ranks"] is True       # the synchronous update's invariant, on real ranks
+    assert m["graph_captured"] is False                         # development mode: gloo cannot be captured, --no-graph
+    assert isinstance(m["allreduce_exposed_ms"], float) and m["learner_without_collectives_ms"] > 0
+    assert m["allreduce_bytes_per_update"] > 14e6               # the flat fp32 bucket of the spec-1 policy
+
+
+@pytest.mark.gpu
+def test_eight_ranks_spawned_in_development_mode():
+    """The driver's 8-GPU launch shape, all eight ranks on GPU 0 over gloo: rendezvous, per-rank seeds, broadcast, eight
+    contributions per all-reduce, the self-describing keys -- a launch-path check, never a measurement."""
+    out = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-roofline"],
+               dict(ARL_BENCH_ONE_GPU="1", ARL_BENCH_BACKEND="gloo"), timeout=900)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+    d = _line(out)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["backend"] == "gloo"
+    assert d["config"]["total_envs"] == 2048 and d["config"]["global_minibatch"] == 4096 and d["value"] > 0
+    _check_multi_gpu_keys(d, 8)
 
 
 @pytest.mark.gpu

@@ -243,3 +243,40 @@ def test_ppo_surrogate_gradient_rules():
     assert PPO(ppo_tie_rule="math").loss_tie_rule == 1
     with pytest.raises(ValueError):
         PPO(ppo_tie_rule="torch")
+
+
+def test_committed_pmc_records_belong_to_the_current_kernels():
+    """bench.py quotes HBM traffic from the committed rocprofv3 --pmc records (it cannot read counters itself) and
+    drops a record whose source hash is not the current kernel file's -- round 3 shipped a stale one and the driver's
+    line carried `traffic: null`.  A kernel edit must be followed by tools/refresh_profiles.sh (or tools/env_step_pmc.sh
+    / the gae passes alone) and a commit of profiles/*.json; this test is what says so."""
+    import hashlib
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rec, key, src in (("gae_pmc_traffic.json", "scan_hip_sha1", "scan.hip"),
+                          ("env_step_pmc.json", "env_hip_sha1", "env.hip")):
+        with open(os.path.join(root, "profiles", rec)) as f:
+            have = json.load(f)[key]
+        with open(os.path.join(root, "accel_rl_amd", "csrc", src), "rb") as f:
+            want = hashlib.sha1(f.read()).hexdigest()
+        assert have == want, "profiles/%s was measured on another %s: re-run the PMC passes and commit the record" % (rec, src)
+
+
+def test_runner_pins_itself_to_gpu_cpus():
+    """accel_rl/runners/accel_rl_base.py:71-72: p.cpu_affinity(affinities.get("gpu_cpus", <unchanged>))."""
+    import os
+    from accel_rl_amd.runners.accel_rl import AccelRLBase
+    before = os.sched_getaffinity(0)
+    r = AccelRLBase.__new__(AccelRLBase)
+    try:
+        r.affinities = dict(gpu=0)
+        assert r.pin_master() is None and os.sched_getaffinity(0) == before
+        one = sorted(before)[-1]
+        r.affinities = dict(gpu=0, gpu_cpus=(one, 10 ** 6))            # a CPU that does not exist is dropped
+        assert r.pin_master() == [one] and os.sched_getaffinity(0) == {one}
+        os.sched_setaffinity(0, before)
+        r.affinities = dict(gpu_cpus=(10 ** 6,))
+        assert r.pin_master() is None and os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
