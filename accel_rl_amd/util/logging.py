@@ -1,48 +1,71 @@
-"""Run directories and logger set-up (reference: accel_rl/util/logging.py:11-49).
+"""Run directories (the contract of accel_rl/util/logging.py:11-49, which the reference's plotting and launch
+tooling read):
 
-`with logger_context(log_dir, name, run_ID, log_params, snapshot_mode): runner.train()` writes
-<log_dir>/<name>_<run_ID>/{progress.csv, debug.log, params.json} (+ itr_N.pkl / params.pkl
-snapshots), the files the reference's plotting and launch tooling read.  The reference roots
-relative directories under rllab.config.LOG_DIR/local/<yyyymmdd>/; here the root is
-$ACCEL_RL_LOG_DIR (default ./data)."""
+    <root>/<name>_<run_ID>/progress.csv   tabular log
+                           debug.log      text log
+                           params.json    the launch parameters + name + run_ID
+                           itr_N.pkl / params.pkl   snapshots, by snapshot_mode
+
+`with logger_context(log_dir, name, run_ID, log_params, snapshot_mode) as exp_dir: runner.train()`.
+A `log_dir` outside the log root is re-rooted under <LOG_DIR>/local/<yyyymmdd>/ as the reference does with
+rllab.config.LOG_DIR; here the root is $ACCEL_RL_LOG_DIR (default ./data).  The outputs are detached again when the
+block is left by an exception too."""
+import contextlib
 import datetime
 import json
 import os
-from contextlib import contextmanager
 
 from accel_rl_amd.util import logger
 
 LOG_DIR = os.path.abspath(os.environ.get("ACCEL_RL_LOG_DIR", os.path.join(os.getcwd(), "data")))
+FILES = dict(tabular="progress.csv", text="debug.log", params="params.json")
 
 
 def make_log_dir(experiment_name, sub_name=None):
-    yyyymmdd = datetime.datetime.today().strftime("%Y%m%d")
-    log_dir = os.path.join(LOG_DIR, "local", yyyymmdd, experiment_name)
-    return log_dir if sub_name is None else os.path.join(log_dir, sub_name)
+    """<LOG_DIR>/local/<yyyymmdd>/<experiment_name>[/<sub_name>]"""
+    parts = [LOG_DIR, "local", datetime.date.today().strftime("%Y%m%d"), experiment_name]
+    return os.path.join(*(parts + ([sub_name] if sub_name is not None else [])))
 
 
-@contextmanager
-def logger_context(log_dir, name, run_ID, log_params=None, snapshot_mode="none"):
-    logger.set_snapshot_mode(snapshot_mode)
-    abs_log_dir = os.path.abspath(log_dir)
-    if LOG_DIR != os.path.commonpath([abs_log_dir, LOG_DIR]):
-        abs_log_dir = make_log_dir(log_dir)
-    exp_dir = os.path.join(abs_log_dir, "{}_{}".format(name, run_ID))
-    tabular_log_file = os.path.join(exp_dir, "progress.csv")
-    text_log_file = os.path.join(exp_dir, "debug.log")
-    params_log_file = os.path.join(exp_dir, "params.json")
-    logger.set_snapshot_dir(exp_dir)
-    logger.add_text_output(text_log_file)
-    logger.add_tabular_output(tabular_log_file)
-    logger.push_prefix("{}_{} ".format(name, run_ID))
-    log_params = dict(log_params or dict())
-    log_params["name"] = name
-    log_params["run_ID"] = run_ID
-    with open(params_log_file, "w") as f:
-        json.dump(log_params, f)
-    try:
-        yield exp_dir
-    finally:
-        logger.remove_tabular_output(tabular_log_file)
-        logger.remove_text_output(text_log_file)
+class RunDir(object):
+    """One run's directory and the logger outputs that live in it."""
+
+    def __init__(self, log_dir, name, run_ID):
+        root = os.path.abspath(log_dir)
+        inside = os.path.commonpath([root, LOG_DIR]) == LOG_DIR
+        self.tag = "{}_{}".format(name, run_ID)
+        self.path = os.path.join(root if inside else make_log_dir(log_dir), self.tag)
+        self.name, self.run_ID = name, run_ID
+
+    def file(self, kind):
+        return os.path.join(self.path, FILES[kind])
+
+    def write_params(self, log_params):
+        record = dict(log_params or ())
+        record.update(name=self.name, run_ID=self.run_ID)
+        os.makedirs(self.path, exist_ok=True)
+        with open(self.file("params"), "w") as f:
+            json.dump(record, f)
+
+    def attach(self, snapshot_mode):
+        logger.set_snapshot_mode(snapshot_mode)
+        logger.set_snapshot_dir(self.path)
+        logger.add_text_output(self.file("text"))
+        logger.add_tabular_output(self.file("tabular"))
+        logger.push_prefix(self.tag + " ")
+
+    def detach(self):
+        logger.remove_tabular_output(self.file("tabular"))
+        logger.remove_text_output(self.file("text"))
         logger.pop_prefix()
+
+
+@contextlib.contextmanager
+def logger_context(log_dir, name, run_ID, log_params=None, snapshot_mode="none"):
+    run = RunDir(log_dir, name, run_ID)
+    run.attach(snapshot_mode)
+    try:
+        run.write_params(log_params)
+        yield run.path
+    finally:
+        run.detach()

@@ -390,12 +390,15 @@ def test_single_frame_observations():
     np.testing.assert_array_equal(policy.get_param_values(), flat)
 
 
-@pytest.mark.parametrize("kind", ["ppo", "a2c"])
-def test_explicit_backward_matches_autograd(kind):
+@pytest.mark.parametrize("kind,tie", [("ppo", "theano"), ("ppo", "math"), ("a2c", "theano")])
+def test_explicit_backward_matches_autograd(kind, tie):
     """flat_grads from the explicit HIP backward == autograd through PyTorch's own conv2d /
-    linear on the same network."""
+    linear on the same network; PPO under both gradient rules of the surrogate's min / clip (the reference's Theano
+    graph -- the default -- and the mathematical derivative)."""
+    from accel_rl_amd import _lib
     n_env, horizon = 16, 5
-    policy, algo, buf, spec = make(kind, n_env, horizon, False)
+    policy, algo, buf, spec = make(kind, n_env, horizon, False, tie=tie)
+    assert algo.loss_tie_rule == dict(theano=_lib.PPO_TIE_THEANO, math=_lib.PPO_TIE_MATH)[tie]
     rs = np.random.RandomState(5)
     fill(buf, policy, rs, n_env, horizon)
     n = n_env * horizon
@@ -410,7 +413,7 @@ def test_explicit_backward_matches_autograd(kind):
         sel = idx.long()
         inv = (1. / valids[sel].sum(dtype=torch.float32)).reshape(1) if use_valids else None
         kid, v_c = (1, 1.0) if kind == "ppo" else (0, 0.25)
-        loss4 = policy.loss_and_grads(mb, kid, 0.2, v_c, 0.01, lr_mult, inv).clone()
+        loss4 = policy.loss_and_grads(mb, kid, 0.2, v_c, 0.01, lr_mult, inv, tie_rule=algo.loss_tie_rule).clone()
         got = policy.flat_grads.clone()
         # autograd on the same internal parameters
         policy.flat_grads.zero_()
@@ -421,7 +424,7 @@ def test_explicit_backward_matches_autograd(kind):
         if kind == "ppo":
             ratio = (pa + TINY) / (mb["old_prob"][sel][torch.arange(32), act] + TINY)
             c = 0.2 * 0.7
-            pi = -torch.sum(w * torch.minimum(ratio * adv[sel], torch.clamp(ratio, 1 - c, 1 + c) * adv[sel]))
+            pi = -torch.sum(w * autograd_ref.ppo_surrogate(ratio, adv[sel], c, tie))
         else:
             pi = -torch.sum(w * torch.log(pa + TINY) * adv[sel])
         vl = v_c * torch.sum(w * (value - ret[sel]) ** 2)
@@ -476,12 +479,12 @@ def test_minibatch_walked_in_passes_is_the_one_pass_gradient(kind, use_valids):
     assert policy.rows_per_pass() == 2304 and policy.rows_per_pass() % 256 == 0        # spec 0 at 4 x 104 x 80
 
 
-@pytest.mark.parametrize("kind", ["ppo", "a2c"])
-def test_fused_losses_match_the_algorithm_formulas(kind):
+@pytest.mark.parametrize("kind,tie", [("ppo", "theano"), ("ppo", "math"), ("a2c", "theano")])
+def test_fused_losses_match_the_algorithm_formulas(kind, tie):
     """The algorithm's `_losses` (HIP forward + fused head kernel + HIP backward, selected by `loss_kind`) against
     the same algorithm's `pi_loss` formula + value / entropy terms (aac_base.py:60-66) differentiated by autograd."""
     n_env, horizon = 16, 5
-    policy, algo, buf, spec = make(kind, n_env, horizon, False)
+    policy, algo, buf, spec = make(kind, n_env, horizon, False, tie=tie)
     rs = np.random.RandomState(9)
     fill(buf, policy, rs, n_env, horizon)
     algo._lr_mult.fill_(0.6)
