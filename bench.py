@@ -549,6 +549,77 @@ def cpu_baseline(device, policy, pools, sampler, algo, itr0, seconds=4.0, n_wind
                        (len(sweep), batches, dt, 2 * n_par, n_par, half // n_par, loop_batches, loop_dt, b1))
 
 
+def replay_roofline(device, algo, batch=4096):
+    """arl_replay_extract (csrc/replay.hip; extract_batch / extract_observations, frame.py:69-90) at a bandwidth-bound
+    batch of the 1M-transition store: per sampled transition two stacked observations (state and the state
+    reward_horizon later), each 33 280 B read from the frame ring and 33 280 B written into the minibatch, + 6 B of
+    scalars -- the algorithmic bytes; timed as 20 launches per hipGraph with HIP events on the launch stream."""
+    from accel_rl_amd import _lib
+    buf = algo.replay_buffer
+    gen = torch.Generator(device=device).manual_seed(11)
+    n_env = buf.frames.shape[0]
+    stack = int(np.prod(buf.frames.shape[2:])) * buf.num_img_obs
+    e_idx = torch.randint(0, n_env, (batch,), dtype=torch.int32, device=device, generator=gen)
+    s_idx = torch.randint(0, buf.env_replay_size - 8, (batch,), dtype=torch.int32, device=device, generator=gen)
+    shape = (batch, buf.num_img_obs) + tuple(buf.frames.shape[2:])
+    obs, nxt = (torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(2))
+    a, r, tm = (torch.empty(batch, dtype=torch.uint8, device=device), torch.empty(batch, device=device),
+                torch.empty(batch, dtype=torch.uint8, device=device))
+    per_graph = 20
+    ms = graph_time_ms(lambda: _lib.replay_extract(buf._rb, e_idx, s_idx, obs, nxt, a, r, tm), per_graph=per_graph, replays=5)
+    nbytes = batch * (2 * 2 * stack + 6)
+    achieved = nbytes / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="extract_kernel (arl_replay_extract), %d transitions = %d stacked observations out of "
+                                    "%.1f GB of frames" % (batch, 2 * batch, buf.frames.numel() / 1e9),
+                achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=None, bytes_per_launch=nbytes, bytes_per_stack=2 * stack, avg_launch_us=round(ms * 1e3, 2),
+                timing="%d launches per hipGraph, 5 replays" % per_graph)
+
+
+def replay_cpu_baseline(n_env, horizon, reward_horizon, batch, updates_per_step, seconds=12.0):
+    """The replay side of config 5 on ONE host core: the oracle's numpy restatement of the reference's frame-dedup
+    replay buffer + parted sum tree (oracle/replay_port.py, pinned to the reference's own classes by G11 / G12) doing
+    what one bench step asks of it -- append of n_env x horizon env-steps with the n-step back-fill, tree advance, then
+    `updates_per_step` x (sample_n of `batch` distinct leaves, importance weights, extract_batch, priority write-back).
+    No emulator, no network: the reference's learner (Theano) is absent.  The store is 400 states per environment
+    instead of 3 908 (host memory; the per-operation cost does not depend on the capacity)."""
+    from oracle import replay_port as R
+    frame = (104, 80)
+    size = n_env * 400
+    rp = R.ReplayPort(n_env, 4, frame, size, reward_horizon, horizon, 0.99)
+    tree = R.SumTreePort(rp.S, n_env, zeros_forward=4, zeros_backward=reward_horizon, default_value=1.0,
+                         n_advance=horizon)
+    rs = np.random.RandomState(0)
+    obs = rs.randint(0, 256, size=(n_env, horizon, 4) + frame, dtype=np.uint8)
+    acts = rs.randint(0, 18, size=(n_env, horizon)).astype(np.uint8)
+
+    def step():
+        rews = rs.randn(n_env, horizon).astype(np.float32)
+        dones = rs.rand(n_env, horizon) < 0.02
+        rp.append(obs, acts, rews, dones)
+        tree.advance()
+        for _ in range(updates_per_step):
+            e, st, probs = tree.sample_n(batch, rs)
+            R.importance_weights(probs, 0.4)
+            rp.extract_batch(e, st)
+            tree.update_last(rs.rand(batch) + 0.1)
+    for _ in range(60):                      # fill enough of the ring for sampling (and warm the caches)
+        rews = rs.randn(n_env, horizon).astype(np.float32)
+        rp.append(obs, acts, rews, rs.rand(n_env, horizon) < 0.02)
+        tree.advance()
+    step()
+    t0, n = time.time(), 0
+    while time.time() - t0 < seconds or n < 3:
+        step()
+        n += 1
+    dt = time.time() - t0
+    return dict(value=round(n * n_env * horizon / dt, 1), unit="env-steps/s", cores=1, kind="port",
+                sample="%d bench steps (%.1f s) of the replay side only: append of %d x %d env-steps + n-step back-fill + tree "
+                       "advance + %d x (sample_n(%d) + importance weights + extract_batch + priority write-back) on the "
+                       "oracle's numpy port (400 states per env instead of 3 908); no emulator, no learner" %
+                       (n, dt, n_env, horizon, updates_per_step, batch))
+
+
 def catdqn_main(args):
     """BASELINE config 5 (not the headline metric): Categorical DQN "seaquest", 1M-transition device replay
     (prioritized), 256 envs x horizon 4, spec-1 trunk, reward horizon 3, training intensity 8."""
@@ -596,6 +667,10 @@ def catdqn_main(args):
                                    "updates per step (training intensity 8), adam" %
                                    (n_env, horizon, algo.replay_buffer.env_replay_size * n_env,
                                     algo.replay_buffer.frames.numel() / 1e9, args.dqn_batch, algo._updates_per_optimize)}}
+    if not args.no_roofline:
+        line["roofline"] = replay_roofline(device, algo)
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = replay_cpu_baseline(n_env, horizon, 3, args.dqn_batch, algo._updates_per_optimize)
     print(json.dumps(line), flush=True)
 
 
