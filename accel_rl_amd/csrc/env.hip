@@ -340,6 +340,7 @@ struct FramePush {
     uint4 a0[PUSH_ITERS], a1[PUSH_ITERS], b0[PUSH_ITERS], b1[PUSH_ITERS];
     uint2 pv[PUSH_ITERS][MAX_STACK - 1];
 
+    template <int KO = 0>
     __device__ __forceinline__ void load(const arl_game& g, const int fa_i, const int fb_i, const int mode,
                                          const uint8_t* prev, const int tid) {
         const int F = g.n_stack;
@@ -360,7 +361,7 @@ struct FramePush {
                     a0[it] = *reinterpret_cast<const uint4*>(fa + src);
                     a1[it] = *reinterpret_cast<const uint4*>(fa + src + ARL_RAW_W);
                 }
-                if (mode == MODE_PUSH) {
+                if (mode == MODE_PUSH && KO != 3) {
 #pragma unroll
                     for (int f = 0; f < MAX_STACK - 1; ++f)
                         if (f < F - 1) pv[it][f] = *reinterpret_cast<const uint2*>(prev + (f + 1) * OBS_FRAME + un * 8);
@@ -370,6 +371,7 @@ struct FramePush {
     }
 
     // stack: oldest -> newest (atari_env.py:156-157)
+    template <int KO = 0>
     __device__ __forceinline__ void store(const arl_game& g, uint8_t* out0, uint8_t* out1, const int tid) const {
         const int F = g.n_stack;
 #pragma unroll
@@ -380,7 +382,7 @@ struct FramePush {
             const int o = un * 8;
 #pragma unroll
             for (int f = 0; f < MAX_STACK - 1; ++f)
-                if (f < F - 1) {
+                if (f < F - 1 && KO != 2 && KO != 3) {
                     *reinterpret_cast<uint2*>(out0 + f * OBS_FRAME + o) = pv[it][f];
                     if (out1) *reinterpret_cast<uint2*>(out1 + f * OBS_FRAME + o) = pv[it][f];
                 }
@@ -480,11 +482,41 @@ __global__ __launch_bounds__(256) void frame_step_kernel(const arl_game g, const
 // observations[e][step + 1], or to step_obs after the batch's last step -- and the previous stack is read from
 // observations[e][step]; the policy then reads the current observations as rows e * horizon + step of the
 // rollout buffer instead of step_obs.  Otherwise step_obs is kept current at every step (second write).
+// HEAD (arl_env_step_policy): the policy's output layers are part of this launch.  The workgroup folds its env's row of
+// the last hidden layer out of that layer's split-K partials (+ bias, rectifier: fold_splits_kernel's order), wave 0
+// runs the output layers and the softmax on it (head_kernel<infer>'s arithmetic, lane for lane), and the action is
+// sampled from the result -- no fold launch, no head launch, no prob / value round trip.  Nothing the frame plan
+// depends on depends on the action (it only enters the reward, see will_reset), so every lane derives the plan with a
+// placeholder action and issues its frame loads FIRST; the hidden row is folded and the heads run under their latency.
+// KO (development, arl_dev_env_variant): knock-outs for timing only (results wrong) -- 1: every env reads bank frame 0;
+// 2: the older planes of the stack are not stored; 3: ... nor loaded.
+struct HeadIn {
+    const float* part;      // f32[splits][n_env][hid]: split-K partial sums of the last hidden layer
+    const float* bias;      // f32[hid] or null
+    const float* w_head;    // f32[A + 1][hid]
+    const float* b_head;    // f32[A + 1]
+    int64_t split_stride;
+    int splits, hid, relu;
+};
+constexpr int HEAD_MAX_HID = 1024;
+
+__device__ __forceinline__ float wave_sum_f(float x) {     // (learner.hip's: the same butterfly, the same bits)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ float readlane_f(float x, int uniform_lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), uniform_lane));
+}
+
+template <bool HEAD, int KO>
 __global__ __launch_bounds__(256) void env_step_kernel(
     const arl_game g, const arl_env_state st, const arl_rollout ro, const float* __restrict__ prob,
     const float* __restrict__ value, const double* __restrict__ uniforms,
     const uint8_t* __restrict__ active, int step, int mid_batch_reset, double max_path_length,
-    double discount, int max_start_noops, int single_write) {
+    double discount, int max_start_noops, int single_write, const HeadIn hd) {
+    __shared__ float s_h[HEAD ? HEAD_MAX_HID : 1];
+    __shared__ float s_pv[HEAD ? ARL_MAX_ACTIONS + 2 : 1];
     const int64_t e = blockIdx.x;
     const int tid = threadIdx.x;
     const int parity = st.epoch[0] & 1;
@@ -495,9 +527,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     const int64_t n_streams = (st.n_env + per - 1) / per;
     // ---- every lane: this env's state, served distribution and uniform (uniform addresses: broadcast loads)
     const EnvRegs in = load_env(st, e);
-    const float* p = prob + e * g.n_actions;
-    const int a_idx = sample_action(p, g.n_actions, uniforms[e]);
-    const float v = value[e];
+    const float* p = HEAD ? s_pv : prob + e * g.n_actions;
+    int a_idx = HEAD ? 0 : sample_action(p, g.n_actions, uniforms[e]);
+    float v = HEAD ? 0.f : value[e];
     const bool is_active = !active || active[e] != 0;
     const int64_t cursor = st.noop_cursor[parity * n_streams + w];
     const uint8_t* flag_now = st.next_reset + (int64_t)fpar * st.n_env;         // written by the previous launch
@@ -527,7 +559,59 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     uint8_t* out1 = single_write ? nullptr : next;            // worker.py:52-53
     const bool fast = g.n_stack <= MAX_STACK;
     FramePush fp;
-    if (o.mode != MODE_SKIP && fast) fp.load(g, o.fa, o.fb, o.mode, prev, tid);
+    if (KO == 1) { o.fa = o.fa >= 0 ? 0 : -1; o.fb = 0; }
+    if (o.mode != MODE_SKIP && fast) fp.template load<KO>(g, o.fa, o.fb, o.mode, prev, tid);
+    if (HEAD) {
+        // ---- the env's row of the last hidden layer: sum of the split-K partials in fold_splits_kernel's order
+        // (sixteen interleaved groups, then the groups in order), + bias, rectifier
+        const int hid = hd.hid;
+        const float* row = hd.part + e * hid;
+        for (int c = tid; c < hid; c += 256) {
+            float acc = 0.f;
+            for (int zg = 0; zg < 16; ++zg) {             // (empty groups add + 0.0, as the fold kernel's do)
+                float t = 0.f;
+                for (int z = zg; z < hd.splits; z += 16) t += row[(int64_t)z * hd.split_stride + c];
+                acc = zg == 0 ? t : acc + t;
+            }
+            if (hd.bias) acc += hd.bias[c];
+            if (hd.relu) acc = fmaxf(acc, 0.f);
+            s_h[c] = acc;
+        }
+        __syncthreads();
+        // ---- output layers + softmax on wave 0: head_kernel<infer>'s arithmetic (lane k owns action k, lane A the value)
+        if (tid < 64) {
+            const int A = g.n_actions, K = A + 1, lane = tid;
+            float val = 0.f, mx = -3.0e38f, mine = 0.f;
+            for (int k = 0; k < K; ++k) {
+                float sdot = 0.f;
+                for (int c = lane; c < hid; c += 64) sdot += s_h[c] * hd.w_head[k * hid + c];
+                const float out = wave_sum_f(sdot) + hd.b_head[k];
+                if (k < A) mx = fmaxf(mx, out); else val = out;
+                mine = (lane == k) ? out : mine;
+            }
+            const bool is_act = lane < A;
+            const float ex = is_act ? expf(mine - mx) : 0.f;
+            float z = 0.f;
+            for (int k = 0; k < A; ++k) z += readlane_f(ex, k);
+            const float pk = ex / z;
+            if (is_act) s_pv[lane] = pk;
+            if (lane == 0) s_pv[ARL_MAX_ACTIONS + 1] = val;
+        }
+        __syncthreads();
+        v = s_pv[ARL_MAX_ACTIONS + 1];
+        a_idx = sample_action(p, g.n_actions, uniforms[e]);
+        if (tid == 0) {                                   // the commit needs the step under the SAMPLED action
+            const int fa = o.fa, fb = o.fb;
+            o = step_compute(g, in, a_idx, is_active, mid_batch_reset, max_path_length, discount);
+            if (o.reset_flag) {
+                int noops = 0;
+                if (max_start_noops > 0)
+                    noops = st.noop_ring[w * st.noop_ring_len + (cursor + rank) % st.noop_ring_len];
+                reset_regs(g, o.s, noops, o.fa, o.fb, o.mode);
+            }
+            if (KO == 1) { o.fa = fa; o.fb = fb; }
+        }
+    }
     // the stores of the scalar part, under the frame loads' latency: lane 0 commits, lanes of wave 1 copy the
     // served distribution (one element each instead of a load -> store chain per action on lane 0)
     if (o.stepped && tid >= 64 && tid - 64 < g.n_actions)
@@ -545,7 +629,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(
         if (mid_batch_reset && is_active && (o.reset_flag != 0) != (carried != 0)) atomicAdd(st.epoch + 2, 1);
     }
     if (o.mode != MODE_SKIP) {
-        if (fast) fp.store(g, out0, out1, tid);
+        if (fast) fp.template store<KO>(g, out0, out1, tid);
         else push_frame(g, o.fa, o.fb, o.mode, prev, out0, out1, tid);
     }
     if (tid == 0) {
@@ -591,6 +675,27 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
         }
         *reinterpret_cast<uint2*>(out + i * OBS_FRAME + un * 8) = box8(a0, a1, b0, b1);
     }
+}
+
+int g_env_variant = 0;               // arl_dev_env_variant: timing knock-outs of env_step_kernel (development)
+
+template <bool HEAD>
+int launch_env_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro, const float* prob,
+                    const float* value, const double* uniforms, const uint8_t* active, int32_t step,
+                    int32_t mid_batch_reset, double max_path_length, double discount, int32_t max_start_noops,
+                    int32_t single_write, const HeadIn& hd, hipStream_t s) {
+#define ARL_ENV_STEP(KO_)                                                                                        \
+    hipLaunchKernelGGL((env_step_kernel<HEAD, KO_>), dim3((unsigned)st->n_env), dim3(256), 0, s, *game, *st, *ro, \
+                       prob, value, uniforms, active, (int)step, (int)mid_batch_reset, max_path_length, discount, \
+                       (int)max_start_noops, (int)single_write, hd)
+    switch (g_env_variant) {
+        case 1: ARL_ENV_STEP(1); break;
+        case 2: ARL_ENV_STEP(2); break;
+        case 3: ARL_ENV_STEP(3); break;
+        default: ARL_ENV_STEP(0);
+    }
+#undef ARL_ENV_STEP
+    return arl::check_launch("env_step_kernel");
 }
 
 int check_env_args(const arl_game* g, const arl_env_state* st, const arl_rollout* ro) {
@@ -660,11 +765,36 @@ extern "C" int arl_env_step(const arl_game* game, const arl_env_state* st, const
                 "single_write needs mid_batch_reset and every env stepping");
     ARL_REQUIRE(st->next_reset && st->launch_count, ARL_E_ARG, "arl_env_step needs st->next_reset and st->launch_count");
     ARL_REQUIRE(max_path_length >= 1.0, ARL_E_RANGE, "arl_env_step needs max_path_length >= 1");
-    hipLaunchKernelGGL(env_step_kernel, dim3((unsigned)st->n_env), dim3(256), 0, (hipStream_t)stream, *game, *st,
-                       *ro, prob, value, uniforms, active_or_null, (int)step, (int)mid_batch_reset,
-                       max_path_length, discount, (int)max_start_noops, (int)single_write);
-    return arl::check_launch("env_step_kernel");
+    return launch_env_step<false>(game, st, ro, prob, value, uniforms, active_or_null, step, mid_batch_reset, max_path_length,
+                                  discount, max_start_noops, single_write, HeadIn{}, (hipStream_t)stream);
 }
+
+extern "C" int arl_env_step_policy(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                                   const arl_head_input* head, const double* uniforms,
+                                   const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
+                                   double max_path_length, double discount, int32_t max_start_noops,
+                                   int32_t single_write, void* stream) {
+    int rc = check_env_args(game, st, ro);
+    if (rc) return rc;
+    ARL_REQUIRE(head && head->part && head->w_head && head->b_head && uniforms, ARL_E_ARG, "null policy inputs");
+    ARL_REQUIRE(head->splits >= 1 && head->hid >= 1 && head->hid <= HEAD_MAX_HID, ARL_E_RANGE,
+                "arl_env_step_policy: 1 <= hid <= 1024, splits >= 1");
+    ARL_REQUIRE(head->splits == 1 || head->split_stride >= st->n_env * (int64_t)head->hid, ARL_E_ARG,
+                "arl_env_step_policy: split_stride shorter than one split");
+    ARL_REQUIRE(ro->rewards && ro->dones && ro->actions && ro->prob && ro->value && ro->observations, ARL_E_ARG,
+                "null rollout arrays");
+    ARL_REQUIRE(step >= 0 && step < ro->horizon, ARL_E_RANGE, "step outside horizon");
+    ARL_REQUIRE(!single_write || (mid_batch_reset && !active_or_null), ARL_E_ARG,
+                "single_write needs mid_batch_reset and every env stepping");
+    ARL_REQUIRE(st->next_reset && st->launch_count, ARL_E_ARG, "arl_env_step needs st->next_reset and st->launch_count");
+    ARL_REQUIRE(max_path_length >= 1.0, ARL_E_RANGE, "arl_env_step needs max_path_length >= 1");
+    HeadIn hd = {head->part, head->bias, head->w_head, head->b_head, head->split_stride, head->splits, head->hid,
+                 head->relu};
+    return launch_env_step<true>(game, st, ro, nullptr, nullptr, uniforms, active_or_null, step, mid_batch_reset,
+                                 max_path_length, discount, max_start_noops, single_write, hd, (hipStream_t)stream);
+}
+
+extern "C" void arl_dev_env_variant(int32_t v) { g_env_variant = (v >= 0 && v <= 3) ? v : 0; }
 
 extern "C" int arl_env_reset(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
                              const uint8_t* flags_or_null, int32_t max_start_noops, void* stream) {

@@ -134,7 +134,7 @@ extern "C" int arl_corun_job_run(const arl_corun_job* job, void* stream) {
 
 namespace {
 int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom, int32_t relu,
-             void* workspace, void* stream) {
+             void* workspace, void* stream, arl_head_input* parts_out = nullptr) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
@@ -203,10 +203,29 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
         else if (small) rc = launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s);
         else rc = launch_rowgather<2, 2, 2, 2, 16, true>(a, splits, s);
     }
+    if (parts_out && !rc) {         // the caller folds (arl_env_step_policy): describe what is left to do
+        parts_out->hid = a.N;
+        if (splits == 1) {          // y is final
+            parts_out->part = y; parts_out->bias = nullptr; parts_out->relu = 0;
+            parts_out->splits = 1; parts_out->split_stride = (int64_t)a.M * a.N;
+        } else {
+            parts_out->part = (const float*)workspace; parts_out->bias = bias_or_null; parts_out->relu = relu;
+            parts_out->splits = splits; parts_out->split_stride = (int64_t)a.M * a.N;
+        }
+        return 0;
+    }
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, bias_or_null, a.N, relu, y, s);
 }
 }  // namespace
+
+extern "C" int arl_conv2d_fwd_parts(const float* x, const float* w, const float* bias_or_null, float* y,
+                                    const arl_conv_geom* geom, int32_t relu, void* workspace, arl_head_input* head,
+                                    void* stream) {
+    ARL_REQUIRE(head, ARL_E_ARG, "null pointer");
+    ARL_ROUTE_SCOPE(geom, nullptr);
+    return fwd_impl(x, w, bias_or_null, y, geom, relu, workspace, stream, head);
+}
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {

@@ -30,6 +30,11 @@ void arl_dev_scan_force_wave(int32_t on);
  * value gives the same results bit for bit.  0 (default) = chosen by the launch's size.                             */
 void arl_dev_scan_wave_groups(int32_t n);
 
+/* Measurement (tools/env_step_bound.sh): timing knock-outs of arl_env_step's kernel, results WRONG -- 1: every env
+ * reads raw frame 0 of the bank (the bank reads all hit one 33 KB line set); 2: the three older planes of the stacked
+ * observation are not stored; 3: ... nor loaded.  0 (default) = the product kernel.                                 */
+void arl_dev_env_variant(int32_t v);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,7 @@ class P(object):
 pol = P(); pol.p = torch.full((n_env, 4), 0.25, device=dev); pol.v = torch.zeros(n_env, device=dev)
 smp.policy_init(pol)
 u = torch.rand(n_env, dtype=torch.float64, device=dev)
+_lib.load().arl_dev_env_variant(int(os.environ.get("ARL_ENV_VARIANT", "0")))     # timing knock-outs (accel_rl_hip_dev.h)
 for single in ((int(sys.argv[2]),) if len(sys.argv) > 2 else (0, 1)):
     def go():
         for s in range(40):
@@ -36,4 +37,5 @@ for single in ((int(sys.argv[2]),) if len(sys.argv) > 2 else (0, 1)):
     t0 = time.perf_counter()
     for _ in range(20): g.replay()
     torch.cuda.synchronize()
-    print("dbg n_env=%d single_write=%d: %.2f us per launch" % (n_env, single, (time.perf_counter() - t0) / 800 * 1e6))
+    print("dbg n_env=%d single_write=%d variant=%s: %.2f us per launch" % (n_env, single, os.environ.get("ARL_ENV_VARIANT", "0"),
+                                                                            (time.perf_counter() - t0) / 800 * 1e6))
