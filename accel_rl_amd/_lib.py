@@ -116,6 +116,8 @@ _SIGNATURES = {
     "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
+    "arl_conv2d_fwd_plan": (_i32, [C.POINTER(ArlConvGeom), C.POINTER(ArlHeadInput)]),
+    "arl_env_step_policy_fits": (_i32, [_i32, _i32, _i32]),
     "arl_conv2d_fwd_parts": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, C.POINTER(ArlHeadInput), _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), C.POINTER(ArlCorunJob), C.POINTER(_i32), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
@@ -501,6 +503,13 @@ def conv2d_fwd(x, w, bias, y, geom, relu, workspace, stream=None):
     _check(load().arl_conv2d_fwd(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                                  y.data_ptr(), C.byref(geom), int(bool(relu)), ptr(workspace),
                                  stream_ptr(stream)), "arl_conv2d_fwd")
+
+
+def head_fits(n_actions, geom):
+    """Can arl_env_step_policy take the dense layer `geom` (at its batch) as the policy's last hidden layer?"""
+    plan = ArlHeadInput()
+    _check(load().arl_conv2d_fwd_plan(C.byref(geom), C.byref(plan)), "arl_conv2d_fwd_plan")
+    return bool(load().arl_env_step_policy_fits(int(n_actions), plan.hid, plan.splits))
 
 
 def conv2d_fwd_parts(x, w, bias, y, geom, relu, workspace, head, stream=None):

@@ -335,10 +335,22 @@ __device__ void resolve_reset(const arl_game& g, const arl_env_state& st, int64_
 // the previous stack's 8-byte pieces each) before anything consumes one; FramePush::store boxes and writes.
 constexpr int PUSH_ITERS = (UNITS + 255) / 256;            // 5
 constexpr int MAX_STACK = 4;                              // previous planes kept in registers (n_stack <= 4 fast path)
+// The older planes of the stack (planes 1 .. F-1 of the previous observation become planes 0 .. F-2 of the new one) move
+// 16 bytes per lane: a wave's store then covers whole 128-byte lines (as 8-byte pieces per pixel unit the same bytes
+// left the L2 as 64-byte write requests, and this copy was 190 of the kernel's 355 us at 16 384 envs:
+// tools/env_step_bound.sh).  A thread owns a 16-byte COLUMN through all planes -- it reads piece q of planes 1 .. F-1
+// and writes piece q of planes 0 .. F-2.  WIDE needs the new observation to live elsewhere than the previous one
+// (single_write: rows t and t + 1 of the rollout buffer): where step_obs is overwritten in place (prev == out0), the
+// thread that writes the new frame's pixels must be the one that read them from the newest old plane, and those are
+// 8-byte units -- the narrow copy (!WIDE: per pixel unit, 8 bytes per plane, all reads of a thread before its writes).
+constexpr int COPY_COLS = OBS_FRAME / 16;                 // 520 pieces per plane
+constexpr int COPY_ITERS = (COPY_COLS + 255) / 256;       // 3 (the third for 8 threads)
 
+template <bool WIDE>
 struct FramePush {
     uint4 a0[PUSH_ITERS], a1[PUSH_ITERS], b0[PUSH_ITERS], b1[PUSH_ITERS];
-    uint2 pv[PUSH_ITERS][MAX_STACK - 1];
+    uint4 cp[WIDE ? COPY_ITERS : 1][MAX_STACK - 1];
+    uint2 pv[WIDE ? 1 : PUSH_ITERS][MAX_STACK - 1];
 
     template <int KO = 0>
     __device__ __forceinline__ void load(const arl_game& g, const int fa_i, const int fb_i, const int mode,
@@ -350,8 +362,6 @@ struct FramePush {
         for (int it = 0; it < PUSH_ITERS; ++it) {
             const int un = tid + it * 256;
             a0[it] = make_uint4(0, 0, 0, 0); a1[it] = a0[it]; b0[it] = a0[it]; b1[it] = a0[it];
-#pragma unroll
-            for (int f = 0; f < MAX_STACK - 1; ++f) pv[it][f] = make_uint2(0, 0);
             if (un < UNITS) {
                 const int y = un / UNITS_PER_ROW, xb = un - y * UNITS_PER_ROW;
                 const int src = (2 * y) * ARL_RAW_W + xb * 16;
@@ -361,10 +371,25 @@ struct FramePush {
                     a0[it] = *reinterpret_cast<const uint4*>(fa + src);
                     a1[it] = *reinterpret_cast<const uint4*>(fa + src + ARL_RAW_W);
                 }
-                if (mode == MODE_PUSH && KO != 3) {
+            }
+            if (!WIDE) {
 #pragma unroll
-                    for (int f = 0; f < MAX_STACK - 1; ++f)
-                        if (f < F - 1) pv[it][f] = *reinterpret_cast<const uint2*>(prev + (f + 1) * OBS_FRAME + un * 8);
+                for (int f = 0; f < MAX_STACK - 1; ++f) {
+                    pv[it][f] = make_uint2(0, 0);                // MODE_BLANK_PUSH: a blank history
+                    if (mode == MODE_PUSH && un < UNITS && f < F - 1)
+                        pv[it][f] = *reinterpret_cast<const uint2*>(prev + (f + 1) * OBS_FRAME + un * 8);
+                }
+            }
+        }
+        if (WIDE) {
+#pragma unroll
+            for (int it = 0; it < COPY_ITERS; ++it) {
+                const int q = tid + it * 256;
+#pragma unroll
+                for (int f = 0; f < MAX_STACK - 1; ++f) {
+                    cp[it][f] = make_uint4(0, 0, 0, 0);
+                    if (mode == MODE_PUSH && KO != 3 && q < COPY_COLS && f < F - 1)
+                        cp[it][f] = reinterpret_cast<const uint4*>(prev + (f + 1) * OBS_FRAME)[q];
                 }
             }
         }
@@ -380,14 +405,28 @@ struct FramePush {
             if (un >= UNITS) continue;
             const uint2 img = box8(a0[it], a1[it], b0[it], b1[it]);
             const int o = un * 8;
+            if (!WIDE) {
 #pragma unroll
-            for (int f = 0; f < MAX_STACK - 1; ++f)
-                if (f < F - 1 && KO != 2 && KO != 3) {
-                    *reinterpret_cast<uint2*>(out0 + f * OBS_FRAME + o) = pv[it][f];
-                    if (out1) *reinterpret_cast<uint2*>(out1 + f * OBS_FRAME + o) = pv[it][f];
-                }
+                for (int f = 0; f < MAX_STACK - 1; ++f)
+                    if (f < F - 1) {
+                        *reinterpret_cast<uint2*>(out0 + f * OBS_FRAME + o) = pv[it][f];
+                        if (out1) *reinterpret_cast<uint2*>(out1 + f * OBS_FRAME + o) = pv[it][f];
+                    }
+            }
             *reinterpret_cast<uint2*>(out0 + (F - 1) * OBS_FRAME + o) = img;
             if (out1) *reinterpret_cast<uint2*>(out1 + (F - 1) * OBS_FRAME + o) = img;
+        }
+        if (!WIDE || KO == 2 || KO == 3) return;
+#pragma unroll
+        for (int it = 0; it < COPY_ITERS; ++it) {
+            const int q = tid + it * 256;
+            if (q >= COPY_COLS) continue;
+#pragma unroll
+            for (int f = 0; f < MAX_STACK - 1; ++f)
+                if (f < F - 1) {
+                    reinterpret_cast<uint4*>(out0 + f * OBS_FRAME)[q] = cp[it][f];
+                    if (out1) reinterpret_cast<uint4*>(out1 + f * OBS_FRAME)[q] = cp[it][f];
+                }
         }
     }
 };
@@ -509,16 +548,40 @@ __device__ __forceinline__ float readlane_f(float x, int uniform_lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), uniform_lane));
 }
 
-template <bool HEAD, int KO>
+// n floats from global memory into LDS by the 256 threads of a workgroup: 16-byte pieces, four independent loads per
+// thread and round, no predicated access (out-of-range lanes re-read the last piece and write the spare slot)
+// (lds4: the workgroup's dynamic LDS as float4s; dst4 / spare4: where the data and the spare slot sit in it)
+__device__ __forceinline__ void stage_lds(float4* lds4, const int dst4, const float* src_f, const int n, const int spare4,
+                                          const int tid) {
+    if ((n & 3) || (reinterpret_cast<uintptr_t>(src_f) & 15)) {
+        float* dst_f = reinterpret_cast<float*>(lds4 + dst4);
+        for (int i = tid; i < n; i += 256) dst_f[i] = src_f[i];
+        return;
+    }
+    const int n4 = n >> 2;
+    const float4* src = reinterpret_cast<const float4*>(src_f);
+    for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = src[i0 + u * 256 < n4 ? i0 + u * 256 : n4 - 1];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lds4[i0 + u * 256 < n4 ? dst4 + i0 + u * 256 : spare4] = q[u];
+    }
+}
+
+template <bool HEAD, int KO, bool SW>
 __global__ __launch_bounds__(256) void env_step_kernel(
     const arl_game g, const arl_env_state st, const arl_rollout ro, const float* __restrict__ prob,
     const float* __restrict__ value, const double* __restrict__ uniforms,
     const uint8_t* __restrict__ active, int step, int mid_batch_reset, double max_path_length,
     double discount, int max_start_noops, int single_write, const HeadIn hd) {
-    __shared__ float s_h[HEAD ? HEAD_MAX_HID : 1];
+    extern __shared__ __attribute__((aligned(16))) float s_head[];                     // HEAD: W_head [A + 1][hid], then the env's hidden row [hid]
     __shared__ float s_pv[HEAD ? ARL_MAX_ACTIONS + 2 : 1];
     const int64_t e = blockIdx.x;
     const int tid = threadIdx.x;
+    float* const s_w = s_head;                                                     // [A + 1][hid]
+    float* const s_part = s_head + (HEAD ? (g.n_actions + 1) * hd.hid : 0);        // [splits][hid]
+    float* const s_h = s_part + (HEAD ? hd.splits * hd.hid : 0);                   // [hid] (+ a spare 16-byte slot)
     const int parity = st.epoch[0] & 1;
     const int fpar = st.launch_count[0] & 1;              // this state's own launch parity (the epoch is shared)
     const int64_t per = st.envs_per_stream;
@@ -527,6 +590,32 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     const int64_t n_streams = (st.n_env + per - 1) / per;
     // ---- every lane: this env's state, served distribution and uniform (uniform addresses: broadcast loads)
     const EnvRegs in = load_env(st, e);
+    if (HEAD) {
+        // With nothing depending on them yet, and in flight TOGETHER with the state loads above (one round trip to L2; a
+        // row's 40 ... 300 scalar weight loads one after the other were 25 us): the output layers' weights and the
+        // env's row of the last hidden layer's split-K partial sums, both as independent 16-byte loads into LDS, four
+        // per thread and round.  (Every load is UNCONDITIONAL on a clamped index and every store goes to its slot or to
+        // a spare one: as predicated loads the compiler put each behind its own branch, one round trip each.)
+        // (the launcher guarantees hid % 4 == 0 and 16-byte aligned partials: whole float4s everywhere)
+        const int hid = hd.hid, n_w = (g.n_actions + 1) * hid, n_p = hd.splits * hid;
+        float4* const lds4 = reinterpret_cast<float4*>(s_head);
+        const int spare4 = (n_w + n_p + hid + 3) >> 2;        // behind the hidden row
+        stage_lds(lds4, 0, hd.w_head, n_w, spare4, tid);
+        const int h4 = hid >> 2, n4 = n_p >> 2, part4 = n_w >> 2;
+        const float4* src = reinterpret_cast<const float4*>(hd.part + e * hid);
+        const int64_t stride4 = hd.split_stride >> 2;
+        for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
+            float4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i4 = i0 + u * 256 < n4 ? i0 + u * 256 : n4 - 1;
+                const int z = i4 / h4;
+                q[u] = src[z * stride4 + (i4 - z * h4)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds4[i0 + u * 256 < n4 ? part4 + i0 + u * 256 : spare4] = q[u];
+        }
+    }
     const float* p = HEAD ? s_pv : prob + e * g.n_actions;
     int a_idx = HEAD ? 0 : sample_action(p, g.n_actions, uniforms[e]);
     float v = HEAD ? 0.f : value[e];
@@ -558,20 +647,21 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     uint8_t* out0 = single_write ? (next ? next : cur) : cur;
     uint8_t* out1 = single_write ? nullptr : next;            // worker.py:52-53
     const bool fast = g.n_stack <= MAX_STACK;
-    FramePush fp;
+    FramePush<SW> fp;                                     // SW == (single_write != 0): the launcher's dispatch
     if (KO == 1) { o.fa = o.fa >= 0 ? 0 : -1; o.fb = 0; }
     if (o.mode != MODE_SKIP && fast) fp.template load<KO>(g, o.fa, o.fb, o.mode, prev, tid);
     if (HEAD) {
-        // ---- the env's row of the last hidden layer: sum of the split-K partials in fold_splits_kernel's order
-        // (sixteen interleaved groups, then the groups in order), + bias, rectifier
         const int hid = hd.hid;
-        const float* row = hd.part + e * hid;
+        __syncthreads();                                  // (the frame loads above are in flight)
+        // the hidden row = the sum of the partials in fold_splits_kernel's order (sixteen interleaved groups, each in
+        // split order from + 0; then the groups in order), + bias, rectifier
         for (int c = tid; c < hid; c += 256) {
             float acc = 0.f;
-            for (int zg = 0; zg < 16; ++zg) {             // (empty groups add + 0.0, as the fold kernel's do)
-                float t = 0.f;
-                for (int z = zg; z < hd.splits; z += 16) t += row[(int64_t)z * hd.split_stride + c];
-                acc = zg == 0 ? t : acc + t;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float grp = 0.f;
+                for (int z = i; z < hd.splits; z += 16) grp += s_part[z * hid + c];
+                acc = i == 0 ? grp : acc + grp;
             }
             if (hd.bias) acc += hd.bias[c];
             if (hd.relu) acc = fmaxf(acc, 0.f);
@@ -584,7 +674,7 @@ __global__ __launch_bounds__(256) void env_step_kernel(
             float val = 0.f, mx = -3.0e38f, mine = 0.f;
             for (int k = 0; k < K; ++k) {
                 float sdot = 0.f;
-                for (int c = lane; c < hid; c += 64) sdot += s_h[c] * hd.w_head[k * hid + c];
+                for (int c = lane; c < hid; c += 64) sdot += s_h[c] * s_w[k * hid + c];
                 const float out = wave_sum_f(sdot) + hd.b_head[k];
                 if (k < A) mx = fmaxf(mx, out); else val = out;
                 mine = (lane == k) ? out : mine;
@@ -679,22 +769,38 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 
 int g_env_variant = 0;               // arl_dev_env_variant: timing knock-outs of env_step_kernel (development)
 
+// LDS of the HEAD kernel: the output layers' weights, the row's split-K partials, the row, a spare 16-byte slot
+size_t head_lds_bytes(int n_actions, int hid, int splits) {
+    return ((size_t)(n_actions + 2 + splits) * hid + 8) * sizeof(float);
+}
+
 template <bool HEAD>
 int launch_env_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro, const float* prob,
                     const float* value, const double* uniforms, const uint8_t* active, int32_t step,
                     int32_t mid_batch_reset, double max_path_length, double discount, int32_t max_start_noops,
                     int32_t single_write, const HeadIn& hd, hipStream_t s) {
-#define ARL_ENV_STEP(KO_)                                                                                        \
-    hipLaunchKernelGGL((env_step_kernel<HEAD, KO_>), dim3((unsigned)st->n_env), dim3(256), 0, s, *game, *st, *ro, \
-                       prob, value, uniforms, active, (int)step, (int)mid_batch_reset, max_path_length, discount, \
-                       (int)max_start_noops, (int)single_write, hd)
-    switch (g_env_variant) {
-        case 1: ARL_ENV_STEP(1); break;
-        case 2: ARL_ENV_STEP(2); break;
-        case 3: ARL_ENV_STEP(3); break;
-        default: ARL_ENV_STEP(0);
+    const size_t lds = HEAD ? head_lds_bytes(game->n_actions, hd.hid, hd.splits) : 0;
+    hipError_t attr = hipSuccess;
+#define ARL_ENV_STEP(KO_, SW_)                                                                                   \
+    do {                                                                                                         \
+        auto k = env_step_kernel<HEAD, KO_, SW_>;                                                                \
+        if (lds > 65536)      /* > 64 KiB of dynamic LDS needs the opt-in, per device: set at every such launch */ \
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds);                                                                \
+        if (attr == hipSuccess)                                                                                  \
+            hipLaunchKernelGGL(k, dim3((unsigned)st->n_env), dim3(256), lds, s, *game, *st, *ro, prob, value,    \
+                               uniforms, active, (int)step, (int)mid_batch_reset, max_path_length, discount,     \
+                               (int)max_start_noops, (int)single_write, hd);                                     \
+    } while (0)
+    if (!single_write) ARL_ENV_STEP(0, false);            // (the timing knock-outs exist for the single-write kernel)
+    else switch (g_env_variant) {
+        case 1: ARL_ENV_STEP(1, true); break;
+        case 2: ARL_ENV_STEP(2, true); break;
+        case 3: ARL_ENV_STEP(3, true); break;
+        default: ARL_ENV_STEP(0, true);
     }
 #undef ARL_ENV_STEP
+    if (attr != hipSuccess) { arl::set_error("hipFuncSetAttribute(env_step_kernel, LDS %zu): %s", lds, hipGetErrorString(attr)); return (int)attr; }
     return arl::check_launch("env_step_kernel");
 }
 
@@ -769,6 +875,11 @@ extern "C" int arl_env_step(const arl_game* game, const arl_env_state* st, const
                                   discount, max_start_noops, single_write, HeadIn{}, (hipStream_t)stream);
 }
 
+extern "C" int arl_env_step_policy_fits(int32_t n_actions, int32_t hid, int32_t splits) {
+    return n_actions >= 1 && n_actions <= ARL_MAX_ACTIONS && splits >= 1 && hid >= 4 && hid <= HEAD_MAX_HID && hid % 4 == 0 &&
+           head_lds_bytes(n_actions, hid, splits) <= (size_t)160 * 1024;
+}
+
 extern "C" int arl_env_step_policy(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
                                    const arl_head_input* head, const double* uniforms,
                                    const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
@@ -777,8 +888,11 @@ extern "C" int arl_env_step_policy(const arl_game* game, const arl_env_state* st
     int rc = check_env_args(game, st, ro);
     if (rc) return rc;
     ARL_REQUIRE(head && head->part && head->w_head && head->b_head && uniforms, ARL_E_ARG, "null policy inputs");
-    ARL_REQUIRE(head->splits >= 1 && head->hid >= 1 && head->hid <= HEAD_MAX_HID, ARL_E_RANGE,
-                "arl_env_step_policy: 1 <= hid <= 1024, splits >= 1");
+    ARL_REQUIRE(arl_env_step_policy_fits(game->n_actions, head->hid, head->splits), ARL_E_RANGE,
+                "arl_env_step_policy: hid a multiple of 4 in 4 .. 1024, splits >= 1, (n_actions + 2 + splits) hid floats "
+                "within 160 KiB of LDS (arl_env_step_policy_fits)");
+    ARL_REQUIRE(arl::aligned16(head->part) && head->split_stride % 4 == 0, ARL_E_ALIGN,
+                "arl_env_step_policy: partials 16-byte aligned, split_stride a multiple of 4");
     ARL_REQUIRE(head->splits == 1 || head->split_stride >= st->n_env * (int64_t)head->hid, ARL_E_ARG,
                 "arl_env_step_policy: split_stride shorter than one split");
     ARL_REQUIRE(ro->rewards && ro->dones && ro->actions && ro->prob && ro->value && ro->observations, ARL_E_ARG,

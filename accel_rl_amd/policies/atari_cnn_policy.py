@@ -346,11 +346,12 @@ class AtariCnnPolicy(object):
             _lib.pg_head_infer(hids[-1], self.params[-2], self.params[-1], prob, value)
             return prob, value
 
-    @property
-    def serves_head(self):
-        """True: the sampler may ask for head_input() and run the output layers inside its env-step launch
-        (arl_env_step_policy) instead of calling prob_value()."""
-        return bool(self._hid_geom) and self._hid_geom[-1][0] <= 1024 and type(self).prob_value is AtariCnnPolicy.prob_value
+    def serves_head(self, n_rows):
+        """True: for batches of n_rows observations the sampler may ask for head_input() and run the output layers
+        inside its env-step launch (arl_env_step_policy) instead of calling prob_value()."""
+        if not self._hid_geom or type(self).prob_value is not AtariCnnPolicy.prob_value:
+            return False
+        return _lib.head_fits(self.n_act, self._layer_geoms(n_rows)[1][-1])
 
     def head_input(self, observations, rows=None):
         """The forward pass up to the last hidden layer's split-K partial sums, as the ArlHeadInput of

@@ -251,7 +251,7 @@ class GpuVecSampler(BaseMbSampler):
         # contiguous copy kept current in step_obs); needs every env to step at every step (mid_batch_reset).
         # policies that hand over their last hidden layer (head_input) get their output layers, the softmax and the
         # sampling run inside the env-step launch (arl_env_step_policy; its forecast needs the limit >= 1 too)
-        self._serves_head = bool(not self._recurrent and getattr(policy, "serves_head", False) and
+        self._serves_head = bool(not self._recurrent and hasattr(policy, "serves_head") and policy.serves_head(n) and
                                  self._kernel_max_path_length() >= 1 and
                                  os.environ.get("ARL_SAMPLER_FUSED_HEAD", "1") != "0")
         self._single_write = bool(self.mid_batch_reset and not self._recurrent and

@@ -259,6 +259,9 @@ typedef struct arl_head_input {
  * (arl_pg_head_infer's arithmetic: the stored prob / value are bit for bit what the two launches give), samples, and
  * steps -- the frame loads are issued before the heads run, since nothing they depend on depends on the action.
  * Everything else as arl_env_step.                                                                                  */
+/* 1 if a head of this shape fits the launch (its LDS holds the output layers' weights, the row's partials and the
+ * row: (n_actions + 2 + splits) * hid floats within 160 KiB), else 0.                                               */
+int arl_env_step_policy_fits(int32_t n_actions, int32_t hid, int32_t splits);
 int arl_env_step_policy(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
                         const arl_head_input* head, const double* uniforms,
                         const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
@@ -421,6 +424,9 @@ int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, fl
  * what is left to do -- the partial sums in `workspace` (which stays live until the consumer has run), or, where the
  * launch did not split, the finished activations in y (splits 1, no bias, no rectifier left).  head->w_head /
  * b_head are the caller's.  The sum of the partials in the fold's order + bias + rectifier IS arl_conv2d_fwd's y.   */
+/* What arl_conv2d_fwd_parts will leave for this geometry, without launching anything: head->splits, hid, split_stride
+ * (a consumer sizes its LDS by the number of splits: arl_env_step_policy_fits).                                    */
+int arl_conv2d_fwd_plan(const arl_conv_geom* geom, arl_head_input* head);
 int arl_conv2d_fwd_parts(const float* x, const float* w, const float* bias_or_null, float* y,
                          const arl_conv_geom* geom, int32_t relu, void* workspace, arl_head_input* head,
                          void* stream);

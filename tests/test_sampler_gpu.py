@@ -353,7 +353,9 @@ def test_eval_sampler_with_a_length_limit_below_the_decorrelation_walk(use_graph
         seen += [ti.Length for ti in infos]                        # raises if a reset was not announced
         assert int(smp._st.traj_len.max().item()) < L
     assert int(smp._st.epoch[2].item()) == 0
-    assert len(seen) >= n and max(seen) == L
+    # an env that LEFT the walk at Length L (the walk ends episodes at Length > L) is one step over the served rule's
+    # limit when its first served step ends it: Length L + 1, as in the reference; every other episode ends at L
+    assert len(seen) >= n and set(seen) <= {L, L + 1} and seen.count(L + 1) == int((lens == L).sum())
     smp.shutdown()
 
 
