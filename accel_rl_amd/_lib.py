@@ -52,11 +52,6 @@ class ArlRollout(C.Structure):
                 ("value", _vp), ("step_obs", _vp)]
 
 
-class ArlHeadInput(C.Structure):
-    _fields_ = [("part", _vp), ("bias", _vp), ("w_head", _vp), ("b_head", _vp), ("split_stride", _i64),
-                ("splits", _i32), ("hid", _i32), ("relu", _i32), ("reserved", _i32)]
-
-
 class ArlConvGeom(C.Structure):
     _fields_ = [("batch", _i64), ("in_h", _i32), ("in_w", _i32), ("in_c", _i32), ("out_c", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad_h", _i32), ("pad_w", _i32), ("route", _i32)]
@@ -100,8 +95,6 @@ _SIGNATURES = {
                                   _i32, _i32, _vp]),
     "arl_env_step": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                             _vp, _vp, _vp, _vp, _i32, _i32, _f64, _f64, _i32, _i32, _vp]),
-    "arl_env_step_policy": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
-                                   C.POINTER(ArlHeadInput), _vp, _vp, _i32, _i32, _f64, _f64, _i32, _i32, _vp]),
     "arl_env_reset": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                              _vp, _i32, _vp]),
     "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -116,9 +109,6 @@ _SIGNATURES = {
     "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
-    "arl_conv2d_fwd_plan": (_i32, [C.POINTER(ArlConvGeom), C.POINTER(ArlHeadInput)]),
-    "arl_env_step_policy_fits": (_i32, [_i32, _i32, _i32]),
-    "arl_conv2d_fwd_parts": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, C.POINTER(ArlHeadInput), _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), C.POINTER(ArlCorunJob), C.POINTER(_i32), _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
     "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem),
@@ -342,15 +332,6 @@ def env_step(game, state, rollout, prob, value, uniforms, step, mid_batch_reset,
                                int(bool(single_write)), stream_ptr(stream)), "arl_env_step")
 
 
-def env_step_policy(game, state, rollout, head, uniforms, step, mid_batch_reset, max_path_length, discount,
-                    max_start_noops, active=None, single_write=False, stream=None):
-    """env_step with the policy's output layers inside the launch; head: ArlHeadInput (conv2d_fwd_parts + the heads)."""
-    _check(load().arl_env_step_policy(C.byref(game), C.byref(state), C.byref(rollout), C.byref(head), ptr(uniforms),
-                                      ptr(active), step, int(bool(mid_batch_reset)), float(max_path_length),
-                                      float(discount), int(max_start_noops), int(bool(single_write)),
-                                      stream_ptr(stream)), "arl_env_step_policy")
-
-
 def env_frame_step(game, state, rollout, step, max_start_noops, stream=None):
     _check(load().arl_env_frame_step(C.byref(game), C.byref(state), C.byref(rollout), step,
                                      int(max_start_noops), stream_ptr(stream)), "arl_env_frame_step")
@@ -503,26 +484,6 @@ def conv2d_fwd(x, w, bias, y, geom, relu, workspace, stream=None):
     _check(load().arl_conv2d_fwd(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                                  y.data_ptr(), C.byref(geom), int(bool(relu)), ptr(workspace),
                                  stream_ptr(stream)), "arl_conv2d_fwd")
-
-
-def head_fits(n_actions, geom):
-    """Can arl_env_step_policy take the dense layer `geom` (at its batch) as the policy's last hidden layer?"""
-    plan = ArlHeadInput()
-    _check(load().arl_conv2d_fwd_plan(C.byref(geom), C.byref(plan)), "arl_conv2d_fwd_plan")
-    return bool(load().arl_env_step_policy_fits(int(n_actions), plan.hid, plan.splits))
-
-
-def conv2d_fwd_parts(x, w, bias, y, geom, relu, workspace, head, stream=None):
-    """conv2d_fwd stopping before the split-K fold: `head` (ArlHeadInput) receives what is left to do."""
-    for t, n in ((x, "x"), (w, "w"), (y, "y")):
-        _want(t, torch.float32, n)
-    ho, wo = conv_out_hw(geom)
-    assert x.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x size"
-    assert w.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w size"
-    assert y.numel() == geom.batch * ho * wo * geom.out_c, "y size"
-    _check(load().arl_conv2d_fwd_parts(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
-                                       y.data_ptr(), C.byref(geom), int(bool(relu)), ptr(workspace), C.byref(head),
-                                       stream_ptr(stream)), "arl_conv2d_fwd_parts")
 
 
 def conv2d_u8_supported(in_h, in_w, out_c, kh, kw, stride, pad_h, pad_w):

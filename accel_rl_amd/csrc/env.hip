@@ -521,67 +521,17 @@ __global__ __launch_bounds__(256) void frame_step_kernel(const arl_game g, const
 // observations[e][step + 1], or to step_obs after the batch's last step -- and the previous stack is read from
 // observations[e][step]; the policy then reads the current observations as rows e * horizon + step of the
 // rollout buffer instead of step_obs.  Otherwise step_obs is kept current at every step (second write).
-// HEAD (arl_env_step_policy): the policy's output layers are part of this launch.  The workgroup folds its env's row of
-// the last hidden layer out of that layer's split-K partials (+ bias, rectifier: fold_splits_kernel's order), wave 0
-// runs the output layers and the softmax on it (head_kernel<infer>'s arithmetic, lane for lane), and the action is
-// sampled from the result -- no fold launch, no head launch, no prob / value round trip.  Nothing the frame plan
-// depends on depends on the action (it only enters the reward, see will_reset), so every lane derives the plan with a
-// placeholder action and issues its frame loads FIRST; the hidden row is folded and the heads run under their latency.
 // KO (development, arl_dev_env_variant): knock-outs for timing only (results wrong) -- 1: every env reads bank frame 0;
 // 2: the older planes of the stack are not stored; 3: ... nor loaded.
-struct HeadIn {
-    const float* part;      // f32[splits][n_env][hid]: split-K partial sums of the last hidden layer
-    const float* bias;      // f32[hid] or null
-    const float* w_head;    // f32[A + 1][hid]
-    const float* b_head;    // f32[A + 1]
-    int64_t split_stride;
-    int splits, hid, relu;
-};
-constexpr int HEAD_MAX_HID = 1024;
-
-__device__ __forceinline__ float wave_sum_f(float x) {     // (learner.hip's: the same butterfly, the same bits)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
-__device__ __forceinline__ float readlane_f(float x, int uniform_lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), uniform_lane));
-}
-
-// n floats from global memory into LDS by the 256 threads of a workgroup: 16-byte pieces, four independent loads per
-// thread and round, no predicated access (out-of-range lanes re-read the last piece and write the spare slot)
-// (lds4: the workgroup's dynamic LDS as float4s; dst4 / spare4: where the data and the spare slot sit in it)
-__device__ __forceinline__ void stage_lds(float4* lds4, const int dst4, const float* src_f, const int n, const int spare4,
-                                          const int tid) {
-    if ((n & 3) || (reinterpret_cast<uintptr_t>(src_f) & 15)) {
-        float* dst_f = reinterpret_cast<float*>(lds4 + dst4);
-        for (int i = tid; i < n; i += 256) dst_f[i] = src_f[i];
-        return;
-    }
-    const int n4 = n >> 2;
-    const float4* src = reinterpret_cast<const float4*>(src_f);
-    for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
-        float4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = src[i0 + u * 256 < n4 ? i0 + u * 256 : n4 - 1];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) lds4[i0 + u * 256 < n4 ? dst4 + i0 + u * 256 : spare4] = q[u];
-    }
-}
-
-template <bool HEAD, int KO, bool SW>
+// SW == (single_write != 0), the launcher's dispatch: the wide copy of the older planes (FramePush<true>).
+template <int KO, bool SW>
 __global__ __launch_bounds__(256) void env_step_kernel(
     const arl_game g, const arl_env_state st, const arl_rollout ro, const float* __restrict__ prob,
     const float* __restrict__ value, const double* __restrict__ uniforms,
     const uint8_t* __restrict__ active, int step, int mid_batch_reset, double max_path_length,
-    double discount, int max_start_noops, int single_write, const HeadIn hd) {
-    extern __shared__ __attribute__((aligned(16))) float s_head[];                     // HEAD: W_head [A + 1][hid], then the env's hidden row [hid]
-    __shared__ float s_pv[HEAD ? ARL_MAX_ACTIONS + 2 : 1];
+    double discount, int max_start_noops, int single_write) {
     const int64_t e = blockIdx.x;
     const int tid = threadIdx.x;
-    float* const s_w = s_head;                                                     // [A + 1][hid]
-    float* const s_part = s_head + (HEAD ? (g.n_actions + 1) * hd.hid : 0);        // [splits][hid]
-    float* const s_h = s_part + (HEAD ? hd.splits * hd.hid : 0);                   // [hid] (+ a spare 16-byte slot)
     const int parity = st.epoch[0] & 1;
     const int fpar = st.launch_count[0] & 1;              // this state's own launch parity (the epoch is shared)
     const int64_t per = st.envs_per_stream;
@@ -590,35 +540,9 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     const int64_t n_streams = (st.n_env + per - 1) / per;
     // ---- every lane: this env's state, served distribution and uniform (uniform addresses: broadcast loads)
     const EnvRegs in = load_env(st, e);
-    if (HEAD) {
-        // With nothing depending on them yet, and in flight TOGETHER with the state loads above (one round trip to L2; a
-        // row's 40 ... 300 scalar weight loads one after the other were 25 us): the output layers' weights and the
-        // env's row of the last hidden layer's split-K partial sums, both as independent 16-byte loads into LDS, four
-        // per thread and round.  (Every load is UNCONDITIONAL on a clamped index and every store goes to its slot or to
-        // a spare one: as predicated loads the compiler put each behind its own branch, one round trip each.)
-        // (the launcher guarantees hid % 4 == 0 and 16-byte aligned partials: whole float4s everywhere)
-        const int hid = hd.hid, n_w = (g.n_actions + 1) * hid, n_p = hd.splits * hid;
-        float4* const lds4 = reinterpret_cast<float4*>(s_head);
-        const int spare4 = (n_w + n_p + hid + 3) >> 2;        // behind the hidden row
-        stage_lds(lds4, 0, hd.w_head, n_w, spare4, tid);
-        const int h4 = hid >> 2, n4 = n_p >> 2, part4 = n_w >> 2;
-        const float4* src = reinterpret_cast<const float4*>(hd.part + e * hid);
-        const int64_t stride4 = hd.split_stride >> 2;
-        for (int i0 = tid; i0 < n4; i0 += 4 * 256) {
-            float4 q[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i4 = i0 + u * 256 < n4 ? i0 + u * 256 : n4 - 1;
-                const int z = i4 / h4;
-                q[u] = src[z * stride4 + (i4 - z * h4)];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) lds4[i0 + u * 256 < n4 ? part4 + i0 + u * 256 : spare4] = q[u];
-        }
-    }
-    const float* p = HEAD ? s_pv : prob + e * g.n_actions;
-    int a_idx = HEAD ? 0 : sample_action(p, g.n_actions, uniforms[e]);
-    float v = HEAD ? 0.f : value[e];
+    const float* p = prob + e * g.n_actions;
+    const int a_idx = sample_action(p, g.n_actions, uniforms[e]);
+    const float v = value[e];
     const bool is_active = !active || active[e] != 0;
     const int64_t cursor = st.noop_cursor[parity * n_streams + w];
     const uint8_t* flag_now = st.next_reset + (int64_t)fpar * st.n_env;         // written by the previous launch
@@ -650,58 +574,6 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     FramePush<SW> fp;                                     // SW == (single_write != 0): the launcher's dispatch
     if (KO == 1) { o.fa = o.fa >= 0 ? 0 : -1; o.fb = 0; }
     if (o.mode != MODE_SKIP && fast) fp.template load<KO>(g, o.fa, o.fb, o.mode, prev, tid);
-    if (HEAD) {
-        const int hid = hd.hid;
-        __syncthreads();                                  // (the frame loads above are in flight)
-        // the hidden row = the sum of the partials in fold_splits_kernel's order (sixteen interleaved groups, each in
-        // split order from + 0; then the groups in order), + bias, rectifier
-        for (int c = tid; c < hid; c += 256) {
-            float acc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float grp = 0.f;
-                for (int z = i; z < hd.splits; z += 16) grp += s_part[z * hid + c];
-                acc = i == 0 ? grp : acc + grp;
-            }
-            if (hd.bias) acc += hd.bias[c];
-            if (hd.relu) acc = fmaxf(acc, 0.f);
-            s_h[c] = acc;
-        }
-        __syncthreads();
-        // ---- output layers + softmax on wave 0: head_kernel<infer>'s arithmetic (lane k owns action k, lane A the value)
-        if (tid < 64) {
-            const int A = g.n_actions, K = A + 1, lane = tid;
-            float val = 0.f, mx = -3.0e38f, mine = 0.f;
-            for (int k = 0; k < K; ++k) {
-                float sdot = 0.f;
-                for (int c = lane; c < hid; c += 64) sdot += s_h[c] * s_w[k * hid + c];
-                const float out = wave_sum_f(sdot) + hd.b_head[k];
-                if (k < A) mx = fmaxf(mx, out); else val = out;
-                mine = (lane == k) ? out : mine;
-            }
-            const bool is_act = lane < A;
-            const float ex = is_act ? expf(mine - mx) : 0.f;
-            float z = 0.f;
-            for (int k = 0; k < A; ++k) z += readlane_f(ex, k);
-            const float pk = ex / z;
-            if (is_act) s_pv[lane] = pk;
-            if (lane == 0) s_pv[ARL_MAX_ACTIONS + 1] = val;
-        }
-        __syncthreads();
-        v = s_pv[ARL_MAX_ACTIONS + 1];
-        a_idx = sample_action(p, g.n_actions, uniforms[e]);
-        if (tid == 0) {                                   // the commit needs the step under the SAMPLED action
-            const int fa = o.fa, fb = o.fb;
-            o = step_compute(g, in, a_idx, is_active, mid_batch_reset, max_path_length, discount);
-            if (o.reset_flag) {
-                int noops = 0;
-                if (max_start_noops > 0)
-                    noops = st.noop_ring[w * st.noop_ring_len + (cursor + rank) % st.noop_ring_len];
-                reset_regs(g, o.s, noops, o.fa, o.fb, o.mode);
-            }
-            if (KO == 1) { o.fa = fa; o.fb = fb; }
-        }
-    }
     // the stores of the scalar part, under the frame loads' latency: lane 0 commits, lanes of wave 1 copy the
     // served distribution (one element each instead of a load -> store chain per action on lane 0)
     if (o.stepped && tid >= 64 && tid - 64 < g.n_actions)
@@ -769,29 +641,14 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
 
 int g_env_variant = 0;               // arl_dev_env_variant: timing knock-outs of env_step_kernel (development)
 
-// LDS of the HEAD kernel: the output layers' weights, the row's split-K partials, the row, a spare 16-byte slot
-size_t head_lds_bytes(int n_actions, int hid, int splits) {
-    return ((size_t)(n_actions + 2 + splits) * hid + 8) * sizeof(float);
-}
-
-template <bool HEAD>
 int launch_env_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro, const float* prob,
                     const float* value, const double* uniforms, const uint8_t* active, int32_t step,
                     int32_t mid_batch_reset, double max_path_length, double discount, int32_t max_start_noops,
-                    int32_t single_write, const HeadIn& hd, hipStream_t s) {
-    const size_t lds = HEAD ? head_lds_bytes(game->n_actions, hd.hid, hd.splits) : 0;
-    hipError_t attr = hipSuccess;
+                    int32_t single_write, hipStream_t s) {
 #define ARL_ENV_STEP(KO_, SW_)                                                                                   \
-    do {                                                                                                         \
-        auto k = env_step_kernel<HEAD, KO_, SW_>;                                                                \
-        if (lds > 65536)      /* > 64 KiB of dynamic LDS needs the opt-in, per device: set at every such launch */ \
-            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds);                                                                \
-        if (attr == hipSuccess)                                                                                  \
-            hipLaunchKernelGGL(k, dim3((unsigned)st->n_env), dim3(256), lds, s, *game, *st, *ro, prob, value,    \
-                               uniforms, active, (int)step, (int)mid_batch_reset, max_path_length, discount,     \
-                               (int)max_start_noops, (int)single_write, hd);                                     \
-    } while (0)
+    hipLaunchKernelGGL((env_step_kernel<KO_, SW_>), dim3((unsigned)st->n_env), dim3(256), 0, s, *game, *st, *ro, \
+                       prob, value, uniforms, active, (int)step, (int)mid_batch_reset, max_path_length, discount, \
+                       (int)max_start_noops, (int)single_write)
     if (!single_write) ARL_ENV_STEP(0, false);            // (the timing knock-outs exist for the single-write kernel)
     else switch (g_env_variant) {
         case 1: ARL_ENV_STEP(1, true); break;
@@ -800,7 +657,6 @@ int launch_env_step(const arl_game* game, const arl_env_state* st, const arl_rol
         default: ARL_ENV_STEP(0, true);
     }
 #undef ARL_ENV_STEP
-    if (attr != hipSuccess) { arl::set_error("hipFuncSetAttribute(env_step_kernel, LDS %zu): %s", lds, hipGetErrorString(attr)); return (int)attr; }
     return arl::check_launch("env_step_kernel");
 }
 
@@ -871,41 +727,8 @@ extern "C" int arl_env_step(const arl_game* game, const arl_env_state* st, const
                 "single_write needs mid_batch_reset and every env stepping");
     ARL_REQUIRE(st->next_reset && st->launch_count, ARL_E_ARG, "arl_env_step needs st->next_reset and st->launch_count");
     ARL_REQUIRE(max_path_length >= 1.0, ARL_E_RANGE, "arl_env_step needs max_path_length >= 1");
-    return launch_env_step<false>(game, st, ro, prob, value, uniforms, active_or_null, step, mid_batch_reset, max_path_length,
-                                  discount, max_start_noops, single_write, HeadIn{}, (hipStream_t)stream);
-}
-
-extern "C" int arl_env_step_policy_fits(int32_t n_actions, int32_t hid, int32_t splits) {
-    return n_actions >= 1 && n_actions <= ARL_MAX_ACTIONS && splits >= 1 && hid >= 4 && hid <= HEAD_MAX_HID && hid % 4 == 0 &&
-           head_lds_bytes(n_actions, hid, splits) <= (size_t)160 * 1024;
-}
-
-extern "C" int arl_env_step_policy(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
-                                   const arl_head_input* head, const double* uniforms,
-                                   const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
-                                   double max_path_length, double discount, int32_t max_start_noops,
-                                   int32_t single_write, void* stream) {
-    int rc = check_env_args(game, st, ro);
-    if (rc) return rc;
-    ARL_REQUIRE(head && head->part && head->w_head && head->b_head && uniforms, ARL_E_ARG, "null policy inputs");
-    ARL_REQUIRE(arl_env_step_policy_fits(game->n_actions, head->hid, head->splits), ARL_E_RANGE,
-                "arl_env_step_policy: hid a multiple of 4 in 4 .. 1024, splits >= 1, (n_actions + 2 + splits) hid floats "
-                "within 160 KiB of LDS (arl_env_step_policy_fits)");
-    ARL_REQUIRE(arl::aligned16(head->part) && head->split_stride % 4 == 0, ARL_E_ALIGN,
-                "arl_env_step_policy: partials 16-byte aligned, split_stride a multiple of 4");
-    ARL_REQUIRE(head->splits == 1 || head->split_stride >= st->n_env * (int64_t)head->hid, ARL_E_ARG,
-                "arl_env_step_policy: split_stride shorter than one split");
-    ARL_REQUIRE(ro->rewards && ro->dones && ro->actions && ro->prob && ro->value && ro->observations, ARL_E_ARG,
-                "null rollout arrays");
-    ARL_REQUIRE(step >= 0 && step < ro->horizon, ARL_E_RANGE, "step outside horizon");
-    ARL_REQUIRE(!single_write || (mid_batch_reset && !active_or_null), ARL_E_ARG,
-                "single_write needs mid_batch_reset and every env stepping");
-    ARL_REQUIRE(st->next_reset && st->launch_count, ARL_E_ARG, "arl_env_step needs st->next_reset and st->launch_count");
-    ARL_REQUIRE(max_path_length >= 1.0, ARL_E_RANGE, "arl_env_step needs max_path_length >= 1");
-    HeadIn hd = {head->part, head->bias, head->w_head, head->b_head, head->split_stride, head->splits, head->hid,
-                 head->relu};
-    return launch_env_step<true>(game, st, ro, nullptr, nullptr, uniforms, active_or_null, step, mid_batch_reset,
-                                 max_path_length, discount, max_start_noops, single_write, hd, (hipStream_t)stream);
+    return launch_env_step(game, st, ro, prob, value, uniforms, active_or_null, step, mid_batch_reset, max_path_length,
+                           discount, max_start_noops, single_write, (hipStream_t)stream);
 }
 
 extern "C" void arl_dev_env_variant(int32_t v) { g_env_variant = (v >= 0 && v <= 3) ? v : 0; }

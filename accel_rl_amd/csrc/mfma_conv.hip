@@ -134,13 +134,13 @@ extern "C" int arl_corun_job_run(const arl_corun_job* job, void* stream) {
 
 namespace {
 int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom, int32_t relu,
-             void* workspace, void* stream, arl_head_input* parts_out = nullptr, bool plan_only = false) {
+             void* workspace, void* stream) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
-    ARL_REQUIRE(plan_only || (x && w && y && workspace), ARL_E_ARG, "null pointer");
-    ARL_REQUIRE(plan_only || (arl::aligned16(x) && arl::aligned16(w) && arl::aligned16(y) && arl::aligned16(workspace) &&
-                              (!bias_or_null || arl::aligned16(bias_or_null))), ARL_E_ALIGN, "16-byte alignment");
+    ARL_REQUIRE(x && w && y && workspace, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(arl::aligned16(x) && arl::aligned16(w) && arl::aligned16(y) && arl::aligned16(workspace) &&
+                    (!bias_or_null || arl::aligned16(bias_or_null)), ARL_E_ALIGN, "16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     GemmArgs a = {};
     a.g.src = x; a.g.Hs = g.H; a.g.Ws = g.W; a.g.Cs = g.C; a.g.out_h = g.Ho; a.g.out_w = g.Wo;
@@ -159,10 +159,6 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (!small && a.N >= 128 && tiles128 * 4 <= TARGET_WGS * 3) plan_split(tiles128, a.K, &splits, &per, TARGET_WGS);
     a.k_per_split = per;
-    if (plan_only) {
-        parts_out->splits = splits; parts_out->hid = a.N; parts_out->split_stride = (int64_t)a.M * a.N;
-        return 0;
-    }
     if (splits > 1) {
         ARL_REQUIRE((int64_t)splits * a.M * a.N * 4 <= arl_conv_workspace_bytes(), ARL_E_RANGE, "workspace too small");
         a.o.out = (float*)workspace; a.split_stride = (int64_t)a.M * a.N;
@@ -207,35 +203,10 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
         else if (small) rc = launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s);
         else rc = launch_rowgather<2, 2, 2, 2, 16, true>(a, splits, s);
     }
-    if (parts_out && !rc) {         // the caller folds (arl_env_step_policy): describe what is left to do
-        parts_out->hid = a.N;
-        if (splits == 1) {          // y is final
-            parts_out->part = y; parts_out->bias = nullptr; parts_out->relu = 0;
-            parts_out->splits = 1; parts_out->split_stride = (int64_t)a.M * a.N;
-        } else {
-            parts_out->part = (const float*)workspace; parts_out->bias = bias_or_null; parts_out->relu = relu;
-            parts_out->splits = splits; parts_out->split_stride = (int64_t)a.M * a.N;
-        }
-        return 0;
-    }
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, bias_or_null, a.N, relu, y, s);
 }
 }  // namespace
-
-extern "C" int arl_conv2d_fwd_plan(const arl_conv_geom* geom, arl_head_input* head) {
-    ARL_REQUIRE(head, ARL_E_ARG, "null pointer");
-    ARL_ROUTE_SCOPE(geom, nullptr);
-    return fwd_impl(nullptr, nullptr, nullptr, nullptr, geom, 0, nullptr, nullptr, head, true);
-}
-
-extern "C" int arl_conv2d_fwd_parts(const float* x, const float* w, const float* bias_or_null, float* y,
-                                    const arl_conv_geom* geom, int32_t relu, void* workspace, arl_head_input* head,
-                                    void* stream) {
-    ARL_REQUIRE(head, ARL_E_ARG, "null pointer");
-    ARL_ROUTE_SCOPE(geom, nullptr);
-    return fwd_impl(x, w, bias_or_null, y, geom, relu, workspace, stream, head);
-}
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {

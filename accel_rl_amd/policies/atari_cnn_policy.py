@@ -165,7 +165,6 @@ class AtariCnnPolicy(object):
         self._g = [self.flat_grads[o:o + n] for o, n in zip(self._offsets, sizes)]
         self._conv_ws = _lib.conv_workspace(self.device)
         self._geoms = dict()
-        self._heads = dict()
         for p, g in zip(self.params, self.grads):
             p.grad = g
         self._n_conv, self._n_hid = len(self._conv_geom), len(self._hid_geom)
@@ -303,12 +302,11 @@ class AtariCnnPolicy(object):
             gs = self._geoms[key] = (conv, dense)
         return gs
 
-    def _trunk(self, x, w=None, tag="", last_parts=None):
+    def _trunk(self, x, w=None, tag=""):
         """Explicit conv/dense stack (no autograd) on NHWC memory.  Returns (conv activations
         [B,Ho,Wo,K], hidden activations [B,units]); every activation is post bias+relu.
         `w`: the layers' (W, b) views to use (default: the trainable ones); `tag` keeps the scratch
-        activations of a second forward (e.g. a target network) apart; `last_parts` (ArlHeadInput): the last hidden
-        layer stops before its split-K fold and describes what is left there (its entry of `hids` is then NOT valid)."""
+        activations of a second forward (e.g. a target network) apart."""
         b = x.shape[0]
         w = self._w if w is None else w
         conv_g, dense_g = self._layer_geoms(b)
@@ -324,10 +322,7 @@ class AtariCnnPolicy(object):
         hids, k = [], 2 * self._n_conv
         for j, (hs, fan_in) in enumerate(self._hid_geom):
             hcur = self._buffer(("hid" + tag, j, b), (b, hs))
-            if last_parts is not None and j == len(self._hid_geom) - 1:
-                _lib.conv2d_fwd_parts(a, w[k], w[k + 1], hcur, dense_g[j], True, self._conv_ws, last_parts)
-            else:
-                _lib.conv2d_fwd(a, w[k], w[k + 1], hcur, dense_g[j], True, self._conv_ws)
+            _lib.conv2d_fwd(a, w[k], w[k + 1], hcur, dense_g[j], True, self._conv_ws)
             hids.append(hcur)
             a = hcur
             k += 2
@@ -345,27 +340,6 @@ class AtariCnnPolicy(object):
             value = torch.empty(b, dtype=torch.float32, device=self.device)
             _lib.pg_head_infer(hids[-1], self.params[-2], self.params[-1], prob, value)
             return prob, value
-
-    def serves_head(self, n_rows):
-        """True: for batches of n_rows observations the sampler may ask for head_input() and run the output layers
-        inside its env-step launch (arl_env_step_policy) instead of calling prob_value()."""
-        if not self._hid_geom or type(self).prob_value is not AtariCnnPolicy.prob_value:
-            return False
-        return _lib.head_fits(self.n_act, self._layer_geoms(n_rows)[1][-1])
-
-    def head_input(self, observations, rows=None):
-        """The forward pass up to the last hidden layer's split-K partial sums, as the ArlHeadInput of
-        arl_env_step_policy: that launch folds each env's row, runs the output layers and the softmax, samples and
-        steps -- prob and value land in the rollout buffer bit for bit as prob_value() would have produced them
-        (_f_prob_value, atari_cnn_policy.py:63-67).  The struct is valid until this policy's next forward."""
-        with torch.no_grad():
-            x = self._scaled(observations, rows)
-            head = self._heads.get(x.shape[0])
-            if head is None:
-                head = self._heads[x.shape[0]] = _lib.ArlHeadInput()
-            self._trunk(x, last_parts=head)
-            head.w_head, head.b_head = self.params[-2].data_ptr(), self.params[-1].data_ptr()
-            return head
 
     # ------------------------------------------------------------- training
     def loss_and_grads(self, mb, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult,

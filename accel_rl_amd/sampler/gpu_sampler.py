@@ -22,8 +22,6 @@ env index e = (group * n_parallel + rank) * envs_per + i (sampler.py:160-185).
 """
 import ctypes
 
-import os
-
 import numpy as np
 import torch
 
@@ -249,11 +247,6 @@ class GpuVecSampler(BaseMbSampler):
         # The current observation of env e at step s is row e * t + s of the rollout buffer.  A policy that serves
         # rows of a buffer in place lets the step kernel write each stacked observation once (no second,
         # contiguous copy kept current in step_obs); needs every env to step at every step (mid_batch_reset).
-        # policies that hand over their last hidden layer (head_input) get their output layers, the softmax and the
-        # sampling run inside the env-step launch (arl_env_step_policy; its forecast needs the limit >= 1 too)
-        self._serves_head = bool(not self._recurrent and hasattr(policy, "serves_head") and policy.serves_head(n) and
-                                 self._kernel_max_path_length() >= 1 and
-                                 os.environ.get("ARL_SAMPLER_FUSED_HEAD", "1") != "0")
         self._single_write = bool(self.mid_batch_reset and not self._recurrent and
                                   getattr(policy, "serves_rows", False) and self._kernel_max_path_length() >= 1)
         self._step_rows = (torch.arange(n, dtype=torch.int32, device=dev)[None, :] * t +
@@ -330,16 +323,12 @@ class GpuVecSampler(BaseMbSampler):
                     buf.agent_infos[key].view(n, t, -1)[:, s].copy_(state)
                 if not self.mid_batch_reset:
                     self._prev_frozen.copy_(self._st.frozen)
-            elif self._serves_head:        # the output layers run inside the env-step launch
-                head = self.policy.head_input(*((buf.observations, self._step_rows[s]) if self._single_write
-                                                else (self.step_obs,)))
-                prob = value = None
             elif self._single_write:
                 prob, value = self.policy.prob_value(buf.observations, self._step_rows[s])
             else:
                 prob, value = self.policy.prob_value(self.step_obs)
             self._env_step(self._state, ro, prob, value, self._uniforms[s], s, self.mid_batch_reset,
-                           single_write=self._single_write, head=head if self._serves_head else None)
+                           single_write=self._single_write)
             if self._recurrent:
                 # step_buf.reset -> policy.reset_one before the next serve (worker.py:46,88; sampler.py:135-138)
                 hit = self._st.reset_flag if self.mid_batch_reset else \
@@ -356,16 +345,13 @@ class GpuVecSampler(BaseMbSampler):
         return self.max_path_length
 
     def _env_step(self, state, ro, prob, value, uniforms, step, mid_batch_reset, active=None, single_write=False,
-                  limit=None, head=None):
+                  limit=None):
         """The env side of one agent step: ONE launch (arl_env_step); the two-launch form only for a limit below
         one step, which the fused kernel's reset forecast does not cover.  limit: episodes end when Length > limit
         (default: this sampler family's rule for served steps)."""
         if limit is None:
             limit = self._kernel_max_path_length()
-        if head is not None:
-            _lib.env_step_policy(self._game, state, ro, head, uniforms, step, mid_batch_reset, limit,
-                                 self.discount, self.env.max_start_noops, active=active, single_write=single_write)
-        elif limit >= 1:
+        if limit >= 1:
             _lib.env_step(self._game, state, ro, prob, value, uniforms, step, mid_batch_reset, limit,
                           self.discount, self.env.max_start_noops, active=active, single_write=single_write)
         else:

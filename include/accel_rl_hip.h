@@ -237,37 +237,6 @@ int arl_env_step(const arl_game* game, const arl_env_state* st, const arl_rollou
                  double max_path_length, double discount, int32_t max_start_noops,
                  int32_t single_write, void* stream);
 
-/* The policy's output layers as arl_env_step_policy reads them: the last hidden layer as the split-K partial sums
- * its forward launch left behind (arl_conv2d_fwd_parts; splits == 1: the finished activations), the bias / rectifier
- * still to be applied to their sum, and the output layers of arl_pg_head_infer.                                  */
-typedef struct arl_head_input {
-    const float* part;       /* f32[splits][n_env][hid]                                   */
-    const float* bias;       /* f32[hid] added to the folded sum, or NULL                 */
-    const float* w_head;     /* f32[n_actions + 1][hid] (rows 0..A-1 pi, row A value)     */
-    const float* b_head;     /* f32[n_actions + 1]                                        */
-    int64_t      split_stride; /* floats between two splits (>= n_env * hid)              */
-    int32_t      splits;     /* >= 1                                                      */
-    int32_t      hid;        /* <= 1024                                                   */
-    int32_t      relu;       /* rectifier on the folded, biased sum                       */
-    int32_t      reserved;
-} arl_head_input;
-
-/* arl_env_step with the policy's output layers inside the launch: the action server's last stage
- * (prob, value = _f_prob_value's output layers, accel_rl/policies/pg/atari_cnn_policy.py:63-67; weighted_sample_n,
- * rllab/misc/special.py:22-27; the scatter of overlap/sampler.py:139-145) and the env step in ONE launch.  Per env the
- * workgroup folds its row of the hidden layer (the fold's summation order), runs the heads and the softmax
- * (arl_pg_head_infer's arithmetic: the stored prob / value are bit for bit what the two launches give), samples, and
- * steps -- the frame loads are issued before the heads run, since nothing they depend on depends on the action.
- * Everything else as arl_env_step.                                                                                  */
-/* 1 if a head of this shape fits the launch (its LDS holds the output layers' weights, the row's partials and the
- * row: (n_actions + 2 + splits) * hid floats within 160 KiB), else 0.                                               */
-int arl_env_step_policy_fits(int32_t n_actions, int32_t hid, int32_t splits);
-int arl_env_step_policy(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
-                        const arl_head_input* head, const double* uniforms,
-                        const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
-                        double max_path_length, double discount, int32_t max_start_noops,
-                        int32_t single_write, void* stream);
-
 /* Reset every env whose flag is set (u8[n_env]; NULL = all): start_envs with
  * max_decorrelation_steps == 0 (sampler/util.py:26-33) and
  * NonResetCollector.reset_needed_envs (overlap/worker.py:108-113, flags =
@@ -419,17 +388,6 @@ int64_t arl_conv_workspace_bytes(void);
  * Deterministic: fp32 MFMA accumulation in k order, split-K folded in a fixed order. */
 int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                    const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream);
-/* The same launch stopping before the split-K fold, for a consumer that folds itself (arl_env_step_policy: the
- * policy's last hidden layer at the rollout batch): fills head->part / bias / split_stride / splits / hid / relu with
- * what is left to do -- the partial sums in `workspace` (which stays live until the consumer has run), or, where the
- * launch did not split, the finished activations in y (splits 1, no bias, no rectifier left).  head->w_head /
- * b_head are the caller's.  The sum of the partials in the fold's order + bias + rectifier IS arl_conv2d_fwd's y.   */
-/* What arl_conv2d_fwd_parts will leave for this geometry, without launching anything: head->splits, hid, split_stride
- * (a consumer sizes its LDS by the number of splits: arl_env_step_policy_fits).                                    */
-int arl_conv2d_fwd_plan(const arl_conv_geom* geom, arl_head_input* head);
-int arl_conv2d_fwd_parts(const float* x, const float* w, const float* bias_or_null, float* y,
-                         const arl_conv_geom* geom, int32_t relu, void* workspace, arl_head_input* head,
-                         void* stream);
 
 /* dx = gradient of the layer input given dy (every element of dx is written).
  * If mask is given (same shape as dx): dx = 0 where mask <= 0 -- the rectifier
