@@ -580,7 +580,7 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     constexpr int BK = 32;
     const size_t lds = (size_t)2 * BK * (bm + bn) * sizeof(float);
     const dim3 grid((a.N + bn - 1) / bn, (a.K_out + bm - 1) / bm, splits);
-    if (g.K > 16 && g_split) {
+    if (g.K > 16 && g_split && g.kw % 8 == 0) {     // (the split kernel gathers whole 8-pixel filter rows)
         rc = launch_wgrad_split<1, 4, 1, 1, BK, true, 2>(a, splits, false, (hipStream_t)stream);
         if (rc) return rc;
     } else if (g.K <= 16) hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);

@@ -1442,7 +1442,13 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     constexpr int A_SZ = BK * BM, B_SZ = BK * BN;
     constexpr int MC4 = BM / 4, NPA = (BK / 2) * MC4;        // split: pair tasks of the dy tile
     constexpr int NA4 = BK * BM / 4, RA = SP ? 2 * ((NPA + 255) / 256) : (NA4 + 255) / 256;
-    constexpr int NC4 = BN / 4, KROWS = 256 / NC4, RB = BK / KROWS;
+    // W8 (u8 observations, split products): a gather task is a whole 8-pixel filter row (ONE 8-byte load) instead of a
+    // 4-pixel chunk.  The launch is bound by L1 ACCESSES (tools/conv1_pmc.sh: 16.7 M per launch at the PPO minibatch,
+    // 65 k per CU): a wave's load touches the same ~16-20 lines either way -- one per (plane, filter row) of its columns
+    // -- so twice the bytes per instruction halves them.  Needs kw % 8 == 0 (the dispatcher's condition).
+    constexpr bool W8 = U8 && SP;
+    constexpr int CW = W8 ? 8 : 4;                           // columns per gather task
+    constexpr int NC4 = BN / CW, KROWS = 256 / NC4, RB = BK / KROWS;
     static_assert(!SP || RB % 2 == 0, "split products: an even number of gather passes (row pairs)");
     constexpr int PB = U8 ? 1 : 3;
     constexpr int SPA = BK * BM * 2, SPB = BK * BN * 2, STAGE = 3 * SPA + PB * SPB;   // bytes per plane / stage
@@ -1486,7 +1492,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     // the reduction row (within a k-tile) that dy pass p of this thread covers
     auto a_row_of = [&](int p) { return SP ? 2 * ((tid + (p >> 1) * 256) / MC4) + (p & 1) : (tid + p * 256) / MC4; };
     const int b_c4 = tid % NC4, b_k0 = tid / NC4;
-    const int r = n0 + b_c4 * 4;
+    const int r = n0 + b_c4 * CW;
     const int tap = r / Cs, ch = r - tap * Cs;
     const int cty = tap / taps_x, ctx = tap - cty * taps_x;
     unsigned cdelta = r < a.N ? (unsigned)(step * (cty * Ws + ctx) * Cs + ch - a.g.dmin) << 2 : OOB;
@@ -1533,6 +1539,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     for (int p = 0; p < RA; ++p) bsum[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 va[RA], vb[RB];
     unsigned vb8[RB];
+    u32x2 vb8w[RB];
     auto issue_loads = [&](int tile) {              // tile index within the split
         const unsigned soffA = (unsigned)((mbeg + tile * BK) * a.K_out) << 2;
         const int grp = tile / TILES_PER_GROUP, tin = tile - grp * TILES_PER_GROUP;
@@ -1549,7 +1556,8 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
             // split: passes 2q, 2q + 1 gather rows 2 (b_k0 + q KROWS), + 1
             const uint2 e = rows[SP ? (p >> 1) * 2 * KROWS + (p & 1) : p * KROWS];
             const unsigned off = e.x + cdelta;      // either term may be the OOB marker (sum stays >= OOB, < 2^32)
-            if constexpr (U8) vb8[p] = buf_ld1s(rsB, off, 0);
+            if constexpr (W8) vb8w[p] = buf_ld2s(rsB, off, 0);
+            else if constexpr (U8) vb8[p] = buf_ld1s(rsB, off, 0);
             else vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
         }
     };
@@ -1582,8 +1590,15 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
             char* dB = dS + 3 * SPA;
 #pragma unroll
             for (int q = 0; q < RB / 2; ++q) {
-                char* d = dB + ((b_k0 + q * KROWS) * BN + b_c4 * 4) * 4;
-                if constexpr (U8) {                 // 0 .. 255 is exact in bf16: one plane
+                char* d = dB + ((b_k0 + q * KROWS) * BN + b_c4 * CW) * 4;
+                if constexpr (W8) {                 // eight columns of the pair of rows: two 16-byte stores
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const float4 f0 = bytes_to_f4(vb8w[2 * q][hh]), f1 = bytes_to_f4(vb8w[2 * q + 1][hh]);
+                        *reinterpret_cast<uint4*>(d + 16 * hh) = make_uint4(hi_pair(f0.x, f1.x), hi_pair(f0.y, f1.y),
+                                                                            hi_pair(f0.z, f1.z), hi_pair(f0.w, f1.w));
+                    }
+                } else if constexpr (U8) {          // 0 .. 255 is exact in bf16: one plane
                     const float4 f0 = bytes_to_f4(vb8[2 * q]), f1 = bytes_to_f4(vb8[2 * q + 1]);
                     *reinterpret_cast<uint4*>(d) = make_uint4(hi_pair(f0.x, f1.x), hi_pair(f0.y, f1.y), hi_pair(f0.z, f1.z),
                                                               hi_pair(f0.w, f1.w));
