@@ -95,6 +95,7 @@ _SIGNATURES = {
                                   _i32, _i32, _vp]),
     "arl_env_step": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                             _vp, _vp, _vp, _vp, _i32, _i32, _f64, _f64, _i32, _i32, _vp]),
+    "arl_rollout_begin": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout), _vp]),
     "arl_env_reset": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                              _vp, _i32, _vp]),
     "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
@@ -335,6 +336,12 @@ def env_step(game, state, rollout, prob, value, uniforms, step, mid_batch_reset,
 def env_frame_step(game, state, rollout, step, max_start_noops, stream=None):
     _check(load().arl_env_frame_step(C.byref(game), C.byref(state), C.byref(rollout), step,
                                      int(max_start_noops), stream_ptr(stream)), "arl_env_frame_step")
+
+
+def rollout_begin(game, state, rollout, stream=None):
+    """observations[:, 0] = step_obs and done_count = 0, one launch."""
+    _check(load().arl_rollout_begin(C.byref(game), C.byref(state), C.byref(rollout), stream_ptr(stream)),
+           "arl_rollout_begin")
 
 
 def env_reset(game, state, rollout, flags, max_start_noops, stream=None):

@@ -733,6 +733,29 @@ extern "C" int arl_env_step(const arl_game* game, const arl_env_state* st, const
 
 extern "C" void arl_dev_env_variant(int32_t v) { g_env_variant = (v >= 0 && v <= 3) ? v : 0; }
 
+// Start of a batch: the current observation of every env becomes row (env, 0) of the rollout buffer (worker.py:30-32)
+// and the completed-trajectory counter restarts -- one launch of 16-byte copies (as two framework launches, a strided
+// element-wise copy and a fill, it was 9.6 + 4.9 us of the 256-env rollout).
+__global__ __launch_bounds__(256) void batch_begin_kernel(const uint4* __restrict__ step_obs, uint4* __restrict__ observations,
+                                                          int row16, int horizon, int32_t* done_count) {
+    const int64_t e = blockIdx.x;
+    const uint4* src = step_obs + e * row16;
+    uint4* dst = observations + e * horizon * row16;
+    for (int i = threadIdx.x; i < row16; i += 256) dst[i] = src[i];
+    if (e == 0 && threadIdx.x == 0) done_count[0] = 0;
+}
+
+extern "C" int arl_rollout_begin(const arl_game* game, const arl_env_state* st, const arl_rollout* ro, void* stream) {
+    int rc = check_env_args(game, st, ro);
+    if (rc) return rc;
+    ARL_REQUIRE(ro->observations, ARL_E_ARG, "null rollout arrays");
+    const int64_t row = (int64_t)game->n_stack * OBS_FRAME;
+    ARL_REQUIRE(arl::aligned16(ro->step_obs) && arl::aligned16(ro->observations), ARL_E_ALIGN, "16-byte alignment");
+    hipLaunchKernelGGL(batch_begin_kernel, dim3((unsigned)st->n_env), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)ro->step_obs, (uint4*)ro->observations, (int)(row / 16), (int)ro->horizon, st->done_count);
+    return arl::check_launch("batch_begin_kernel");
+}
+
 extern "C" int arl_env_reset(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
                              const uint8_t* flags_or_null, int32_t max_start_noops, void* stream) {
     int rc = check_env_args(game, st, ro);

@@ -311,9 +311,7 @@ class GpuVecSampler(BaseMbSampler):
         n, t = self._total_n_envs, self.horizon
         buf, ro, env = self.samples_buf, self._rollout, self.env
         self._uniforms.view(-1).copy_(self._uniforms_host, non_blocking=True)
-        self._st.done_count.zero_()
-        obs = buf.observations.view(n, t, *buf.observations.shape[1:])
-        obs[:, 0].copy_(self.step_obs)                         # worker.py:30-32
+        _lib.rollout_begin(self._game, self._state, ro)        # observations[:, 0] = step_obs (worker.py:30-32), done_count = 0
         for s in range(t):
             if hasattr(self.policy, "set_step"):
                 self.policy.set_step(s)

@@ -237,6 +237,10 @@ int arl_env_step(const arl_game* game, const arl_env_state* st, const arl_rollou
                  double max_path_length, double discount, int32_t max_start_noops,
                  int32_t single_write, void* stream);
 
+/* Start of a batch: observations[env * horizon + 0] = step_obs[env] for every env (the collectors' first row,
+ * overlap/worker.py:30-32) and st->done_count[0] = 0 (a fresh traj_infos queue), in one launch.                  */
+int arl_rollout_begin(const arl_game* game, const arl_env_state* st, const arl_rollout* ro, void* stream);
+
 /* Reset every env whose flag is set (u8[n_env]; NULL = all): start_envs with
  * max_decorrelation_steps == 0 (sampler/util.py:26-33) and
  * NonResetCollector.reset_needed_envs (overlap/worker.py:108-113, flags =

@@ -1,5 +1,5 @@
 # PMC passes over conv 1's two kernels at the PPO minibatch: bash tools/conv1_pmc.sh [out file]   (repo root, GPU box)
-R=$(pwd); O=$R/${1:-gpurun_out/r04/conv1_pmc.txt}; cd /tmp; export TMPDIR=/tmp
+R=$(pwd); O=$R/${1:-gpurun_out/r04/conv1_pmc.txt}; mkdir -p $(dirname $O); cd /tmp; export TMPDIR=/tmp
 {
 for set in "GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA" \
            "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU" \

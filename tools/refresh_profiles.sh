@@ -1,5 +1,5 @@
-# Regenerates the one-box part of profiles/r03 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
-# ~7 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r03
+# Regenerates the one-box part of profiles/r04 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
+# ~12 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r04 (and profiles/*.json: the PMC records bench.py reads)
 set -x
 R=$(pwd); O=$R/gpurun_out/fin; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
@@ -7,6 +7,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pA -o b
 tail -n 200 $O/prof.log | grep '^{"metric' | tail -n 1 > $O/bench_profiled.json
 cp $(find /tmp/pA -name "*kernel_stats.csv" | head -n 1) $O/bench_kernel_stats.csv
 python $R/tools/trace_summary.py $(find /tmp/pA -name "*kernel_trace.csv" | head -n 1) 200 560 40 > $O/bench_steady_state_summary.txt
+python $R/tools/step_timeline.py $(find /tmp/pA -name "*kernel_trace.csv" | head -n 1) 50 > $O/step_timeline.txt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pB -o g -- python $R/bench.py --roofline-only > $O/gae.log 2>&1
 cp $(find /tmp/pB -name "*kernel_stats.csv" | head -n 1) $O/gae_kernel_stats.csv
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pC -o f -- python $R/bench.py --roofline-only > $O/gaef.log 2>&1
@@ -33,11 +34,15 @@ python tools/learner_probe.py 2>&1 | grep minibatch > $O/learner_probe.txt
 unset ARL_CONV_PRECISION
 (for n in 256 1024 4096 16384 32768; do python tools/env_step_probe.py $n 2>&1 | grep dbg; done) > $O/env_step_probe.txt
 python tools/batch_sweep.py 2>&1 | grep "^spec" > $O/batch_sweep_passes.txt
-bash tools/sync_ab.sh gpurun_out/fin > /dev/null 2>&1
 timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/null | tail -n 1 > $O/bench_a2c1024.json
 timeout 300 python bench.py --scaling strong --total-envs 2048 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > $O/bench_strong_2048_n1.json
-timeout 300 python bench.py --workload catdqn --steps 30 --warmup 5 --dqn-batch 512 2>/dev/null | tail -n 1 > $O/bench_catdqn_batch512.json
-ARL_BENCH_ONE_GPU=1 ARL_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 3 --warmup 2 --no-graph 2>/dev/null | tail -n 1 > $O/bench_spawn_2ranks_devmode.json
+timeout 400 python bench.py --workload catdqn --steps 30 --warmup 5 --dqn-batch 512 2>/dev/null | tail -n 1 > $O/bench_catdqn_batch512.json
+ARL_BENCH_ONE_GPU=1 ARL_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_spawn_2ranks_devmode.json
+ARL_BENCH_ONE_GPU=1 ARL_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 8 --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_spawn_8ranks_devmode.json
+ARL_FORCE_SYNC=1 timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_force_sync_n1.json
+bash tools/env_step_bound.sh 16384 gpurun_out/fin > /dev/null 2>&1
+bash tools/conv1_pmc.sh gpurun_out/fin/conv1_pmc.txt > /dev/null 2>&1
+python tools/replay_bench.py 2>&1 | grep -v amdgpu > $O/replay_bench.txt
 (for k in "conv2 fwd" "conv2 wgrad" "conv2 dgrad" "dense pair"; do echo "== $k"; bash tools/pmc_one.sh $k 2>&1 | grep -v amdgpu; done) > $O/pmc_one_split_kernels.txt
 python tools/wave_scan_probe.py 26 2>&1 | grep -v amdgpu > $O/wave_scan_probe.txt
 ls -la $O

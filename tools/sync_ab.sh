@@ -1,7 +1,7 @@
 # The N > 1 learner's structure at world size 1 (collective forced, backend nccl = RCCL), next to the single-GPU line:
 # captured in one hipGraph (default), eager minibatches, and captured with ONE blocking all-reduce per minibatch.
 # usage: bash tools/sync_ab.sh <out dir>
-O=${1:-gpurun_out/r03}; mkdir -p $O
+O=${1:-gpurun_out/r04}; mkdir -p $O
 run() { tag=$1; shift; env "$@" timeout 600 python bench.py --no-cpu-baseline --no-roofline --steps 300 --warmup 30 2>/dev/null | tail -n 1 > $O/bench_$tag.json
   python - <<PY
 import json
