@@ -63,6 +63,14 @@ def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind=
         algo = mPPO(discount=0.99, gae_lambda=0.95, optimizer_args=dict(minibatch_size=MINIBATCH))
     else:
         algo = PPO(discount=0.99, gae_lambda=0.95, optimizer_args=dict(minibatch_size=MINIBATCH))
+    affinities = dict(gpu=device.index)
+    if world > 1:
+        # accel_rl_base.py:71-72 pins each runner to its affinities["gpu_cpus"] (the launcher's table,
+        # scripts/launching/affinities.py): here the process's CPUs dealt out evenly to the node's ranks, so that eight
+        # ranks replaying their graphs do not share cores
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // world)
+        affinities["gpu_cpus"] = tuple(cpus[(rank % world) * per:(rank % world + 1) * per]) or tuple(cpus)
     if multi:
         algo.optimizer._force_collective = True
         if os.environ.get("ARL_SYNC_GRAPH") == "0":     # A/B switch: eager minibatches instead of one captured hipGraph
@@ -70,10 +78,10 @@ def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind=
         if os.environ.get("ARL_SYNC_OVERLAP") == "0":   # A/B switch: ONE blocking all-reduce per minibatch, no tail / head split
             algo.optimizer._overlap_allreduce = False
         runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
-                             affinities=dict(gpu=device.index), log_interval_steps=1e8)
+                             affinities=affinities, log_interval_steps=1e8)
     else:
         runner = AccelRL(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=seed,
-                         affinities=dict(gpu=device.index), log_interval_steps=1e8)
+                         affinities=affinities, log_interval_steps=1e8)
     runner.startup()
     return runner, sampler, algo, policy
 
@@ -706,17 +714,39 @@ def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, t
            "param_checksum": [int(x) for x in cmin.tolist()],
            "graph_captured": bool(getattr(algo, "_graph", None) is not None and opt.graph_ready()),
            "overlapped_allreduce": bool(getattr(opt, "_overlap_allreduce", False)),
+           "host_cpus_of_rank0": len(os.sched_getaffinity(0)),
            "allreduce_bytes_per_update": int(policy.flat_grads.numel() * 4)}
-    # the same learner without its collectives: drop the captured graph, two eager calls, re-capture, time
-    opt._elide_collective = True
-    algo._graph, algo._graph_out, algo._warm_calls = None, None, 0
-    for i in range(3):
-        algo.optimize_policy(itr + i, samples)
-    t_quiet = timed(lambda i: algo.optimize_policy(itr + 3 + i, samples), reps)
-    quiet = f64(t_quiet * 1e3)
-    dist.all_reduce(quiet, op=dist.ReduceOp.MAX)
-    out["learner_without_collectives_ms"] = round(float(quiet[0]), 4)
-    out["allreduce_exposed_ms"] = round(float(hi[2]) - float(quiet[0]), 4)
+    # The same learner without its collectives: two eager calls, a re-capture, then timed.  It runs LAST, issues no
+    # collective of its own while it can fail, and cannot take the line with it: a rank that fails says so in ONE
+    # all-reduce that every rank reaches exactly once, and the figure is then reported as null.  The graph of the timed
+    # region stays alive (a graph that holds RCCL nodes is not destroyed while its communicator lives).
+    out["learner_without_collectives_ms"] = out["allreduce_exposed_ms"] = None
+    if os.environ.get("ARL_BENCH_NO_EXPOSED") == "1":
+        return out
+    keep = (getattr(algo, "_graph", None), getattr(algo, "_graph_out", None))          # noqa: F841
+    t_quiet, failure = 0.0, None
+    try:
+        opt._elide_collective = True
+        algo._graph, algo._graph_out, algo._warm_calls = None, None, 0
+        for i in range(3):
+            algo.optimize_policy(itr + i, samples)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            algo.optimize_policy(itr + 3 + i, samples)
+        torch.cuda.synchronize()
+        t_quiet = (time.perf_counter() - t0) / reps
+    except Exception as e:                  # noqa: BLE001 -- whatever it is, the line must still be printed
+        failure = repr(e)
+    quiet = f64(-1.0 if failure else t_quiet * 1e3)
+    worst = quiet.clone()
+    dist.all_reduce(quiet, op=dist.ReduceOp.MIN)          # (-1 from any rank: the figure is void)
+    dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+    if float(quiet[0]) >= 0:
+        out["learner_without_collectives_ms"] = round(float(worst[0]), 4)
+        out["allreduce_exposed_ms"] = round(float(hi[2]) - float(worst[0]), 4)
+    elif failure:
+        out["exposed_error"] = failure[:200]
     return out
 
 
@@ -815,6 +845,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A rank that stops making progress (a captured collective waiting for a peer that is not there) would otherwise sit
+    # until the launcher's own timeout without a word: a watchdog thread names the step it stalled in and ends the rank.
+    progress = {"itr": 0, "phase": "start-up", "t": time.time()}
+
+    def tick(phase, i):
+        progress.update(itr=i, phase=phase, t=time.time())
+    if world > 1:
+        import threading
+
+        def watchdog(limit=float(os.environ.get("ARL_BENCH_STALL_S", "240"))):
+            while True:
+                time.sleep(5.0)
+                if time.time() - progress["t"] > limit:
+                    sys.stderr.write("bench.py rank %d: no progress for %.0f s in %s of step %d (graph_collectives=%s, backend=%s); "
+                                     "ARL_SYNC_GRAPH=0 runs the collectives eagerly\n" %
+                                     (rank, limit, progress["phase"], progress["itr"],
+                                      getattr(algo.optimizer, "graph_collectives", None), backend))
+                    sys.stderr.flush()
+                    os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+
+    def one_step(i, sampler, algo):             # (shadows the module-level helper: the same two calls + the heartbeat)
+        tick("rollout", i)
+        samples, _ = sampler.obtain_samples(i)
+        tick("learner", i)
+        algo.optimize_policy(i, samples)
+
     itr = 0
     # Priming (untimed, whatever --warmup says): the sampler captures its hipGraph in its first batch and the learner in
     # its third call (two eager calls first) -- a caller that asks for fewer than three warm-up steps would otherwise
@@ -876,6 +933,7 @@ def main():
     t_learn = timed(lambda i: algo.optimize_policy(itr + i, samples), reps)
     line["phases"] = {"rollout_ms": round(t_roll * 1e3, 4), "learner_ms": round(t_learn * 1e3, 4),
                       "rollout_only_env_steps_per_s": round(N_ENVS * HORIZON / t_roll, 1)}
+    tick("diagnostics", itr)
     if world > 1:
         line["multi_gpu"] = multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, timed, reps,
                                                   itr + 2 * reps, elapsed_local / args.steps, t_roll, t_learn)
