@@ -538,11 +538,13 @@ __global__ __launch_bounds__(256) void env_step_kernel(
     const int64_t w = e / per, g0 = w * per;
     const int64_t hi = g0 + per < st.n_env ? g0 + per : st.n_env;
     const int64_t n_streams = (st.n_env + per - 1) / per;
-    // ---- every lane: this env's state, served distribution and uniform (uniform addresses: broadcast loads)
-    const EnvRegs in = load_env(st, e);
+    // ---- wave 0 derives the step from the env's state, the served distribution and the uniform (uniform addresses:
+    // broadcast loads) and hands the frame plan to the other three waves through LDS.  (Rounds 2-3 had EVERY lane derive
+    // it -- no hand-off, but ~270 of a wave's ~870 vector instructions, a quarter of the launch's issue time at 16 384
+    // envs: tools/env_step_bound.sh.)
+    __shared__ int s_plan[4];                             // fa, fb, mode, stepped
+    const bool planner = tid < 64;                        // (wave-uniform)
     const float* p = prob + e * g.n_actions;
-    const int a_idx = sample_action(p, g.n_actions, uniforms[e]);
-    const float v = value[e];
     const bool is_active = !active || active[e] != 0;
     const int64_t cursor = st.noop_cursor[parity * n_streams + w];
     const uint8_t* flag_now = st.next_reset + (int64_t)fpar * st.n_env;         // written by the previous launch
@@ -556,14 +558,24 @@ __global__ __launch_bounds__(256) void env_step_kernel(
         }
     }
     const uint8_t carried = flag_now[e];
-    __syncthreads();                                      // every lane has its inputs: lane 0 may now overwrite them
-    StepOut o = step_compute(g, in, a_idx, is_active, mid_batch_reset, max_path_length, discount);
-    if (o.reset_flag) {                                   // env.reset() (worker.py:47): start no-ops from the stream's ring
-        int noops = 0;
-        if (max_start_noops > 0)                          // randint(0, 1) draws nothing
-            noops = st.noop_ring[w * st.noop_ring_len + (cursor + rank) % st.noop_ring_len];
-        reset_regs(g, o.s, noops, o.fa, o.fb, o.mode);
+    StepOut o = {};
+    float v = 0.f;
+    if (planner) {
+        const EnvRegs in = load_env(st, e);
+        const int a_idx = sample_action(p, g.n_actions, uniforms[e]);
+        v = value[e];
+        o = step_compute(g, in, a_idx, is_active, mid_batch_reset, max_path_length, discount);
+        if (o.reset_flag) {                               // env.reset() (worker.py:47): start no-ops from the stream's ring
+            int noops = 0;
+            if (max_start_noops > 0)                      // randint(0, 1) draws nothing
+                noops = st.noop_ring[w * st.noop_ring_len + (cursor + rank) % st.noop_ring_len];
+            reset_regs(g, o.s, noops, o.fa, o.fb, o.mode);
+        }
+        if (tid == 0) { s_plan[0] = o.fa; s_plan[1] = o.fb; s_plan[2] = o.mode; s_plan[3] = o.stepped; }
     }
+    __syncthreads();                                      // the plan is out (and every wave-0 lane has read the state
+    //                                                       lane 0 is about to overwrite)
+    o.fa = s_plan[0]; o.fb = s_plan[1]; o.mode = s_plan[2]; o.stepped = s_plan[3];
     const int64_t row_bytes = (int64_t)g.n_stack * OBS_FRAME;
     uint8_t* cur = ro.step_obs + e * row_bytes;
     uint8_t* next = step + 1 < ro.horizon ? ro.observations + (e * ro.horizon + step + 1) * row_bytes : nullptr;
