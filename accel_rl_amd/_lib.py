@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libaccel_rl_hip.so")
 
 ARL_ABI_VERSION = 2
 PROMO_NEP50, PROMO_LEGACY, PROMO_ASSOC = 0, 1, 2
-PPO_TIE_THEANO, PPO_TIE_MATH = 0, 1      # ARL_PPO_TIE_*: whose gradient min() / clip() hand on (accel_rl_hip.h)
+PPO_TIE_THEANO, PPO_TIE_MATH, PPO_TIE_BOTH = 0, 1, 2      # ARL_PPO_TIE_*: whose gradient min() / clip() hand on (accel_rl_hip.h)
 OPT_ADAM, OPT_RMSPROP = 0, 1
 MAX_ACTIONS = 18
 REPLAY_MAX_HORIZON = 16

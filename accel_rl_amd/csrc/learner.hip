@@ -280,8 +280,13 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
             const bool in_range = (ratio >= lo) && (ratio <= hi);
             float g_ratio;
             if (a.tie_rule == ARL_PPO_TIE_THEANO) {
-                // the reference's graph: Minimum.L_op hands eq(min, x) g to BOTH arguments, Clip.L_op passes g
-                // for lo <= r <= hi -- inside the range s1 and s2 are the same number and the sample counts twice
+                // the reference's graph as Theano >= 0.8 differentiates it: Minimum.L_op, e = eq(min, x), gives e g to
+                // its FIRST argument (s1 here: T.minimum(surr_1, surr_2)) and (1 - e) g to the second -- a tie goes to
+                // the first alone --, Clip.L_op passes g for lo <= r <= hi
+                g_ratio = (pi_term == s1) ? adv : (in_range ? adv : 0.f);
+            } else if (a.tie_rule == ARL_PPO_TIE_BOTH) {
+                // Theano <= 0.7: eq(min, x) g to EVERY argument equal to the minimum -- inside the range s1 and s2 are the
+                // same number and the sample counts twice
                 g_ratio = ((pi_term == s1) ? adv : 0.f) + ((pi_term == s2 && in_range) ? adv : 0.f);
             } else {
                 g_ratio = in_range ? adv : (s1 < s2 ? adv : 0.f);
@@ -510,8 +515,8 @@ extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const
     ARL_REQUIRE(h && w_head && b_head && actions && advantages && returns && lr_mult && dout && dh &&
                     dw_head && db_head && loss4 && workspace && items3, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(kind == 0 || (kind == 1 && old_prob), ARL_E_ARG, "kind must be 0 (A2C) or 1 (PPO, needs old_prob)");
-    ARL_REQUIRE(tie_rule == ARL_PPO_TIE_THEANO || tie_rule == ARL_PPO_TIE_MATH, ARL_E_ARG,
-                "tie_rule must be ARL_PPO_TIE_THEANO or ARL_PPO_TIE_MATH");
+    ARL_REQUIRE(tie_rule == ARL_PPO_TIE_THEANO || tie_rule == ARL_PPO_TIE_MATH || tie_rule == ARL_PPO_TIE_BOTH, ARL_E_ARG,
+                "tie_rule must be ARL_PPO_TIE_THEANO, ARL_PPO_TIE_MATH or ARL_PPO_TIE_BOTH");
     int rc = check_head(batch, hid, n_actions);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;

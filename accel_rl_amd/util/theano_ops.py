@@ -1,28 +1,35 @@
 """Theano's gradient rules for the two element-wise ops of PPO's surrogate (accel_rl/algos/pg/ppo.py:47-49),
 as torch autograd Functions.  Theano is a third-party dependency of the reference (absent from /root/reference
-and from this image: restated from its published source, theano/scalar/basic.py `Minimum.L_op`, `Clip.L_op`;
-parity unpinned):
+and from this image: restated from its published source, theano/scalar/basic.py; parity unpinned).  The reference
+imports theano.gpuarray, i.e. runs on Theano >= 0.9, and since 0.8 the rules are
 
-    minimum(x, y):  gx = eq(out, x) g,  gy = eq(out, y) g     -- a tie hands g to BOTH arguments
-    clip(x, lo, hi): gx = ((x >= lo) & (x <= hi)) g            -- bounds included
+    minimum(x, y):   e = eq(out, x);  gx = e g;  gy = (1 - e) g     -- a tie hands g to the FIRST argument alone
+                     ("This form handle the case when both value are the same. In that case, gx will be gz, gy will
+                      be 0."; theano/tensor/tests/test_basic.py::test_maximum_minimum_grad asserts [[1], [0]] at x == y)
+    clip(x, lo, hi): gx = ((x >= lo) & (x <= hi)) g                 -- bounds included
 
-The learner never calls these (the same rule lives inside `head_kernel`, csrc/learner.hip, selected by
-ARL_PPO_TIE_THEANO); `BasePPO.pi_loss` is written with them so that the formula the numerics tests differentiate
-is the reference's graph and not torch.minimum's (which splits a tie's gradient evenly)."""
+(`both=True` is Theano <= 0.7's minimum: gx = eq(out, x) g, gy = eq(out, y) g -- a tie feeds both arguments.)
+
+The learner never calls these (the same rules live inside `head_kernel`, csrc/learner.hip, selected by
+ARL_PPO_TIE_*); `BasePPO.pi_loss` is written with them so that the formula the numerics tests differentiate is the
+reference's graph and not torch.minimum's (which splits a tie's gradient evenly)."""
 import torch
 
 
 class _Minimum(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y):
+    def forward(ctx, x, y, both):
         out = torch.minimum(x, y)
         ctx.save_for_backward(x, y, out)
+        ctx.both = both
         return out
 
     @staticmethod
     def backward(ctx, g):
         x, y, out = ctx.saved_tensors
-        return (out == x).to(g.dtype) * g, (out == y).to(g.dtype) * g
+        e = (out == x).to(g.dtype)
+        gy = (out == y).to(g.dtype) if ctx.both else 1 - e
+        return e * g, gy * g, None
 
 
 class _Clip(torch.autograd.Function):
@@ -37,8 +44,8 @@ class _Clip(torch.autograd.Function):
         return ((x >= lo) & (x <= hi)).to(g.dtype) * g, None, None      # the bounds are not parameters here
 
 
-def minimum(x, y):
-    return _Minimum.apply(x, y)
+def minimum(x, y, both=False):
+    return _Minimum.apply(x, y, both)
 
 
 def clip(x, lo, hi):

@@ -316,20 +316,29 @@ int arl_pg_head_infer(const float* h, const float* w_head, const float* b_head, 
  * (aac_base.py:60-66, categorical.py:66-78); means are valids_mean when valids
  * is given (algos/pg/util.py:49-53; inv_count = 1/sum(valids) over the minibatch).
  * Rows of the batch arrays are selected by idx (NULL = identity).
- * tie_rule (PPO only) = how min() and clip() hand their gradient on:
- *   ARL_PPO_TIE_THEANO  the reference learner's graph: T.minimum gives eq(min, x) g to EVERY argument
- *                       equal to the minimum, T.clip passes g for lo <= r <= hi (bounds included;
- *                       theano/scalar/basic.py Minimum.L_op / Clip.L_op; Theano is a third-party
- *                       dependency absent from /root/reference: restated, parity unpinned), so
- *                       d surr / d r = adv ((surr == s1) + (surr == s2)(lo <= r <= hi)):
- *                       2 adv inside the clip range, adv where s1 < s2 outside it, else 0;
- *   ARL_PPO_TIE_MATH    the mathematical derivative (adv inside the range): what an autograd that
- *                       splits a tie's gradient to sum 1 (torch.minimum) gives.
+ * tie_rule (PPO only) = how min() and clip() hand their gradient on (s1 = r adv, s2 = clip(r) adv, surr = min(s1, s2)):
+ *   ARL_PPO_TIE_THEANO  the reference learner's graph as its Theano differentiates it.  accel_rl runs on
+ *                       theano.gpuarray, i.e. Theano >= 0.9; since 0.8 theano/scalar/basic.py has
+ *                           Minimum.L_op:  e = eq(min, x);  gx = e gz;  gy = (1 - e) gz
+ *                           ("This form handle the case when both value are the same. In that case, gx will be
+ *                            gz, gy will be 0."; theano/tensor/tests/test_basic.py::test_maximum_minimum_grad:
+ *                            "we only pass the gradient to the first input in that case")
+ *                           Clip.L_op:     gx = ((x >= min) & (x <= max)) gz
+ *                       and ppo.py:49 is T.minimum(surr_1, surr_2), so
+ *                           d surr / d r = adv [surr == s1] + adv [surr != s1] [lo <= r <= hi]:
+ *                       adv inside the clip range (the tie goes to the unclipped branch alone) and where s1 < s2
+ *                       outside it, else 0.  Theano is a third-party dependency absent from /root/reference:
+ *                       restated from its published source, parity unpinned.
+ *   ARL_PPO_TIE_MATH    the mathematical derivative: adv inside the range, adv where s1 < s2 outside, else 0 (differs
+ *                       from the above only where s1 == s2 by rounding OUTSIDE the range).
+ *   ARL_PPO_TIE_BOTH    Theano <= 0.7 (gx = eq(min, x) gz, gy = eq(min, y) gz: a tie feeds BOTH arguments):
+ *                       2 adv inside the clip range, bounds included; for comparing against runs of that vintage.
  *   out: dout f32[batch][A+1], dh f32[batch][hid] (before the hidden relu mask),
  *        dw_head f32[A+1][hid], db_head f32[A+1], loss4 f32[4] = pi, v, ent, pi+v+ent
  *   workspace >= arl_pg_head_workspace_bytes()                                  */
 #define ARL_PPO_TIE_THEANO 0
 #define ARL_PPO_TIE_MATH   1
+#define ARL_PPO_TIE_BOTH   2
 int64_t arl_pg_head_workspace_bytes(void);
 int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
                      const uint8_t* actions, const float* advantages, const float* returns,

@@ -575,22 +575,31 @@ def ppo_surrogate(ratio, adv, clip, tie_rule="theano"):
     """surr = minimum(ratio adv, clip(ratio, 1 - clip, 1 + clip) adv) (ppo.py:45-49) and d surr / d ratio, f32.
 
     PARITY UNPINNED for the gradient: it is produced by Theano's symbolic differentiation, and Theano (unpinned
-    in the reference, absent from /root/reference and from this image) cannot be run here.  Restated from its
-    published scalar-op rules, theano/scalar/basic.py:
-        Minimum.L_op:  gx = eq(minimum(x, y), x) gz,  gy = eq(minimum(x, y), y) gz   (BOTH on a tie)
+    in the reference's environment.yml, absent from /root/reference and from this image) cannot be run here.
+    Restated from its published scalar-op rules, theano/scalar/basic.py.  The reference imports theano.gpuarray
+    (accel_rl/runners/accel_rl_base.py:62-64), i.e. it runs on Theano >= 0.9, where
+        Minimum.L_op:  e = eq(minimum(x, y), x);  gx = e gz;  gy = (1 - e) gz
+                       ("This form handle the case when both value are the same. In that case, gx will be gz, gy
+                        will be 0."; theano/tensor/tests/test_basic.py::test_maximum_minimum_grad: at x == y the
+                        gradients are [[1], [0]] -- "we only pass the gradient to the first input in that case")
         Clip.L_op:     gx = ((x >= min) & (x <= max)) gz                              (bounds included)
-    so with s1 = ratio adv, s2 = clip(ratio) adv:
-        d surr / d ratio = adv [surr == s1] + adv [surr == s2] [lo <= ratio <= hi]
-    = 2 adv inside the clip range (s1 and s2 are the same number there), adv where s1 < s2 outside it, 0 where
-    the clipped branch is the minimum.  tie_rule="math" is the mathematical derivative (adv inside the range)."""
+    so with s1 = ratio adv (the FIRST argument, ppo.py:49), s2 = clip(ratio) adv:
+        tie_rule="theano":  d surr / d ratio = adv [surr == s1] + adv [surr != s1] [lo <= ratio <= hi]
+    = adv inside the clip range (the tie goes to the unclipped branch alone), adv where s1 < s2 outside it, 0 where the
+    clipped branch alone is the minimum.  tie_rule="math" is the mathematical derivative (equal to the above except
+    where s1 == s2 by rounding outside the range); tie_rule="both" is Theano <= 0.7 (gx = eq(min, x) gz AND gy =
+    eq(min, y) gz): 2 adv inside the range."""
     ratio, adv = np.asarray(ratio, F32), np.asarray(adv, F32)
     lo, hi = F32(1) - F32(clip), F32(1) + F32(clip)
     s1 = ratio * adv
     s2 = np.minimum(np.maximum(ratio, lo), hi) * adv
     surr = np.minimum(s1, s2)
     inside = (ratio >= lo) & (ratio <= hi)
+    first = surr == s1
     if tie_rule == "theano":
-        grad = adv * (surr == s1).astype(F32) + adv * ((surr == s2) & inside).astype(F32)
+        grad = adv * first.astype(F32) + adv * (~first & inside).astype(F32)
+    elif tie_rule == "both":
+        grad = adv * first.astype(F32) + adv * ((surr == s2) & inside).astype(F32)
     elif tie_rule == "math":
         grad = np.where(inside, adv, np.where(s1 < s2, adv, F32(0))).astype(F32)
     else:

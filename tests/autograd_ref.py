@@ -41,28 +41,32 @@ def losses(algo, mb):
 
 class _TheanoSurrogate(torch.autograd.Function):
     """PPO's surrogate minimum(r A, clip(r, lo, hi) A) (accel_rl/algos/pg/ppo.py:45-49) with the gradient Theano's
-    symbolic differentiation produces (theano/scalar/basic.py Minimum.L_op: eq(out, x) g to BOTH arguments; Clip.L_op:
-    g for lo <= x <= hi) -- the closed form of oracle/ref_port.py::ppo_surrogate, written independently of
-    accel_rl_amd/util/theano_ops.py (which composes the two ops)."""
+    symbolic differentiation produces -- the closed form of oracle/ref_port.py::ppo_surrogate, written independently
+    of accel_rl_amd/util/theano_ops.py (which composes the two ops).  Theano >= 0.8 (`both` False): a tie of the
+    minimum goes to its first argument alone, d/dr = A [surr == s1] + A [surr != s1] [lo <= r <= hi]; Theano <= 0.7
+    (`both`): every argument equal to the minimum receives it, d/dr = A [surr == s1] + A [surr == s2] [lo <= r <= hi]."""
 
     @staticmethod
-    def forward(ctx, ratio, adv, lo, hi):
+    def forward(ctx, ratio, adv, lo, hi, both):
         s1 = ratio * adv
         s2 = torch.minimum(torch.maximum(ratio, lo), hi) * adv
         surr = torch.minimum(s1, s2)
-        ctx.save_for_backward(adv, (surr == s1), (surr == s2) & (ratio >= lo) & (ratio <= hi))
+        inside = (ratio >= lo) & (ratio <= hi)
+        first = surr == s1
+        ctx.save_for_backward(adv, first, ((surr == s2) if both else ~first) & inside)
         return surr
 
     @staticmethod
     def backward(ctx, g):
         adv, first, second = ctx.saved_tensors
-        return g * adv * (first.to(g.dtype) + second.to(g.dtype)), None, None, None
+        return g * adv * (first.to(g.dtype) + second.to(g.dtype)), None, None, None, None
 
 
 def ppo_surrogate(ratio, adv, clip, tie_rule="theano"):
-    """surr[B]; tie_rule "theano" = the reference's graph (default of the product), "math" = torch.minimum's."""
+    """surr[B]; tie_rule "theano" = the reference's graph under Theano >= 0.8 (default of the product), "both" = under
+    Theano <= 0.7, "math" = torch.minimum's own rule."""
     lo = torch.as_tensor(1. - clip, dtype=ratio.dtype, device=ratio.device)
     hi = torch.as_tensor(1. + clip, dtype=ratio.dtype, device=ratio.device)
-    if tie_rule == "theano":
-        return _TheanoSurrogate.apply(ratio, adv, lo, hi)
+    if tie_rule in ("theano", "both"):
+        return _TheanoSurrogate.apply(ratio, adv, lo, hi, tie_rule == "both")
     return torch.minimum(ratio * adv, torch.clamp(ratio, float(lo), float(hi)) * adv)

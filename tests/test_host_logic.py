@@ -217,30 +217,43 @@ def test_logger_context_files_and_snapshots(tmp_path, monkeypatch):
 def test_ppo_surrogate_gradient_rules():
     """The three statements of Theano's min / clip gradient agree on the samples where the rules differ: the oracle's
     closed form (oracle/ref_port.py::ppo_surrogate), the product's composed autograd ops (util/theano_ops.py, what
-    BasePPO.pi_loss is written with) and the tests' one-Function restatement (tests/autograd_ref.py).  Inside the
-    clip range -- bounds included -- the reference's graph yields 2 A (accel_rl/algos/pg/ppo.py:47-49)."""
+    BasePPO.pi_loss is written with) and the tests' one-Function restatement (tests/autograd_ref.py).  Theano >= 0.8
+    (what the reference runs on; the default) hands a tie of T.minimum(surr_1, surr_2) to surr_1 alone: A inside the clip
+    range; Theano <= 0.7 ("both") fed both arguments: 2 A inside the range, bounds included
+    (accel_rl/algos/pg/ppo.py:47-49)."""
     import torch
     import autograd_ref
     from accel_rl_amd.util import theano_ops
     from oracle import ref_port as P
     clip = 0.25                                                    # 0.75 and 1.25 are exact in fp32
-    ratio = np.array([1.0, 0.75, 1.25, 0.7499999, 1.2500001, 0.5, 2.0, 0.5, 2.0, 1.0, 0.9, 1.1, 3.0], np.float32)
-    adv = np.array([1.5, -2.0, 0.5, 1.0, 1.0, 1.0, 1.0, -1.0, -1.0, 0.0, -0.25, 4.0, 0.0], np.float32)
-    surr, g = P.ppo_surrogate(ratio, adv, clip, "theano")
-    want = np.array([3.0, -4.0, 1.0, 1.0, 0.0, 1.0, 0.0, 0.0, -1.0, 0.0, -0.5, 8.0, 0.0], np.float32)
-    assert np.array_equal(g, want)
-    _, g_math = P.ppo_surrogate(ratio, adv, clip, "math")
-    assert np.array_equal(g_math, np.array([1.5, -2.0, 0.5, 1.0, 0.0, 1.0, 0.0, 0.0, -1.0, 0.0, -0.25, 4.0, 0.0], np.float32))
-    for build in (lambda r, a: theano_ops.minimum(r * a, theano_ops.clip(r, 1. - clip, 1. + clip) * a),
-                  lambda r, a: autograd_ref.ppo_surrogate(r, a, clip, "theano")):
-        r = torch.from_numpy(ratio).requires_grad_()
-        out = build(r, torch.from_numpy(adv))
-        out.sum().backward()
-        assert np.array_equal(out.detach().numpy(), surr)
-        assert np.array_equal(r.grad.numpy(), g)
+    ratio = np.array([1.0, 0.75, 1.25, 0.7499999, 1.2500001, 0.5, 2.0, 0.5, 2.0, 1.0, 0.9, 1.1, 3.0, 1.3], np.float32)
+    adv = np.array([1.5, -2.0, 0.5, 1.0, 1.0, 1.0, 1.0, -1.0, -1.0, 0.0, -0.25, 4.0, 0.0, 1e-45], np.float32)
+    want = dict(
+        theano=[1.5, -2.0, 0.5, 1.0, 0.0, 1.0, 0.0, 0.0, -1.0, 0.0, -0.25, 4.0, 0.0, 1e-45],
+        both=[3.0, -4.0, 1.0, 1.0, 0.0, 1.0, 0.0, 0.0, -1.0, 0.0, -0.5, 8.0, 0.0, 1e-45],
+        # (last sample: outside the range the two branches are EQUAL by rounding -- the smallest denormal as advantage:
+        #  1.3 x 1e-45 and 1.25 x 1e-45 are both 1e-45 -- and the tie goes to the first argument; the mathematical derivative is 0)
+        math=[1.5, -2.0, 0.5, 1.0, 0.0, 1.0, 0.0, 0.0, -1.0, 0.0, -0.25, 4.0, 0.0, 0.0])
+    surr = None
+    for rule, w in want.items():
+        surr, g = P.ppo_surrogate(ratio, adv, clip, rule)
+        assert np.array_equal(g, np.array(w, np.float32)), rule
+    for rule in ("theano", "both"):
+        _, g = P.ppo_surrogate(ratio, adv, clip, rule)
+        for build in (lambda r, a: theano_ops.minimum(r * a, theano_ops.clip(r, 1. - clip, 1. + clip) * a, both=rule == "both"),
+                      lambda r, a: autograd_ref.ppo_surrogate(r, a, clip, rule)):
+            r = torch.from_numpy(ratio).requires_grad_()
+            out = build(r, torch.from_numpy(adv))
+            out.sum().backward()
+            assert np.array_equal(out.detach().numpy(), surr)
+            assert np.array_equal(r.grad.numpy(), g), rule
+    # theano/tensor/tests/test_basic.py::test_maximum_minimum_grad: at x == y the gradients are [[1], [0]]
+    x, y = torch.ones(1, requires_grad=True), torch.ones(1, requires_grad=True)
+    theano_ops.minimum(x, y).sum().backward()
+    assert x.grad.item() == 1. and y.grad.item() == 0.
     from accel_rl_amd.algos.pg.ppo import PPO
     assert PPO().ppo_tie_rule == "theano" and PPO().loss_tie_rule == 0
-    assert PPO(ppo_tie_rule="math").loss_tie_rule == 1
+    assert PPO(ppo_tie_rule="math").loss_tie_rule == 1 and PPO(ppo_tie_rule="both").loss_tie_rule == 2
     with pytest.raises(ValueError):
         PPO(ppo_tie_rule="torch")
 

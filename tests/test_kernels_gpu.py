@@ -539,13 +539,13 @@ def test_bias_relu_and_backward(L, rows, ch):
 
 
 @pytest.mark.parametrize("n_act,hid,batch", [(4, 512, 512), (6, 256, 100), (18, 512, 64), (4, 64, 5), (9, 1024, 33)])
-@pytest.mark.parametrize("kind,tie", [(0, "theano"), (1, "theano"), (1, "math")])
+@pytest.mark.parametrize("kind,tie", [(0, "theano"), (1, "theano"), (1, "math"), (1, "both")])
 @pytest.mark.parametrize("masked", [False, True])
 def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, tie, masked):
     """heads + softmax + A2C/PPO/value/entropy losses and all gradients vs PyTorch autograd
-    on the reference's formulas (aac_base.py:60-70, a2c.py:43-46, ppo.py:42-51); PPO under both gradient rules
-    for the surrogate's min / clip: the reference's Theano graph (default: 2 A inside the clip range) and the
-    mathematical derivative."""
+    on the reference's formulas (aac_base.py:60-70, a2c.py:43-46, ppo.py:42-51); PPO under the three gradient rules
+    for the surrogate's min / clip: the reference's Theano (>= 0.8: a tie goes to the first argument, the default), the
+    mathematical derivative, and Theano <= 0.7 (a tie feeds both arguments: 2 A inside the clip range)."""
     gen = torch.Generator(device=DEV).manual_seed(n_act * 1000 + hid + batch)
     n_rows = batch * 3
     h = torch.relu(torch.randn(batch, hid, device=DEV, generator=gen)).requires_grad_()
@@ -589,7 +589,7 @@ def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, tie, masked):
     ws = L.pg_head_workspace(DEV)
     L.pg_head_loss(h.detach(), w.detach(), bh.detach(), act, adv, ret, old, valids, idx, lr_mult, inv,
                    n_act, kind, clip, c_v, c_e, dout, dh, dw, db, loss4, ws,
-                   tie_rule=dict(theano=L.PPO_TIE_THEANO, math=L.PPO_TIE_MATH)[tie])
+                   tie_rule=dict(theano=L.PPO_TIE_THEANO, math=L.PPO_TIE_MATH, both=L.PPO_TIE_BOTH)[tie])
     assert torch.allclose(loss4[:3], torch.stack([pi, vl, el]).detach(), rtol=1e-4, atol=1e-6)
     for got, want, name in ((dh, gh, "dh"), (dw, gw, "dw"), (db, gb, "db")):
         scale = max(want.abs().max().item(), 1e-6)
@@ -601,14 +601,15 @@ def test_pg_head_loss_vs_autograd(L, n_act, hid, batch, kind, tie, masked):
     assert torch.allclose(p2, prob.detach(), rtol=1e-5, atol=1e-7) and torch.allclose(v2, value.detach(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("tie", ["theano", "math"])
+@pytest.mark.parametrize("tie", ["theano", "both", "math"])
 def test_ppo_tie_rule_on_the_boundaries_at_the_config2_shape(L, tie):
     """BASELINE config 2's minibatch (512 rows, 4 actions, 512 hidden units).  The samples the two gradient rules
     differ on, placed deliberately: ratio == 1 exactly (old probability = the kernel's own), ratio exactly ON the
     lower / upper bound (clip chosen as 1 - ratio, resp. ratio - 1, of a row: both exact in fp32), advantage == 0,
-    clip == 0 (both bounds coincide with ratio 1), and ordinary rows either side of the range.  Theano's rule
-    (ppo.py:47-49 through Minimum.L_op / Clip.L_op): 2 A wherever lo <= ratio <= hi, bounds INCLUDED; A where the
-    unclipped branch is the smaller outside; 0 otherwise.  The reference side is autograd on the same formulas with
+    clip == 0 (both bounds coincide with ratio 1), and ordinary rows either side of the range.  The reference's rule
+    (ppo.py:47-49 through Theano >= 0.8's Minimum.L_op / Clip.L_op): A wherever the unclipped branch IS the minimum --
+    inside the range, bounds INCLUDED, it ties with the clipped one and takes the whole gradient --, 0 otherwise;
+    "both" (Theano <= 0.7): 2 A inside the range, bounds included.  The reference side is autograd on the same formulas with
     the forward value of the ratio pinned to the kernel's own bits (straight-through), so that a last-bit difference
     between torch's softmax and the kernel's cannot move a sample across a bound."""
     batch, n_act, hid = 512, 4, 512
@@ -659,7 +660,7 @@ def test_ppo_tie_rule_on_the_boundaries_at_the_config2_shape(L, tie):
         dw, db, loss4 = torch.empty_like(w0), torch.empty_like(b0), torch.zeros(4, device=DEV)
         L.pg_head_loss(h0, w0, b0, act, adv, ret, old, None, None, lr_mult, None, n_act, 1, clip, c_v, c_e,
                        dout, dh, dw, db, loss4, L.pg_head_workspace(DEV),
-                       tie_rule=dict(theano=L.PPO_TIE_THEANO, math=L.PPO_TIE_MATH)[tie])
+                       tie_rule=dict(theano=L.PPO_TIE_THEANO, math=L.PPO_TIE_MATH, both=L.PPO_TIE_BOTH)[tie])
         assert torch.allclose(loss4[:3], torch.stack([pi, vl, el]).detach(), rtol=1e-4, atol=1e-6), clip
         for got, want, name in ((dh, gh, "dh"), (dw, gw, "dw"), (db, gb, "db")):
             scale = max(want.abs().max().item(), 1e-6)

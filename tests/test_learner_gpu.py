@@ -61,8 +61,8 @@ def ref_loss(kind, params, spec, mb, clip, v_coeff, ent_coeff=0.01, tie="theano"
     mean = torch.mean if valids is None else (lambda x: torch.sum(valids * x) * (1. / torch.sum(valids)))
     if kind == "ppo":
         ratio = (pa + TINY) / (mb["old_prob"][torch.arange(len(act)), act] + TINY)
-        # the reference's graph differentiated as Theano does (ppo.py:47-49; tests/autograd_ref.py): an unclipped
-        # sample's gradient is 2 adv; tie="math" = torch.minimum's own rule, the product's PPO(ppo_tie_rule="math")
+        # the reference's graph differentiated as Theano (>= 0.8) does (ppo.py:47-49; tests/autograd_ref.py): a tie of
+        # the minimum goes to the unclipped branch; tie="math" = torch.minimum's own rule, "both" = Theano <= 0.7
         pi = -mean(autograd_ref.ppo_surrogate(ratio, mb["adv"], float(clip), tie))
     else:
         pi = -mean(torch.log(pa + TINY) * mb["adv"])
@@ -122,6 +122,7 @@ def fill(buf, policy, rs, n_env, horizon):
 LEARNER_CASES = {
     "ppo_tiny": ("ppo", 16, dict()),
     "ppo_tiny_math_tie": ("ppo", 16, dict(tie="math")),
+    "ppo_tiny_both_tie": ("ppo", 16, dict(tie="both")),
     "a2c_tiny": ("a2c", 16, dict()),
     "ppo_config2": ("ppo", 256, dict(spec_id=1, n_act=4, minibatch=512, epochs=4)),
     "a2c_config3": ("a2c", 1024, dict(spec_id=0, n_act=4)),
@@ -390,15 +391,15 @@ def test_single_frame_observations():
     np.testing.assert_array_equal(policy.get_param_values(), flat)
 
 
-@pytest.mark.parametrize("kind,tie", [("ppo", "theano"), ("ppo", "math"), ("a2c", "theano")])
+@pytest.mark.parametrize("kind,tie", [("ppo", "theano"), ("ppo", "math"), ("ppo", "both"), ("a2c", "theano")])
 def test_explicit_backward_matches_autograd(kind, tie):
     """flat_grads from the explicit HIP backward == autograd through PyTorch's own conv2d /
-    linear on the same network; PPO under both gradient rules of the surrogate's min / clip (the reference's Theano
-    graph -- the default -- and the mathematical derivative)."""
+    linear on the same network; PPO under the three gradient rules of the surrogate's min / clip (the reference's
+    Theano -- the default --, the mathematical derivative, Theano <= 0.7's both-arguments rule)."""
     from accel_rl_amd import _lib
     n_env, horizon = 16, 5
     policy, algo, buf, spec = make(kind, n_env, horizon, False, tie=tie)
-    assert algo.loss_tie_rule == dict(theano=_lib.PPO_TIE_THEANO, math=_lib.PPO_TIE_MATH)[tie]
+    assert algo.loss_tie_rule == dict(theano=_lib.PPO_TIE_THEANO, math=_lib.PPO_TIE_MATH, both=_lib.PPO_TIE_BOTH)[tie]
     rs = np.random.RandomState(5)
     fill(buf, policy, rs, n_env, horizon)
     n = n_env * horizon
@@ -479,7 +480,7 @@ def test_minibatch_walked_in_passes_is_the_one_pass_gradient(kind, use_valids):
     assert policy.rows_per_pass() == 2304 and policy.rows_per_pass() % 256 == 0        # spec 0 at 4 x 104 x 80
 
 
-@pytest.mark.parametrize("kind,tie", [("ppo", "theano"), ("ppo", "math"), ("a2c", "theano")])
+@pytest.mark.parametrize("kind,tie", [("ppo", "theano"), ("ppo", "math"), ("ppo", "both"), ("a2c", "theano")])
 def test_fused_losses_match_the_algorithm_formulas(kind, tie):
     """The algorithm's `_losses` (HIP forward + fused head kernel + HIP backward, selected by `loss_kind`) against
     the same algorithm's `pi_loss` formula + value / entropy terms (aac_base.py:60-66) differentiated by autograd."""
