@@ -318,7 +318,8 @@ int arl_pg_head_infer(const float* h, const float* w_head, const float* b_head, 
  * Rows of the batch arrays are selected by idx (NULL = identity).
  * tie_rule (PPO only) = how min() and clip() hand their gradient on (s1 = r adv, s2 = clip(r) adv, surr = min(s1, s2)):
  *   ARL_PPO_TIE_THEANO  the reference learner's graph as its Theano differentiates it.  accel_rl runs on
- *                       theano.gpuarray, i.e. Theano >= 0.9; since 0.8 theano/scalar/basic.py has
+ *                       theano.gpuarray (runners/accel_rl_base.py:62-64; algos/dqn/cat_dqn.py:85-86 names
+ *                       "Theano 0.9" / "1.0"), i.e. Theano >= 0.9; since 0.8 theano/scalar/basic.py has
  *                           Minimum.L_op:  e = eq(min, x);  gx = e gz;  gy = (1 - e) gz
  *                           ("This form handle the case when both value are the same. In that case, gx will be
  *                            gz, gy will be 0."; theano/tensor/tests/test_basic.py::test_maximum_minimum_grad:

@@ -577,7 +577,8 @@ def ppo_surrogate(ratio, adv, clip, tie_rule="theano"):
     PARITY UNPINNED for the gradient: it is produced by Theano's symbolic differentiation, and Theano (unpinned
     in the reference's environment.yml, absent from /root/reference and from this image) cannot be run here.
     Restated from its published scalar-op rules, theano/scalar/basic.py.  The reference imports theano.gpuarray
-    (accel_rl/runners/accel_rl_base.py:62-64), i.e. it runs on Theano >= 0.9, where
+    (accel_rl/runners/accel_rl_base.py:62-64) and names "Theano 0.9" / "Theano 1.0" in its comments
+    (accel_rl/algos/dqn/cat_dqn.py:85-86), i.e. it runs on Theano >= 0.9, where
         Minimum.L_op:  e = eq(minimum(x, y), x);  gx = e gz;  gy = (1 - e) gz
                        ("This form handle the case when both value are the same. In that case, gx will be gz, gy
                         will be 0."; theano/tensor/tests/test_basic.py::test_maximum_minimum_grad: at x == y the
