@@ -99,6 +99,7 @@ _SIGNATURES = {
     "arl_env_reset": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                              _vp, _i32, _vp]),
     "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "arl_copy_bytes": (_i32, [_vp, _vp, _i64, _vp]),
     "arl_gather_scale_obs": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "arl_gather_scale_obs_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
     "arl_bias_relu": (_i32, [_vp, _vp, _i64, _i32, _vp]),
@@ -222,6 +223,28 @@ def ptr(t):
     if not t.is_contiguous():
         raise RuntimeError("tensor must be contiguous")
     return t.data_ptr()
+
+
+def staged_ptr(t):
+    """Pointer of a device tensor OR of a pinned host tensor (the device addresses pinned memory directly)."""
+    if not (t.is_cuda or t.is_pinned()):
+        raise RuntimeError("staging copies take device tensors or PINNED host tensors; got pageable host memory")
+    if not t.is_contiguous():
+        raise RuntimeError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+STAGE_WITH_KERNELS = os.environ.get("ARL_STAGE_KERNELS", "1") != "0"      # (A/B switch: 0 = framework copies = memcpy nodes)
+
+
+def copy_bytes(dst, src, stream=None):
+    """dst <- src as a kernel (a kernel node when captured); either side may be a pinned host tensor."""
+    if not STAGE_WITH_KERNELS:
+        dst.view(-1).copy_(src.view(-1), non_blocking=True)
+        return
+    n = src.numel() * src.element_size()
+    assert n == dst.numel() * dst.element_size(), "size mismatch"
+    _check(load().arl_copy_bytes(staged_ptr(dst), staged_ptr(src), n, stream_ptr(stream)), "arl_copy_bytes")
 
 
 def stream_ptr(stream=None):

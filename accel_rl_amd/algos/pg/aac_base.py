@@ -146,7 +146,7 @@ class AdvActorCriticBase(RLAlgorithm):
         return opt_data, {k: v.clone() for k, v in infos.items()}
 
     def _device_optimize(self, itr, samples_data):
-        self._lr_mult.copy_(self._lr_mult_host, non_blocking=True)
+        _lib.copy_bytes(self._lr_mult, self._lr_mult_host)
         opt_data = self.process_samples(itr, samples_data)
         opt_input_values = self.prep_opt_inputs(itr, samples_data, opt_data)
         if hasattr(self.optimizer, "device_updates"):

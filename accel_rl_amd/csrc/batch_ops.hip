@@ -159,6 +159,45 @@ extern "C" int arl_sample_categorical(const float* prob, const double* uniforms,
     return arl::check_launch("sample_kernel");
 }
 
+// Small staging copies as KERNEL nodes: the per-batch host hand-offs (action uniforms, minibatch permutations, the
+// learning-rate multiplier in; completed-episode records and gradient norms out) live in pinned host memory, which the
+// device addresses directly.  As memcpy nodes inside the hipGraphs each of them was a 4.4 us blit launch with 6-14 us of
+// idle in front of it (the queue switches engines; profiles/r04/bench_steady_state_summary.txt: every idle gap of a step
+// sits in front of a copy node).
+__global__ __launch_bounds__(256) void copy_words_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n16,
+                                                         const unsigned char* __restrict__ src_tail,
+                                                         unsigned char* __restrict__ dst_tail, int tail) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = i0; i < n16; i += stride) dst[i] = src[i];
+    if (i0 < tail) dst_tail[i0] = src_tail[i0];
+}
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                         int64_t n) {
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = i0; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int arl_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream) {
+    ARL_REQUIRE(nbytes >= 0 && (nbytes == 0 || (dst && src)), ARL_E_ARG, "null pointer / negative size");
+    if (nbytes == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = !((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15);
+    if (vec) {
+        const int64_t n16 = nbytes >> 4;
+        const int tail = (int)(nbytes & 15);
+        int64_t grid = (n16 + 255) / 256;
+        grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+        hipLaunchKernelGGL(copy_words_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, n16,
+                           (const unsigned char*)src + (n16 << 4), (unsigned char*)dst + (n16 << 4), tail);
+    } else {
+        int64_t grid = (nbytes + 255) / 256;
+        grid = grid > 1024 ? 1024 : grid;
+        hipLaunchKernelGGL(copy_bytes_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const unsigned char*)src,
+                           (unsigned char*)dst, nbytes);
+    }
+    return arl::check_launch("copy_kernel");
+}
+
 extern "C" int arl_gather_scale_obs(const uint8_t* obs, const int32_t* idx_or_null, int64_t batch,
                                     int64_t row_bytes, float scale, float* out, void* stream) {
     ARL_REQUIRE(obs && out, ARL_E_ARG, "null pointer");

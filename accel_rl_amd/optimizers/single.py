@@ -3,6 +3,8 @@ single/ppo_optimizer.py:11-75)."""
 import numpy as np
 import torch
 
+from accel_rl_amd import _lib
+
 from accel_rl_amd.optimizers.base import BaseOptimizer, iterate_mb_idxs
 
 
@@ -93,7 +95,7 @@ class PpoOptimizer(BaseOptimizer):
         data = dict(zip(self._input_names, inputs))      # "_f_load": already on the device
         if not self._n_minibatches:
             return [], []
-        self._idx_dev.copy_(self._idx_host, non_blocking=True)
+        _lib.copy_bytes(self._idx_dev, self._idx_host)
         if self._overlap_allreduce:
             return self._overlapped_minibatches(data)
         losses = []

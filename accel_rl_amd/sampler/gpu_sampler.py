@@ -310,7 +310,7 @@ class GpuVecSampler(BaseMbSampler):
         """All device work of one batch, on the current stream (graph-capturable)."""
         n, t = self._total_n_envs, self.horizon
         buf, ro, env = self.samples_buf, self._rollout, self.env
-        self._uniforms.view(-1).copy_(self._uniforms_host, non_blocking=True)
+        _lib.copy_bytes(self._uniforms, self._uniforms_host)   # (a kernel node reading the pinned buffer: no memcpy node)
         _lib.rollout_begin(self._game, self._state, ro)        # observations[:, 0] = step_obs (worker.py:30-32), done_count = 0
         for s in range(t):
             if hasattr(self.policy, "set_step"):
@@ -336,7 +336,7 @@ class GpuVecSampler(BaseMbSampler):
             buf.extra_observations.copy_(self.step_obs)        # sampler.py:147-151
         if not self.mid_batch_reset:                           # worker.py:108-113
             _lib.env_reset(self._game, self._state, ro, self._st.frozen, env.max_start_noops)
-        self._host_block.copy_(self._results_block, non_blocking=True)
+        _lib.copy_bytes(self._host_block, self._results_block)
 
     def _kernel_max_path_length(self):
         """The kernels end an episode when Length > limit (worker.py:42)."""

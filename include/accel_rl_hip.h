@@ -258,6 +258,14 @@ int arl_preprocess_frames(const uint8_t* raw_a_or_null, const uint8_t* raw_b,
  * Learner side: minibatch gather and the flat-bucket optimiser step
  * ------------------------------------------------------------------------- */
 
+/* dst[0 .. nbytes) = src[0 .. nbytes) as a KERNEL (capturable as a kernel node).  The one exception to "device
+ * pointers only": either side may be PINNED host memory (hipHostMalloc / a pinned torch tensor), which the device
+ * addresses directly -- this is how the per-batch host hand-offs (action uniforms, minibatch permutations, lr
+ * multiplier in; episode records, gradient norms out: the reference's shared-memory step buffers and queues,
+ * sampler/act_server/buffers.py:24-30, optimizers/util.py:8-18) enter and leave the hipGraphs without memcpy nodes.
+ * A write to host memory is visible to the host once the stream has passed an event / synchronisation after it.   */
+int arl_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream);
+
 /* out[b] = float(obs[idx[b]]) * scale  (u8 -> f32 gather; the reference gathers
  * on device with `s[idxs]`, accel_rl/optimizers/util.py:86-89, and scales by
  * 1/255 in ScalarFixedScaleLayer, accel_rl/policies/layers.py:22-41).
