@@ -333,7 +333,7 @@ class GpuVecSampler(BaseMbSampler):
                     self._st.frozen * (1 - self._prev_frozen)
                 self.policy.reset_rows(hit)
         if self.need_extra_obs:
-            buf.extra_observations.copy_(self.step_obs)        # sampler.py:147-151
+            _lib.copy_bytes(buf.extra_observations, self.step_obs)     # sampler.py:147-151 (a kernel node, 16-byte copies)
         if not self.mid_batch_reset:                           # worker.py:108-113
             _lib.env_reset(self._game, self._state, ro, self._st.frozen, env.max_start_noops)
         _lib.copy_bytes(self._host_block, self._results_block)
