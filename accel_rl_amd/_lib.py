@@ -100,6 +100,7 @@ _SIGNATURES = {
                              _vp, _i32, _vp]),
     "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "arl_copy_bytes": (_i32, [_vp, _vp, _i64, _vp]),
+    "arl_ring_append": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "arl_gather_scale_obs": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "arl_gather_scale_obs_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _f32, _vp, _vp]),
     "arl_bias_relu": (_i32, [_vp, _vp, _i64, _i32, _vp]),
@@ -245,6 +246,15 @@ def copy_bytes(dst, src, stream=None):
     n = src.numel() * src.element_size()
     assert n == dst.numel() * dst.element_size(), "size mismatch"
     _check(load().arl_copy_bytes(staged_ptr(dst), staged_ptr(src), n, stream_ptr(stream)), "arl_copy_bytes")
+
+
+def ring_append(src, ring, counter, stream=None):
+    """ring[counter % len(ring)] = src; counter += 1 (device-side; see arl_ring_append)."""
+    _want(src, torch.float32, "src")
+    _want(ring, torch.float32, "ring")
+    _want(counter, torch.int32, "counter")
+    _check(load().arl_ring_append(ptr(src), src.numel(), ptr(ring), ring.shape[0], ptr(counter), stream_ptr(stream)),
+           "arl_ring_append")
 
 
 def stream_ptr(stream=None):

@@ -80,6 +80,10 @@ class AdvActorCriticBase(RLAlgorithm):
         self._graph_samples = None
         self._warm_calls = 0
         self._done_event = None
+        # diagnostics of a replayed update: appended INSIDE the graph to a device ring (arl_ring_append); the caller
+        # gets slot (replay number % INFO_RING) -- valid for INFO_RING further iterations, no launch between two replays
+        self._info_ring = None
+        self._info_replays = 0
 
     def set_n_itr(self, n_itr):
         self.n_itr = n_itr
@@ -113,7 +117,9 @@ class AdvActorCriticBase(RLAlgorithm):
         if self._graph is None:
             self._warm_calls += 1
             if self._warm_calls <= 2:
-                return self._device_optimize(itr, samples_data)
+                out = self._device_optimize(itr, samples_data)
+                self._ensure_info_ring(out[1])              # (allocated here: not from the capture's private pool)
+                return out
             torch.cuda.synchronize(self.policy.device)
             graph, failure = torch.cuda.CUDAGraph(), None
             # a capture that fails part-way leaves the optimiser's host-side call counters advanced by a partial call
@@ -123,6 +129,7 @@ class AdvActorCriticBase(RLAlgorithm):
             try:
                 with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
                     self._graph_out = self._device_optimize(itr, samples_data)
+                    self._append_infos(self._graph_out[1])
             except Exception as e:          # single GPU: a bug, raise.  N > 1: every rank must take the same road
                 if not sync:
                     raise
@@ -140,10 +147,26 @@ class AdvActorCriticBase(RLAlgorithm):
             self._graph, self._graph_samples = graph, samples_data
         assert samples_data is self._graph_samples, "the sampler must hand over the same buffer"
         self._graph.replay()
-        # the graph owns its outputs and every replay overwrites them: callers that keep the diagnostics across
-        # iterations (AccelRL.store_diagnostics) get their own copy
+        # the graph owns its outputs and every replay overwrites them: callers keep the diagnostics across iterations
+        # (AccelRL.store_diagnostics) -- the graph itself left this replay's copy in a ring slot
         opt_data, infos = self._graph_out
-        return opt_data, {k: v.clone() for k, v in infos.items()}
+        slot = self._info_replays % self.INFO_RING
+        self._info_replays += 1
+        return opt_data, {k: self._info_ring[k][slot] for k in infos}
+
+    INFO_RING = 4096            # iterations a returned diagnostics tensor stays valid (runners log far more often)
+
+    def _ensure_info_ring(self, infos):
+        if self._info_ring is None:
+            self._info_ring = {k: torch.zeros((self.INFO_RING,) + tuple(v.shape), dtype=torch.float32, device=v.device)
+                               for k, v in infos.items()}
+            self._info_counts = {k: torch.zeros(1, dtype=torch.int32, device=v.device) for k, v in infos.items()}
+            self._info_replays = 0
+
+    def _append_infos(self, infos):
+        """(inside the capture) every diagnostics tensor of the call -> the next slot of its ring."""
+        for k, v in infos.items():
+            _lib.ring_append(v.reshape(-1), self._info_ring[k], self._info_counts[k])
 
     def _device_optimize(self, itr, samples_data):
         _lib.copy_bytes(self._lr_mult, self._lr_mult_host)

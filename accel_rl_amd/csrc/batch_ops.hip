@@ -177,6 +177,23 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(const unsigned char* __
     for (int64_t i = i0; i < n; i += stride) dst[i] = src[i];
 }
 
+// Append `n` floats to slot counter % n_slots of a ring and advance the device-side counter: an update's diagnostics
+// leave a captured hipGraph without an eager copy between two graph replays (the host knows the slot: it counts replays).
+__global__ __launch_bounds__(256) void ring_append_kernel(const float* __restrict__ src, int n, float* __restrict__ ring,
+                                                          int n_slots, int32_t* counter) {
+    const int slot = counter[0] % n_slots;
+    for (int i = threadIdx.x; i < n; i += 256) ring[(int64_t)slot * n + i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) counter[0] = counter[0] + 1;
+}
+
+extern "C" int arl_ring_append(const float* src, int32_t n, float* ring, int32_t n_slots, int32_t* counter, void* stream) {
+    ARL_REQUIRE(src && ring && counter, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(n > 0 && n_slots > 0, ARL_E_RANGE, "non-positive size");
+    hipLaunchKernelGGL(ring_append_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, src, (int)n, ring, (int)n_slots, counter);
+    return arl::check_launch("ring_append_kernel");
+}
+
 extern "C" int arl_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream) {
     ARL_REQUIRE(nbytes >= 0 && (nbytes == 0 || (dst && src)), ARL_E_ARG, "null pointer / negative size");
     if (nbytes == 0) return 0;

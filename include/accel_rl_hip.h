@@ -265,6 +265,10 @@ int arl_preprocess_frames(const uint8_t* raw_a_or_null, const uint8_t* raw_b,
  * sampler/act_server/buffers.py:24-30, optimizers/util.py:8-18) enter and leave the hipGraphs without memcpy nodes.
  * A write to host memory is visible to the host once the stream has passed an event / synchronisation after it.   */
 int arl_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream);
+/* ring[(counter[0] % n_slots)][0 .. n) = src[0 .. n); counter[0] += 1 -- the per-iteration diagnostics of an update
+ * (the opt_infos of accel_rl/algos/pg/aac_base.py:104-106, e.g. GradNorm) leave a captured hipGraph into a slot the host
+ * can name without a launch of its own (it counts the replays).  ring f32[n_slots][n], counter i32[1] on the device. */
+int arl_ring_append(const float* src, int32_t n, float* ring, int32_t n_slots, int32_t* counter, void* stream);
 
 /* out[b] = float(obs[idx[b]]) * scale  (u8 -> f32 gather; the reference gathers
  * on device with `s[idxs]`, accel_rl/optimizers/util.py:86-89, and scales by
