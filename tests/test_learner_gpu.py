@@ -244,8 +244,10 @@ def test_graph_learner_is_bit_identical_to_eager(case):
     horizon = 5
     twins = [make(kind, n_env, horizon, g, **kw) for g in (False, True)]
     np.testing.assert_array_equal(twins[0][0].get_param_values(), twins[1][0].get_param_values())
+    twins[1][1].INFO_RING = 2           # the replayed learner's diagnostics ring wraps twice inside this test
     rs = np.random.RandomState(1)
-    for itr in range(5):
+    held = []                           # (a diagnostics tensor handed out stays valid for INFO_RING - 1 more iterations)
+    for itr in range(7):
         fill(twins[0][2], twins[0][0], rs, n_env, horizon)
         for k in ("observations", "extra_observations", "rewards", "dones", "actions"):
             twins[1][2][k].copy_(twins[0][2][k])
@@ -261,6 +263,9 @@ def test_graph_learner_is_bit_identical_to_eager(case):
             outs.append((policy.flat_params.clone(), algo.optimizer._slot0.clone(), infos["GradNorm"].clone()))
         for a, b in zip(*outs):
             assert torch.equal(a, b), (case, itr)
+        if held:                        # last iteration's tensor of the graph twin still holds last iteration's values
+            assert torch.equal(held[-1][0], held[-1][1]), (case, itr)
+        held.append((infos["GradNorm"], outs[1][2]))
     assert twins[1][1]._graph is not None and twins[0][1]._graph is None
 
 
