@@ -665,3 +665,54 @@ def test_ppo_tie_rule_on_the_boundaries_at_the_config2_shape(L, tie):
         for got, want, name in ((dh, gh, "dh"), (dw, gw, "dw"), (db, gb, "db")):
             scale = max(want.abs().max().item(), 1e-6)
             assert torch.allclose(got, want, rtol=1e-3, atol=1e-5 * scale), (clip, name, (got - want).abs().max().item())
+
+
+def test_staging_copy_and_ring_append(L):
+    """arl_copy_bytes (the staging copy that is a kernel node: device <-> PINNED host memory, any size / alignment) and
+    arl_ring_append (a captured graph's diagnostics into the slot the host can name by counting replays)."""
+    rs = np.random.RandomState(3)
+    for n in (1, 15, 16, 17, 4096, 10240 + 3, 1 << 20):
+        src_h = torch.from_numpy(rs.randint(0, 256, size=n + 1, dtype=np.uint8)).pin_memory()
+        dev = torch.zeros(n + 1, dtype=torch.uint8, device=DEV)
+        back = torch.zeros(n + 1, dtype=torch.uint8).pin_memory()
+        for off in (0, 1):                                   # 16-byte aligned and not
+            dev.zero_()
+            back.zero_()
+            L.copy_bytes(dev[off:off + n], src_h[off:off + n])            # pinned host -> device
+            L.copy_bytes(back[off:off + n], dev[off:off + n])             # device -> pinned host
+            torch.cuda.synchronize()
+            assert torch.equal(dev[off:off + n].cpu(), src_h[off:off + n]) and torch.equal(back[off:off + n], src_h[off:off + n])
+            assert int(dev.sum().item()) == int(src_h[off:off + n].sum().item())   # nothing written next to the range
+    with pytest.raises(RuntimeError, match="PINNED"):
+        L.copy_bytes(dev, torch.zeros(n + 1, dtype=torch.uint8))
+    # the same copy as a node of a hipGraph: every replay reads the pinned buffer's CURRENT contents
+    host = torch.zeros(64, dtype=torch.float32).pin_memory()
+    d = torch.zeros(64, device=DEV)
+    L.copy_bytes(d, host)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        L.copy_bytes(d, host)
+    for k in range(3):
+        host.fill_(float(k + 1))
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.all(d == k + 1)
+    # ring: slot (counter % slots), counter advances on the device
+    ring = torch.zeros((3, 5), device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    src = torch.zeros(5, device=DEV)
+    g2 = torch.cuda.CUDAGraph()
+    L.ring_append(src, ring, count)
+    count.zero_()
+    ring.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g2):
+        L.ring_append(src, ring, count)
+    for k in range(7):
+        src.fill_(float(10 + k))
+        g2.replay()
+        torch.cuda.synchronize()
+        assert int(count.item()) == k + 1 and torch.all(ring[k % 3] == 10 + k)
+        if k >= 1:
+            assert torch.all(ring[(k - 1) % 3] == 10 + k - 1)         # the previous slot is untouched
