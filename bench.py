@@ -69,8 +69,9 @@ def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind=
         # scripts/launching/affinities.py): here the process's CPUs dealt out evenly to the node's ranks, so that eight
         # ranks replaying their graphs do not share cores
         cpus = sorted(os.sched_getaffinity(0))
-        per = max(1, len(cpus) // world)
-        affinities["gpu_cpus"] = tuple(cpus[(rank % world) * per:(rank % world + 1) * per]) or tuple(cpus)
+        per = len(cpus) // world
+        if per >= 4:        # (fewer: a rank's main thread would share its core with RCCL's polling proxy thread -- leave it)
+            affinities["gpu_cpus"] = tuple(cpus[(rank % world) * per:(rank % world + 1) * per])
     if multi:
         algo.optimizer._force_collective = True
         if os.environ.get("ARL_SYNC_GRAPH") == "0":     # A/B switch: eager minibatches instead of one captured hipGraph
