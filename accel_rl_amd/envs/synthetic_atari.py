@@ -50,12 +50,24 @@ def draw_noops(rng, max_start_noops, size=None):
     return rng.randint(0, max_start_noops + 1, size=size)
 
 
+def padded_action_set(action_set, pad_actions_to):
+    """One action space for a suite of games that share a policy (BASELINE config 4: eight games, one synchronous
+    clique, ONE flat gradient bucket -- every runner must build the same head): the game's minimal action set followed
+    by NOOP (ALE code 0) up to `pad_actions_to` entries.  None = the minimal set, as the reference (atari_env.py:42-43)."""
+    action_set = list(action_set)
+    if pad_actions_to is None:
+        return action_set
+    if pad_actions_to < len(action_set):
+        raise ValueError("pad_actions_to=%d is smaller than the game's %d actions" % (pad_actions_to, len(action_set)))
+    return action_set + [0] * (int(pad_actions_to) - len(action_set))
+
+
 class SynthAtariEnv(object):
     batched_device_env = True    # protocol marker checked by GpuVecSampler
 
     def __init__(self, game="pong", frame_skip=4, num_img_obs=4, clip_reward=True,
                  episodic_lives=True, max_start_noops=30, repeat_action_probability=0.,
-                 rng=None):
+                 rng=None, pad_actions_to=None):
         if game not in GAMES:
             raise IOError("You asked for game {} but it is not one of {}".format(
                 game, sorted(GAMES)))
@@ -64,6 +76,7 @@ class SynthAtariEnv(object):
         rng = np.random if rng is None else rng
         self.game = game
         self.game_id, self.action_set, self.start_lives = GAMES[game]
+        self.action_set = padded_action_set(self.action_set, pad_actions_to)
         self.frame_skip = int(frame_skip)
         self.num_img_obs = int(num_img_obs)
         self.clip_reward = bool(clip_reward)

@@ -4,8 +4,9 @@ sampler shard + learner, gradients are all-reduced inside the optimizer.
 Reference: accel_rl/runners/multigpu_rl_base.py:10-153,216-231 and the MRO
 composition accel_rl/runners/multigpu_rl.py:7-15 (AccelRLSync / SyncWorker).
 There the master forks n-1 worker runners and bootstraps an NCCL clique through
-a multiprocessing Manager dict; here ranks are separate processes started by
-`python -m torch.distributed.run` (one per GPU), rendez-vous is the
+a multiprocessing Manager dict; here ranks are separate processes either forked by rank 0's
+`startup()` from the list of affinities (as the reference does) or started by
+`python -m torch.distributed.run` (one per GPU); rendez-vous is the
 torch.distributed TCP store, the initial parameters are broadcast from rank 0
 (replaces the pickled vector in the manager dict, multigpu_rl_base.py:119,
 142-143) and completed-trajectory infos are gathered to rank 0 at log time
@@ -23,23 +24,150 @@ from accel_rl_amd.util import logger
 
 
 class AccelRLSync(AccelRL):
+    """`affinities` is the list of per-GPU dicts of the reference (multigpu_rl_base.py:20-45), one runner per entry.
+    Two ways to get the n processes, one per GPU:
+
+    * started as a plain `python script.py` (no WORLD_SIZE in the environment): `train()` / `startup()` forks the
+      n - 1 worker runners itself, as the reference's `launch_workers` does -- same point in the program (nothing of
+      the sampler, policy or algorithm is initialised yet, so the children inherit what the script built), same
+      seeds (`seed + 100 * rank`), rank 0 stays in the calling process and joins the workers at shutdown;
+    * started under `python -m torch.distributed.run` (RANK / WORLD_SIZE set): every process runs the script and is
+      its own rank; a list of affinities must then have exactly WORLD_SIZE entries (ValueError otherwise).
+
+    A single dict (or None) means one runner."""
 
     def __init__(self, affinities=None, seed=None, backend=None, **kwargs):
         self._backend = backend
-        self.rank = int(os.environ.get("RANK", 0))
-        self.n_runners = int(os.environ.get("WORLD_SIZE", 1))
-        if isinstance(affinities, (list, tuple)):                  # list of per-GPU dicts
-            affinities = affinities[self.rank]
+        self._worker_affinities = None          # set: this process still has to fork ranks 1 .. n-1 (launch_workers)
+        self._worker_procs = []
+        as_list = list(affinities) if isinstance(affinities, (list, tuple)) else None
+        if "WORLD_SIZE" in os.environ:                                # launched: one process per rank already exists
+            self.rank = int(os.environ.get("RANK", 0))
+            self.n_runners = int(os.environ["WORLD_SIZE"])
+            if as_list is not None:
+                if len(as_list) != self.n_runners:
+                    raise ValueError("AccelRLSync got %d affinities but WORLD_SIZE=%d: one entry per launched rank "
+                                     "(multigpu_rl_base.py:21)" % (len(as_list), self.n_runners))
+                affinities = as_list[self.rank]
+            if seed is not None:
+                seed = seed + 100 * self.rank                          # multigpu_rl_base.py:28
+        else:
+            self.rank = 0
+            self.n_runners = len(as_list) if as_list is not None else 1
+            if as_list is not None:
+                if not as_list:
+                    raise ValueError("AccelRLSync: empty list of affinities")
+                affinities = as_list[0]
+                if self.n_runners > 1:
+                    self._worker_affinities = as_list
         if affinities is None:
             affinities = dict(gpu=int(os.environ.get("LOCAL_RANK", self.rank)))
-        if seed is not None:
-            seed = seed + 100 * self.rank                          # multigpu_rl_base.py:28
         super().__init__(affinities=affinities, seed=seed, **kwargs)
+
+    # ------------------------------------------------------------------ ranks
+    def launch_workers(self):
+        """reference: MultiGpuRLBase.launch_workers (multigpu_rl_base.py:20-45): n_runners = len(affinities); workers
+        1 .. n-1 get seed + 100 * rank and affinities[rank] and are forked here, before anything touches the GPU.  The
+        Manager dict / barrier / queue of the reference are torch.distributed's TCP store on 127.0.0.1."""
+        import multiprocessing as mp
+        import socket
+        import threading
+        from accel_rl_amd.util.misc import make_seed
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            raise RuntimeError("AccelRLSync cannot fork its %d worker runners: this process has already initialised the "
+                               "GPU runtime (a forked child cannot use it).  Construct and train() the runner before any "
+                               "device work, or start the script under `python -m torch.distributed.run "
+                               "--nproc-per-node %d`." % (self.n_runners - 1, self.n_runners))
+        table, self._worker_affinities = self._worker_affinities, None
+        self._launched_here = True
+        if self.seed is None:
+            self.seed = make_seed()                                    # :22-23 (workers derive theirs from it)
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(self.n_runners),
+                          RANK="0", LOCAL_RANK="0")
+        ctx = mp.get_context("fork")
+        base_seed = self.seed
+        for rank in range(1, self.n_runners):
+            p = ctx.Process(target=self._worker_main, args=(rank, base_seed + 100 * rank, table[rank]), daemon=True)
+            p.start()
+            self._worker_procs.append(p)
+
+        def monitor(procs=tuple(self._worker_procs)):
+            # a worker that dies leaves rank 0 inside a collective that never completes: say so and end the job
+            while True:
+                time.sleep(1.0)
+                if getattr(self, "_workers_joined", False):
+                    return
+                dead = [(i + 1, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+                if dead:
+                    import sys
+                    sys.stderr.write("AccelRLSync: worker runner(s) %s exited abnormally; ending the job\n" % dead)
+                    sys.stderr.flush()
+                    for p in procs:
+                        if p.is_alive():
+                            p.terminate()
+                    os._exit(70)
+        threading.Thread(target=monitor, daemon=True).start()
+
+    def _worker_main(self, rank, seed, affinities):
+        """A forked worker runner (the reference's SyncWorker.train, multigpu_rl_base.py:66-103): same loop, own rank."""
+        code = 0
+        try:
+            os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank))
+            self.rank, self.seed, self.affinities = rank, seed, affinities
+            self._worker_procs, self._launched_here = [], True
+            if self.affinities is None:
+                self.affinities = dict(gpu=rank)
+            self.train()
+        except BaseException:          # noqa: BLE001 -- the exit code is the message to rank 0's monitor
+            import traceback
+            traceback.print_exc()
+            code = 1
+        finally:
+            import sys
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(code)             # no interpreter finalisation in a forked child (the parent's atexit hooks are not ours)
+
+    def shutdown(self):
+        """reference: SyncBase.shutdown (multigpu_rl_base.py:124-127): rank 0 joins its workers; a worker only closes its
+        sampler (MultiGpuWorkerBase.shutdown, :92-93).  A process group this runner created for ranks it forked itself is
+        also torn down here (under a launcher that belongs to the script)."""
+        if self.rank == 0:
+            super().shutdown()
+        else:
+            self.sampler.shutdown()
+        if self._launched_here and self.n_runners > 1 and dist.is_initialized():
+            import threading
+            dist.barrier()
+            t = threading.Timer(20.0, lambda: os._exit(0))         # a teardown that blocks must not hang a finished run
+            t.daemon = True
+            t.start()
+            dist.destroy_process_group()
+            t.cancel()
+        for p in self._worker_procs:
+            p.join(60)
+        self._workers_joined = True
+
+    _launched_here = False      # True in the process that forked its workers and in those workers
 
     def startup(self):
         """reference: multigpu_rl_base.py:12-18 (master) / :85-91 (worker)"""
+        if self._worker_affinities is not None:
+            self.launch_workers()
         if self.n_runners > 1 and not dist.is_initialized():
-            dist.init_process_group(self._backend or ("nccl" if torch.cuda.is_available() else "gloo"))
+            backend = self._backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            kw = dict()
+            if backend == "nccl":
+                # accel_rl_base.py:62-64: the runner's GPU is affinities["gpu"]; RCCL binds its communicator to it
+                gpu = self.affinities.get("gpu") if hasattr(self.affinities, "get") else None
+                dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", self.rank)) if gpu is None else int(gpu))
+                torch.cuda.set_device(dev)
+                kw["device_id"] = dev
+            dist.init_process_group(backend, rank=self.rank, world_size=self.n_runners, **kw)
         if self.rank != 0:
             logger.set_quiet(True)
         n_itr = super().startup(master=True)
@@ -50,6 +178,16 @@ class AccelRLSync(AccelRL):
     def init_comm(self):
         """reference: SyncBase.init_comm / SyncWorkerBase.init_comm (:111-122,136-149)"""
         if self.n_runners > 1:
+            # one flat gradient bucket per all-reduce: every runner of the clique must have built the same network
+            # (the reference forks ONE policy object, multigpu_rl_base.py:24-33; different games per rank need one
+            # action space -- SynthAtariEnv(pad_actions_to=...))
+            n = torch.tensor([self.policy.flat_params.numel()], dtype=torch.int64, device=self.policy.flat_params.device)
+            lo, hi = n.clone(), n.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if int(lo) != int(hi):
+                raise ValueError("AccelRLSync: the runners' policies differ in size (%d ... %d parameters, %d here): a "
+                                 "synchronous clique all-reduces ONE flat bucket" % (int(lo), int(hi), int(n)))
             dist.broadcast(self.policy.flat_params, src=0)          # initial_param_values
             self._initial_param_vector = self.policy.flat_params.clone()
         self.algo.optimizer.init_comm(None, self.rank, self.n_runners)

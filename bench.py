@@ -40,7 +40,7 @@ N_ENVS, HORIZON, GAME, CNN_SPEC, MINIBATCH = 256, 5, "breakout", 1, 512
 GAMES_8 = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_rider", "enduro", "ms_pacman"]
 
 
-def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind="ppo"):
+def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind="ppo", pad_actions_to=None):
     from accel_rl_amd.algos.pg.a2c import A2C, mA2C
     from accel_rl_amd.algos.pg.ppo import PPO, mPPO
     from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
@@ -51,7 +51,8 @@ def build_workload(device, seed, rank, world, game, use_graph, quiet=True, kind=
     from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
     from accel_rl_amd.util import logger
     logger.set_quiet(quiet)
-    sampler = GpuVecSampler(EnvCls=SynthAtariEnv, env_args=dict(game=game), horizon=HORIZON,
+    env_args = dict(game=game) if pad_actions_to is None else dict(game=game, pad_actions_to=pad_actions_to)
+    sampler = GpuVecSampler(EnvCls=SynthAtariEnv, env_args=env_args, horizon=HORIZON,
                             n_parallel=16, envs_per=N_ENVS // 32, max_path_length=int(27e3),
                             mid_batch_reset=True, max_decorrelation_steps=2000, device=device,
                             use_graph=use_graph)
@@ -683,7 +684,8 @@ def catdqn_main(args):
     print(json.dumps(line), flush=True)
 
 
-def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, timed, reps, itr, t_step, t_roll, t_learn):
+def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, timed, reps, itr, t_step, t_roll, t_learn,
+                          tick=lambda *a: None):
     """What the N > 1 line says about itself (every rank computes, rank 0 prints):
       per_rank_ms                         min / max over the ranks of each rank's own step, rollout and learner time
                                           (a straggler shows as max >> min; the headline takes the max);
@@ -730,10 +732,12 @@ def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, t
         opt._elide_collective = True
         algo._graph, algo._graph_out, algo._warm_calls = None, None, 0
         for i in range(3):
+            tick("diagnostics: learner without collectives (re-capture)")
             algo.optimize_policy(itr + i, samples)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(reps):
+            tick("diagnostics: learner without collectives")
             algo.optimize_policy(itr + 3 + i, samples)
         torch.cuda.synchronize()
         t_quiet = (time.perf_counter() - t0) / reps
@@ -753,17 +757,67 @@ def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, t
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, as the
-    reference's runner forks its n-1 workers from one process (accel_rl/runners/multigpu_rl_base.py:20-45).
-    Re-executes this command line under torch.distributed.run (rendezvous on 127.0.0.1, a free port)."""
+    reference's runner forks its n-1 workers from one process (accel_rl/runners/multigpu_rl_base.py:20-45): this command
+    line again under torch.distributed.run (rendezvous on 127.0.0.1, a free port) -- as a SUPERVISED child.  The
+    learner of N > 1 is one hipGraph with RCCL's all-reduces captured inside; a node on which that capture
+    throws is handled inside the ranks (`ranks_agree`), one on which it HANGS ends in the ranks' watchdog (exit 3) and no
+    JSON line.  In that case -- any non-zero exit, or no line -- the job is run ONCE more with the collectives eager
+    (`ARL_SYNC_GRAPH=0`: the same sums in the same order, sync_ppo_optimizer.py:27-34,61-71) and the line says so in
+    `graph_fallback`.  Returns the exit code."""
+    import signal
     import socket
-    sock = socket.socket()
-    sock.bind(("127.0.0.1", 0))
-    port = sock.getsockname()[1]
-    sock.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    sys.stdout.flush()
-    os.execv(sys.executable, cmd)
+    import subprocess
+
+    def attempt(extra_env):
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.update(extra_env)
+        sys.stdout.flush()
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, start_new_session=True)
+        limit = float(os.environ.get("ARL_BENCH_ATTEMPT_S", "1500"))
+        import threading
+
+        def reaper():                       # belt and braces behind the ranks' own watchdogs
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except OSError:
+                pass
+        timer = threading.Timer(limit, reaper)
+        timer.daemon = True
+        timer.start()
+        lines = []
+        for ln in child.stdout:
+            if ln.startswith('{"metric"'):
+                lines.append(ln.rstrip("\n"))          # held back: the supervisor prints ONE line at the end
+            else:
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+        rc = child.wait()
+        timer.cancel()
+        return rc, lines
+
+    rc, lines = attempt({})
+    if rc == 0 and len(lines) == 1:
+        print(lines[0], flush=True)
+        return 0
+    reason = ("exit code %d" % rc) if rc else ("%d JSON lines" % len(lines))
+    if os.environ.get("ARL_SYNC_GRAPH") == "0" or os.environ.get("ARL_BENCH_NO_RETRY") == "1":
+        sys.stderr.write("bench.py: the %d-rank run failed (%s)\n" % (n, reason))
+        return rc or 1
+    sys.stderr.write("bench.py: the %d-rank run failed (%s); retrying once with eager collectives (ARL_SYNC_GRAPH=0)\n" % (n, reason))
+    sys.stderr.flush()
+    rc, lines = attempt({"ARL_SYNC_GRAPH": "0", "ARL_BENCH_NO_EXPOSED": "1",
+                         "ARL_BENCH_GRAPH_FALLBACK": "eager after " + reason})
+    if rc == 0 and len(lines) == 1:
+        print(lines[0], flush=True)
+        return 0
+    sys.stderr.write("bench.py: the eager retry failed too (%s)\n" % (("exit code %d" % rc) if rc else "no JSON line"))
+    return rc or 1
 
 
 def main():
@@ -795,7 +849,7 @@ def main():
     if args.workload == "catdqn":
         return catdqn_main(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        return spawn_ranks(args.gpus)
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -815,6 +869,31 @@ def main():
         cpu_pool = start_cpu_pool()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    # A rank that stops making progress (a rendezvous that never completes, a captured collective waiting for a peer
+    # that is not there) would otherwise sit until the launcher's own timeout without a word: a watchdog thread names the
+    # phase it stalled in and ends the rank with exit code 3 -- which the supervising parent (spawn_ranks) answers with
+    # ONE retry on eager collectives.  Every phase that can legitimately take long ticks: start-up, each priming /
+    # warm-up / timed step, each repetition of the phase split and of the diagnostics.
+    progress = {"itr": 0, "phase": "start-up", "t": time.time(), "graph_collectives": None}
+
+    def tick(phase, i=None):
+        progress.update(phase=phase, t=time.time())
+        if i is not None:
+            progress["itr"] = i
+    if world > 1:
+        import threading
+
+        def watchdog(limit=float(os.environ.get("ARL_BENCH_STALL_S", "240"))):
+            while True:
+                time.sleep(min(5.0, limit / 4))
+                if time.time() - progress["t"] > limit:
+                    sys.stderr.write("bench.py rank %d: no progress for %.0f s in %s of step %d (graph_collectives=%s, backend=%s); "
+                                     "ARL_SYNC_GRAPH=0 runs the collectives eagerly\n" %
+                                     (rank, limit, progress["phase"], progress["itr"], progress["graph_collectives"],
+                                      os.environ.get("ARL_BENCH_BACKEND", "nccl")))
+                    sys.stderr.flush()
+                    os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
     # ARL_BENCH_ONE_GPU=1 + ARL_BENCH_BACKEND=gloo: development check of the N>1 control flow with every
     # rank on GPU 0 (RCCL refuses two ranks on one device); never a measurement.
     device = torch.device("cuda", 0 if os.environ.get("ARL_BENCH_ONE_GPU") == "1" else local)
@@ -830,15 +909,24 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    tick("build")
     import __graft_entry__
     __graft_entry__.build()
+    tick("start-up")
     if args.roofline_only:
         print(json.dumps({"roofline": roofline_gae(device, args.roofline_log2, 30)}), flush=True)
         return
 
     game = GAMES_8[rank % 8] if args.suite else GAME
     runner, sampler, algo, policy = build_workload(device, 0, rank, world, game, not args.no_graph,
-                                                   kind="a2c" if args.workload == "a2c1024" else "ppo")
+                                                   kind="a2c" if args.workload == "a2c1024" else "ppo",
+                                                   pad_actions_to=18 if args.suite else None)   # one head for the 8 games
+    progress["graph_collectives"] = getattr(algo.optimizer, "graph_collectives", None)
+    tick("priming")
+    # test hook (tests/test_bench_launch.py): a capture that hangs instead of throwing -- the last rank never reaches its
+    # collectives while the others wait in theirs.  Only while the collectives are to be captured: the eager retry runs.
+    inject_hang = (os.environ.get("ARL_BENCH_INJECT") == "capture_hang" and world > 1 and rank == world - 1
+                   and os.environ.get("ARL_SYNC_GRAPH") != "0")
 
     def barrier():
         torch.cuda.synchronize()
@@ -846,31 +934,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # A rank that stops making progress (a captured collective waiting for a peer that is not there) would otherwise sit
-    # until the launcher's own timeout without a word: a watchdog thread names the step it stalled in and ends the rank.
-    progress = {"itr": 0, "phase": "start-up", "t": time.time()}
-
-    def tick(phase, i):
-        progress.update(itr=i, phase=phase, t=time.time())
-    if world > 1:
-        import threading
-
-        def watchdog(limit=float(os.environ.get("ARL_BENCH_STALL_S", "240"))):
-            while True:
-                time.sleep(5.0)
-                if time.time() - progress["t"] > limit:
-                    sys.stderr.write("bench.py rank %d: no progress for %.0f s in %s of step %d (graph_collectives=%s, backend=%s); "
-                                     "ARL_SYNC_GRAPH=0 runs the collectives eagerly\n" %
-                                     (rank, limit, progress["phase"], progress["itr"],
-                                      getattr(algo.optimizer, "graph_collectives", None), backend))
-                    sys.stderr.flush()
-                    os._exit(3)
-        threading.Thread(target=watchdog, daemon=True).start()
-
     def one_step(i, sampler, algo):             # (shadows the module-level helper: the same two calls + the heartbeat)
         tick("rollout", i)
         samples, _ = sampler.obtain_samples(i)
         tick("learner", i)
+        if inject_hang and i == 2:
+            tick("learner (injected capture hang)", i)
+            time.sleep(1e6)
         algo.optimize_policy(i, samples)
 
     itr = 0
@@ -925,6 +995,7 @@ def main():
         barrier()
         t = time.perf_counter()
         for i in range(reps):
+            tick("phase split / diagnostics")
             fn(i)
         barrier()
         return (time.perf_counter() - t) / reps
@@ -937,7 +1008,9 @@ def main():
     tick("diagnostics", itr)
     if world > 1:
         line["multi_gpu"] = multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, timed, reps,
-                                                  itr + 2 * reps, elapsed_local / args.steps, t_roll, t_learn)
+                                                  itr + 2 * reps, elapsed_local / args.steps, t_roll, t_learn, tick)
+        if os.environ.get("ARL_BENCH_GRAPH_FALLBACK"):
+            line["graph_fallback"] = os.environ["ARL_BENCH_GRAPH_FALLBACK"]
     if rank == 0 and world == 1:
         if not args.no_roofline:
             line["roofline"] = roofline_gae(device, args.roofline_log2, 30)

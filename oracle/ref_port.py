@@ -208,10 +208,12 @@ class PortedAtariEnv(object):
 
     def __init__(self, game="pong", frame_skip=4, num_img_obs=4, clip_reward=True,
                  episodic_lives=True, max_start_noops=30,
-                 repeat_action_probability=0., rng=None):
+                 repeat_action_probability=0., rng=None, pad_actions_to=None):
         self.rng = np.random if rng is None else rng
         self.game = game
         self.game_id, self.action_set, self.start_lives = synth_ale.GAMES[game]
+        if pad_actions_to is not None:                   # suite mode (envs/synthetic_atari.py: padded_action_set)
+            self.action_set = list(self.action_set) + [0] * (int(pad_actions_to) - len(self.action_set))
         self.bank = synth_ale.frame_bank(self.game_id)
         self.n_actions = len(self.action_set)
         self.frame_skip = frame_skip

@@ -1,0 +1,80 @@
+"""A user script of the reference's shape (accel_rl/scripts/example/example_train_mppo.py with only its imports changed):
+builds algo / policy / sampler, hands AccelRLSync a LIST of affinities and calls train() -- started as plain
+`python script.py`, no launcher.  The runner must fork its worker runners itself (multigpu_rl_base.py:20-45).
+
+argv: out_dir n_ranks mode      mode = "fake" (CPU stand-ins from test_sync_gloo, gloo)
+                                     | "real" (mPPO + AtariCnnPolicy + GpuVecSampler, every rank on GPU 0 over gloo:
+                                               RCCL refuses two ranks on one device -- a launch-path check)
+Every rank leaves <out_dir>/rank<k>.json behind."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+
+def main():
+    out_dir, n, mode = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    from accel_rl_amd.runners.sync import AccelRLSync
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    if mode == "fake":
+        from test_sync_gloo import _FakeAlgo, _FakePolicy, _FakeSampler
+        algo, policy, sampler = _FakeAlgo(), _FakePolicy(), _FakeSampler()
+        crash = os.environ.get("ARL_TEST_CRASH_RANK")
+        if crash is not None:                       # a worker runner that dies mid-run (rank 0 must not hang on it)
+            served = sampler.obtain_samples
+
+            def obtain_samples(itr):
+                if itr == 1 and os.environ["RANK"] == crash:
+                    raise RuntimeError("injected failure in rank " + crash)
+                return served(itr)
+            sampler.obtain_samples = obtain_samples
+        affinities = [dict(gpu=k) for k in range(n)]
+        kw = dict(n_steps=200, log_interval_steps=80)
+    else:
+        from accel_rl_amd.algos.pg.ppo import mPPO
+        from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+        from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+        from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+        from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
+        sampler = GpuVecSampler(EnvCls=SynthAtariEnv, env_args=dict(game="breakout"), horizon=5, n_parallel=2,
+                                envs_per=2, max_decorrelation_steps=0)
+        algo = mPPO(optimizer_args=dict(minibatch_size=20, epochs=2))
+        policy = AtariCnnPolicy(**cnn_specs[0])
+        affinities = [dict(gpu=0) for _ in range(n)]
+        kw = dict(n_steps=8 * 40 * n, log_interval_steps=4 * 40 * n)
+    runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, seed=7, affinities=affinities, backend="gloo", **kw)
+    if mode == "fake":
+        runner.init_policy = lambda env_spec: policy.initialize(env_spec)
+        runner.save_itr_snapshot = lambda itr: None
+        orig = runner.init_logging
+
+        def init_logging():
+            orig()
+            runner._log_entropy = False
+        runner.init_logging = init_logging
+    orig_shutdown = runner.shutdown
+
+    def shutdown():                      # every rank (forked children included) reports before it leaves
+        import numpy as np
+        p = policy.flat_params
+        if p.device.type != "cpu":
+            import torch
+            torch.cuda.synchronize()
+        p = p.detach().cpu().numpy()
+        rec = dict(rank=runner.rank, pid=os.getpid(), seed=runner.seed, sampler_seed=sampler.seed, n_itr=runner._n_itr,
+                   n_runners=runner.n_runners, gpu=runner.affinities.get("gpu"), world=os.environ.get("WORLD_SIZE"),
+                   params_crc=int(np.frombuffer(p.tobytes(), dtype=np.uint32).astype(np.uint64).sum()),
+                   params_head=[float(x) for x in p[:4]])
+        with open(os.path.join(out_dir, "rank%d.json" % runner.rank), "w") as f:
+            json.dump(rec, f)
+        orig_shutdown()
+    runner.shutdown = shutdown
+    runner.train()
+    print("rank0 done", flush=True)
+
+
+main()          # no __main__ guard on purpose: the reference's example scripts have none, and fork does not need one

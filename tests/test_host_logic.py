@@ -293,3 +293,20 @@ def test_runner_pins_itself_to_gpu_cpus():
         assert r.pin_master() is None and os.sched_getaffinity(0) == before
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_padded_action_set_for_a_shared_suite_head():
+    """BASELINE config 4 (one policy for eight games): minimal action set + NOOP padding; the oracle's env port pads
+    the same way; None keeps the reference's minimal set (atari_env.py:42-43)."""
+    from accel_rl_amd.envs.synthetic_atari import GAMES, SynthAtariEnv, padded_action_set
+    from oracle.ref_port import PortedAtariEnv
+    assert padded_action_set([0, 1, 3, 4], None) == [0, 1, 3, 4]
+    assert padded_action_set([0, 1, 3, 4], 6) == [0, 1, 3, 4, 0, 0]
+    with pytest.raises(ValueError):
+        padded_action_set(list(range(18)), 6)
+    for game in GAMES:
+        env = SynthAtariEnv(game=game, pad_actions_to=18, rng=np.random.RandomState(0))
+        port = PortedAtariEnv(game=game, pad_actions_to=18, rng=np.random.RandomState(0))
+        assert env.action_space.n == 18 and list(env.action_set) == list(port.action_set)
+        assert list(env.action_set[:len(GAMES[game][1])]) == GAMES[game][1]
+        assert SynthAtariEnv(game=game, rng=np.random.RandomState(0)).action_space.n == len(GAMES[game][1])

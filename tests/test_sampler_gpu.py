@@ -184,6 +184,18 @@ SUITE_GAMES = ["pong", "breakout", "seaquest", "space_invaders", "qbert", "beam_
 
 @pytest.mark.parametrize("game", SUITE_GAMES)
 def test_gpu_sampler_matches_oracle_on_every_suite_game(game):
+    _suite_game_against_the_oracle(game, None)
+
+
+@pytest.mark.parametrize("game", ["breakout", "pong", "beam_rider", "seaquest"])
+def test_suite_games_on_one_shared_action_space(game):
+    """Config 4 as bench.py --suite runs it: eight games behind ONE policy head (a synchronous clique all-reduces one
+    flat bucket), every game's minimal action set padded with NOOP to 18 entries (SynthAtariEnv(pad_actions_to=18)).
+    The padded entries must behave as NOOP on the device exactly as in the oracle's env port."""
+    _suite_game_against_the_oracle(game, 18)
+
+
+def _suite_game_against_the_oracle(game, pad):
     """BASELINE config 4's workload: each of the 8 suite games at the per-GPU shard size (256 envs = 2 x 16 x 8,
     horizon 5), every array of 14 batches bit-identical to the oracle's sampler port.  Covers the 6- and 9-action
     sets and the 0 / 3 / 4 / 5 start-lives rules (envs/synthetic_atari.py GAMES); 70 steps with max_path_length 66
@@ -191,12 +203,12 @@ def test_gpu_sampler_matches_oracle_on_every_suite_game(game):
     resets both occur (asserted)."""
     from accel_rl_amd.envs.synthetic_atari import GAMES
     seed, horizon, n_parallel, envs_per, n_batches, max_len = 23, 5, 16, 8, 14, 66
-    n_act = len(GAMES[game][1])
+    n_act = len(GAMES[game][1]) if pad is None else pad
     rs = np.random.RandomState(100 + GAMES[game][0])
     logits = rs.randn(64, n_act) * 1.5
     p = np.exp(logits - logits.max(1, keepdims=True))
     tables = ((p / p.sum(1, keepdims=True)).astype(np.float32), (rs.randn(64) * 2).astype(np.float32))
-    kw = dict(max_start_noops=30)
+    kw = dict(max_start_noops=30) if pad is None else dict(max_start_noops=30, pad_actions_to=pad)
     smp = make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, True, max_len, kw, tables, 0.99, True,
                            serves_rows=GAMES[game][0] % 2 == 0)
     assert smp.env_spec.action_space.n == n_act

@@ -222,3 +222,36 @@ def test_sync_runner_world2():
     # rank 0 saw both ranks' completed trajectories at log time; rank 1 logs nothing
     assert r0["trajs"] == 4 and r1["trajs"] == 0      # itrs 0..3 contribute one episode each (gather at itr 1, 3)
     assert r0["tab"] is not None and r0["tab"]["CumTotalSteps"] == 4 * 40 and r1["tab"] is None
+
+
+def _mismatch_worker(rank, world, port, out):
+    """Runners whose policies differ in size (e.g. one game per rank with each game's own action set) cannot share one
+    flat gradient bucket: AccelRLSync.init_comm must say so on every rank instead of all-reducing mismatched buffers."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from accel_rl_amd.runners.sync import AccelRLSync
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+    algo, policy, sampler = _FakeAlgo(), _FakePolicy(), _FakeSampler()
+
+    def initialize(env_spec):
+        n = 16 + 4 * rank
+        policy.flat_params, policy.flat_grads, policy.n_params = torch.zeros(n), torch.zeros(n), n
+    runner = AccelRLSync(algo=algo, policy=policy, sampler=sampler, n_steps=200, seed=7,
+                         log_interval_steps=80, backend="gloo")
+    runner.init_policy = initialize
+    try:
+        runner.startup()
+        out.put((rank, "no error"))
+    except ValueError as e:
+        out.put((rank, str(e)))
+    leave_group(dist)
+
+
+def test_runners_of_one_clique_must_build_the_same_network():
+    ctx = mp.get_context("spawn")
+    out, port = ctx.Queue(), _free_port()
+    codes, got = run_ranks(ctx, _mismatch_worker, [(r, 2, port, out) for r in range(2)], 120,
+                           before_join=lambda: sorted(out.get(timeout=110) for _ in range(2)))
+    assert codes == [0, 0], codes
+    assert all("differ in size (16 ... 20 parameters" in msg for _, msg in got), got
