@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libaccel_rl_hip.so")
 
-ARL_ABI_VERSION = 2
+ARL_ABI_VERSION = 3
 PROMO_NEP50, PROMO_LEGACY, PROMO_ASSOC = 0, 1, 2
 PPO_TIE_THEANO, PPO_TIE_MATH, PPO_TIE_BOTH = 0, 1, 2      # ARL_PPO_TIE_*: whose gradient min() / clip() hand on (accel_rl_hip.h)
 OPT_ADAM, OPT_RMSPROP = 0, 1
@@ -28,7 +28,11 @@ class ArlGame(C.Structure):
     _fields_ = [("bank", _vp), ("n_frames", _i32), ("n_actions", _i32),
                 ("action_set", _i32 * MAX_ACTIONS), ("start_lives", _i32),
                 ("life_period", _i32), ("frame_skip", _i32), ("n_stack", _i32),
-                ("clip_reward", _i32), ("episodic_lives", _i32)]
+                ("clip_reward", _i32), ("episodic_lives", _i32), ("resample_mode", _i32)]
+
+
+RESAMPLE_BOX2X, RESAMPLE_NEAREST = 0, 1       # ARL_RESAMPLE_* (atari_env.py:155; box2x = what the reference computes)
+RESAMPLE_MODES = dict(box2x=RESAMPLE_BOX2X, nearest=RESAMPLE_NEAREST)
 
 
 EPOCH_WORDS = 32 * 17         # ARL_EPOCH_WORDS: launch epoch + arl_env_step's arrival tickets
@@ -98,7 +102,7 @@ _SIGNATURES = {
     "arl_rollout_begin": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout), _vp]),
     "arl_env_reset": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                              _vp, _i32, _vp]),
-    "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "arl_preprocess_frames": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "arl_copy_bytes": (_i32, [_vp, _vp, _i64, _vp]),
     "arl_ring_append": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp]),
     "arl_gather_scale_obs": (_i32, [_vp, _vp, _i64, _i64, _f32, _vp, _vp]),
@@ -253,6 +257,9 @@ def ring_append(src, ring, counter, stream=None):
     _want(src, torch.float32, "src")
     _want(ring, torch.float32, "ring")
     _want(counter, torch.int32, "counter")
+    if not (ring.is_contiguous() and src.is_contiguous() and ring.shape[0] > 0 and ring[0].numel() == src.numel()):
+        raise ValueError("ring_append: a ring slot must hold exactly the %d floats of src (ring %s)" %
+                         (src.numel(), tuple(ring.shape)))
     _check(load().arl_ring_append(ptr(src), src.numel(), ptr(ring), ring.shape[0], ptr(counter), stream_ptr(stream)),
            "arl_ring_append")
 
@@ -328,12 +335,12 @@ def sample_categorical(prob, uniforms, actions, stream=None):
                                          stream_ptr(stream)), "arl_sample_categorical")
 
 
-def preprocess_frames(raw_a, raw_b, out, stream=None):
+def preprocess_frames(raw_a, raw_b, out, stream=None, resample="box2x"):
     _want(raw_b, torch.uint8, "raw_b")
     n = raw_b.shape[0]
     assert tuple(raw_b.shape[1:3]) == (RAW_H, RAW_W) and tuple(out.shape) == (n, OBS_H, OBS_W)
-    _check(load().arl_preprocess_frames(ptr(raw_a), ptr(raw_b), n, ptr(out), stream_ptr(stream)),
-           "arl_preprocess_frames")
+    _check(load().arl_preprocess_frames(ptr(raw_a), ptr(raw_b), n, RESAMPLE_MODES[resample], ptr(out),
+                                        stream_ptr(stream)), "arl_preprocess_frames")
 
 
 def gather_scale_obs(obs, idx, out, scale, stream=None):

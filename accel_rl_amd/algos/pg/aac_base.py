@@ -150,15 +150,27 @@ class AdvActorCriticBase(RLAlgorithm):
         # the graph owns its outputs and every replay overwrites them: callers keep the diagnostics across iterations
         # (AccelRL.store_diagnostics) -- the graph itself left this replay's copy in a ring slot
         opt_data, infos = self._graph_out
-        slot = self._info_replays % self.INFO_RING
+        slot = self._info_replays % self._ring_slots()
         self._info_replays += 1
         return opt_data, {k: self._info_ring[k][slot] for k in infos}
 
-    INFO_RING = 4096            # iterations a returned diagnostics tensor stays valid (runners log far more often)
+    INFO_RING = 4096            # least number of iterations a returned diagnostics tensor stays valid
+    _log_interval_itrs = 0      # set_log_interval_itrs: how long the runner keeps the tensors before it reads them
+
+    def set_log_interval_itrs(self, n):
+        """The runner holds an iteration's diagnostics until its next log line (AccelRL.store_diagnostics: up to
+        `log_interval_steps // sample_size` iterations, e.g. 12 500 for 80-step batches and 1e6-step intervals): the
+        ring is sized so that no slot is rewritten while the runner still holds it."""
+        self._log_interval_itrs = int(n)
+        if self._info_ring is not None and self._ring_slots() > next(iter(self._info_ring.values())).shape[0]:
+            raise RuntimeError("set_log_interval_itrs(%d) after the diagnostics ring was sized" % n)
+
+    def _ring_slots(self):
+        return max(self.INFO_RING, self._log_interval_itrs + 2)
 
     def _ensure_info_ring(self, infos):
         if self._info_ring is None:
-            self._info_ring = {k: torch.zeros((self.INFO_RING,) + tuple(v.shape), dtype=torch.float32, device=v.device)
+            self._info_ring = {k: torch.zeros((self._ring_slots(),) + tuple(v.shape), dtype=torch.float32, device=v.device)
                                for k, v in infos.items()}
             self._info_counts = {k: torch.zeros(1, dtype=torch.int32, device=v.device) for k, v in infos.items()}
             self._info_replays = 0

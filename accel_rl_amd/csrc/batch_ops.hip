@@ -181,10 +181,11 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(const unsigned char* __
 // leave a captured hipGraph without an eager copy between two graph replays (the host knows the slot: it counts replays).
 __global__ __launch_bounds__(256) void ring_append_kernel(const float* __restrict__ src, int n, float* __restrict__ ring,
                                                           int n_slots, int32_t* counter) {
-    const int slot = counter[0] % n_slots;
+    const int c = counter[0];
+    const int slot = ((c % n_slots) + n_slots) % n_slots;      // (a counter handed in out of range still names a slot)
     for (int i = threadIdx.x; i < n; i += 256) ring[(int64_t)slot * n + i] = src[i];
     __syncthreads();
-    if (threadIdx.x == 0) counter[0] = counter[0] + 1;
+    if (threadIdx.x == 0) counter[0] = (slot + 1) % n_slots;   // kept reduced: never overflows, however long the run
 }
 
 extern "C" int arl_ring_append(const float* src, int32_t n, float* ring, int32_t n_slots, int32_t* counter, void* stream) {

@@ -300,6 +300,24 @@ __device__ __forceinline__ uint2 box8(uint4 a0, uint4 a1, uint4 b0, uint4 b1) {
     return make_uint2(lo, hi);
 }
 
+// cv2.INTER_NEAREST for the exact 2x decimation (what atari_env.py:155 names but does not get, SURVEY a-11):
+// dst(y, x) = src(2y, 2x) -- OpenCV's nearest-neighbour source index is floor(dst * scale), no half-pixel shift.
+// One 32-bit word = 4 input pixels of row 2y of frames a, b -> the even bytes of their max, packed as in box_word.
+__device__ __forceinline__ uint32_t nearest_word(uint32_t a_top, uint32_t b_top) {
+    const uint32_t m = pk_max(a_top & 0x00ff00ffu, b_top & 0x00ff00ffu);
+    return (m & 0xffu) | ((m >> 8) & 0xff00u);
+}
+
+// One 8-pixel output unit under the game's resample mode (wave-uniform switch).
+__device__ __forceinline__ uint2 resample8(const int mode, uint4 a0, uint4 a1, uint4 b0, uint4 b1) {
+    if (mode == ARL_RESAMPLE_NEAREST) {
+        const uint32_t lo = nearest_word(a0.x, b0.x) | (nearest_word(a0.y, b0.y) << 16);
+        const uint32_t hi = nearest_word(a0.z, b0.z) | (nearest_word(a0.w, b0.w) << 16);
+        return make_uint2(lo, hi);
+    }
+    return box8(a0, a1, b0, b1);
+}
+
 // Resolve a pending reset for env e (lane 0 of its workgroup).  Order of the
 // start-noop draws inside a stream = env order among the envs that reset in
 // this launch (the reference worker loops over its envs, worker.py:38-50).
@@ -403,7 +421,7 @@ struct FramePush {
         for (int it = 0; it < PUSH_ITERS; ++it) {
             const int un = tid + it * 256;
             if (un >= UNITS) continue;
-            const uint2 img = box8(a0[it], a1[it], b0[it], b1[it]);
+            const uint2 img = resample8(g.resample_mode, a0[it], a1[it], b0[it], b1[it]);
             const int o = un * 8;
             if (!WIDE) {
 #pragma unroll
@@ -451,7 +469,7 @@ __device__ __forceinline__ void push_frame(const arl_game& g, const int fa_i, co
             a0 = *reinterpret_cast<const uint4*>(fa + src);
             a1 = *reinterpret_cast<const uint4*>(fa + src + ARL_RAW_W);
         }
-        const uint2 img = box8(a0, a1, b0, b1);
+        const uint2 img = resample8(g.resample_mode, a0, a1, b0, b1);
         const int o = un * 8;
         for (int f = 0; f < F - 1; ++f) {
             uint2 pv = make_uint2(0, 0);
@@ -633,7 +651,7 @@ __global__ void epoch_kernel(int32_t* epoch, int32_t* launch_count) {
 
 __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ a,
                                                          const uint8_t* __restrict__ b,
-                                                         uint8_t* __restrict__ out) {
+                                                         uint8_t* __restrict__ out, const int resample_mode) {
     const int64_t i = blockIdx.x;
     const uint8_t* fb = b + i * RAW_FRAME;
     const uint8_t* fa = a ? a + i * RAW_FRAME : nullptr;
@@ -647,7 +665,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restri
             a0 = *reinterpret_cast<const uint4*>(fa + src);
             a1 = *reinterpret_cast<const uint4*>(fa + src + ARL_RAW_W);
         }
-        *reinterpret_cast<uint2*>(out + i * OBS_FRAME + un * 8) = box8(a0, a1, b0, b1);
+        *reinterpret_cast<uint2*>(out + i * OBS_FRAME + un * 8) = resample8(resample_mode, a0, a1, b0, b1);
     }
 }
 
@@ -737,6 +755,10 @@ extern "C" int arl_env_step(const arl_game* game, const arl_env_state* st, const
     ARL_REQUIRE(step >= 0 && step < ro->horizon, ARL_E_RANGE, "step outside horizon");
     ARL_REQUIRE(!single_write || (mid_batch_reset && !active_or_null), ARL_E_ARG,
                 "single_write needs mid_batch_reset and every env stepping");
+    // single_write moves the older planes 16 bytes per lane (FramePush<true>): rows of the rollout buffer are
+    // 33 280-byte multiples, so 16-byte aligned bases make every access aligned
+    ARL_REQUIRE(!single_write || (arl::aligned16(ro->observations) && arl::aligned16(ro->step_obs)),
+                ARL_E_ALIGN, "single_write needs 16-byte aligned observations and step_obs");
     ARL_REQUIRE(st->next_reset && st->launch_count, ARL_E_ARG, "arl_env_step needs st->next_reset and st->launch_count");
     ARL_REQUIRE(max_path_length >= 1.0, ARL_E_RANGE, "arl_env_step needs max_path_length >= 1");
     return launch_env_step(game, st, ro, prob, value, uniforms, active_or_null, step, mid_batch_reset, max_path_length,
@@ -782,13 +804,15 @@ extern "C" int arl_env_reset(const arl_game* game, const arl_env_state* st, cons
 }
 
 extern "C" int arl_preprocess_frames(const uint8_t* raw_a_or_null, const uint8_t* raw_b, int64_t n,
-                                     uint8_t* out, void* stream) {
+                                     int32_t resample_mode, uint8_t* out, void* stream) {
     ARL_REQUIRE(raw_b && out, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(n >= 0, ARL_E_ARG, "negative n");
+    ARL_REQUIRE(resample_mode == ARL_RESAMPLE_BOX2X || resample_mode == ARL_RESAMPLE_NEAREST, ARL_E_ARG,
+                "resample_mode must be ARL_RESAMPLE_BOX2X or ARL_RESAMPLE_NEAREST");
     ARL_REQUIRE(arl::aligned16(raw_b) && (!raw_a_or_null || arl::aligned16(raw_a_or_null)) &&
                     !(reinterpret_cast<uintptr_t>(out) & 7u), ARL_E_ALIGN, "frames must be 16-byte aligned");
     if (n == 0) return 0;
     hipLaunchKernelGGL(preprocess_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                       raw_a_or_null, raw_b, out);
+                       raw_a_or_null, raw_b, out, (int)resample_mode);
     return arl::check_launch("preprocess_kernel");
 }

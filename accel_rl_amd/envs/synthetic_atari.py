@@ -67,7 +67,7 @@ class SynthAtariEnv(object):
 
     def __init__(self, game="pong", frame_skip=4, num_img_obs=4, clip_reward=True,
                  episodic_lives=True, max_start_noops=30, repeat_action_probability=0.,
-                 rng=None, pad_actions_to=None):
+                 rng=None, pad_actions_to=None, resample="box2x"):
         if game not in GAMES:
             raise IOError("You asked for game {} but it is not one of {}".format(
                 game, sorted(GAMES)))
@@ -83,6 +83,10 @@ class SynthAtariEnv(object):
         self.episodic_lives = bool(episodic_lives)
         self.max_start_noops = int(max_start_noops)
         self.repeat_action_probability = repeat_action_probability
+        if resample not in ("box2x", "nearest"):
+            raise ValueError("resample must be 'box2x' (what atari_env.py:155 computes: the constant sits in cv2.resize's "
+                             "dst slot, so INTER_LINEAR runs) or 'nearest' (what it names)")
+        self.resample = resample
         self._action_space = Discrete(len(self.action_set))
         self._observation_space = UintBox(shape=(self.num_img_obs, OBS_H, OBS_W), bits=8)
         self.phase = draw_phase(rng)                    # emulator construction

@@ -49,6 +49,8 @@ class AccelRLBase(Runner):
         if master:
             n_itr = self.get_n_itr(sample_size)
             self.algo.set_n_itr(n_itr)
+            if hasattr(self.algo, "set_log_interval_itrs"):          # (diagnostics held until the next log line)
+                self.algo.set_log_interval_itrs(self._log_interval_itrs)
             self.init_logging()
             return n_itr
 

@@ -73,7 +73,9 @@ class AccelRLSync(AccelRL):
         import socket
         import threading
         from accel_rl_amd.util.misc import make_seed
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
+        # (torch.cuda.is_initialized() only: is_available() / device_count() themselves mark the process so that a forked
+        # child refuses the GPU -- "Cannot re-initialize CUDA in forked subprocess")
+        if torch.cuda.is_initialized():
             raise RuntimeError("AccelRLSync cannot fork its %d worker runners: this process has already initialised the "
                                "GPU runtime (a forked child cannot use it).  Construct and train() the runner before any "
                                "device work, or start the script under `python -m torch.distributed.run "
@@ -122,9 +124,14 @@ class AccelRLSync(AccelRL):
             if self.affinities is None:
                 self.affinities = dict(gpu=rank)
             self.train()
-        except BaseException:          # noqa: BLE001 -- the exit code is the message to rank 0's monitor
+        except BaseException as e:     # noqa: BLE001 -- the exit code is the message to rank 0's monitor
             import traceback
             traceback.print_exc()
+            if "forked subprocess" in str(e):
+                import sys
+                sys.stderr.write("AccelRLSync: the script queried the GPU runtime (torch.cuda.is_available(), device_count(), a "
+                                 "device tensor ...) before train() forked its worker runners; move that after train() starts or "
+                                 "launch the script under `python -m torch.distributed.run`\n")
             code = 1
         finally:
             import sys
@@ -159,7 +166,7 @@ class AccelRLSync(AccelRL):
         if self._worker_affinities is not None:
             self.launch_workers()
         if self.n_runners > 1 and not dist.is_initialized():
-            backend = self._backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            backend = self._backend or ("nccl" if torch.cuda.is_available() else "gloo")     # (after the fork)
             kw = dict()
             if backend == "nccl":
                 # accel_rl_base.py:62-64: the runner's GPU is affinities["gpu"]; RCCL binds its communicator to it

@@ -160,6 +160,7 @@ class GpuVecSampler(BaseMbSampler):
         g.start_lives, g.life_period = env.start_lives, synth.LIFE_PERIOD
         g.frame_skip, g.n_stack = env.frame_skip, f
         g.clip_reward, g.episodic_lives = int(env.clip_reward), int(env.episodic_lives)
+        g.resample_mode = _lib.RESAMPLE_MODES[getattr(env, "resample", "box2x")]
         self._game = g
 
         # -- per-env state (SoA) and the simulated workers' RNG streams

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ARL_ABI_VERSION 2
+#define ARL_ABI_VERSION 3
 
 #define ARL_E_ARG      (-1)   /* null pointer / non-positive size                 */
 #define ARL_E_RANGE    (-2)   /* size outside what the kernels support             */
@@ -114,6 +114,16 @@ int arl_sample_categorical(const float* prob, const double* uniforms,
 #define ARL_OBS_H 104     /* accel_rl/envs/atari_env.py:13 */
 #define ARL_OBS_W 80
 
+/* How the cropped 208 x 160 maximum of two raw frames becomes the 104 x 80 observation plane
+ * (accel_rl/envs/atari_env.py:155: `cv2.resize(self._max_frame[:-2], (W, H), cv2.INTER_NEAREST)`).  In cv2's Python
+ * signature resize(src, dsize[, dst[, fx[, fy[, interpolation]]]]) the constant lands in the `dst` slot, so what
+ * RUNS is the default INTER_LINEAR, which for an exact 2x decimation is the rounded 2x2 box (a+b+c+d+2)>>2:
+ * ARL_RESAMPLE_BOX2X, the default and the parity mode.  ARL_RESAMPLE_NEAREST is what the call NAMES (and what a
+ * reference with the argument fixed would compute): dst(y, x) = src(2y, 2x), OpenCV's floor(dst * scale) rule.
+ * OpenCV (opencv3=3.1.0, environment.yml:24) is not under /root/reference: both restated, parity unpinned.        */
+#define ARL_RESAMPLE_BOX2X    0
+#define ARL_RESAMPLE_NEAREST  1
+
 /* Static description of one game + AtariEnv constructor arguments
  * (accel_rl/envs/atari_env.py:18-26).  Plain data, passed by pointer (host). */
 typedef struct arl_game {
@@ -127,6 +137,7 @@ typedef struct arl_game {
     int32_t n_stack;            /* num_img_obs, atari_env.py:21 */
     int32_t clip_reward;        /* atari_env.py:22 */
     int32_t episodic_lives;     /* atari_env.py:23 */
+    int32_t resample_mode;      /* ARL_RESAMPLE_*; atari_env.py:155 (0 = what the reference computes) */
 } arl_game;
 
 /* Per-env mutable state, struct-of-arrays; every pointer is device memory of
@@ -230,7 +241,8 @@ int arl_env_frame_step(const arl_game* game, const arl_env_state* st, const arl_
  *   single_write != 0 (needs mid_batch_reset != 0 and active_or_null == NULL): the new stacked observation is
  *   written once -- to observations[env*horizon + step + 1], or to step_obs after the last step of the batch --
  *   and the previous stack is read from observations[env*horizon + step] (which the caller has filled for
- *   step 0, overlap/worker.py:30-32); step_obs is then only current after the last step.                      */
+ *   step 0, overlap/worker.py:30-32); step_obs is then only current after the last step.  In this mode
+ *   observations and step_obs must be 16-byte aligned (ARL_E_ALIGN otherwise; 8-byte alignment suffices without). */
 int arl_env_step(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
                  const float* prob, const float* value, const double* uniforms,
                  const uint8_t* active_or_null, int32_t step, int32_t mid_batch_reset,
@@ -249,10 +261,11 @@ int arl_env_reset(const arl_game* game, const arl_env_state* st, const arl_rollo
                   const uint8_t* flags_or_null, int32_t max_start_noops, void* stream);
 
 /* Stand-alone preprocess of explicit raw frame pairs (testing / other
- * emulators): out[i] = box2x(crop(max(a[i], b[i]))); a may be NULL (zeros).
+ * emulators): out[i] = resample(crop(max(a[i], b[i]))), resample_mode = ARL_RESAMPLE_BOX2X (the reference's
+ * arithmetic) or ARL_RESAMPLE_NEAREST; a may be NULL (zeros).
  * Replaces envs/atari_env.py:151-155.  a,b u8[n][210][160], out u8[n][104][80] */
 int arl_preprocess_frames(const uint8_t* raw_a_or_null, const uint8_t* raw_b,
-                          int64_t n, uint8_t* out, void* stream);
+                          int64_t n, int32_t resample_mode, uint8_t* out, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * Learner side: minibatch gather and the flat-bucket optimiser step
@@ -265,7 +278,7 @@ int arl_preprocess_frames(const uint8_t* raw_a_or_null, const uint8_t* raw_b,
  * sampler/act_server/buffers.py:24-30, optimizers/util.py:8-18) enter and leave the hipGraphs without memcpy nodes.
  * A write to host memory is visible to the host once the stream has passed an event / synchronisation after it.   */
 int arl_copy_bytes(void* dst, const void* src, int64_t nbytes, void* stream);
-/* ring[(counter[0] % n_slots)][0 .. n) = src[0 .. n); counter[0] += 1 -- the per-iteration diagnostics of an update
+/* ring[(counter[0] % n_slots)][0 .. n) = src[0 .. n); counter[0] = (counter[0] + 1) % n_slots (kept reduced) -- the per-iteration diagnostics of an update
  * (the opt_infos of accel_rl/algos/pg/aac_base.py:104-106, e.g. GradNorm) leave a captured hipGraph into a slot the host
  * can name without a launch of its own (it counts the replays).  ring f32[n_slots][n], counter i32[1] on the device. */
 int arl_ring_append(const float* src, int32_t n, float* ring, int32_t n_slots, int32_t* counter, void* stream);

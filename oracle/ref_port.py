@@ -183,15 +183,21 @@ def sample_actions(prob, uniforms):
 # Frame preprocessing                (accel_rl/envs/atari_env.py:151-157)
 # =============================================================================
 
-def preprocess_pair(frame_a, frame_b):
+def preprocess_pair(frame_a, frame_b, resample="box2x"):
     """max of two raw u8[210,160] frames, drop the last 2 rows, rounded 2x2 box
-    mean -> u8[104,80].  `frame_a=None` means an all-zero first frame."""
+    mean -> u8[104,80].  `frame_a=None` means an all-zero first frame.
+    resample="box2x": what atari_env.py:155 computes (cv2's default INTER_LINEAR at an exact 2x decimation -- the
+    INTER_NEAREST constant sits in the `dst` slot); "nearest": what the call names, dst(y, x) = src(2y, 2x) (OpenCV's
+    nearest source index is floor(dst * scale)).  Both restated from OpenCV's documented behaviour: cv2 is absent."""
     fb = np.asarray(frame_b, np.uint8).reshape(synth_ale.RAW_H, synth_ale.RAW_W)
     if frame_a is None:
         m = fb
     else:
         fa = np.asarray(frame_a, np.uint8).reshape(synth_ale.RAW_H, synth_ale.RAW_W)
         m = np.maximum(fa, fb)
+    if resample == "nearest":
+        return m[:synth_ale.RAW_H - CROP_ROWS][0::2, 0::2].copy()
+    assert resample == "box2x", resample
     m = m[:synth_ale.RAW_H - CROP_ROWS].astype(np.uint16)
     box = m[0::2, 0::2] + m[0::2, 1::2] + m[1::2, 0::2] + m[1::2, 1::2]
     return ((box + 2) >> 2).astype(np.uint8)
@@ -208,7 +214,7 @@ class PortedAtariEnv(object):
 
     def __init__(self, game="pong", frame_skip=4, num_img_obs=4, clip_reward=True,
                  episodic_lives=True, max_start_noops=30,
-                 repeat_action_probability=0., rng=None, pad_actions_to=None):
+                 repeat_action_probability=0., rng=None, pad_actions_to=None, resample="box2x"):
         self.rng = np.random if rng is None else rng
         self.game = game
         self.game_id, self.action_set, self.start_lives = synth_ale.GAMES[game]
@@ -221,6 +227,7 @@ class PortedAtariEnv(object):
         self.clip_reward = clip_reward
         self.episodic_lives = episodic_lives
         self.max_start_noops = max_start_noops
+        self.resample = resample
         self.has_fire = 1 in self.action_set             # atari_env.py:56 ("FIRE" = code 1)
         self.has_up = 2 in self.action_set               # atari_env.py:57 ("UP"   = code 2)
         # emulator state (SynthALE.loadROM draws the phase)
@@ -258,7 +265,7 @@ class PortedAtariEnv(object):
     # -- wrapper --------------------------------------------------------------
     def _push_frame(self):
         """atari_env.py:151-157: grab frame 2, max with frame 1, resample, shift."""
-        img = preprocess_pair(self.first, self._screen())
+        img = preprocess_pair(self.first, self._screen(), self.resample)
         self.stack = np.concatenate([self.stack[1:], img[None]])
 
     def _blank(self):

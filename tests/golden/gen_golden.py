@@ -63,7 +63,8 @@ def save(name, **arrays):
 # shared random scan inputs
 # -----------------------------------------------------------------------------
 
-SCAN_SHAPES = [(16, 5), (64, 5), (8, 128), (7, 1), (33, 32), (5, 17)]
+SCAN_SHAPES = [(16, 5), (64, 5), (8, 128), (7, 1), (33, 32), (5, 17),
+               (256, 5), (64, 128)]     # SURVEY 8c's list: config 2's batch and a long horizon (appended: cases 0-17 keep their draws)
 SCAN_PARAMS = [(0.99, 0.95), (0.99, 1.0), (1.0, 1.0), (0.9, 0.0)]
 DONE_PROBS = [0.0, 0.1, 1.0]
 

@@ -52,14 +52,14 @@ def test_the_boundary_header_keeps_no_state():
 
 
 def test_abi_version_and_arg_errors(lib):
-    assert lib.arl_abi_version() == 2
+    assert lib.arl_abi_version() == 3
     # null pointers / bad sizes are rejected before any HIP call is made
     assert lib.arl_gae_scan(None, None, None, None, 0.99, 0.95, 4, 5, 0, None, None, None) == -1
     assert b"null" in lib.arl_last_error()
     assert lib.arl_sample_categorical(None, None, 1, 4, None, None) == -1
     assert lib.arl_valids_mask(None, 1, 1, None, None, None, None, None) == -1
     assert lib.arl_standardize(None, None, 1, 1e-6, None, None) == -1
-    assert lib.arl_preprocess_frames(None, None, 1, None, None) == -1
+    assert lib.arl_preprocess_frames(None, None, 1, 0, None, None) == -1
     assert lib.arl_standardize_workspace_bytes() >= 3 * 8
 
 

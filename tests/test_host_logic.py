@@ -310,3 +310,17 @@ def test_padded_action_set_for_a_shared_suite_head():
         assert env.action_space.n == 18 and list(env.action_set) == list(port.action_set)
         assert list(env.action_set[:len(GAMES[game][1])]) == GAMES[game][1]
         assert SynthAtariEnv(game=game, rng=np.random.RandomState(0)).action_space.n == len(GAMES[game][1])
+
+
+def test_diagnostics_ring_outlives_the_runners_log_interval():
+    """A replayed learner hands out VIEWS of a device ring; the runner keeps them until its next log line
+    (accel_rl.py:55-74: up to log_interval_steps // sample_size iterations).  The runner tells the algorithm that
+    interval and the ring is sized from it (round-4 advice: 80-step batches with a 1e6-step interval = 12 500
+    iterations against a fixed 4096-slot ring silently aliased newer iterations)."""
+    from accel_rl_amd.algos.pg.a2c import A2C
+    algo = A2C()
+    assert algo._ring_slots() == algo.INFO_RING == 4096
+    algo.set_log_interval_itrs(12500)
+    assert algo._ring_slots() == 12502
+    algo.set_log_interval_itrs(10)
+    assert algo._ring_slots() == 4096

@@ -78,7 +78,7 @@ def test_nstep_golden_bit_exact(L):
             ret_l, _ = run_nstep(L, g[ik + "_r"], g[ik + "_d"], g[ik + "_v"], g[ik + "_lv"], float(gam), promo=1)
             np.testing.assert_array_equal(ret_l, g[key + "_nret_legacy"], err_msg=key + " legacy")
             n += 1
-    assert n == 54
+    assert n == 72
 
 
 @pytest.mark.parametrize("n,t", [(256, 5), (1024, 5), (2048, 5), (1, 5), (257, 5), (1000, 1),
@@ -314,6 +314,26 @@ def test_preprocess_vs_oracle(L):
     L.preprocess_frames(None, dev(b), out)
     want = np.stack([P.preprocess_pair(None, b[i]) for i in range(n)])
     np.testing.assert_array_equal(out.cpu().numpy(), want)
+
+
+def test_preprocess_nearest_mode_vs_oracle(L):
+    """ARL_RESAMPLE_NEAREST (SURVEY a-11 / 7.2: the mode atari_env.py:155 NAMES; box2x is what it computes and stays
+    the default): dst(y, x) = max(a, b)(2y, 2x), bit for bit, with and without a first frame; and the two modes differ
+    on random frames (the switch is not a no-op)."""
+    rs = np.random.RandomState(14)
+    n = 19
+    a = rs.randint(0, 256, size=(n, 210, 160), dtype=np.uint8)
+    b = rs.randint(0, 256, size=(n, 210, 160), dtype=np.uint8)
+    out = torch.empty((n, 104, 80), dtype=torch.uint8, device=DEV)
+    L.preprocess_frames(dev(a), dev(b), out, resample="nearest")
+    want = np.stack([P.preprocess_pair(a[i], b[i], "nearest") for i in range(n)])
+    np.testing.assert_array_equal(out.cpu().numpy(), want)
+    np.testing.assert_array_equal(want, np.maximum(a, b)[:, 0:208:2, 0::2])
+    L.preprocess_frames(None, dev(b), out, resample="nearest")
+    np.testing.assert_array_equal(out.cpu().numpy(), b[:, 0:208:2, 0::2])
+    box = torch.empty_like(out)
+    L.preprocess_frames(None, dev(b), box)
+    assert (box != out).float().mean().item() > 0.9
 
 
 def test_preprocess_bank_frames(L):
@@ -698,7 +718,7 @@ def test_staging_copy_and_ring_append(L):
         g.replay()
         torch.cuda.synchronize()
         assert torch.all(d == k + 1)
-    # ring: slot (counter % slots), counter advances on the device
+    # ring: slot (counter % slots), counter advances on the device and stays reduced (never overflows)
     ring = torch.zeros((3, 5), device=DEV)
     count = torch.zeros(1, dtype=torch.int32, device=DEV)
     src = torch.zeros(5, device=DEV)
@@ -713,6 +733,12 @@ def test_staging_copy_and_ring_append(L):
         src.fill_(float(10 + k))
         g2.replay()
         torch.cuda.synchronize()
-        assert int(count.item()) == k + 1 and torch.all(ring[k % 3] == 10 + k)
+        assert int(count.item()) == (k + 1) % 3 and torch.all(ring[k % 3] == 10 + k)
         if k >= 1:
             assert torch.all(ring[(k - 1) % 3] == 10 + k - 1)         # the previous slot is untouched
+    count.fill_(2 ** 31 - 1)                                          # a counter handed in out of range still names a slot
+    g2.replay()
+    torch.cuda.synchronize()
+    assert int(count.item()) == ((2 ** 31 - 1) % 3 + 1) % 3 and torch.all(ring[(2 ** 31 - 1) % 3] == 16)
+    with pytest.raises(ValueError):                                   # a slot must hold exactly src
+        L.ring_append(src[:4], ring, count)

@@ -37,7 +37,7 @@ def test_gae_bit_exact_vs_reference():
         np.testing.assert_array_equal(adv, g[key + "_adv"], err_msg=key)
         np.testing.assert_array_equal(ret, g[key + "_ret"], err_msg=key)
         n += 1
-    assert n == 72
+    assert n == 96                      # 8 shapes (incl. SURVEY 8c: (16,5), (256,5), (64,128)) x 3 done rates x 4 (gamma, lambda)
 
 
 def test_gae_legacy_promotion_bit_exact_and_close():
@@ -66,7 +66,7 @@ def test_nstep_bit_exact_vs_reference():
         tol = 1e-5 * np.maximum(1, np.abs(ret))
         assert np.all(np.abs(ret64 - ret) <= tol), key
         n += 1
-    assert n == 54
+    assert n == 72
 
 
 # -- G3 -----------------------------------------------------------------------

@@ -195,7 +195,13 @@ def test_suite_games_on_one_shared_action_space(game):
     _suite_game_against_the_oracle(game, 18)
 
 
-def _suite_game_against_the_oracle(game, pad):
+def test_nearest_resample_mode_through_the_sampler():
+    """SynthAtariEnv(resample="nearest") reaches every pixel path of the device sampler (fused step kernel, resets,
+    bootstrap observation): observations bit-identical to the oracle's env port in the same mode."""
+    _suite_game_against_the_oracle("breakout", None, extra_env=dict(resample="nearest"))
+
+
+def _suite_game_against_the_oracle(game, pad, extra_env=None):
     """BASELINE config 4's workload: each of the 8 suite games at the per-GPU shard size (256 envs = 2 x 16 x 8,
     horizon 5), every array of 14 batches bit-identical to the oracle's sampler port.  Covers the 6- and 9-action
     sets and the 0 / 3 / 4 / 5 start-lives rules (envs/synthetic_atari.py GAMES); 70 steps with max_path_length 66
@@ -209,6 +215,7 @@ def _suite_game_against_the_oracle(game, pad):
     p = np.exp(logits - logits.max(1, keepdims=True))
     tables = ((p / p.sum(1, keepdims=True)).astype(np.float32), (rs.randn(64) * 2).astype(np.float32))
     kw = dict(max_start_noops=30) if pad is None else dict(max_start_noops=30, pad_actions_to=pad)
+    kw.update(extra_env or {})
     smp = make_gpu_sampler(game, horizon, n_parallel, envs_per, seed, True, max_len, kw, tables, 0.99, True,
                            serves_rows=GAMES[game][0] % 2 == 0)
     assert smp.env_spec.action_space.n == n_act
