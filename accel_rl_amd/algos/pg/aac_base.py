@@ -162,7 +162,8 @@ class AdvActorCriticBase(RLAlgorithm):
         `log_interval_steps // sample_size` iterations, e.g. 12 500 for 80-step batches and 1e6-step intervals): the
         ring is sized so that no slot is rewritten while the runner still holds it."""
         self._log_interval_itrs = int(n)
-        if self._info_ring is not None and self._ring_slots() > next(iter(self._info_ring.values())).shape[0]:
+        ring = getattr(self, "_info_ring", None)          # (allocated with the first replayed update)
+        if ring is not None and self._ring_slots() > next(iter(ring.values())).shape[0]:
             raise RuntimeError("set_log_interval_itrs(%d) after the diagnostics ring was sized" % n)
 
     def _ring_slots(self):
