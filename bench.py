@@ -155,12 +155,34 @@ def roofline_gae(device, log2_elems, reps):
                 avg_launch_us=round(mean_ms * 1e3, 2), median_launch_us=round(med_ms * 1e3, 2))
 
 
-def pmc_traffic(log2_elems):
+def roofline_nstep(device, log2_elems, reps):
+    """The n-step return scan (discount_returns + adv = ret - v, algos/pg/util.py:26-37, aac_base.py:121 -- config 3's
+    process_samples) at the same bandwidth-bound size: 17 B per (env, t) + 4 B per env, as the GAE scan."""
+    from accel_rl_amd import _lib
+    t = HORIZON
+    n = (1 << log2_elems) // t
+    gen = torch.Generator(device=device).manual_seed(1)
+    r = torch.randn(n * t, device=device, generator=gen)
+    v = torch.randn(n * t, device=device, generator=gen)
+    d = (torch.rand(n * t, device=device, generator=gen) < 0.05).to(torch.uint8)
+    lv = torch.randn(n, device=device, generator=gen)
+    adv, ret = torch.empty_like(r), torch.empty_like(r)
+    mean_ms, med_ms = event_time_ms(lambda: _lib.nstep_return(r, d, v, lv, 0.99, n, t, ret, adv), reps)
+    nbytes = 17 * n * t + 4 * n
+    achieved = nbytes / (mean_ms * 1e-3) / 1e9
+    return dict(bound="hbm", kernel="scan_lds_kernel<NSTEP,NEP50,256>", achieved=round(achieved, 1),
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
+                traffic=pmc_traffic(log2_elems, "nstep_pmc_traffic.json"),
+                bytes_per_launch=nbytes, n_env=n, horizon=t, launches=reps,
+                avg_launch_us=round(mean_ms * 1e3, 2), median_launch_us=round(med_ms * 1e3, 2))
+
+
+def pmc_traffic(log2_elems, record="gae_pmc_traffic.json"):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (bench.py cannot
     read PMC counters itself); None if no profile for this size is committed -- or if it was taken from another
     version of the scan kernels (the record carries the sha1 of scan.hip; tools/refresh_profiles.sh renews it)."""
     import hashlib
-    path = os.path.join(ROOT, "profiles", "gae_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", record)
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -478,7 +500,7 @@ def start_cpu_pool():
     return pools
 
 
-def cpu_baseline(device, policy, pools, sampler, algo, itr0, seconds=4.0, n_windows=3):
+def cpu_baseline(device, policy, pools, sampler, algo, itr0, seconds=4.0, n_windows=3, gae_lambda=0.95):
     """The reference's CPU sampler restated (oracle/, pinned to the real reference by the golden
     fixtures) on this box's host cores, on the same workload; every figure is the MEDIAN of its windows:
       * `value`: multi-process, as the reference runs it -- master + 2*n_parallel workers in two alternating
@@ -497,7 +519,7 @@ def cpu_baseline(device, policy, pools, sampler, algo, itr0, seconds=4.0, n_wind
         buf, _ = s.obtain_samples(served)
         lv = policy.value(torch.from_numpy(buf["extra_observations"]).to(device)).cpu().numpy()
         P.process_samples(buf["rewards"].reshape(N_ENVS, HORIZON), buf["dones"].reshape(N_ENVS, HORIZON),
-                          buf["value"].reshape(N_ENVS, HORIZON), lv, None, 0.99, 0.95)
+                          buf["value"].reshape(N_ENVS, HORIZON), lv, None, 0.99, gae_lambda)
 
     dst = sampler.samples_buf
     pairs = lambda buf: (                                            # noqa: E731
@@ -551,12 +573,28 @@ def cpu_baseline(device, policy, pools, sampler, algo, itr0, seconds=4.0, n_wind
                 undisturbed=round(N_ENVS * HORIZON / float(np.percentile(bt, 10)), 1),
                 host_load_1min=round(load0, 1),
                 sample="best of %d pool shapes, each the median of 2 windows (chosen: %d batches, %.1f s) of the same workload's rollout + "
-                       "process_samples (256 envs x 5 steps): numpy restatement of the reference sampler / "
+                       "process_samples (%d envs x %d steps): numpy restatement of the reference sampler / "
                        "AtariEnv / GAE, master + %d worker processes (2 alternating groups x %d, %d envs each, "
                        "pinned), actions served by the same policy on the GPU, no learner update; whole_loop = "
                        "the same sampler + H2D of the batch + the device learner of `value`, serial "
                        "(%d batches, %.1f s); single_core = the sampler walked by one process (%d batches)" %
-                       (len(sweep), batches, dt, 2 * n_par, n_par, half // n_par, loop_batches, loop_dt, b1))
+                       (len(sweep), batches, dt, N_ENVS, HORIZON, 2 * n_par, n_par, half // n_par, loop_batches, loop_dt, b1))
+
+
+def replay_pmc_traffic(batch):
+    """HBM bytes per arl_replay_extract launch from the committed rocprofv3 --pmc passes (tools/replay_pmc.sh); None
+    when the record is missing, of another batch, or of another version of replay.hip."""
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "profiles", "replay_extract_pmc.json")) as f:
+            rec = json.load(f)
+        with open(os.path.join(ROOT, "accel_rl_amd", "csrc", "replay.hip"), "rb") as f:
+            sha = hashlib.sha1(f.read()).hexdigest()
+        if rec.get("batch") != batch or rec.get("replay_hip_sha1") != sha:
+            return None
+        return rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def replay_roofline(device, algo, batch=4096):
@@ -582,7 +620,7 @@ def replay_roofline(device, algo, batch=4096):
     return dict(bound="hbm", kernel="extract_kernel (arl_replay_extract), %d transitions = %d stacked observations out of "
                                     "%.1f GB of frames" % (batch, 2 * batch, buf.frames.numel() / 1e9),
                 achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4),
-                traffic=None, bytes_per_launch=nbytes, bytes_per_stack=2 * stack, avg_launch_us=round(ms * 1e3, 2),
+                traffic=replay_pmc_traffic(batch), bytes_per_launch=nbytes, bytes_per_stack=2 * stack, avg_launch_us=round(ms * 1e3, 2),
                 timing="%d launches per hipGraph, 5 replays" % per_graph)
 
 
@@ -845,7 +883,6 @@ def main():
     global N_ENVS, CNN_SPEC, MINIBATCH
     if args.workload == "a2c1024":
         N_ENVS, CNN_SPEC = 1024, 0
-        args.no_cpu_baseline = args.no_roofline = True
     if args.workload == "catdqn":
         return catdqn_main(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -914,7 +951,8 @@ def main():
     __graft_entry__.build()
     tick("start-up")
     if args.roofline_only:
-        print(json.dumps({"roofline": roofline_gae(device, args.roofline_log2, 30)}), flush=True)
+        leg = roofline_nstep if args.workload == "a2c1024" else roofline_gae
+        print(json.dumps({"roofline": leg(device, args.roofline_log2, 30)}), flush=True)
         return
 
     game = GAMES_8[rank % 8] if args.suite else GAME
@@ -1012,13 +1050,18 @@ def main():
         if os.environ.get("ARL_BENCH_GRAPH_FALLBACK"):
             line["graph_fallback"] = os.environ["ARL_BENCH_GRAPH_FALLBACK"]
     if rank == 0 and world == 1:
-        if not args.no_roofline:
+        if not args.no_roofline and args.workload == "a2c1024":
+            # config 3 is sampler-bound (BASELINE.json): its HBM-bound kernels are the 5-step return scan and the env step
+            line["roofline"] = roofline_nstep(device, args.roofline_log2, 30)
+            line["kernels"] = [env_step_sweep(device)]
+        elif not args.no_roofline:
             line["roofline"] = roofline_gae(device, args.roofline_log2, 30)
             line["kernels"] = kernel_table(device, sampler, algo, policy)
             line["kernels"].append(env_step_sweep(device))
             line["mfma"] = mfma_table(device, policy)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cb = cpu_baseline(device, policy, cpu_pool, sampler, algo, itr + 2 * reps)
+            line["cpu_baseline"] = cb = cpu_baseline(device, policy, cpu_pool, sampler, algo, itr + 2 * reps,
+                                                     gae_lambda=1.0 if args.workload == "a2c1024" else 0.95)
             line["gpu_over_cpu"] = {
                 "rollout_only": round(line["phases"]["rollout_only_env_steps_per_s"] / cb["value"], 2),
                 "whole_loop": round(line["value"] / cb["whole_loop"], 2),

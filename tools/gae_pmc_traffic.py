@@ -1,7 +1,8 @@
 """HBM bytes per launch of the GAE scan from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate
 runs of `python bench.py --roofline-only`), corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
 (gfx950 reports half of the wide coalesced read traffic).
-usage: gae_pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [log2_elems] > gae_pmc_traffic.json"""
+usage: gae_pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [log2_elems [kernel label]] > gae_pmc_traffic.json
+(the same passes over `bench.py --workload a2c1024 --roofline-only` give the n-step scan's record: tools/nstep_pmc.sh)"""
 import csv
 import hashlib
 import json
@@ -28,7 +29,7 @@ t = 5
 n_env = (1 << log2) // t
 fetch_b, write_b = int(fetch_kb * 1024 * 2), int(write_kb * 1024)
 print(json.dumps(dict(
-    log2_elems=log2, kernel="scan_lds_kernel<false,0,256>", FETCH_SIZE_KB=fetch_kb, WRITE_SIZE_KB=write_kb,
+    log2_elems=log2, kernel=sys.argv[4] if len(sys.argv) > 4 else "scan_lds_kernel<false,0,256>", FETCH_SIZE_KB=fetch_kb, WRITE_SIZE_KB=write_kb,
     fetch_bytes_corrected=fetch_b, write_bytes=write_b, hbm_bytes_per_launch=fetch_b + write_b,
     algorithmic_bytes_per_launch=17 * n_env * t + 4 * n_env,
     scan_hip_sha1=hashlib.sha1(open(SCAN_SRC, "rb").read()).hexdigest(),      # bench.py drops the figure when scan.hip changes

@@ -1,5 +1,5 @@
-# Regenerates the one-box part of profiles/r04 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
-# ~12 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r04 (and profiles/*.json: the PMC records bench.py reads)
+# Regenerates the one-box part of profiles/r05 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
+# ~12 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r05 (and profiles/*.json: the PMC records bench.py reads)
 set -x
 R=$(pwd); O=$R/gpurun_out/fin; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
@@ -16,6 +16,8 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pD -o w -- py
 cp $(find /tmp/pD -name "*counter_collection.csv" | head -n 1) $O/gae_pmc_WRITE_SIZE.csv
 python $R/tools/gae_pmc_traffic.py $O/gae_pmc_FETCH_SIZE.csv $O/gae_pmc_WRITE_SIZE.csv > $O/gae_pmc_traffic.json
 cp $O/gae_pmc_traffic.json $R/profiles/gae_pmc_traffic.json     # bench.py reads it (roofline.traffic; keyed by scan.hip's sha1)
+cd $R; bash tools/nstep_pmc.sh gpurun_out/fin > /dev/null 2>&1; cp $O/nstep_pmc_traffic.json $R/profiles/nstep_pmc_traffic.json    # config 3's roofline.traffic
+bash tools/replay_pmc.sh 4096 gpurun_out/fin > /dev/null 2>&1; cp $O/replay_extract_pmc.json $R/profiles/replay_extract_pmc.json   # config 5's
 cd $R; bash tools/env_step_pmc.sh 32768 gpurun_out/fin > /dev/null 2>&1
 cp $O/env_step_pmc.json $R/profiles/env_step_pmc.json     # bench.py reads it (env_step@sweep traffic; keyed by env.hip's sha1)
 cd $R; timeout 900 python bench.py > $O/bench.log 2>$O/bench.err; tail -n 1 $O/bench.log > $O/bench.json
