@@ -24,6 +24,10 @@
 #pragma once
 #include "arl_optim_dev.h"
 
+#ifndef ARL_AHEAD2
+#define ARL_AHEAD2 0        // development switch (A/B builds: ARL_HIPCC_FLAGS=-DARL_AHEAD2=1); measured SLOWER, see igemm_body
+#endif
+
 #include <stdlib.h>
 #include <type_traits>
 
@@ -870,7 +874,17 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     // layout [row tile][16-k step][piece]; rd_: the fp32 tile in flight, split into fd_ at the end of the tile before.
     constexpr int DST = BK / 16;
     int tyA = ty, txA = tx, ch0A = ch0;
-    float4 rd_[TM][DST][2];
+    // AHEAD2 (round 5; the 64-column layers' kernels, TN >= 2): the direct operand runs TWO tiles ahead -- tile kt + 2 is
+    // loaded during tile kt into the register set tile kt left, and the split of tile kt + 1 (loaded a whole tile
+    // earlier: landed) can be dealt out between the MFMAs from the first one on.  One tile ahead, the split waits for
+    // loads issued at the top of the SAME tile: hipcc then clusters the first ~15 MFMAs of a tile without vector work
+    // and the last ~20 with seven vector instructions each (profiles/r05/ring_conv_evidence.md).  + 16 registers: only
+    // where the kernel is not at a register cliff (the 128 x 32 kernels lost a resident wave to it in round 2).
+    // MEASURED (profiles/r05/ahead2_ab.txt, same box, two rounds): conv 2 / conv 3 forward 34.0 / 35.9 -> 36.9 / 39.1 us,
+    // conv 3 data gradient 37.3 -> 38.8, bench line 343.5 -> 332.7 k env-steps/s.  OFF; kept as a switch for the record.
+    constexpr bool AHEAD2 = ARL_AHEAD2 && ADIR && !U8 && TM * TN >= 2;
+    constexpr int NRD = AHEAD2 ? 2 : 1;
+    float4 rd_[NRD][TM][DST][2];
     unsigned rd8_[TM][DST][2];
     u32x4 fd_[2][TM][DST][3];
     auto issue_A = [&](auto rs_c) {
@@ -888,13 +902,14 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         }
         const unsigned soffA = (unsigned)(step * (tyA * Ws + txA) * Cs + ch0A - g.dmin) << 2;
         const int bit = tyA * taps_x + txA;
+        constexpr int rr = AHEAD2 ? rs : 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const unsigned off = HAS_PAD ? mask_off(imaskD[i], bit, voffD[i]) : voffD[i];
 #pragma unroll
             for (int ks = 0; ks < DST; ++ks) {
-                rd_[i][ks][0] = buf_ld4s(rsA, off + ks * 64, soffA);
-                rd_[i][ks][1] = buf_ld4s(rsA, off + ks * 64 + 16, soffA);
+                rd_[rr][i][ks][0] = buf_ld4s(rsA, off + ks * 64, soffA);
+                rd_[rr][i][ks][1] = buf_ld4s(rsA, off + ks * 64 + 16, soffA);
             }
         }
     };
@@ -925,7 +940,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int ks = 0; ks < DST; ++ks) {
-                    const float4 q0 = rd_[i][ks][0], q1 = rd_[i][ks][1];
+                    const float4 q0 = rd_[AHEAD2 ? rs : 0][i][ks][0], q1 = rd_[AHEAD2 ? rs : 0][i][ks][1];
                     unsigned h[4], m[4], l[4];
                     split_pair(q0.x, q0.y, h[0], m[0], l[0]);
                     split_pair(q0.z, q0.w, h[1], m[1], l[1]);
@@ -1219,12 +1234,14 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             if constexpr (ADIR) issue_A(C1{});
             issue_loads(kbeg, 1);
             if (nk > 1) { next_tile(); issue_loads(kbeg + BK, 0); }
+            if constexpr (AHEAD2) { if (nk > 1) { next_tile_A(); issue_A(C0{}); } }      // tile 1
             store_tiles(1, 1);
             if constexpr (ADIR) split_A(C1{});
         } else {
             if constexpr (ADIR) issue_A(C0{});
             issue_loads(kbeg, 0);
             next_tile(); issue_loads(kbeg + BK, 1);
+            if constexpr (AHEAD2) { next_tile_A(); issue_A(C1{}); }                       // tile 1 (nk >= 2)
             store_tiles(0, 0);
             if constexpr (ADIR) split_A(C0{});
         }
@@ -1236,7 +1253,8 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         // the LDS stores out between the MFMAs, where they cost nothing (tools/mfma_bf16_mix.hip: 4-6 per MFMA are free).
         constexpr int NPROD = PA == 1 ? 3 : SPLIT;
         constexpr int NM = TM * TN * NPROD * STEPS;                                     // MFMAs per k-tile and wave
-        constexpr int NV = RA * (U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44);   // the split's vector instructions
+        constexpr int NV = RA * (U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44)    // the split's vector instructions
+                           + (AHEAD2 ? TM * DST * 44 : 0);                           // (+ the direct operand's, where it can start at once)
         constexpr int NW = RA * PA + (B_KC ? RB * 3 : (RB / 2) * 3);                    // its LDS stores
         constexpr int VPM = (NV + NM - 1) / NM < 6 ? (NV + NM - 1) / NM : 6;
         constexpr int WEV = NM / NW > 0 ? NM / NW : 1;
@@ -1246,7 +1264,25 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                 next_tile();
                 issue_loads(kbeg + (kt + 2) * BK, buf);
             }
-            if constexpr (ADIR) {                       // tile kt + 1 of the direct operand
+            if constexpr (AHEAD2) {                     // tile kt + 2 of the direct operand -> the set tile kt has left
+                if (kt + 2 < nk) {
+                    next_tile_A();
+                    issue_A(buf_c);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_steps(buf_c, C0{}, CS_{});
+                store_tiles(buf ^ 1, buf ^ 1);
+                split_A(std::integral_constant<int, (buf ^ 1)>{});     // tile kt + 1: loaded during tile kt - 1
+                __builtin_amdgcn_sched_group_barrier(0x100, STEPS * TN * 3, 0);
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    if (m % WEV == WEV - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                __syncthreads();
+                return;
+            } else if constexpr (ADIR) {                // tile kt + 1 of the direct operand
                 next_tile_A();
                 issue_A(std::integral_constant<int, (buf ^ 1)>{});
                 __builtin_amdgcn_sched_barrier(0);
