@@ -43,11 +43,11 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
     l = hi_pair(lo_part(r0), lo_part(r1));
 }
 
-constexpr int BM = 128, BN = 64, BK = 32;
-constexpr int A_BYTES = BM * BK * 4;            // 16 KB: [row][128 B], 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7)
+constexpr int BN = 64, BK = 32;
 constexpr int W_PLANE = BN * BK * 2;            // 4 KB:  [col][64 B],  16-byte chunk q of col n at slot q ^ ((n >> 2) & 3)
 constexpr int W_BYTES = 3 * W_PLANE;
-constexpr int SLOT = A_BYTES + W_BYTES;         // 28 KB
+constexpr int a_bytes(int cw) { return 32 * cw * BK * 4; }      // [row][128 B], 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7)
+constexpr int slot_bytes(int cw) { return a_bytes(cw) + W_BYTES; }   // 28 KB at 4 compute waves, 44 KB at 8
 #ifndef DMA_PER_UNIT_
 #define DMA_PER_UNIT_ 7
 #endif
@@ -79,12 +79,25 @@ __global__ void wprep_ring_kernel(const float* w, char* img, int K) {
 // unit range of workgroup g of G: [g * U / G, (g + 1) * U / G)
 __host__ __device__ inline int unit_begin(int g, int G, int U) { return (int)(((long long)g * U) / G); }
 
-template <int C, int KH, int KW, int STRIDE, int PAD, int S, bool BUFDMA, int KO = 0>
-__global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
+// FLAGS: no workgroup barrier in the main loop.  The ring is a producer / consumer queue on LDS counters: ready[slot]
+// counts loader-wave arrivals (4 per unit), done[slot] compute-wave releases (CW per unit); a compute wave checks the
+// counter of the NEXT unit half a unit before it reads it (the check's LDS read rides with the fragment reads), a loader
+// wave spins (s_sleep) until the slot it is about to refill has been released by every compute wave.  With a barrier per
+// unit the waves of a workgroup stay in phase: the two compute waves of a SIMD then reach their pipeline fill / drain
+// together and the matrix pipe idles ~800 of every 3 100 cycles (KO "no barrier": 2 300).
+template <int C, int KH, int KW, int STRIDE, int PAD, int S, bool BUFDMA, int KO = 0, int CW = 4, bool FLAGS = false>
+__global__ __launch_bounds__(64 * (CW + 4)) void ring_conv_kernel(const RingArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    volatile unsigned* const ctrl = reinterpret_cast<volatile unsigned*>(lds + S * slot_bytes(CW));   // ready[S], done[S]
+    if (FLAGS) {
+        if (threadIdx.x < 2 * S) ctrl[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    constexpr int BM = 32 * CW, A_BYTES = a_bytes(CW), SLOT = slot_bytes(CW), NAP = CW;   // NAP: A pieces per loader wave
+    static_assert(CW == 4 || CW == 8, "4 compute waves (one per SIMD) or 8 (two)");
     constexpr int CB = C / BK;                          // k-tiles per filter tap
     constexpr int D = S - 1;                            // k-tiles the loaders run ahead
-    constexpr int DMA_PER_UNIT = (KO & 16) ? 3 : (KO & 32) ? 4 : 7;   // per loader wave: 4 pieces of the gathered operand, 3 of the weights
+    constexpr int DMA_PER_UNIT = (KO & 16) ? 3 : (KO & 32) ? CW : CW + 3;   // per loader wave: CW pieces of the gathered operand, 3 of the weights
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -94,20 +107,20 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
     unsigned long long t0 = 0, t1 = 0;
     if (a.trace) t0 = __builtin_readcyclecounter();
 
-    if (wave >= 4) {
+    if (wave >= CW) {
         if (KO & 2048) return;                           // (with KO 1: the compute waves have the CU to themselves)
         // ================================================================ loaders
-        const int L = wave - 4;
+        const int L = wave - CW;
         const int sub = lane >> 3;                      // row within an 8-row piece
         const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.wimg), 0, (unsigned)(KT * W_BYTES), 0x00020000);
         int cur_tile = -1;
-        int rbase[4];                                   // element offset of the row's tap origin (may be negative)
-        unsigned vmask[4];                              // bit ty * KW + tx set = tap inside the image
+        int rbase[NAP];                                 // element offset of the row's tap origin (may be negative)
+        unsigned vmask[NAP];                            // bit ty * KW + tx set = tap inside the image
         auto decode = [&](int tile) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 32 * L + 8 * i + sub, m = tile * BM + row;
+            for (int i = 0; i < NAP; ++i) {
+                const int row = 8 * NAP * L + 8 * i + sub, m = tile * BM + row;
                 const int b = m / (a.OH * a.OW), r = m - b * (a.OH * a.OW), oy = r / a.OW, ox = r - oy * a.OW;
                 const int y0 = oy * STRIDE - PAD, x0 = ox * STRIDE - PAD;
                 rbase[i] = ((b * a.H + y0) * a.W + x0) * C;
@@ -126,11 +139,11 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
             char* slot = lds + (j % S) * SLOT;
             if (KO & 4) return;
 #pragma unroll
-            for (int i = 0; i < ((KO & 16) ? 0 : 4); ++i) {
-                const int row = 32 * L + 8 * i + sub;
+            for (int i = 0; i < ((KO & 16) ? 0 : NAP); ++i) {
+                const int row = 8 * NAP * L + 8 * i + sub;
                 const int chunk = (lane & 7) ^ ((row >> 1) & 7);
                 const bool ok = (vmask[i] >> tap) & 1;
-                char* dst = slot + (32 * L + 8 * i) * 128;
+                char* dst = slot + (8 * NAP * L + 8 * i) * 128;
                 if constexpr (BUFDMA) {                  // out-of-range offset: the hardware's bounds check writes zeros
                     const unsigned off = ok ? (unsigned)(rbase[i] + tap_off + chunk * 4) << 2 : 0x7ffffff0u;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, LDS_PTR(dst), 16, off, 0, 0, 0);
@@ -150,6 +163,25 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
         // the first half of unit it + 1 -- so unit it + 1 must be in the ring when iteration `it` begins, and the slot the
         // loaders refill during iteration `it` is the one of unit it - 1: D = S - 1 units issued ahead, all but the newest
         // one landed at every barrier.
+        if constexpr (FLAGS) {
+            constexpr int Q = 2;                         // units a loader wave keeps in flight
+            for (int j = 0; j < n; ++j) {
+                const int slot_j = j % S;
+                if (j >= S) {                            // every compute wave has released unit j - S
+                    const unsigned need = (unsigned)CW * (unsigned)(j / S);
+                    while (__builtin_amdgcn_readfirstlane(ctrl[S + slot_j]) < need) __builtin_amdgcn_s_sleep(1);
+                }
+                issue(j);
+                if (j >= Q - 1) {                        // unit j - (Q - 1) has landed: say so
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "i"(DMA_PER_UNIT * (Q - 1)) : "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(&ctrl[(j - (Q - 1)) % S]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int j = n - (Q - 1) < 0 ? 0 : n - (Q - 1); j < n; ++j)
+                if (lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(&ctrl[j % S]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return;
+        }
         for (int j = 0; j < D && j < n; ++j) issue(j);
         if (n > D - 1 && D >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(DMA_PER_UNIT * (D - 2)) : "memory");   // units 0, 1 landed
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -174,9 +206,14 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
     const unsigned w_off = (unsigned)A_BYTES + (unsigned)l31 * 64u;
     const unsigned w_swz = (unsigned)((l31 >> 2) & 3);
     float* const slab = a.partial + (size_t)g * (BM * BN);       // this workgroup's partial tile (register layout)
-    unsigned* const my_flag = a.flags + g * 4 + w;
+    unsigned* const my_flag = a.flags + g * 8 + w;
     int pending_flag = -1;                              // iteration after which the published partial's flag goes out
-    if (!(KO & 2048)) __builtin_amdgcn_s_barrier();     // unit 0 is in the ring
+    auto wait_ready = [&](int j) {                      // unit j of this workgroup is in the ring (all four loader waves)
+        const unsigned need = 4u * (unsigned)(j / S + 1);
+        while (__builtin_amdgcn_readfirstlane(ctrl[j % S]) < need) __builtin_amdgcn_s_sleep(0);
+    };
+    if (FLAGS) { if (n > 0) wait_ready(0); }
+    else if (!(KO & 2048)) __builtin_amdgcn_s_barrier();     // unit 0 is in the ring
     if (a.trace) t1 = __builtin_readcyclecounter();
     // Software pipeline over 16-k steps: while the 18 MFMAs of step t run, the fragments of step t + 1 are read (2 + 6
     // ds_read_b128) and its gathered operand is split (44 vector instructions) -- register sets t & 1.
@@ -321,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
                     if (stamp) ts[2 + 2 * i + j] = __builtin_readcyclecounter();
                 }
             if (stamp && g == 0 && w == 0 && lane == 0)
-                for (int q = 0; q < 20; ++q) a.trace[4096 + q] = ts[q];
+                for (int q = 0; q < 20; ++q) a.trace[12288 + q] = ts[q];
             if (KO & 512) {
                 fa[sr][0] = u32x4{__float_as_uint(xs[0]), __float_as_uint(xs[1]), __float_as_uint(xs[2]), __float_as_uint(xs[3])};
                 fa[sr][1] = u32x4{__float_as_uint(xs[4]), __float_as_uint(xs[5]), __float_as_uint(xs[6]), __float_as_uint(xs[7])};
@@ -337,14 +374,17 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
             const char* slot_next = lds + ((it + 1) % S) * SLOT;       // (after the last unit: read, never used)
             if (!(KO & 2)) {
                 step(slot, I1{}, I1{}, I0{});            // MFMAs of step (it, 0); fragments of step (it, 1) read and split
+                if (FLAGS && it + 1 < n) wait_ready(it + 1);
                 step(slot_next, I0{}, I0{}, I1{});       // MFMAs of step (it, 1); fragments of step (it + 1, 0)
+                // every read of unit `it` has been issued (and the LDS serves a wave's operations in order): release its slot
+                if (FLAGS && lane == 0) __hip_atomic_fetch_add(const_cast<unsigned*>(&ctrl[S + it % S]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             if (pending_flag == it) {                    // the partial's stores were issued two iterations ago
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0) __hip_atomic_store(my_flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pending_flag = -1;
             }
-            if (!(KO & 1)) __builtin_amdgcn_s_barrier();
+            if (!FLAGS && !(KO & 1)) __builtin_amdgcn_s_barrier();
         }
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");     // the last MFMA's result (asm: the compiler pads nothing)
         if (!has_head) {
@@ -364,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
             if (!has_tail) {
                 // a head piece (the LAST thing this workgroup computes): the rest of the tile is workgroup g + 1's first
                 // piece -- wait for its flag (set long ago), add its partial sums
-                const unsigned* flag = a.flags + (g + 1) * 4 + w;
+                const unsigned* flag = a.flags + (g + 1) * 8 + w;
                 if (!(KO & 8)) {
                     unsigned spins = 0;
                     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch && ++spins < (1u << 24))
@@ -416,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void ring_conv_kernel(const RingArgs a) {
         if (lane == 0) __hip_atomic_store(my_flag, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (a.trace && lane == 0) {
-        unsigned long long* t = a.trace + ((size_t)g * 4 + w) * 4;
+        unsigned long long* t = a.trace + ((size_t)g * CW + w) * 4;
         t[0] = t0; t[1] = t1; t[2] = __builtin_readcyclecounter(); t[3] = n;
     }
 }
@@ -442,46 +482,48 @@ __global__ void ref_conv_kernel(const float* x, const float* w, const float* bia
 }
 
 template <typename K>
-float run(K k, const char* what, RingArgs a, int grid, size_t lds_bytes, int reps, unsigned* epoch) {
+float run(K k, const char* what, RingArgs a, int grid, size_t lds_bytes, int reps, unsigned* epoch, int threads = 512) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) { a.epoch = ++*epoch; hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_bytes, 0, a); }
+    for (int i = 0; i < 3; ++i) { a.epoch = ++*epoch; hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds_bytes, 0, a); }
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; ++i) { a.epoch = ++*epoch; hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_bytes, 0, a); }
+    for (int i = 0; i < reps; ++i) { a.epoch = ++*epoch; hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds_bytes, 0, a); }
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     // one more launch with per-wave timestamps
     static unsigned long long* dtr = nullptr;
-    if (!dtr) CK(hipMalloc(&dtr, (size_t)8192 * 8));
-    CK(hipMemset(dtr, 0, 8192 * 8));
+    if (!dtr) CK(hipMalloc(&dtr, (size_t)16384 * 8));
+    CK(hipMemset(dtr, 0, 16384 * 8));
     RingArgs at = a; at.trace = dtr; at.epoch = ++*epoch;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds_bytes, 0, at);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(threads), lds_bytes, 0, at);
     CK(hipDeviceSynchronize());
-    std::vector<unsigned long long> tr((size_t)grid * 16);
-    CK(hipMemcpy(tr.data(), dtr, (size_t)grid * 16 * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> tr((size_t)grid * 32);
+    CK(hipMemcpy(tr.data(), dtr, (size_t)grid * 32 * 8, hipMemcpyDeviceToHost));
     double pro = 0, loop = 0, units = 0; unsigned long long first = ~0ull, last = 0;
-    for (int i = 0; i < grid * 4; ++i) {
+    const int cw = threads / 64 - 4;
+    for (int i = 0; i < grid * cw; ++i) {
         pro += tr[4 * i + 1] - tr[4 * i]; loop += tr[4 * i + 2] - tr[4 * i + 1]; units += tr[4 * i + 3];
         if (tr[4 * i] < first) first = tr[4 * i];
         if (tr[4 * i + 2] > last) last = tr[4 * i + 2];
     }
     {
         std::vector<unsigned long long> st(20);
-        CK(hipMemcpy(st.data(), dtr + 4096, 20 * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(st.data(), dtr + 12288, 20 * 8, hipMemcpyDeviceToHost));
         if (st[0]) {
             printf("      step timeline (cycles since the top): reads issued %llu |", st[1] - st[0]);
             for (int q = 2; q < 20; ++q) printf(" %llu", st[q] - st[0]);
             printf("\n");
         }
     }
-    printf("%-58s %7.2f us | per compute wave: %6.0f cycles to the first unit, loop %6.0f = %5.0f per k-tile\n", what, ms / reps * 1e3,
-           pro / (grid * 4), loop / (grid * 4), loop / units);
+    printf("%-62s %7.2f us | per compute wave: %6.0f cycles to the first unit, loop %6.0f = %5.0f per k-tile\n", what, ms / reps * 1e3,
+           pro / (grid * cw), loop / (grid * cw), loop / units);
     return ms / reps * 1e3f;
 }
 
-template <int C, int KH, int KW, int STRIDE, int PAD>
+template <int C, int KH, int KW, int STRIDE, int PAD, int CW>
 void layer(const char* name, int n_img, int H, int W, int reps) {
+    constexpr int BM = 32 * CW;
     const int N = 64, OH = (H + 2 * PAD - KH) / STRIDE + 1, OW = (W + 2 * PAD - KW) / STRIDE + 1, K = KH * KW * C;
     const size_t nx = (size_t)n_img * H * W * C, ny = (size_t)n_img * OH * OW * N, nw = (size_t)N * K;
     std::vector<float> hx(nx), hw(nw), hb(N);
@@ -493,8 +535,8 @@ void layer(const char* name, int n_img, int H, int W, int reps) {
     const int cus = 256;
     CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&db, N * 4)); CK(hipMalloc(&dy, ny * 4));
     CK(hipMalloc(&dref, ny * 8)); CK(hipMalloc(&dimg, (size_t)(K / BK) * W_BYTES)); CK(hipMalloc(&dzero, 256));
-    CK(hipMalloc(&dpart, (size_t)(cus + 1) * BM * BN * 4)); CK(hipMalloc(&dflags, (cus + 1) * 4 * 4));
-    CK(hipMemset(dzero, 0, 256)); CK(hipMemset(dflags, 0, (cus + 1) * 4 * 4));
+    CK(hipMalloc(&dpart, (size_t)(cus + 1) * 256 * BN * 4)); CK(hipMalloc(&dflags, (cus + 1) * 8 * 4));
+    CK(hipMemset(dzero, 0, 256)); CK(hipMemset(dflags, 0, (cus + 1) * 8 * 4));
     CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
@@ -508,8 +550,8 @@ void layer(const char* name, int n_img, int H, int W, int reps) {
     // every workgroup needs at least one whole tile's worth of units (a tile is then cut at most once)
     int grid = cus;
     while (grid > 1 && a.n_units / grid < a.kt_per_tile) --grid;
-    printf("== %s, %d images: M %d (%d tiles), K %d (%d k-tiles per tile), %d units = %.2f per workgroup on %d workgroups; %.2f GF fp32 (x9 bf16)\n",
-           name, n_img, a.M, a.n_tiles, K, a.kt_per_tile, a.n_units, a.n_units / (double)grid, grid, 2.0 * a.M * N * K * 1e-9);
+    printf("== %s, %d compute waves per workgroup, %d images: M %d (%d tiles), K %d (%d k-tiles per tile), %d units = %.2f per workgroup on %d workgroups; %.2f GF fp32 (x9 bf16)\n",
+           name, CW, n_img, a.M, a.n_tiles, K, a.kt_per_tile, a.n_units, a.n_units / (double)grid, grid, 2.0 * a.M * N * K * 1e-9);
     unsigned epoch = 0;
     auto check = [&](const char* tag, float us) {
         std::vector<float> hy(ny); std::vector<double> href(ny);
@@ -526,39 +568,40 @@ void layer(const char* name, int n_img, int H, int W, int reps) {
                tag, worst, big, bad, ny, bad ? "FAIL" : "ok", 2.0 * a.M * N * K / us * 1e-6, 18.0 * a.M * N * K / us * 1e-6);
     };
     float us;
+    const int threads = 64 * (CW + 4);
+    constexpr int SLOT = slot_bytes(CW);
+#define VAR(S_, BUF_, KO_) ring_conv_kernel<C, KH, KW, STRIDE, PAD, S_, BUF_, KO_, CW>
+#define VARF(S_, KO_) ring_conv_kernel<C, KH, KW, STRIDE, PAD, S_, true, KO_, CW, true>
+    if (CW == 4) {
+        CK(hipMemset(dy, 0xff, ny * 4));
+        us = run(VAR(4, false, 0), "ring 4 slots, global_load_lds + zero page", a, grid, 4 * SLOT, reps, &epoch, threads);
+        check("S=4 global", us);
+        CK(hipMemset(dy, 0xff, ny * 4));
+        us = run(VAR(4, true, 0), "ring 4 slots, buffer_load lds (bounds check = padding)", a, grid, 4 * SLOT, reps, &epoch, threads);
+        check("S=4 buffer", us);
+    }
     CK(hipMemset(dy, 0xff, ny * 4));
-    us = run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, false>, "ring 4 slots, global_load_lds + zero page", a, grid, 4 * SLOT, reps, &epoch);
-    check("S=4 global", us);
-    CK(hipMemset(dy, 0xff, ny * 4));
-    us = run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true>, "ring 4 slots, buffer_load lds (bounds check = padding)", a, grid, 4 * SLOT, reps, &epoch);
-    check("S=4 buffer", us);
-    CK(hipMemset(dy, 0xff, ny * 4));
-    us = run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 5, true>, "ring 5 slots, buffer_load lds", a, grid, 5 * SLOT, reps, &epoch);
-    check("S=5 buffer", us);
-    CK(hipMemset(dy, 0xff, ny * 4));
-    us = run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 3, true>, "ring 3 slots, buffer_load lds", a, grid, 3 * SLOT, reps, &epoch);
+    us = run(VAR(3, true, 0), "ring 3 slots, buffer_load lds", a, grid, 3 * SLOT, reps, &epoch, threads);
     check("S=3 buffer", us);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 1>, "   KO: no barrier (results wrong)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 2>, "   KO: no LDS reads / split / MFMAs (loaders alone)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4>, "   KO: no DMA (compute alone, results wrong)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 8>, "   KO: no flag wait (results may be wrong)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4 + 256 + 512>, "   KO: no DMA, MFMAs only (no LDS reads, no split)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4 + 512>, "   KO: no DMA, LDS reads + MFMAs (no split)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4 + 256>, "   KO: no DMA, split + MFMAs (no LDS reads)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4 + 1024>, "   KO: no DMA, LDS reads + split (no MFMAs)", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4 + 256 + 512 + 1>, "   KO: no DMA, MFMAs only, no barrier", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4 + 256 + 512 + 1 + 2048>, "   KO: MFMAs only, no barrier, loader waves exit at once", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4 + 1 + 2048>, "   KO: compute alone, no barrier, loader waves exit at once", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4096>, "   stamped: full kernel", a, grid, 4 * SLOT, 3, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4096 + 4 + 1 + 2048>, "   stamped: compute alone, no barrier, loaders exit", a, grid, 4 * SLOT, 3, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4096 + 4 + 1 + 2048 + 256>, "   stamped: ... no LDS reads", a, grid, 4 * SLOT, 3, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 4096 + 4 + 1 + 2048 + 512>, "   stamped: ... no split", a, grid, 4 * SLOT, 3, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 2 + 16>, "   KO: loaders alone, weights only", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 2 + 32>, "   KO: loaders alone, gathered operand only", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 2 + 64>, "   KO: loaders alone, eight L2-hot tiles", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, true, 2 + 32 + 64>, "   KO: loaders alone, gathered operand only, L2-hot", a, grid, 4 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 5, true, 2 + 32>, "   KO: loaders alone, gathered operand only, 5 slots", a, grid, 5 * SLOT, reps, &epoch);
-    run(ring_conv_kernel<C, KH, KW, STRIDE, PAD, 4, false, 2 + 32>, "   KO: loaders alone, gathered operand only, global_load_lds", a, grid, 4 * SLOT, reps, &epoch);
+    CK(hipMemset(dy, 0xff, ny * 4));
+    us = run(VARF(3, 0), "ring 3 slots, LDS counters instead of barriers", a, grid, 3 * SLOT + 64, reps, &epoch, threads);
+    check("S=3 flags", us);
+    if (CW == 4) {
+        CK(hipMemset(dy, 0xff, ny * 4));
+        us = run(VARF(4, 0), "ring 4 slots, LDS counters instead of barriers", a, grid, 4 * SLOT + 64, reps, &epoch, threads);
+        check("S=4 flags", us);
+        CK(hipMemset(dy, 0xff, ny * 4));
+        us = run(VARF(5, 0), "ring 5 slots, LDS counters instead of barriers", a, grid, 5 * SLOT + 64, reps, &epoch, threads);
+        check("S=5 flags", us);
+    }
+    run(VAR(3, true, 1), "   KO: no barrier (results wrong)", a, grid, 3 * SLOT, reps, &epoch, threads);
+    run(VAR(3, true, 2), "   KO: no LDS reads / split / MFMAs (loaders alone)", a, grid, 3 * SLOT, reps, &epoch, threads);
+    run(VAR(3, true, 4), "   KO: no DMA (compute alone, results wrong)", a, grid, 3 * SLOT, reps, &epoch, threads);
+    run(VAR(3, true, 4 + 1 + 2048), "   KO: compute alone, no barrier, loader waves exit at once", a, grid, 3 * SLOT, reps, &epoch, threads);
+    run(VAR(3, true, 4 + 256 + 512 + 1 + 2048), "   KO: MFMAs only, no barrier, loader waves exit at once", a, grid, 3 * SLOT, reps, &epoch, threads);
+    run(VAR(3, true, 4 + 1024), "   KO: no DMA, LDS reads + split (no MFMAs)", a, grid, 3 * SLOT, reps, &epoch, threads);
+#undef VAR
+#undef VARF
     CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dy)); CK(hipFree(dref)); CK(hipFree(dimg)); CK(hipFree(dzero));
     CK(hipFree(dpart)); CK(hipFree(dflags));
 }
@@ -566,7 +609,9 @@ void layer(const char* name, int n_img, int H, int W, int reps) {
 int main(int argc, char** argv) {
     const int n_img = argc > 1 ? atoi(argv[1]) : 512;
     const int reps = argc > 2 ? atoi(argv[2]) : 50;
-    layer<32, 4, 4, 2, 1>("conv2 fwd (25x19x32 -> 12x9x64, 4x4 s2 p1)", n_img, 25, 19, reps);
-    layer<64, 3, 3, 1, 1>("conv3 fwd (12x9x64 -> 12x9x64, 3x3 s1 p1)", n_img, 12, 9, reps);
+    layer<32, 4, 4, 2, 1, 4>("conv2 fwd (25x19x32 -> 12x9x64, 4x4 s2 p1)", n_img, 25, 19, reps);
+    layer<32, 4, 4, 2, 1, 8>("conv2 fwd (25x19x32 -> 12x9x64, 4x4 s2 p1)", n_img, 25, 19, reps);
+    layer<64, 3, 3, 1, 1, 4>("conv3 fwd (12x9x64 -> 12x9x64, 3x3 s1 p1)", n_img, 12, 9, reps);
+    layer<64, 3, 3, 1, 1, 8>("conv3 fwd (12x9x64 -> 12x9x64, 3x3 s1 p1)", n_img, 12, 9, reps);
     return 0;
 }
