@@ -24,6 +24,9 @@
 #pragma once
 #include "arl_optim_dev.h"
 
+#ifndef ARL_PIN_ARGS
+#define ARL_PIN_ARGS 1      // development switch (A/B builds); see pin_gemm_args
+#endif
 #ifndef ARL_AHEAD2
 #define ARL_AHEAD2 0        // development switch (A/B builds: ARL_HIPCC_FLAGS=-DARL_AHEAD2=1); measured SLOWER, see igemm_body
 #endif
@@ -99,6 +102,14 @@ struct GemmArgs {
     } par[4];
 };
 
+// Kernel arguments in ONE round trip.  hipcc loads a by-value argument struct lazily, field by field, in whichever basic
+// block first needs it, each s_load followed by its own s_waitcnt: the prologue of igemm_split_kernel made ten dependent
+// trips to the kernarg segment (~250-950 cycles each inside a hipGraph: tools/proto/kernarg_probe.hip) before it issued its
+// first operand load -- 3 000-3 600 of a 5 400-cycle prologue (tools/prologue_stamps.py).  Naming the scalars a prologue
+// needs in one empty asm statement at the top makes the compiler fetch them all at once (one batch of s_loads, one wait).
+#define ARL_ARG1(x) asm volatile("" :: "s"(x))
+__device__ __forceinline__ void pin_gemm_args(const struct GemmArgs& a);
+
 // XCD-aware placement.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, each with its own
 // 4 MB L2: tiles that share an operand panel (the column tiles of one weight-gradient split, the 64 tiles of one
 // forward split of a dense layer, the row tiles over one weight panel) and therefore have neighbouring ids end up on
@@ -108,6 +119,17 @@ struct GemmArgs {
 __device__ __forceinline__ int xcd_chunk(int id, int n) {
     const int q = n >> 3, r = n & 7, x = id & 7, j = id >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+__device__ __forceinline__ void pin_gemm_args(const GemmArgs& a) {
+    asm volatile("" :: "s"(a.g.src), "s"(a.g.src_bytes), "s"(a.g.Hs), "s"(a.g.Ws), "s"(a.g.Cs), "s"(a.g.out_h), "s"(a.g.out_w),
+                 "s"(a.g.mul), "s"(a.g.add_y), "s"(a.g.add_x), "s"(a.g.taps_x), "s"(a.g.step), "s"(a.g.taps_y), "s"(a.g.rmin),
+                 "s"(a.g.dmin), "s"(a.g.origin), "s"(a.g.mg_w), "s"(a.g.mg_h));
+    asm volatile("" :: "s"(a.b.w), "s"(a.b.w_bytes), "s"(a.b.ld), "s"(a.b.kc), "s"(a.b.taps_x), "s"(a.b.i0), "s"(a.b.j0),
+                 "s"(a.b.si), "s"(a.b.kw), "s"(a.b.c));
+    asm volatile("" :: "s"(a.o.out), "s"(a.o.bias), "s"(a.o.mask), "s"(a.o.out_bytes), "s"(a.o.relu), "s"(a.o.dense), "s"(a.o.OH),
+                 "s"(a.o.OW), "s"(a.o.omul), "s"(a.o.oadd_y), "s"(a.o.oadd_x), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.k_per_split),
+                 "s"(a.split_stride), "s"(a.trace), "s"(a.n_par), "s"(a.xcd));
 }
 
 // Hardware-bounds-checked 16-byte loads: a raw buffer load whose byte offset lies outside
@@ -769,6 +791,9 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     const int kend = (kbeg + a.k_per_split < a.K) ? kbeg + a.k_per_split : a.K;
     const int Cs = g.Cs, taps_x = g.taps_x, Ws = g.Ws, step = g.step;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0, rt0 = 0;
+#ifdef ARL_PROLOGUE_STAMPS
+    unsigned long long st_a = 0, st_b = 0;
+#endif
     if (a.trace) { tr0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     // descriptor origins: the smallest element offset a valid (row, tap) pair can produce
     const __amdgpu_buffer_rsrc_t rsA = U8 ? make_rsrc(reinterpret_cast<const float*>(g.src8), g.src_bytes)
@@ -1230,20 +1255,29 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     using CS_ = std::integral_constant<int, STEPS>;
     if constexpr (SP) {
         // tile j: register set and LDS stage (j + nk) & 1 (the loop ends on stage 1)
+#ifdef ARL_PROLOGUE_STAMPS      // development: where a workgroup's prologue goes (tools/prologue_stamps.py, t[6] / t[7])
+#define ARL_STAMP(x) do { if (a.trace) { __builtin_amdgcn_sched_barrier(0); x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define ARL_STAMP(x) do { } while (0)
+#endif
         if (nk & 1) {                                   // uniform
             if constexpr (ADIR) issue_A(C1{});
             issue_loads(kbeg, 1);
             if (nk > 1) { next_tile(); issue_loads(kbeg + BK, 0); }
             if constexpr (AHEAD2) { if (nk > 1) { next_tile_A(); issue_A(C0{}); } }      // tile 1
+            ARL_STAMP(st_a);
             store_tiles(1, 1);
             if constexpr (ADIR) split_A(C1{});
+            ARL_STAMP(st_b);
         } else {
             if constexpr (ADIR) issue_A(C0{});
             issue_loads(kbeg, 0);
             next_tile(); issue_loads(kbeg + BK, 1);
             if constexpr (AHEAD2) { next_tile_A(); issue_A(C1{}); }                       // tile 1 (nk >= 2)
+            ARL_STAMP(st_a);
             store_tiles(0, 0);
             if constexpr (ADIR) split_A(C0{});
+            ARL_STAMP(st_b);
         }
         __syncthreads();
         if (a.trace) tr1 = __builtin_readcyclecounter();
@@ -1384,8 +1418,14 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         unsigned long long* t = a.trace + ((size_t)(bz * gridDim.y + by) * gridDim.x + bx) * 8;     // plain launches only
         t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_readcyclecounter();
         t[4] = rt0; t[5] = __builtin_amdgcn_s_memrealtime();
+#ifdef ARL_PROLOGUE_STAMPS
+        if constexpr (SP) { t[6] = st_a; t[7] = st_b; }
+        else
+#endif
+        {
         t[6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
         t[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+        }
     }
 }
 
@@ -1406,6 +1446,9 @@ template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool MULTI_TAP, b
           bool CORUN = false, bool ADIR = false>
 __global__ __launch_bounds__(256, MINW) void igemm_split_kernel(const GemmArgs a, const arl::OptSeg c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#if ARL_PIN_ARGS
+    pin_gemm_args(a);
+#endif
     int bx = blockIdx.x;
     if constexpr (CORUN) {
         if (bx < c.co_blocks) {
