@@ -793,6 +793,18 @@ def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, t
     return out
 
 
+STALL_MARKER = os.path.join(os.environ.get("TMPDIR", "/tmp"), "arl_bench_sync_graph_stalled")
+
+
+def stalled_before(max_age_s=6 * 3600):
+    """An earlier multi-rank run on this node stalled with its collectives captured (the watchdog's note, above)."""
+    try:
+        with open(STALL_MARKER) as f:
+            return time.time() - int(f.read().split()[0]) < max_age_s
+    except (OSError, ValueError, IndexError):
+        return False
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, as the
     reference's runner forks its n-1 workers from one process (accel_rl/runners/multigpu_rl_base.py:20-45): this command
@@ -924,6 +936,15 @@ def main():
             while True:
                 time.sleep(min(5.0, limit / 4))
                 if time.time() - progress["t"] > limit:
+                    # Leave a note for the NEXT run on this node: the driver launches N = 2, 4, 8 back to back under its
+                    # own torch.distributed.run (no supervising parent to retry for it) -- a stall while the collectives
+                    # are captured costs this run its line, but the following runs take the eager path by themselves.
+                    if progress["graph_collectives"] and os.environ.get("ARL_SYNC_GRAPH") != "0":
+                        try:
+                            with open(STALL_MARKER, "w") as f:
+                                f.write("%d %d %s\n" % (int(time.time()), world, progress["phase"]))
+                        except OSError:
+                            pass
                     sys.stderr.write("bench.py rank %d: no progress for %.0f s in %s of step %d (graph_collectives=%s, backend=%s); "
                                      "ARL_SYNC_GRAPH=0 runs the collectives eagerly\n" %
                                      (rank, limit, progress["phase"], progress["itr"], progress["graph_collectives"],
@@ -936,6 +957,9 @@ def main():
     device = torch.device("cuda", 0 if os.environ.get("ARL_BENCH_ONE_GPU") == "1" else local)
     torch.cuda.set_device(device)
     backend = None
+    if world > 1 and "ARL_SYNC_GRAPH" not in os.environ and stalled_before():
+        os.environ["ARL_SYNC_GRAPH"] = "0"
+        os.environ.setdefault("ARL_BENCH_GRAPH_FALLBACK", "eager after a capture stall in an earlier run on this node")
     if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

@@ -103,13 +103,15 @@ def test_strong_scaling_mode_splits_the_job():
 
 
 @pytest.mark.gpu
-def test_a_hung_capture_still_yields_one_line_on_eager_collectives():
+def test_a_hung_capture_still_yields_one_line_on_eager_collectives(tmp_path):
     """The first multi-GPU node this code meets may hang in the capture of its collectives instead of throwing
     (DESIGN 7).  Injected here: the last rank never arrives at its third learner call.  The ranks' watchdogs end the
-    attempt (exit 3), the supervisor re-runs once with ARL_SYNC_GRAPH=0, and ONE line comes out that says so."""
+    attempt (exit 3), the supervisor re-runs once with ARL_SYNC_GRAPH=0, and ONE line comes out that says so.  The
+    watchdog also leaves a note on the node, so that a run started by a LAUNCHER afterwards (the driver's N = 4, 8 after
+    a failed N = 2: no supervising parent) takes the eager path by itself."""
     out = _run(["--gpus", "2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-roofline"],
                dict(ARL_BENCH_ONE_GPU="1", ARL_BENCH_BACKEND="gloo", ARL_BENCH_INJECT="capture_hang",
-                    ARL_BENCH_STALL_S="25"), timeout=900)
+                    ARL_BENCH_STALL_S="25", TMPDIR=str(tmp_path)), timeout=900)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     assert "no progress for 25 s in learner (injected capture hang)" in out.stderr
     assert out.stderr.count("retrying once with eager collectives") == 1
@@ -118,6 +120,19 @@ def test_a_hung_capture_still_yields_one_line_on_eager_collectives():
     assert d["multi_gpu"]["graph_captured"] is False
     assert d["multi_gpu"]["params_bit_identical_across_ranks"] is True
     assert d["n_gpus"] == 2 and d["value"] > 0
+    assert os.path.exists(os.path.join(str(tmp_path), "arl_bench_sync_graph_stalled"))
+    # the driver's launch shape, after the stall: torch.distributed.run around bench.py, nothing injected
+    env = dict(os.environ, ARL_BENCH_ONE_GPU="1", ARL_BENCH_BACKEND="gloo", TMPDIR=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ARL_SYNC_GRAPH"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-roofline"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    d = _line(out)
+    assert d["graph_fallback"] == "eager after a capture stall in an earlier run on this node"
+    assert d["multi_gpu"]["graph_captured"] is False and d["multi_gpu"]["params_bit_identical_across_ranks"] is True
 
 
 @pytest.mark.gpu
