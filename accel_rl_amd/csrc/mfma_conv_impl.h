@@ -27,6 +27,9 @@
 #ifndef ARL_PIN_ARGS
 #define ARL_PIN_ARGS 1      // development switch (A/B builds); see pin_gemm_args
 #endif
+#ifndef ARL_WGRAD_INTERLEAVE
+#define ARL_WGRAD_INTERLEAVE 1   // development switch (A/B builds); see wgrad_fast_body's k_tile
+#endif
 #ifndef ARL_AHEAD2
 #define ARL_AHEAD2 0        // development switch (A/B builds: ARL_HIPCC_FLAGS=-DARL_AHEAD2=1); measured SLOWER, see igemm_body
 #endif
@@ -1728,13 +1731,121 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     __syncthreads();
     if (a.trace) tr1 = __builtin_readcyclecounter();
     // one k-tile with a compile-time buffer index (as in igemm_body: no vector address math between MFMAs)
-    auto k_tile = [&](auto buf_c, int kt) {
+    // Split products (round 5): the next tile's split (88 vector instructions + 6 LDS stores per thread) is dealt out
+    // BETWEEN this tile's MFMAs -- it runs on the vector unit while the matrix pipe works, where the fp32-MFMA route
+    // (which shares the vector unit's issue) wants it fenced behind them.  With the fence hipcc emitted, per wave and
+    // k-tile: 12 reads, 9 MFMAs, 12 reads, 9 MFMAs, THEN the whole split, THEN the barrier.  Needs the tile loop without
+    // a branch between the MFMAs and the stores: tiles 0 .. nk - 2 (LAST = false) always stage their successor.
+    constexpr bool WIL = SP && ARL_WGRAD_INTERLEAVE && TM * TN == 1;   // (the 128 x 128 pair kernels run out of registers)
+    auto k_tile = [&](auto buf_c, int kt, auto last_c) __attribute__((always_inline)) {
         constexpr int buf = decltype(buf_c)::value;
-        if (kt + 1 < nk) issue_loads(kt + 1);
+        constexpr bool LAST = decltype(last_c)::value;
+        if (WIL ? !LAST : kt + 1 < nk) issue_loads(kt + 1);
         // tile kt+1 was the last reader of group (kt+1)/T when it is that group's last tile; the
         // slot is rewritten (group + 2) one iteration later, after this iteration's barrier.
         if (kt % TILES_PER_GROUP == 0 && kt >= TILES_PER_GROUP) produce_rows(((kt / TILES_PER_GROUP) + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WIL && !LAST && !U8) {
+            // Hand-made interleave (hipcc sinks the split behind the last MFMA under every scheduling hint tried:
+            // profiles/r05/ring_conv_evidence.md): the MFMAs as volatile asm in the production order, and after MFMA n
+            // the next few SLICES of the split of tile kt + 1 -- a task = one pack4 = 4 pairs x 4 stages of 3 / 3 / 3 / 2
+            // vector instructions, then its three 16-byte LDS stores -- each slice pinned by an operand-tied empty asm.
+            const unsigned* cA = reinterpret_cast<const unsigned*>(sS + buf * STAGE) + (half * 4) * BM + wm * TM * 32 + l31;
+            const unsigned* cB = reinterpret_cast<const unsigned*>(sS + buf * STAGE + 3 * SPA) + (half * 4) * BN + wn * TN * 32 + l31;
+            constexpr int NTA = RA / 2, NT = RA / 2 + RB / 2;       // split tasks of this thread: dy pairs, gathered pairs
+            constexpr int ITEMS = NT * 19;                          // 16 slices + 3 stores per task
+            constexpr int NMW = SP ? TM * TN * SPLIT * (BK / 16) : 1;   // (SP is true here; the other value keeps the
+            constexpr int N0 = NMW >= 12 ? NMW / 6 : 0;                 //  discarded instantiations well-formed)
+            constexpr int PER = (ITEMS + (NMW - N0) - 1) / (NMW - N0);  // the first MFMAs run while the tile's loads land
+            float t0[NT][4], t1[NT][4], r0[NT][4], r1[NT][4];
+            unsigned hh[NT][4], mm[NT][4], ll[NT][4];
+            char* const dS = sS + (buf ^ 1) * STAGE;
+            auto item = [&](const int it_) __attribute__((always_inline)) {     // (a constant after unrolling)
+                const int T = it_ / 19, w = it_ - T * 19;
+                const bool isA = T < NTA;
+                const int q = isA ? T : T - NTA;
+                const float4 v0 = isA ? va[2 * q] : vb[2 * q], v1 = isA ? va[2 * q + 1] : vb[2 * q + 1];
+                if (w < 16) {
+                    const int pr = w >> 2, stg = w & 3;
+                    const float x0 = pr == 0 ? v0.x : pr == 1 ? v0.y : pr == 2 ? v0.z : v0.w;
+                    const float x1 = pr == 0 ? v1.x : pr == 1 ? v1.y : pr == 2 ? v1.z : v1.w;
+                    if (stg == 0) {
+                        t0[T][pr] = __uint_as_float(__float_as_uint(x0) & HI16);
+                        t1[T][pr] = __uint_as_float(__float_as_uint(x1) & HI16);
+                        hh[T][pr] = hi_pair(x0, x1);
+                        asm volatile("" : "+v"(t0[T][pr]), "+v"(t1[T][pr]), "+v"(hh[T][pr]));
+                    } else if (stg == 1) {
+                        r0[T][pr] = x0 - t0[T][pr];
+                        r1[T][pr] = x1 - t1[T][pr];
+                        t0[T][pr] = __uint_as_float(__float_as_uint(r0[T][pr]) & HI16);
+                        asm volatile("" : "+v"(r0[T][pr]), "+v"(r1[T][pr]), "+v"(t0[T][pr]));
+                    } else if (stg == 2) {
+                        t1[T][pr] = __uint_as_float(__float_as_uint(r1[T][pr]) & HI16);
+                        mm[T][pr] = hi_pair(r0[T][pr], r1[T][pr]);
+                        r0[T][pr] = r0[T][pr] - t0[T][pr];
+                        asm volatile("" : "+v"(t1[T][pr]), "+v"(mm[T][pr]), "+v"(r0[T][pr]));
+                    } else {
+                        r1[T][pr] = r1[T][pr] - t1[T][pr];
+                        ll[T][pr] = hi_pair(r0[T][pr], r1[T][pr]);
+                        asm volatile("" : "+v"(r1[T][pr]), "+v"(ll[T][pr]));
+                    }
+                } else {
+                    const int pl = w - 16;
+                    char* d = isA ? dS + (tid + q * 256) * 16 + pl * SPA
+                                  : dS + 3 * SPA + ((b_k0 + q * KROWS) * BN + b_c4 * CW) * 4 + pl * SPB;
+                    const bool live = !isA || NPA % 256 == 0 || tid + q * 256 < NPA;
+                    const uint4 v = pl == 0 ? make_uint4(hh[T][0], hh[T][1], hh[T][2], hh[T][3])
+                                  : pl == 1 ? make_uint4(mm[T][0], mm[T][1], mm[T][2], mm[T][3])
+                                            : make_uint4(ll[T][0], ll[T][1], ll[T][2], ll[T][3]);
+                    if (live) *reinterpret_cast<uint4*>(d) = v;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            constexpr int NPR = SPLIT == 6 ? 6 : 9;                 // products, smallest first (split_products' order)
+            constexpr int PA_[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0}, PB_[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
+            constexpr int P0 = 9 - NPR;                             // (six products: the three smallest are dropped)
+            static_assert(!SP || PER * (NMW - N0) >= ITEMS, "every slice has a slot");
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                u32x4 fa[TM][3], fb[TN][3];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned* q = cA + pl * (SPA / 4) + ks * 8 * BM + i * 32;
+                        fa[i][pl] = u32x4{q[0], q[BM], q[2 * BM], q[3 * BM]};
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const unsigned* q = cB + pl * (SPB / 4) + ks * 8 * BN + j * 32;
+                        fb[j][pl] = u32x4{q[0], q[BN], q[2 * BN], q[3 * BN]};
+                    }
+#pragma unroll
+                for (int pi = 0; pi < NPR; ++pi)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][j])
+                                         : "v"(fa[i][PA_[P0 + pi]]), "v"(fb[j][PB_[P0 + pi]]));
+                            const int n = ((ks * NPR + pi) * TM + i) * TN + j;       // this MFMA's number in the tile
+#pragma unroll
+                            for (int e = 0; e < PER; ++e) {
+                                const int idx = (n - N0) * PER + e;
+                                if (n >= N0 && idx < ITEMS) item(idx);
+                            }
+                        }
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int p = 0; p < RA; ++p) { bsum[p].x += va[p].x; bsum[p].y += va[p].y; bsum[p].z += va[p].z; bsum[p].w += va[p].w; }
+            }
+            asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");       // the last asm MFMA's result before anything else reads it
+            __syncthreads();
+            return;
+        }
         if constexpr (SP) {
             // fragment = column l31 (of its 32-wide tile), k octet 2 ks + half = pair rows 8 ks + 4 half .. + 3
             const unsigned* cA = reinterpret_cast<const unsigned*>(sS + buf * STAGE) + (half * 4) * BM + wm * TM * 32 + l31;
@@ -1798,18 +1909,47 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][q], fb[j][q], acc[i][j], 0, 0, 0);
         }
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) {
-            store_tiles(buf ^ 1, true);
-            __syncthreads();
+        if constexpr (WIL) {
+            if constexpr (!LAST) {
+                store_tiles(buf ^ 1, true);
+                constexpr int NMW = TM * TN * (PB == 1 ? 3 : SPLIT) * (BK / 16);        // MFMAs per k-tile and wave
+                constexpr int NVW = (RA / 2) * 44 + (RB / 2) * (U8 ? 12 : 44);           // the split's vector instructions
+                constexpr int NWW = (RA / 2) * 3 + (RB / 2) * PB;                        // its LDS stores
+                constexpr int VPMW = (NVW + NMW - 1) / NMW < 6 ? (NVW + NMW - 1) / NMW : 6;
+                constexpr int WEVW = NMW / NWW > 0 ? NMW / NWW : 1;
+                __builtin_amdgcn_sched_group_barrier(0x100, (BK / 16) * 4 * (TM * 3 + TN * PB), 0);   // every fragment read first
+#pragma unroll
+                for (int m = 0; m < NMW; ++m) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, VPMW, 0);
+                    if (m % WEVW == WEVW - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+                __syncthreads();
+            }
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) {
+                store_tiles(buf ^ 1, true);
+                __syncthreads();
+            }
         }
     };
-    {   // an odd tile count peels its FIRST tile (from buffer 1); the rest is whole (buffer 0, buffer 1) pairs
+    using WC0 = std::integral_constant<int, 0>;
+    using WC1 = std::integral_constant<int, 1>;
+    if constexpr (WIL) {        // tile j sits in buffer (j + nk) & 1: the last tile in buffer 1
         int kt = 0;
-        if (nk & 1) { k_tile(std::integral_constant<int, 1>{}, 0); kt = 1; }
+        if (!(nk & 1)) { k_tile(WC0{}, 0, std::false_type{}); kt = 1; }
+        for (; kt + 1 < nk; kt += 2) {
+            k_tile(WC1{}, kt, std::false_type{});
+            k_tile(WC0{}, kt + 1, std::false_type{});
+        }
+        if (nk > 0) k_tile(WC1{}, nk - 1, std::true_type{});
+    } else {   // an odd tile count peels its FIRST tile (from buffer 1); the rest is whole (buffer 0, buffer 1) pairs
+        int kt = 0;
+        if (nk & 1) { k_tile(WC1{}, 0, std::false_type{}); kt = 1; }
         for (; kt < nk; kt += 2) {
-            k_tile(std::integral_constant<int, 0>{}, kt);
-            k_tile(std::integral_constant<int, 1>{}, kt + 1);
+            k_tile(WC0{}, kt, std::false_type{});
+            k_tile(WC1{}, kt + 1, std::false_type{});
         }
     }
     if (a.trace) tr2 = __builtin_readcyclecounter();
