@@ -563,7 +563,12 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     a.K_out = g.K; a.N = g.C * g.kh * g.kw; a.Mred = (int)(g.batch * g.Ho * g.Wo);
     a.dy_bytes = (unsigned)((int64_t)a.Mred * g.K * 4);
     a.trace = g_trace; a.xcd = 1;
-    const int bm = g.K <= 16 ? 16 : 32, bn = 128;
+    // split route, 256 columns (spec 1: 4 planes x 8 x 8): ONE column tile of 256 -- a wave owns two 32-column tiles, so
+    // every dy tile is loaded and split once per 256 columns instead of once per 128 -- at twice the k-splits (the same
+    // 512 workgroups, the same partials to fold): 34.7 -> 33.1 us with its fold (profiles/r05/conv1_wgrad_wide_ab.txt;
+    // 256 workgroups 37.5, 768 / 1 024 slower again)
+    const bool wide = g.K > 16 && g_split && g.kw % 8 == 0 && a.N % 256 == 0;
+    const int bm = g.K <= 16 ? 16 : 32, bn = wide ? 256 : 128;
     const int tiles = ((a.K_out + bm - 1) / bm) * ((a.N + bn - 1) / bn);
     int splits, per;
     // residency: the 16-row tiles (<= 16 filters) are small enough for 4 workgroups per CU (A2C-1024 batch:
@@ -581,7 +586,8 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
     const size_t lds = (size_t)2 * BK * (bm + bn) * sizeof(float);
     const dim3 grid((a.N + bn - 1) / bn, (a.K_out + bm - 1) / bm, splits);
     if (g.K > 16 && g_split && g.kw % 8 == 0) {     // (the split kernel gathers whole 8-pixel filter rows)
-        rc = launch_wgrad_split<1, 4, 1, 1, BK, true, 2>(a, splits, false, (hipStream_t)stream);
+        if (wide) rc = launch_wgrad_split<1, 4, 1, 2, BK, true, 2>(a, splits, false, (hipStream_t)stream);
+        else rc = launch_wgrad_split<1, 4, 1, 1, BK, true, 2>(a, splits, false, (hipStream_t)stream);
         if (rc) return rc;
     } else if (g.K <= 16) hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, true>), grid, dim3(256), lds, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((wgrad_u8_kernel<1, 4, 1, 1, BK, false>), grid, dim3(256), lds, (hipStream_t)stream, a);

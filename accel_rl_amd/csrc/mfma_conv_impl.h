@@ -2395,7 +2395,8 @@ int launch_conv1_img(const unsigned char* obs, int64_t obs_rows, const int32_t* 
     T int launch_wgrad_split<2, 2, 2, 2, 32, false, 1>(const WgradArgs&, int, bool, hipStream_t); \
     T int launch_wgrad_split<2, 2, 1, 1, 32, false, 2>(const WgradArgs&, int, bool, hipStream_t); \
     T int launch_wgrad_split<1, 4, 1, 1, 32, false, 2>(const WgradArgs&, int, bool, hipStream_t); \
-    T int launch_wgrad_split<1, 4, 1, 1, 32, true, 2>(const WgradArgs&, int, bool, hipStream_t);
+    T int launch_wgrad_split<1, 4, 1, 1, 32, true, 2>(const WgradArgs&, int, bool, hipStream_t); \
+    T int launch_wgrad_split<1, 4, 1, 2, 32, true, 2>(const WgradArgs&, int, bool, hipStream_t);
 #define ARL_P5(T) \
     T int launch_pair<2, 2, 2, 2, 2, 2, 2, 2, 32>(const DgradPlan&, const WgradPlan&, bool, hipStream_t); \
     T int launch_pair<2, 2, 2, 2, 2, 2, 2, 2, 16>(const DgradPlan&, const WgradPlan&, bool, hipStream_t);

@@ -1,5 +1,5 @@
 """A/B aid: run a script of this repo against another build of the library.
-usage: python tools/ab_lib.py <path/to/lib.so> <script.py> [args...]"""
+usage: python tools/ab_lib.py <path/to/lib.so> <script.py | -m module> [args...]"""
 import os
 import runpy
 import sys
@@ -9,4 +9,8 @@ from accel_rl_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 sys.argv = sys.argv[2:]
-runpy.run_path(sys.argv[0], run_name="__main__")
+if sys.argv[0] == "-m":
+    sys.argv = sys.argv[1:]
+    runpy.run_module(sys.argv[0], run_name="__main__", alter_sys=True)
+else:
+    runpy.run_path(sys.argv[0], run_name="__main__")
