@@ -8,6 +8,7 @@ namespace arlc {
 thread_local CallCtx t_ctx = {9, nullptr, false};
 unsigned long long* g_trace = nullptr;
 bool g_force_generic = false;
+int g_fwd_tile = -1;            // arl_dev_fwd_tile: -1 = chosen by the launch's size (fwd_impl)
 }  // namespace arlc
 
 namespace {
@@ -113,6 +114,8 @@ extern "C" void arl_dev_conv_trace_buffer(void* device_u64_or_null) { g_trace = 
 
 extern "C" void arl_dev_conv_force_generic(int32_t on) { g_force_generic = on != 0; }
 
+extern "C" void arl_dev_fwd_tile(int32_t v) { g_fwd_tile = (v >= 0 && v <= 2) ? v : -1; }
+
 extern "C" int arl_corun_job_init(arl_corun_job* job, const arl_opt_state* opt, int32_t method, float learning_rate,
                                   float avg_factor, float beta1_or_rho, float beta2, float epsilon, int32_t k,
                                   float* step_pp, double* norm_parts, int64_t hole_first, int64_t hole_count) {
@@ -186,7 +189,16 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
         if (a.N <= 16 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 2, 1, 16, true, true>(a, splits, multi_tap, has_pad, s);        // 16-wide MFMA tiles
         else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
-        else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
+        else if (g_split && a.N <= 64) {
+            // 33 .. 64 columns.  0: 128 x 64 tiles (a wave owns a 32-row tile and both 32-column halves); 1: 128 x 32
+            // tiles, two column tiles per row tile (twice the workgroups, each wave half the MFMA chain; the gathered
+            // operand is loaded and split once per column tile); 2: 64 x 64 tiles, both operands through LDS.  All
+            // three issue the same piece products in the same k order: bit-identical outputs.
+            const int v = g_fwd_tile >= 0 ? g_fwd_tile : 0;
+            if (v == 1) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
+            else if (v == 2) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
+            else rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
+        }
         else if (g_split && small) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
         else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, true, false, 1>(a, multi_tap, has_pad, s, splits);
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))

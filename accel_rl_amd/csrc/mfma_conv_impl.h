@@ -2270,6 +2270,7 @@ constexpr int BKT = 32;             // k-tile of the skinny configurations (host
 
 extern unsigned long long* g_trace;   // arl_dev_conv_trace_buffer
 extern bool g_force_generic;          // arl_dev_conv_force_generic: route every call to the generic kernels (tests)
+extern int g_fwd_tile;                // arl_dev_fwd_tile: tile shape of the 33 .. 64-column forward kernels (-1: by size)
 
 struct Geom {
     int64_t batch;
