@@ -150,7 +150,9 @@ class AdvActorCriticBase(RLAlgorithm):
         # the graph owns its outputs and every replay overwrites them: callers keep the diagnostics across iterations
         # (AccelRL.store_diagnostics) -- the graph itself left this replay's copy in a ring slot
         opt_data, infos = self._graph_out
-        slot = self._info_replays % self._ring_slots()
+        # (the modulus is the ALLOCATED ring's length -- what ring_append's device counter wraps at -- not the current
+        #  _ring_slots(): a log interval lowered after the ring was sized must not move the host's idea of the slot)
+        slot = self._info_replays % next(iter(self._info_ring.values())).shape[0]
         self._info_replays += 1
         return opt_data, {k: self._info_ring[k][slot] for k in infos}
 

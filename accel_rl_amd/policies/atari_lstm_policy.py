@@ -112,17 +112,22 @@ class RecurrentCnnPolicy(AtariCnnPolicy):
             prob, value, _ = self._step(observations, prev, tag="v")
             return prob, value
 
-    def act_step(self, observations):
+    def act_step(self, observations, rows=None):
         """The sampler's serving call: (prob, value, *previous state) and the state advances
         (get_actions, atari_lstm_policy.py:161-169).  The returned previous state is only valid
-        until the next act_step."""
+        until the next act_step.  rows = (lo, hi): the observations are those of state rows lo .. hi - 1 only (a
+        sampler serving its envs in groups: the reference's pair of per-group states, policies/base.py:44-93, kept
+        side by side in one tensor)."""
         with torch.no_grad():
             b = observations.shape[0]
-            ret = [self._buffer(("prev_ret%d" % i, b), (b, self._H)) for i in range(len(self._state))]
-            for r, s in zip(ret, self._state):
+            state = self._state if rows is None else [s[rows[0]:rows[1]] for s in self._state]
+            if state[0].shape[0] != b:
+                raise ValueError("act_step: %d observations for %d state rows" % (b, state[0].shape[0]))
+            ret = [self._buffer(("prev_ret%d" % i, b), (b, self._H)) for i in range(len(state))]
+            for r, s in zip(ret, state):
                 r.copy_(s)
-            prob, value, new = self._step(observations, self._state)
-            for s, n in zip(self._state, new):
+            prob, value, new = self._step(observations, state)
+            for s, n in zip(state, new):
                 s.copy_(n)
             return (prob, value) + tuple(ret)
 

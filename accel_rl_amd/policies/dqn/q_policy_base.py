@@ -186,6 +186,21 @@ class QPolicyBase(AtariCnnPolicy):
                 self._zero_value = torch.zeros(b, dtype=torch.float32, device=self.device)
             return onehot, self._zero_value
 
+    def serve_group(self, observations, row0, n_envs):
+        """prob_value for the B observations of envs [row0, row0 + B) of an n_envs-wide rollout: a sampler that serves
+        its envs in groups (HostEnvSampler, the reference's two alternating halves) reads the group's slice of the
+        step's row of the override table that host_draws(horizon, n_envs) filled."""
+        with torch.no_grad():
+            b = observations.shape[0]
+            logits, _, _ = self._logits(self._scaled(observations))
+            onehot = torch.empty((b, self.n_act), dtype=torch.float32, device=self.device)
+            table = self._overrides[n_envs][1]
+            if self._step >= table.shape[0] or row0 + b > table.shape[1]:
+                raise IndexError("serve_group: step %d / rows %d..%d outside the %s override table" %
+                                 (self._step, row0, row0 + b, tuple(table.shape)))
+            self._serve(logits, table[self._step, row0:row0 + b], onehot)
+            return onehot, torch.zeros(b, dtype=torch.float32, device=self.device)
+
     def greedy_actions(self, observations):
         with torch.no_grad():
             b = observations.shape[0]

@@ -70,7 +70,6 @@ class AccelRLSync(AccelRL):
         1 .. n-1 get seed + 100 * rank and affinities[rank] and are forked here, before anything touches the GPU.  The
         Manager dict / barrier / queue of the reference are torch.distributed's TCP store on 127.0.0.1."""
         import multiprocessing as mp
-        import socket
         import threading
         from accel_rl_amd.util.misc import make_seed
         # (torch.cuda.is_initialized() only: is_available() / device_count() themselves mark the process so that a forked
@@ -84,13 +83,12 @@ class AccelRLSync(AccelRL):
         self._launched_here = True
         if self.seed is None:
             self.seed = make_seed()                                    # :22-23 (workers derive theirs from it)
-        sock = socket.socket()
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-        sock.close()
-        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(self.n_runners),
-                          RANK="0", LOCAL_RANK="0")
+        # Rendez-vous without touching os.environ (a second runner built later in this process must not find a stale
+        # WORLD_SIZE and take the launched-by-torchrun road) and without a bind / close / re-bind window on the port:
+        # rank 0 creates the TCP store on port 0 AFTER the fork and hands the port it got to the workers through shared
+        # memory (startup()).
         ctx = mp.get_context("fork")
+        self._rendezvous = (ctx.Array("i", 1), ctx.Event())
         base_seed = self.seed
         for rank in range(1, self.n_runners):
             p = ctx.Process(target=self._worker_main, args=(rank, base_seed + 100 * rank, table[rank]), daemon=True)
@@ -111,6 +109,7 @@ class AccelRLSync(AccelRL):
                     for p in procs:
                         if p.is_alive():
                             p.terminate()
+                    self._abandon_sampler()
                     os._exit(70)
         threading.Thread(target=monitor, daemon=True).start()
 
@@ -118,7 +117,6 @@ class AccelRLSync(AccelRL):
         """A forked worker runner (the reference's SyncWorker.train, multigpu_rl_base.py:66-103): same loop, own rank."""
         code = 0
         try:
-            os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank))
             self.rank, self.seed, self.affinities = rank, seed, affinities
             self._worker_procs, self._launched_here = [], True
             if self.affinities is None:
@@ -133,11 +131,22 @@ class AccelRLSync(AccelRL):
                                  "device tensor ...) before train() forked its worker runners; move that after train() starts or "
                                  "launch the script under `python -m torch.distributed.run`\n")
             code = 1
+            self._abandon_sampler()
         finally:
             import sys
             sys.stdout.flush()
             sys.stderr.flush()
             os._exit(code)             # no interpreter finalisation in a forked child (the parent's atexit hooks are not ours)
+
+    def _abandon_sampler(self):
+        """Failure paths leave through os._exit (no atexit, no multiprocessing reaping): a sampler with processes of its
+        own (HostEnvSampler's simulation workers) must be told to end them first, best effort and bounded."""
+        try:
+            kill = getattr(self.sampler, "kill_workers", None)
+            if kill is not None:
+                kill()
+        except Exception:       # noqa: BLE001
+            pass
 
     def shutdown(self):
         """reference: SyncBase.shutdown (multigpu_rl_base.py:124-127): rank 0 joins its workers; a worker only closes its
@@ -160,6 +169,7 @@ class AccelRLSync(AccelRL):
         self._workers_joined = True
 
     _launched_here = False      # True in the process that forked its workers and in those workers
+    _rendezvous = None          # (port box, ready event) shared with the workers this runner forked
 
     def startup(self):
         """reference: multigpu_rl_base.py:12-18 (master) / :85-91 (worker)"""
@@ -171,9 +181,24 @@ class AccelRLSync(AccelRL):
             if backend == "nccl":
                 # accel_rl_base.py:62-64: the runner's GPU is affinities["gpu"]; RCCL binds its communicator to it
                 gpu = self.affinities.get("gpu") if hasattr(self.affinities, "get") else None
-                dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", self.rank)) if gpu is None else int(gpu))
+                local = self.rank if self._rendezvous is not None else int(os.environ.get("LOCAL_RANK", self.rank))
+                dev = torch.device("cuda", local if gpu is None else int(gpu))
                 torch.cuda.set_device(dev)
                 kw["device_id"] = dev
+            if self._rendezvous is not None:                   # ranks this runner forked itself (launch_workers)
+                import datetime
+                box, ready = self._rendezvous
+                if self.rank == 0:
+                    store = dist.TCPStore("127.0.0.1", 0, self.n_runners, is_master=True, wait_for_workers=False,
+                                          timeout=datetime.timedelta(seconds=300))
+                    box[0] = store.port
+                    ready.set()
+                else:
+                    if not ready.wait(300):
+                        raise RuntimeError("AccelRLSync worker %d: rank 0 never opened the rendez-vous store" % self.rank)
+                    store = dist.TCPStore("127.0.0.1", int(box[0]), self.n_runners, is_master=False,
+                                          timeout=datetime.timedelta(seconds=300))
+                kw["store"] = store
             dist.init_process_group(backend, rank=self.rank, world_size=self.n_runners, **kw)
         if self.rank != 0:
             logger.set_quiet(True)

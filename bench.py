@@ -416,6 +416,123 @@ def mfma_table(device, policy, batch=512, reps=20):
     return out
 
 
+ROUTE_NAMES = {9: "split9", 6: "split6", 0: "fp32_mfma"}
+SPEC1_LAYERS = [("conv1", 104, 80, 4, 32, 8, 4, 0), ("conv2", 25, 19, 32, 64, 4, 2, 1),
+                ("conv3", 12, 9, 64, 64, 3, 1, 1), ("dense1", 1, 1, 6912, 512, 1, 1, 0)]
+
+
+def route_accuracy(device, batch=48, modes=(9, 6, 0), seed=3):
+    """Error of every contraction kernel of the spec-1 network (config 2's layer shapes) on each arithmetic route
+    (arl_conv_geom.route: nine / six exact bf16-split products, fp32 MFMA chain) against a FLOAT64 contraction of the
+    same inputs: {layer: {pass: {"rms_err_vs_f64": {route: rms(err) / rms(ref)}, "max_err_vs_f64": {route: max|err| /
+    max|ref|}}}}.  The float64 reference is torch's (ATen) convolution -- a checker, not the product path.  The batch
+    is small because the float64 reference is slow; the errors do not depend on it (every output is its own dot
+    product)."""
+    import torch.nn.functional as F
+    from accel_rl_amd import _lib
+    ws = _lib.conv_workspace(device)
+    gen = torch.Generator(device=device).manual_seed(seed)
+    was, cudnn_was = _lib.conv_precision(), torch.backends.cudnn.enabled
+    torch.backends.cudnn.enabled = False          # (ATen's own convolution: no MIOpen search on a fresh box)
+    table = {}
+
+    def err(got, want):
+        d = (got.double() - want).abs()
+        return (d.max().item() / max(want.abs().max().item(), 1e-30),
+                (d.pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item())
+    try:
+        for name, h, w, c, k, ks, st, p in SPEC1_LAYERS:
+            geom0 = _lib.conv_geom(batch, h, w, c, k, ks, ks, st, p, p)
+            ho, wo = _lib.conv_out_hw(geom0)
+            x = torch.randn(batch, h, w, c, device=device, generator=gen).relu()
+            wt = torch.randn(k, ks, ks, c, device=device, generator=gen) / np.sqrt(ks * ks * c)
+            bias = torch.randn(k, device=device, generator=gen)
+            dy = torch.randn(batch, ho, wo, k, device=device, generator=gen)
+            y, dx, dw = torch.empty(batch, ho, wo, k, device=device), torch.empty_like(x), torch.empty_like(wt)
+            u8 = name == "conv1"
+            obs = torch.randint(0, 256, (batch, c, h, w), device=device, dtype=torch.int32, generator=gen).to(torch.uint8) if u8 else None
+            w8 = wt.permute(0, 3, 1, 2).contiguous() if u8 else None
+            dw8 = torch.empty_like(w8) if u8 else None
+            dyd = dy.double().permute(0, 3, 1, 2)
+            ref = {}
+            if u8:              # conv 1 as the step runs it: straight from the u8 observations, no data gradient
+                o8r, w8r = (obs.double() / 255.0).requires_grad_(), w8.double().requires_grad_()
+                out8 = F.conv2d(o8r, w8r, None, stride=st)
+                ref["fwd"] = (out8 + bias.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).detach()
+                ref["wgrad"] = torch.autograd.grad(out8, w8r, dyd)[0]
+            else:
+                xr, wr = x.double().permute(0, 3, 1, 2).requires_grad_(), wt.double().permute(0, 3, 1, 2).requires_grad_()
+                out = F.conv2d(xr, wr, None, stride=st, padding=p)
+                gx, gw = torch.autograd.grad(out, (xr, wr), dyd)
+                ref = dict(fwd=(out + bias.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1).detach(),
+                           dgrad=gx.permute(0, 2, 3, 1), wgrad=gw.permute(0, 2, 3, 1))
+            table[name] = {op: dict(rms_err_vs_f64={}, max_err_vs_f64={}) for op in ref}
+            for mode in modes:
+                _lib.set_conv_precision(mode)
+                geom = _lib.with_route(geom0)
+                if u8:
+                    folds, db = _lib.FoldList(), torch.empty(k, device=device)
+
+                    def u8w():
+                        folds.conv2d_u8_bwd_weight(dy, obs, None, 1.0 / 255.0, dw8, geom, ws, dbias=db)
+                        folds.run()
+                    ops = dict(fwd=(lambda: _lib.conv2d_u8_fwd(obs, None, 1.0 / 255.0, w8, bias, y, geom, False), y),
+                               wgrad=(u8w, dw8))
+                else:
+                    ops = dict(fwd=(lambda: _lib.conv2d_fwd(x, wt, bias, y, geom, False, ws), y),
+                               dgrad=(lambda: _lib.conv2d_bwd_data(dy, wt, None, dx, geom), dx),
+                               wgrad=(lambda: _lib.conv2d_bwd_weight(dy, x, dw, geom, ws), dw))
+                for op, (fn, out_t) in ops.items():
+                    out_t.fill_(float("nan"))
+                    fn()
+                    torch.cuda.synchronize()
+                    mx, rms = err(out_t, ref[op])
+                    table[name][op]["rms_err_vs_f64"][ROUTE_NAMES[mode]] = float("%.4g" % rms)
+                    table[name][op]["max_err_vs_f64"][ROUTE_NAMES[mode]] = float("%.4g" % mx)
+    finally:
+        _lib.set_conv_precision(was)
+        torch.backends.cudnn.enabled = cudnn_was
+    return table
+
+
+def alt_routes(device, steps, warmup, priming, modes=(6, 0)):
+    """The SAME workload, steps and timed region as the headline on the other arithmetic routes of the fp32
+    contractions (arl_conv_geom.route): a second and a third runner built from scratch with the route stamped into
+    every layer geometry, primed, warmed up and timed exactly like `value`.  The default route is not changed."""
+    from accel_rl_amd import _lib
+    out, was = {}, _lib.conv_precision()
+    try:
+        for mode in modes:
+            _lib.set_conv_precision(mode)
+            runner, sampler, algo, policy = build_workload(device, 0, 0, 1, GAME, True)
+            itr = 0
+            for _ in range(priming + warmup):
+                one_step(itr, sampler, algo)
+                itr += 1
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_step(itr, sampler, algo)
+                itr += 1
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            out[ROUTE_NAMES[mode]] = dict(value=round(steps * N_ENVS * HORIZON / dt, 1), ms_per_step=round(dt / steps * 1e3, 4),
+                                          steps=steps, products_per_multiply=mode if mode else 1)
+            runner.shutdown()
+            algo._graph = algo._graph_out = None
+            sampler._graph = None
+            del runner, sampler, algo, policy
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+    finally:
+        _lib.set_conv_precision(was)
+    out["note"] = ("same workload, steps, warm-up and timed region as `value`, which runs on split9 (the default, unchanged): "
+                   "split6 drops the three piece products below 2^-24 of a product (m*l, l*m, l*l), fp32_mfma is the "
+                   "v_mfma_f32_32x32x2_f32 chain; per-layer errors of all three against float64 are in `accuracy`")
+    return out
+
+
 def _served(device, policy):
     """The action server of the CPU baselines: H2D of the u8 observations, the SAME torch policy
     on the GPU, D2H, categorical sampling on the host (the reference's master does exactly this
@@ -668,15 +785,44 @@ def replay_cpu_baseline(n_env, horizon, reward_horizon, batch, updates_per_step,
                        (n, dt, n_env, horizon, updates_per_step, batch))
 
 
-def catdqn_main(args):
-    """BASELINE config 5 (not the headline metric): Categorical DQN "seaquest", 1M-transition device replay
-    (prioritized), 256 envs x horizon 4, spec-1 trunk, reward horizon 3, training intensity 8."""
+def _catdqn_run(device, batch, steps, warmup):
+    """One Categorical-DQN workload built from scratch and timed: (runner, algo, env-steps/s, ms per step)."""
     from accel_rl_amd.algos.dqn.cat_dqn import CategoricalDQN
     from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
     from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
     from accel_rl_amd.policies.dqn.atari_cat_dqn_policy import AtariCatDqnPolicy
     from accel_rl_amd.runners.accel_rl import AccelRLEval
     from accel_rl_amd.sampler.gpu_sampler_with_eval import GpuVecEvalSampler
+    n_env, horizon = 256, 4
+    sampler = GpuVecEvalSampler(eval_steps=12800, eval_envs_per=1, EnvCls=SynthAtariEnv, env_args=dict(game="seaquest"),
+                                horizon=horizon, n_parallel=16, envs_per=n_env // 32, max_path_length=int(27e3),
+                                max_decorrelation_steps=0, device=device)
+    algo = CategoricalDQN(batch_size=batch, min_steps_learn=40 * n_env * horizon, replay_size=int(1e6), training_intensity=8,
+                          reward_horizon=3, prioritized_replay=True, double_dqn=True)
+    policy = AtariCatDqnPolicy(**cnn_specs[1])
+    runner = AccelRLEval(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=0, eval_interval_steps=1e8)
+    runner.startup()
+    itr = 0
+    for _ in range(40 + warmup):                    # 40 sampling-only steps fill the replay, then the warm-up
+        samples, _ = sampler.obtain_samples(itr)
+        algo.optimize_policy(itr, samples)
+        itr += 1
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        samples, _ = sampler.obtain_samples(itr)
+        algo.optimize_policy(itr, samples)
+        itr += 1
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return runner, algo, round(steps * n_env * horizon / el, 1), round(el / steps * 1e3, 4)
+
+
+def catdqn_main(args):
+    """BASELINE config 5 (not the headline metric): Categorical DQN "seaquest", 1M-transition device replay
+    (prioritized), 256 envs x horizon 4, spec-1 trunk, reward horizon 3, training intensity 8 -- at the reference's own
+    minibatch of 32 rows (accel_rl/algos/dqn/dqn.py:18, used at :88-94,180), i.e. 256 updates per 1024-transition batch;
+    `alt` re-times the same workload at 512 rows x 16 updates (the same rows per sampled transition)."""
     from accel_rl_amd.util import logger
     import __graft_entry__
     __graft_entry__.build()
@@ -684,41 +830,34 @@ def catdqn_main(args):
     device = torch.device("cuda", 0)
     torch.cuda.set_device(device)
     n_env, horizon = 256, 4
-    sampler = GpuVecEvalSampler(eval_steps=12800, eval_envs_per=1, EnvCls=SynthAtariEnv, env_args=dict(game="seaquest"),
-                                horizon=horizon, n_parallel=16, envs_per=n_env // 32, max_path_length=int(27e3),
-                                max_decorrelation_steps=0, device=device)
-    algo = CategoricalDQN(batch_size=args.dqn_batch, min_steps_learn=40 * n_env * horizon, replay_size=int(1e6), training_intensity=8,
-                          reward_horizon=3, prioritized_replay=True, double_dqn=True)
-    policy = AtariCatDqnPolicy(**cnn_specs[1])
-    runner = AccelRLEval(algo=algo, policy=policy, sampler=sampler, n_steps=1e9, seed=0, eval_interval_steps=1e8)
-    runner.startup()
-    itr = 0
-    for _ in range(40 + args.warmup):               # 40 sampling-only steps fill the replay, then the warm-up
-        samples, _ = sampler.obtain_samples(itr)
-        algo.optimize_policy(itr, samples)
-        itr += 1
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        samples, _ = sampler.obtain_samples(itr)
-        algo.optimize_policy(itr, samples)
-        itr += 1
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    runner, algo, value, ms = _catdqn_run(device, args.dqn_batch, args.steps, args.warmup)
     line = {"metric": "env-steps/sec (whole node), Categorical-DQN Seaquest, 1M-transition replay (BASELINE config 5, "
                       "not the headline metric)",
-            "value": round(args.steps * n_env * horizon / el, 1), "unit": "env-steps/s", "n_gpus": 1,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4),
+            "value": value, "unit": "env-steps/s", "n_gpus": 1,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Cat-DQN seaquest, %d envs x horizon %d, spec-1 trunk, 51 atoms, prioritized replay "
                                    "of %d transitions (frames %.1f GB in HBM), n-step 3, double DQN, minibatch %d x %d "
                                    "updates per step (training intensity 8), adam" %
                                    (n_env, horizon, algo.replay_buffer.env_replay_size * n_env,
-                                    algo.replay_buffer.frames.numel() / 1e9, args.dqn_batch, algo._updates_per_optimize)}}
+                                    algo.replay_buffer.frames.numel() / 1e9, args.dqn_batch, algo._updates_per_optimize),
+                       "minibatch": args.dqn_batch, "updates_per_step": algo._updates_per_optimize}}
     if not args.no_roofline:
         line["roofline"] = replay_roofline(device, algo)
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = replay_cpu_baseline(n_env, horizon, 3, args.dqn_batch, algo._updates_per_optimize)
+    if not args.no_alt_routes:
+        other = 512 if args.dqn_batch != 512 else 32
+        runner.shutdown()
+        algo._graph = None
+        del runner, algo
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        runner, algo, v2, ms2 = _catdqn_run(device, other, args.steps, args.warmup)
+        line["alt"] = {"minibatch": other, "updates_per_step": algo._updates_per_optimize, "value": v2, "ms_per_step": ms2,
+                       "note": "the same workload at another replay minibatch (same training intensity: rows trained per "
+                               "sampled transition); the reference's own default is 32 (dqn.py:18)"}
     print(json.dumps(line), flush=True)
 
 
@@ -793,16 +932,37 @@ def multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, t
     return out
 
 
-STALL_MARKER = os.path.join(os.environ.get("TMPDIR", "/tmp"), "arl_bench_sync_graph_stalled")
+def _stall_marker():
+    """The watchdog's note for the NEXT run of THIS build by THIS user on this node: keyed on the built library's hash and
+    the uid, so that another checkout, another user or a rebuilt tree (the cause fixed) starts with captured collectives."""
+    import hashlib
+    tag = "nolib"
+    try:
+        with open(os.path.join(ROOT, "accel_rl_amd", "libaccel_rl_hip.so"), "rb") as f:
+            tag = hashlib.sha256(f.read()).hexdigest()[:12]
+    except OSError:
+        pass
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "arl_bench_sync_graph_stalled.%d.%s" % (os.getuid(), tag))
+
+
+STALL_MARKER = _stall_marker()
 
 
 def stalled_before(max_age_s=6 * 3600):
-    """An earlier multi-rank run on this node stalled with its collectives captured (the watchdog's note, above)."""
+    """An earlier multi-rank run of this build on this node stalled with its collectives captured (the watchdog's note)."""
     try:
         with open(STALL_MARKER) as f:
             return time.time() - int(f.read().split()[0]) < max_age_s
     except (OSError, ValueError, IndexError):
         return False
+
+
+def clear_stall_marker():
+    """A run with captured collectives completed: whatever stalled before does not any more."""
+    try:
+        os.remove(STALL_MARKER)
+    except OSError:
+        pass
 
 
 def spawn_ranks(n):
@@ -878,6 +1038,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-alt-routes", action="store_true",
+                    help="skip the re-timing of the headline on the six-product and fp32-MFMA routes and the accuracy table")
     ap.add_argument("--roofline-log2", type=int, default=26)
     ap.add_argument("--roofline-only", action="store_true",
                     help="only the GAE-scan roofline leg (used for the rocprofv3 --pmc passes)")
@@ -886,7 +1048,8 @@ def main():
                     help="weak: 256 envs and minibatch 512 PER GPU (default); strong: --total-envs and a global "
                          "minibatch of 4096 rows split over the GPUs (SURVEY 8d)")
     ap.add_argument("--total-envs", type=int, default=2048, help="--scaling strong: environments of the whole job")
-    ap.add_argument("--dqn-batch", type=int, default=512, help="catdqn workload: replay minibatch size")
+    ap.add_argument("--dqn-batch", type=int, default=32,
+                    help="catdqn workload: replay minibatch size (default: the reference's, accel_rl/algos/dqn/dqn.py:18)")
     ap.add_argument("--workload", choices=["ppo256", "a2c1024", "catdqn"], default="ppo256",
                     help="ppo256 = BASELINE config 2 (the metric's config, default); a2c1024 = config 3 "
                          "(A2C, 1024 envs, 5-step returns, spec-0 CNN, one rmsprop step per batch)")
@@ -960,6 +1123,11 @@ def main():
     if world > 1 and "ARL_SYNC_GRAPH" not in os.environ and stalled_before():
         os.environ["ARL_SYNC_GRAPH"] = "0"
         os.environ.setdefault("ARL_BENCH_GRAPH_FALLBACK", "eager after a capture stall in an earlier run on this node")
+        if rank == 0:
+            sys.stderr.write("bench.py: an earlier %d-rank run of this build stalled while its collectives were captured "
+                             "(%s): this run issues them eagerly (ARL_SYNC_GRAPH=0; the line says so in graph_fallback). "
+                             "Delete the file or set ARL_SYNC_GRAPH=1 to capture again.\n" % (world, STALL_MARKER))
+            sys.stderr.flush()
     if world > 1 or os.environ.get("ARL_FORCE_SYNC") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -1073,6 +1241,8 @@ def main():
                                                   itr + 2 * reps, elapsed_local / args.steps, t_roll, t_learn, tick)
         if os.environ.get("ARL_BENCH_GRAPH_FALLBACK"):
             line["graph_fallback"] = os.environ["ARL_BENCH_GRAPH_FALLBACK"]
+        if rank == 0 and line["multi_gpu"].get("graph_captured"):
+            clear_stall_marker()
     if rank == 0 and world == 1:
         if not args.no_roofline and args.workload == "a2c1024":
             # config 3 is sampler-bound (BASELINE.json): its HBM-bound kernels are the 5-step return scan and the env step
@@ -1096,6 +1266,10 @@ def main():
                         "`value` (rollout + PPO learner on the device) vs the CPU sampler port feeding the same device "
                         "learner serially, as the reference's runner does; rollout_only_vs_undisturbed_cpu: against "
                         "the CPU sampler's 10th-percentile batch time (what it does when the shared host is quiet)"}
+    if rank == 0 and world == 1 and args.workload == "ppo256" and not args.no_alt_routes and not args.no_graph:
+        tick("alt routes")
+        line["alt_routes"] = alt_routes(device, args.steps, args.warmup, PRIMING)
+        line["accuracy"] = route_accuracy(device)
     runner.shutdown()
     if dist.is_initialized():
         dist.barrier()

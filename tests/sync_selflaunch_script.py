@@ -28,7 +28,7 @@ def main():
             served = sampler.obtain_samples
 
             def obtain_samples(itr):
-                if itr == 1 and os.environ["RANK"] == crash:
+                if itr == 1 and str(runner.rank) == crash:
                     raise RuntimeError("injected failure in rank " + crash)
                 return served(itr)
             sampler.obtain_samples = obtain_samples

@@ -146,7 +146,8 @@ class _FakeSampler(object):
 
     def obtain_samples(self, itr):
         from accel_rl_amd.sampler.util import TrajInfo
-        rank = int(os.environ["RANK"])
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_initialized() else int(os.environ.get("RANK", 0))
         infos = [TrajInfo(Length=10 + rank, Return=float(itr))] if itr % 2 == rank else []
         return dict(), infos
 
@@ -174,7 +175,7 @@ class _FakeAlgo(object):
 
     def optimize_policy(self, itr, samples):
         self.calls += 1
-        self.policy.flat_grads.fill_(float(int(os.environ["RANK"]) + 1))
+        self.policy.flat_grads.fill_(float(__import__("torch").distributed.get_rank() + 1))
         self.optimizer._share_grad()
         self.policy.flat_params.sub_(self.policy.flat_grads * self.optimizer._avg_factor() * 0.1)
         return None, dict(GradNorm=torch.tensor([1.0]))
