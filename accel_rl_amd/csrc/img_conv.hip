@@ -4,7 +4,7 @@
 // conv1_img_kernel: the first convolution straight from the sampler's u8 observations (arl_conv2d_u8_fwd; the
 // reference's network input is obs * (1 / 255): accel_rl/policies/pg/atari_cnn_policy.py:88-91, first layer
 // pg_cnn.py:47-52) for 32 filters of 8 x 8 pixels:
-//   * the layer's weights are split ONCE per workgroup -- exactly, into three bf16 planes (mfma_conv_impl.h, SPLIT) --
+//   * the layer's weights are split ONCE per workgroup -- exactly, into three bf16 planes (mfma_common.h, SPLIT) --
 //     and stay in LDS in MFMA-fragment order for the workgroup's whole life (48 KB at 4 planes);
 //   * an image (33 KB of u8) arrives with coalesced 16-byte loads into one of two LDS buffers while the previous image
 //     is being computed; one barrier per image;

@@ -280,7 +280,8 @@ def test_epsilon_greedy_serving_on_host_envs_matches_the_device_sampler(with_eva
         else:
             smp = ActsrvAltOvrlpSampler(EnvCls=env_cls, **common)
         try:
-            np.random.seed(77)
+            from accel_rl_amd.util.seed import set_seed
+            set_seed(77)                               # the runner's call (also seeds the conv initialiser's private stream)
             env_spec = smp.initialize(seed=78, affinities=dict(), discount=0.99, need_extra_obs=False)[0]
             policy = _dqn_policy(epsilon=0.35)
             policy.initialize(env_spec, device=DEV)
