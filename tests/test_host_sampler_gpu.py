@@ -322,7 +322,7 @@ def test_dqn_trains_on_host_envs():
     from accel_rl_amd.sampler import AAOEvalSampler
     from accel_rl_amd.util import logger
     logger.set_quiet(True)
-    sampler = AAOEvalSampler(eval_steps=8 * 12, eval_envs_per=1, EnvCls=PortEnv, env_args=dict(game="pong"), horizon=4,
+    sampler = AAOEvalSampler(eval_steps=4 * 100, eval_envs_per=1, EnvCls=PortEnv, env_args=dict(game="pong"), horizon=4,
                              n_parallel=2, envs_per=2, max_path_length=40, max_decorrelation_steps=0, device=DEV)
     policy = _dqn_policy(epsilon=1)
     algo = DQN(batch_size=16, min_steps_learn=64, replay_size=2048, training_intensity=4)
@@ -331,4 +331,4 @@ def test_dqn_trains_on_host_envs():
     runner.train()
     torch.cuda.synchronize()
     assert torch.isfinite(policy.flat_params).all() and not sampler.workers
-    assert runner.last_tabular["TrajsInEval"] >= 1
+    assert runner.last_tabular["TrajsInEval"] >= 4            # 100 evaluation steps per env, episodes end at Length 40
