@@ -244,7 +244,7 @@ def env_step_sweep(device, n_env=ENV_SWEEP_ENVS):
                 avg_launch_us=round(ms * 1e3, 2), bytes_per_launch=nbytes, achieved=round(achieved, 1), peak=HBM_PEAK_GBS,
                 unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                 # what the DRAM really moves (PMC bytes / launch time): the 2 MB raw-frame bank is served from L2 / MALL,
-                # so this is BELOW the algorithmic fraction -- the kernel is not HBM-bound
+                # so this is BELOW the algorithmic fraction -- the kernel is not HBM-bound (LABNOTES.md, rounds 1-5 section 6, round 4)
                 frac_dram=(round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                 timing="%d launches per hipGraph, 5 replays" % per_graph)
 

@@ -1,4 +1,4 @@
-"""The stand-alone kernel prototypes under tools/proto/ are evidence: DESIGN.md and profiles/ quote their timings as the
+"""The stand-alone kernel prototypes under tools/proto/ are evidence: LABNOTES.md / DESIGN.md and profiles/ quote their timings as the
 reason a structure was NOT adopted.  A prototype whose numbers are quoted must still compile and still agree with its own
 float64 reference (each prints `ok` / `FAIL` per variant).  Built here with hipcc for gfx950, run at a reduced size."""
 import os
@@ -37,10 +37,11 @@ def test_prototype_still_matches_its_float64_reference(name, args, min_ok, tmp_p
 
 
 def test_hardware_probes_run(tmp_path):
-    """The three measurements the round-5 reading rests on: per-CU L2 bandwidth, the lone-wave MFMA stream, kernel-argument
-    latency.  (Values are box-dependent; what is checked is that the probes still build and print their tables.)"""
+    """The measurements the round-5 / round-6 readings rest on: per-CU L2 bandwidth, the lone-wave MFMA stream,
+    kernel-argument latency, weights straight from L2 into the MFMA stream (round 6).  (Values are box-dependent; what is
+    checked is that the probes still build and print their tables.)"""
     for name, needle in (("cu_bw_probe", "GB/s per CU"), ("mfma_stream_probe", "cycles per MFMA"),
-                         ("kernarg_probe", "cycles until the arguments")):
+                         ("kernarg_probe", "cycles until the arguments"), ("bdirect_probe", "cycles per 36 MFMAs")):
         exe = _build(name, tmp_path)
         out = subprocess.run(["timeout", "120", exe], capture_output=True, text=True, timeout=200)
         assert out.returncode == 0 and needle in out.stdout, (name, out.stdout[-1500:], out.stderr[-1500:])
