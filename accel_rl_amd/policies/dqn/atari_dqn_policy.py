@@ -7,7 +7,10 @@ target network and action serving are QPolicyBase's; the output layer "output_q"
 call whose row is padded to 32 columns (zero weights, zero gradients) so that its data gradient
 runs on the scalar-addressed kernels, followed by csrc/dqn.hip (arl_dqn_act, arl_dqn_loss).
 Dueling (`dueling=True`): see QPolicyBase -- the stored row is n_actions advantages followed by the value.
-The shared scalar output bias is not implemented.
+`shared_last_bias=True` (dqn_cnn.py:67-82: the output layer has no bias of its own, a BiasLayer with shared_axes=(0, 1) adds ONE
+scalar to every action's value): the stored bias vector keeps one entry per action, all equal -- their gradient is the sum
+over the actions, written back to every entry after the backward pass's folds, so an elementwise optimiser keeps them
+equal; the reference-layout vector (get / set_param_values) carries the one scalar.
 """
 import numpy as np
 import torch
@@ -21,11 +24,10 @@ class AtariDqnPolicy(QPolicyBase):
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=(),
                  pixel_scale=255., epsilon=1, dueling=False, shared_last_bias=False, initial_param_values=None):
-        if shared_last_bias:
-            raise NotImplementedError("shared_last_bias (dqn_cnn.py:73-88) is not built (INTEGRATION.md, section E)")
         super().__init__(conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=hidden_sizes,
                          pixel_scale=pixel_scale, initial_param_values=initial_param_values)
         self._epsilon = epsilon
+        self._shared_last_bias = bool(shared_last_bias)
         self._set_dueling(dueling)
 
     # ---- output layer: "output_q" dense, n_actions units (dqn_cnn.py:73-80) [+ "Val", 1 unit (:100-107)]
@@ -40,26 +42,30 @@ class AtariDqnPolicy(QPolicyBase):
 
     def _head_reference_init(self, fan, n_act):
         self._q_stride = (n_act + int(self._dueling) + 31) // 32 * 32
+        out_b = np.zeros(1 if self._shared_last_bias else n_act, np.float32)     # (a shared bias is ONE parameter)
         if self._dueling:
-            return self._duel_head_ref, ["OutputW", "Outputb", "ValW", "Valb"]
-        return [_norm_c((fan, n_act), 0.01), np.zeros(n_act, np.float32)], ["OutputW", "Outputb"]
+            ref = list(self._duel_head_ref)
+            ref[1] = out_b
+            return ref, ["OutputW", "Outputb", "ValW", "Valb"]
+        return [_norm_c((fan, n_act), 0.01), out_b], ["OutputW", "Outputb"]
 
     def _head_internal_shapes(self, fan, n_act):
         return [(self._q_stride, fan), (self._q_stride,)]
 
     def _head_to_reference(self, wh, bh):
         a = self.n_act
+        out_b = bh[:1] if self._shared_last_bias else bh[:a]        # (gradients / optimiser slots: every entry holds the sum)
         if self._dueling:
             hs = self.hidden_sizes[0]
-            return [wh[:a, :hs].T, bh[:a], wh[a:a + 1, hs:].T, bh[a:a + 1]]
-        return [wh[:a].T, bh[:a]]
+            return [wh[:a, :hs].T, out_b, wh[a:a + 1, hs:].T, bh[a:a + 1]]
+        return [wh[:a].T, out_b]
 
     def _head_to_internal(self, ref_tail):
         a = self.n_act
         fan = ref_tail[0].shape[0] * (2 if self._dueling else 1)
         w = np.zeros((self._q_stride, fan), np.float32)
         b = np.zeros(self._q_stride, np.float32)
-        b[:a] = ref_tail[1]
+        b[:a] = ref_tail[1]                    # (a shared bias broadcasts its one value to every action's entry)
         if self._dueling:
             hs = self.hidden_sizes[0]
             w[:a, :hs] = ref_tail[0].T
@@ -106,4 +112,7 @@ class AtariDqnPolicy(QPolicyBase):
             _lib.dqn_loss(q, tgt_q, pol_next, actions, returns, terminals, is_weights, self.n_act, gamma_n,
                           delta_clip, dq, loss_rows, td_abs, dueling=self._dueling)
             self._head_backward(dq, x, acts, hids)
+            if self._shared_last_bias:          # the folds have run: d loss / d (shared scalar) = the sum over the actions
+                gb = self.grads[self._k_head + 1]
+                gb[:self.n_act] = gb[:self.n_act].sum()
             return loss_rows, td_abs

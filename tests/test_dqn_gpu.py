@@ -80,14 +80,14 @@ def test_q_action_kernel_greedy_and_override():
         _lib.dqn_act(q.view(-1)[:b * 16].view(b, 16), None, a, onehot)
 
 
-def _make_policy(n_act=6, eps=0.3):
+def _make_policy(n_act=6, eps=0.3, **kw):
     from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
     from accel_rl_amd.policies.dqn.atari_dqn_policy import AtariDqnPolicy
     from accel_rl_amd.spaces import Discrete, UintBox, EnvSpec
     from accel_rl_amd.util.seed import set_seed
     set_seed(5)
     spec = dict(cnn_specs[0])
-    policy = AtariDqnPolicy(epsilon=eps, **spec)
+    policy = AtariDqnPolicy(epsilon=eps, **spec, **kw)
     policy.initialize(EnvSpec(UintBox((4, 104, 80)), Discrete(n_act)), device=DEV)
     return policy, spec
 
@@ -202,5 +202,50 @@ def test_dqn_trains_with_prioritized_replay_and_eval():
         assert algo.replay_buffer.beta > 0.4
         finals.append(policy.get_param_values())
     np.testing.assert_array_equal(finals[0], finals[1])
-    with pytest.raises(NotImplementedError):
-        AtariDqnPolicy(shared_last_bias=True, **cnn_specs[0])
+
+
+def test_shared_last_bias_is_one_scalar_parameter():
+    """`shared_last_bias=True` (dqn_cnn.py:67-82: output layer without a bias + a BiasLayer with shared_axes=(0, 1)): the
+    reference-layout vector has ONE bias element after the output weights; forward, every gradient of a training step (the
+    scalar's = the sum over the actions) against autograd through plain PyTorch; an adam step keeps the stored per-action
+    entries equal."""
+    policy, spec = _make_policy(shared_last_bias=True)
+    plain, _ = _make_policy()
+    assert policy._ref_shapes[-2] == (256, 6) and policy._ref_shapes[-1] == (1,) and policy.n_params == plain.n_params - 5
+    flat = policy.get_param_values()
+    flat[-1] = 0.37
+    policy.set_param_values(flat)
+    np.testing.assert_array_equal(policy.get_param_values(), flat)
+    rs = np.random.RandomState(3)
+    b = 32
+    obs = torch.from_numpy(rs.randint(0, 256, size=(b, 4, 104, 80), dtype=np.uint8)).to(DEV)
+    nxt = torch.from_numpy(rs.randint(0, 256, size=(b, 4, 104, 80), dtype=np.uint8)).to(DEV)
+    act = torch.from_numpy(rs.randint(0, 6, size=b).astype(np.uint8)).to(DEV)
+    ret = torch.from_numpy((rs.randn(b) * 0.02 + 0.37).astype(np.float32)).to(DEV)
+    term = torch.from_numpy((rs.rand(b) < 0.2).astype(np.uint8)).to(DEV)
+    isw = torch.from_numpy((rs.rand(b) + 0.2).astype(np.float32)).to(DEV)
+    rp = _ref_params(policy, policy.flat_params)
+    scale = np.float32(1. / 255)
+    with torch.no_grad():
+        want_q = _ref_logits(rp, spec, obs.float() * scale)
+    assert torch.allclose(policy.q(obs), want_q, rtol=1e-4, atol=1e-6)
+    policy.flat_target.copy_(policy.flat_params * 0.9)
+    gamma_n = float(np.float32(0.99))
+    rows, td = policy.q_loss_and_grads(obs, nxt, act, ret, term, isw, gamma_n, 0.01, double_dqn=True)
+    got = policy.bucket_to_reference(policy.flat_grads)
+    rt = _ref_params(policy, policy.flat_target)
+    q = _ref_logits(rp, spec, obs.float() * scale)
+    with torch.no_grad():
+        tgt = _ref_logits(rt, spec, nxt.float() * scale)
+        pol = _ref_logits(rp, spec, nxt.float() * scale)
+    loss, _ = ref_q_loss(q, tgt, pol, act, ret, term, isw, gamma_n, 0.01)
+    grads = torch.autograd.grad(loss, rp)
+    want = np.concatenate([g.detach().cpu().numpy().reshape(-1) for g in grads])
+    assert got.size == want.size and abs(want[-1]) > 0
+    assert np.allclose(got, want, rtol=2e-3, atol=2e-5 * max(np.abs(want).max(), 1e-3)), np.abs(got - want).max()
+    gb = policy.grads[policy._k_head + 1]
+    assert torch.equal(gb[:6], gb[:1].expand(6)) and not gb[6:].any()       # every action's entry holds the sum
+    with torch.no_grad():
+        bias = policy.params[policy._k_head + 1]
+        bias.sub_(0.1 * gb)                                                   # any elementwise update keeps them equal
+        assert torch.equal(bias[:6], bias[:1].expand(6))
