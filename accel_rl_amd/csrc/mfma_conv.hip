@@ -194,7 +194,11 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
             // tiles, two column tiles per row tile (twice the workgroups, each wave half the MFMA chain; the gathered
             // operand is loaded and split once per column tile); 2: 64 x 64 tiles, both operands through LDS.  All
             // three issue the same piece products in the same k order: bit-identical outputs.
-            const int v = g_fwd_tile >= 0 ? g_fwd_tile : 0;
+            // By size (round 6, profiles/r06/fwd_tile_probe.txt): while every half tile still gets a CU of its own (at most
+            // 128 row tiles: the DQN updates' 32 .. 64-row batches, evaluation groups) the column split is the faster
+            // launch (108 row tiles: 19.1 -> 15.6 us); from 129 row tiles on two half workgroups per CU cost what one
+            // whole one does, plus the second load and split of the gathered operand (216 row tiles: 19.8 -> 22.7 us).
+            const int v = g_fwd_tile >= 0 ? g_fwd_tile : (2 * ((a.M + 127) / 128) <= TARGET_WGS ? 1 : 0);
             if (v == 1) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
             else if (v == 2) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
             else rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
@@ -316,7 +320,13 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         }
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
         else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, false, false, 2>(a, false, has_pad, s);
-        else if (g_split && a.N <= 64) rc = launch_igemm_split<4, 1, 1, 2, FBK, false, false, 2>(a, false, has_pad, s);
+        else if (g_split && a.N <= 64) {
+            // (as in the forward: the column split while every half tile gets a CU of its own; same products, same order)
+            const int tiles = ((a.M + 127) / 128) * (a.n_par ? a.n_par : 1);
+            const int v = g_fwd_tile >= 0 ? (g_fwd_tile == 1) : (2 * tiles <= TARGET_WGS);
+            if (v) rc = launch_igemm_split<4, 1, 1, 1, FBK, false, false, 2>(a, false, has_pad, s);
+            else rc = launch_igemm_split<4, 1, 1, 2, FBK, false, false, 2>(a, false, has_pad, s);
+        }
         else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, false, false, 1>(a, false, has_pad, s);
         // 17 .. 32 columns: 64x32 tiles on 16-wide MFMAs at five waves per SIMD (3 800 tiles instead of 1 900 of 128 rows
         // for the stride-2 gradient of the PPO minibatch: 52.5 -> 49.5 us; 32- and 96-row tiles, six waves: no better)

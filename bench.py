@@ -1236,6 +1236,13 @@ def main():
     line["phases"] = {"rollout_ms": round(t_roll * 1e3, 4), "learner_ms": round(t_learn * 1e3, 4),
                       "rollout_only_env_steps_per_s": round(N_ENVS * HORIZON / t_roll, 1)}
     tick("diagnostics", itr)
+    if rank == 0 and world == 1 and args.workload == "ppo256" and not args.no_alt_routes and not args.no_graph:
+        # (here, under the headline's own conditions -- the CPU baseline's worker pools still parked on their barriers --
+        #  and not behind cpu_baseline(): the teardown of its 200-odd processes was seen to cost the leg that followed it
+        #  15 % on one box, profiles/r06/bench_alt_after_cpu_baseline.json)
+        tick("alt routes")
+        line["alt_routes"] = alt_routes(device, args.steps, args.warmup, PRIMING)
+        line["accuracy"] = route_accuracy(device)
     if world > 1:
         line["multi_gpu"] = multi_gpu_diagnostics(device, world, rank, algo, policy, sampler, samples, timed, reps,
                                                   itr + 2 * reps, elapsed_local / args.steps, t_roll, t_learn, tick)
@@ -1266,10 +1273,6 @@ def main():
                         "`value` (rollout + PPO learner on the device) vs the CPU sampler port feeding the same device "
                         "learner serially, as the reference's runner does; rollout_only_vs_undisturbed_cpu: against "
                         "the CPU sampler's 10th-percentile batch time (what it does when the shared host is quiet)"}
-    if rank == 0 and world == 1 and args.workload == "ppo256" and not args.no_alt_routes and not args.no_graph:
-        tick("alt routes")
-        line["alt_routes"] = alt_routes(device, args.steps, args.warmup, PRIMING)
-        line["accuracy"] = route_accuracy(device)
     runner.shutdown()
     if dist.is_initialized():
         dist.barrier()

@@ -563,3 +563,36 @@ def test_six_product_route_is_within_a_quarter_of_the_fp32_mfma_chains_error():
                 assert rms[route] <= 1.25 * rms["fp32_mfma"], (layer, op, route, rms)
                 assert mx[route] <= 1.5 * mx["fp32_mfma"], (layer, op, route, mx)
             assert rms["fp32_mfma"] < 1e-6 and mx["fp32_mfma"] < 3e-6, (layer, op, rms, mx)
+
+
+@pytest.mark.parametrize("batch", [32, 64, 118, 119, 256])
+@pytest.mark.parametrize("layer", [(25, 19, 32, 64, 4, 2, 1), (12, 9, 64, 64, 3, 1, 1)], ids=["conv2", "conv3"])
+def test_tile_shapes_of_the_64_column_kernels_are_bit_identical(layer, batch):
+    """The forward / data-gradient kernels of the 33 .. 64-column layers pick their tile by the launch's size (the column
+    split up to 128 row tiles: batches 118 / 119 sit on either side of it): every shape issues the same piece products in
+    the same order, so the choice can never show in a result (arl_dev_fwd_tile pins it for the comparison)."""
+    from accel_rl_amd import _lib
+    lib = _lib.load()
+    h, w, c, k, ks, st, p = layer
+    geom = _lib.conv_geom(batch, h, w, c, k, ks, ks, st, p, p)
+    ho, wo = _lib.conv_out_hw(geom)
+    ws = _lib.conv_workspace(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(batch)
+    x = torch.randn(batch, h, w, c, device=DEV, generator=gen).relu()
+    wt = torch.randn(k, ks, ks, c, device=DEV, generator=gen) / np.sqrt(ks * ks * c)
+    bias = torch.randn(k, device=DEV, generator=gen)
+    dy = torch.randn(batch, ho, wo, k, device=DEV, generator=gen)
+    outs = []
+    try:
+        for v in (-1, 0, 1, 2):
+            lib.arl_dev_fwd_tile(v)
+            y, dx = torch.full((batch, ho, wo, k), float("nan"), device=DEV), torch.full_like(x, float("nan"))
+            _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws)
+            _lib.conv2d_bwd_data(dy, wt, x, dx, geom)              # (masked by the layer's input, as the learner runs it)
+            torch.cuda.synchronize()
+            outs.append((y, dx))
+    finally:
+        lib.arl_dev_fwd_tile(-1)
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
+    for y, dx in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(dx, outs[0][1])

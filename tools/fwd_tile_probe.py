@@ -17,7 +17,7 @@ NAMES = {0: "128x64", 1: "128x32 x2", 2: "64x64"}
 
 def main():
     lib = _lib.load()
-    batches = [int(x) for x in sys.argv[1:]] or [128, 152, 256, 303, 400, 512, 606, 1024]
+    batches = [int(x) for x in sys.argv[1:]] or [32, 64, 128, 152, 256, 303, 400, 512, 606, 1024]
     for name, (h, w, c, k, ks, st, p) in LAYERS.items():
         for b in batches:
             geom = _lib.conv_geom(b, h, w, c, k, ks, ks, st, p, p)
@@ -37,6 +37,10 @@ def main():
                     ref = y.clone()
                 line.append("%s %6.2f us%s" % (NAMES[v], ms * 1e3, "" if torch.equal(ref, y) else " (DIFFERS)"))
             lib.arl_dev_fwd_tile(-1)
+            y = torch.empty(b, ho, wo, k, device=DEV)
+            ms = graph_time_ms(lambda: _lib.conv2d_fwd(x, wt, bias, y, geom, True, ws))
+            torch.cuda.synchronize()
+            line.append("by size %6.2f us%s" % (ms * 1e3, "" if torch.equal(ref, y) else " (DIFFERS)"))
             print("%s fwd B=%4d rows=%6d tiles(128)=%4d: %s" % (name, b, rows, (rows + 127) // 128, "   ".join(line)), flush=True)
 
 

@@ -1,5 +1,5 @@
-# Regenerates the one-box part of profiles/r05 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
-# ~12 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r05 (and profiles/*.json: the PMC records bench.py reads)
+# Regenerates the one-box part of profiles/r06 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
+# ~12 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r06 (and profiles/*.json: the PMC records bench.py reads)
 set -x
 R=$(pwd); O=$R/gpurun_out/fin; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
@@ -27,7 +27,7 @@ python tools/mfma_pmc_summary.py $(find /tmp/pE -name "*counter_collection.csv" 
 python tools/gae_sweep.py > $O/gae_sweep.txt 2>&1
 # the bf16-split routes: accuracy of every kernel against float64 and launch times per route; the bench line per route
 python tools/split_check.py 512 48 2>&1 | grep -v amdgpu.ids > $O/split_check.txt
-for m in 0 6; do ARL_CONV_PRECISION=$m timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_precision_$m.json; done
+# (the bench line per route is in bench.json itself since round 6: alt_routes / accuracy)
 # tile / persistence / timeline probes of the fp32 MFMA chain (ARL_CONV_PRECISION=0: arl_conv_geom.route = ARL_CONV_ROUTE_FP32), whose tile choices they label
 export ARL_CONV_PRECISION=0
 (for w in c1f c2f c3f df c3d c2d; do python tools/context_trace.py $w 2>&1 | grep -v amdgpu.ids; done) > $O/context_trace.txt
@@ -38,7 +38,8 @@ unset ARL_CONV_PRECISION
 python tools/batch_sweep.py 2>&1 | grep "^spec" > $O/batch_sweep_passes.txt
 timeout 300 python bench.py --workload a2c1024 --steps 200 --warmup 20 2>/dev/null | tail -n 1 > $O/bench_a2c1024.json
 timeout 300 python bench.py --scaling strong --total-envs 2048 --steps 20 --warmup 5 2>/dev/null | tail -n 1 > $O/bench_strong_2048_n1.json
-timeout 400 python bench.py --workload catdqn --steps 30 --warmup 5 --dqn-batch 512 2>/dev/null | tail -n 1 > $O/bench_catdqn_batch512.json
+timeout 600 python bench.py --workload catdqn --steps 30 --warmup 5 2>/dev/null | tail -n 1 > $O/bench_catdqn.json    # the reference's minibatch 32; alt: 512
+python tools/fwd_tile_probe.py 2>&1 | grep -v amdgpu > $O/fwd_tile_probe.txt
 ARL_BENCH_ONE_GPU=1 ARL_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_spawn_2ranks_devmode.json
 ARL_BENCH_ONE_GPU=1 ARL_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 8 --steps 3 --warmup 2 --no-graph --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_spawn_8ranks_devmode.json
 ARL_FORCE_SYNC=1 timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | tail -n 1 > $O/bench_force_sync_n1.json
