@@ -163,6 +163,7 @@ _DEV_SIGNATURES = {
     "arl_dev_conv_force_generic": (None, [_i32]),
     "arl_dev_conv_variant": (None, [_i32]),
     "arl_dev_fwd_tile": (None, [_i32]),
+    "arl_dev_fold_wide_from": (None, [_i32]),
     "arl_dev_scan_force_wave": (None, [_i32]),
     "arl_dev_scan_wave_groups": (None, [_i32]),
     "arl_dev_env_variant": (None, [_i32]),

@@ -12,31 +12,59 @@ int g_fwd_tile = -1;            // arl_dev_fwd_tile: -1 = chosen by the launch's
 }  // namespace arlc
 
 namespace {
-// out[i] = act(sum_z part[z][i] + bias[i % n_bias]), float4 lanes, fixed summation order:
-// 16 threads share one output float4 (thread zg sums splits zg, zg+16, ...), then the 16
-// partial sums are added in index order -- enough parallelism for the small, many-split
-// weight gradients (conv 1: 2048 float4 x 128 splits) without giving up determinism.
-__global__ __launch_bounds__(256) void fold_splits_kernel(const float4* __restrict__ part, int splits,
-                                                          int64_t total4, const float4* __restrict__ bias,
-                                                          int bias4, int relu, const float4* __restrict__ mask,
-                                                          float4* __restrict__ out) {
-    __shared__ float4 lds[16][16];
-    const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
-    const int64_t i = (int64_t)blockIdx.x * 16 + o;
+// out[i] = act(sum_z part[z][i] + bias[i % n_bias]), float4 lanes, fixed summation order: ZG threads share one output
+// float4 (thread zg sums splits zg, zg + ZG, ...), then the ZG partial sums are added in index order -- enough parallelism
+// for the small, many-split weight gradients without giving up determinism.  ZG = 16, or 64 from FOLD_WIDE splits on
+// (round 6: conv 1's weight gradient, 2048 float4 x 512 splits = 16.8 MB, was folded by 128 workgroups whose threads each
+// walked 32 dependent-latency loads: 11 us at 1.5 TB/s).  Blocks are 1024 threads: one group of 64 x 16 threads (16
+// outputs) in the wide mode, four independent groups of 16 x 16 threads (64 outputs) otherwise -- the arithmetic of an
+// item below FOLD_WIDE splits is exactly what the 256-thread kernel of rounds 1-5 did.
+constexpr int FOLD_WIDE = 128, FOLD_THREADS = 1024;
+int g_fold_wide = FOLD_WIDE;            // arl_dev_fold_wide_from (A/B of the threshold)
+
+struct FoldSlot { int64_t i; int zg, zgn, row0, o; };
+__device__ __forceinline__ FoldSlot fold_slot(int splits, int local_block, int wide_from) {
+    FoldSlot f;
+    const int tid = threadIdx.x;
+    f.o = tid & 15;
+    if (splits >= wide_from) { f.zg = tid >> 4; f.zgn = 64; f.row0 = 0; f.i = (int64_t)local_block * 16 + f.o; }
+    else {
+        const int grp = tid >> 8;
+        f.zg = (tid >> 4) & 15; f.zgn = 16; f.row0 = grp * 16; f.i = ((int64_t)local_block * 4 + grp) * 16 + f.o;
+    }
+    return f;
+}
+inline int fold_blocks(int splits, int64_t total4) {
+    const int per = splits >= g_fold_wide ? 16 : 64;
+    return (int)((total4 + per - 1) / per);
+}
+__device__ __forceinline__ float4 fold_sum(const float4* __restrict__ part, int splits, int64_t total4, const FoldSlot& f,
+                                           float4 (*lds)[16]) {
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < total4)
-        for (int z = zg; z < splits; z += 16) {
-            const float4 v = part[(int64_t)z * total4 + i];
+    if (f.i < total4)
+        for (int z = f.zg; z < splits; z += f.zgn) {
+            const float4 v = part[(int64_t)z * total4 + f.i];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-    lds[zg][o] = s;
+    lds[f.row0 + f.zg][f.o] = s;
     __syncthreads();
-    if (zg == 0 && i < total4) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const float4 v = lds[k][o];
+    if (f.zg == 0 && f.i < total4)
+        for (int k = 1; k < f.zgn; ++k) {
+            const float4 v = lds[f.row0 + k][f.o];
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    return s;
+}
+
+__global__ __launch_bounds__(FOLD_THREADS) void fold_splits_kernel(const float4* __restrict__ part, int splits,
+                                                                   int64_t total4, const float4* __restrict__ bias,
+                                                                   int bias4, int relu, const float4* __restrict__ mask,
+                                                                   float4* __restrict__ out, int wide_from) {
+    __shared__ float4 lds[64][16];
+    const FoldSlot f = fold_slot(splits, (int)blockIdx.x, wide_from);
+    float4 s = fold_sum(part, splits, total4, f, lds);
+    const int64_t i = f.i;
+    if (f.zg == 0 && i < total4) {
         if (bias) {
             const float4 b = bias[i % bias4];
             s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
@@ -53,38 +81,26 @@ __global__ __launch_bounds__(256) void fold_splits_kernel(const float4* __restri
     }
 }
 
-// Several independent folds in one launch (arl_fold_many): block -> (item, 16 output float4s) through
-// a block-offset table in the kernel arguments; per item the same fixed summation order as above.
+// Several independent folds in one launch (arl_fold_many): block -> (item, its outputs) through a block-offset table in
+// the kernel arguments; per item the same fixed summation order as above.
 struct FoldManyArgs {
     arl_fold_item items[ARL_FOLD_MAX_ITEMS];
     int block_start[ARL_FOLD_MAX_ITEMS + 1];
-    int n;
+    int n, wide_from;
 };
 
-__global__ __launch_bounds__(256) void fold_many_kernel(const FoldManyArgs a) {
-    __shared__ float4 lds[16][16];
+__global__ __launch_bounds__(FOLD_THREADS) void fold_many_kernel(const FoldManyArgs a) {
+    __shared__ float4 lds[64][16];
     int it = 0;
     while (it + 1 < a.n && (int)blockIdx.x >= a.block_start[it + 1]) ++it;      // uniform
     const float4* part = reinterpret_cast<const float4*>(a.items[it].part);
     float4* out = reinterpret_cast<float4*>(a.items[it].out);
     const int64_t total4 = a.items[it].total >> 2;
     const int splits = a.items[it].splits;
-    const int o = threadIdx.x & 15, zg = threadIdx.x >> 4;
-    const int64_t i = (int64_t)((int)blockIdx.x - a.block_start[it]) * 16 + o;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < total4)
-        for (int z = zg; z < splits; z += 16) {
-            const float4 v = part[(int64_t)z * total4 + i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    lds[zg][o] = s;
-    __syncthreads();
-    if (zg == 0 && i < total4) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const float4 v = lds[k][o];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
+    const FoldSlot f = fold_slot(splits, (int)blockIdx.x - a.block_start[it], a.wide_from);
+    const float4 s = fold_sum(part, splits, total4, f, lds);
+    const int64_t i = f.i;
+    if (f.zg == 0 && i < total4) {
         const int64_t valid = a.items[it].valid;            // > 0: `out` holds only this many floats
         if (valid <= 0 || 4 * i + 3 < valid) {
             out[i] = s;
@@ -100,9 +116,9 @@ __global__ __launch_bounds__(256) void fold_many_kernel(const FoldManyArgs a) {
 int launch_fold(const float* part, int splits, int64_t total, const float* bias, int n_bias, int relu,
                 float* out, hipStream_t s, const float* mask = nullptr) {
     const int64_t total4 = total >> 2;
-    hipLaunchKernelGGL(fold_splits_kernel, dim3((unsigned)((total4 + 15) / 16)), dim3(256), 0, s,
+    hipLaunchKernelGGL(fold_splits_kernel, dim3((unsigned)fold_blocks(splits, total4)), dim3(FOLD_THREADS), 0, s,
                        (const float4*)part, splits, total4, (const float4*)bias, n_bias >> 2, relu,
-                       (const float4*)mask, (float4*)out);
+                       (const float4*)mask, (float4*)out, g_fold_wide);
     return arl::check_launch("fold_splits_kernel");
 }
 
@@ -113,6 +129,8 @@ extern "C" int64_t arl_conv_workspace_bytes(void) { return (int64_t)64 << 20; }
 extern "C" void arl_dev_conv_trace_buffer(void* device_u64_or_null) { g_trace = (unsigned long long*)device_u64_or_null; }
 
 extern "C" void arl_dev_conv_force_generic(int32_t on) { g_force_generic = on != 0; }
+
+extern "C" void arl_dev_fold_wide_from(int32_t splits) { g_fold_wide = splits > 0 ? splits : FOLD_WIDE; }
 
 extern "C" void arl_dev_fwd_tile(int32_t v) { g_fwd_tile = (v >= 0 && v <= 2) ? v : -1; }
 
@@ -680,10 +698,11 @@ extern "C" int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream
         ARL_REQUIRE(arl::aligned16(items[i].part) && arl::aligned16(items[i].out), ARL_E_ALIGN, "16-byte alignment");
         a.items[a.n] = items[i];
         a.block_start[a.n++] = blocks;
-        blocks += (int)(((items[i].total >> 2) + 15) / 16);
+        blocks += fold_blocks(items[i].splits, items[i].total >> 2);
     }
     if (a.n == 0) return 0;
     a.block_start[a.n] = blocks;
-    hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    a.wide_from = g_fold_wide;
+    hipLaunchKernelGGL(fold_many_kernel, dim3((unsigned)blocks), dim3(FOLD_THREADS), 0, (hipStream_t)stream, a);
     return arl::check_launch("fold_many_kernel");
 }

@@ -25,6 +25,11 @@ void arl_dev_conv_force_generic(int32_t on);
  * -1 (default) = chosen by the launch's size: the column split while every half tile gets a CU of its own.           */
 void arl_dev_fwd_tile(int32_t v);
 
+/* A-B measurements: split count from which a fold (arl_fold_many, the dense forward's fold) sums an output with 64
+ * threads instead of 16 (csrc/mfma_conv.hip, FOLD_WIDE).  0 = the default (128).  Changes the association of the sums of
+ * the items it moves across the threshold (still a fixed order), nothing else.                                       */
+void arl_dev_fold_wide_from(int32_t splits);
+
 /* Tests / A-B measurements: bit 0 set = the image-stationary kernels (csrc/img_conv.hip) are not used; the tap-gathering
  * kernels they replace run instead (same results bit for bit).                                                      */
 void arl_dev_conv_variant(int32_t v);
