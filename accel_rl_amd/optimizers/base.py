@@ -169,7 +169,11 @@ class BaseOptimizer(object):
         """Device tensor [count]: global grad norms of this call's updates (no host sync)."""
         assert 0 < count <= self._opt_state.norm_log_len
         self._finish_updates(count)
-        return self._norm_log[:count].clone()
+        # (inside a graph capture the log slice itself is the output: it lives exactly as long as a clone made by the
+        #  graph would -- until the next replay -- and the learner's graph copies it into its diagnostics ring anyway;
+        #  eager callers keep the tensor across calls and get their own copy)
+        out = self._norm_log[:count]
+        return out if (out.is_cuda and torch.cuda.is_current_stream_capturing()) else out.clone()
 
     def _finish_updates(self, count):
         """Close a call of `count` no-clip updates (norm log, Lasagne's t); every call must end with this."""
