@@ -12,7 +12,7 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libaccel_rl_hip.so")
 SOURCES = ["mfma_conv_p1.hip", "mfma_conv_p2.hip", "mfma_conv_p3.hip", "mfma_conv_p4.hip", "mfma_conv_p5.hip", "mfma_conv_p6.hip",
-           "mfma_conv_p7.hip", "mfma_conv.hip", "img_conv.hip", "batch_ops.hip", "scan.hip", "env.hip", "optim.hip", "learner.hip", "replay.hip",
+           "mfma_conv_p7.hip", "mfma_conv.hip", "img_conv.hip", "batch_ops.hip", "scan.hip", "env.hip", "serve_step.hip", "optim.hip", "learner.hip", "replay.hip",
            "dqn.hip", "lstm.hip", "gru.hip"]
 ARCH = "gfx950"
 

@@ -72,6 +72,16 @@ class ArlFoldItem(C.Structure):
 FOLD_MAX_ITEMS = 24
 
 
+class ArlServeHead(C.Structure):
+    _fields_ = [("hidden", ArlFoldItem), ("hidden_bias", _vp), ("hidden_relu", _i32), ("hid", _i32),
+                ("w_head", _vp), ("b_head", _vp)]
+
+
+class ArlServeConv1(C.Structure):
+    _fields_ = [("geom", C.POINTER(ArlConvGeom)), ("w", _vp), ("bias", _vp), ("y", _vp), ("scale", _f32),
+                ("relu", _i32)]
+
+
 class ArlReplay(C.Structure):
     _fields_ = [("n_env", _i64), ("size", _i32), ("n_stack", _i32), ("frame_bytes", _i32),
                 ("reward_horizon", _i32), ("frames", _vp), ("n_blanks", _vp), ("acts", _vp),
@@ -121,6 +131,10 @@ _SIGNATURES = {
     "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem),
                                            _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_fold_many": (_i32, [C.POINTER(ArlFoldItem), _i32, _vp]),
+    "arl_conv2d_fwd_parts": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, C.POINTER(ArlFoldItem), _vp]),
+    "arl_serve_conv1_supported": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlConvGeom)]),
+    "arl_env_step_served": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
+                                   C.POINTER(ArlServeHead), C.POINTER(ArlServeConv1), _vp, _i32, _f64, _f64, _i32, _vp]),
     "arl_conv2d_u8_fwd": (_i32, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp]),
     "arl_conv2d_u8_bwd_weight_parts": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
                                               C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), _vp]),
@@ -375,6 +389,22 @@ def env_step(game, state, rollout, prob, value, uniforms, step, mid_batch_reset,
                                int(bool(single_write)), stream_ptr(stream)), "arl_env_step")
 
 
+def serve_conv1_supported(game, geom):
+    """Can arl_env_step_served evaluate this first convolution inside its launch?"""
+    return bool(load().arl_serve_conv1_supported(C.byref(game), C.byref(geom)))
+
+
+def env_step_served(game, state, rollout, head, conv1, uniforms, step, max_path_length, discount, max_start_noops,
+                    stream=None):
+    """Hidden-layer fold + heads + softmax + action draw + env step (+ the next observation's conv 1) as ONE launch.
+    head: ArlServeHead; conv1: ArlServeConv1 or None.  Both hold raw pointers: the caller keeps the tensors alive."""
+    _want(uniforms, torch.float64, "uniforms")
+    _check(load().arl_env_step_served(C.byref(game), C.byref(state), C.byref(rollout), C.byref(head),
+                                      None if conv1 is None else C.byref(conv1), ptr(uniforms), int(step),
+                                      float(max_path_length), float(discount), int(max_start_noops),
+                                      stream_ptr(stream)), "arl_env_step_served")
+
+
 def env_frame_step(game, state, rollout, step, max_start_noops, stream=None):
     _check(load().arl_env_frame_step(C.byref(game), C.byref(state), C.byref(rollout), step,
                                      int(max_start_noops), stream_ptr(stream)), "arl_env_frame_step")
@@ -533,6 +563,22 @@ def conv2d_fwd(x, w, bias, y, geom, relu, workspace, stream=None):
     _check(load().arl_conv2d_fwd(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                                  y.data_ptr(), C.byref(geom), int(bool(relu)), ptr(workspace),
                                  stream_ptr(stream)), "arl_conv2d_fwd")
+
+
+def conv2d_fwd_parts(x, w, bias, y, geom, relu, workspace, stream=None):
+    """conv2d_fwd that leaves a split reduction unfolded: returns the ArlFoldItem describing the partial sums in
+    `workspace` (splits == 0: the launch did not split and y is final, bias / rectifier applied)."""
+    for t, n in ((x, "x"), (w, "w"), (y, "y")):
+        _want(t, torch.float32, n)
+    ho, wo = conv_out_hw(geom)
+    assert x.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x size"
+    assert w.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w size"
+    assert y.numel() == geom.batch * ho * wo * geom.out_c, "y size"
+    item = ArlFoldItem()
+    _check(load().arl_conv2d_fwd_parts(x.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                       y.data_ptr(), C.byref(geom), int(bool(relu)), ptr(workspace), C.byref(item),
+                                       stream_ptr(stream)), "arl_conv2d_fwd_parts")
+    return item
 
 
 def conv2d_u8_supported(in_h, in_w, out_c, kh, kw, stride, pad_h, pad_w):

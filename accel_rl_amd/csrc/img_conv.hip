@@ -17,33 +17,16 @@
 // instruction: bound by the texture addresser, 24.5 us at the PPO minibatch); this one runs 19 us there and 10.9 us
 // instead of 15.6 us at the rollout's 256 rows (tools/proto/conv1_img_proto.hip, profiles/r03/conv1_img_proto.txt).
 #include "mfma_conv_impl.h"
+#include "img_conv_dev.h"
 
 namespace arlc {
 
-struct Conv1ImgArgs {
-    const unsigned char* obs;   // u8 [rows][C][H][W]
-    const int* idx;             // row of image b, or null
-    const float* w;             // f32 [32][C][8][8]
-    const float* bias;          // f32 [32] or null
-    float* y;                   // f32 [B][OH][OW][32]
-    float scale;
-    int n_img, C, H, W, OH, OW, stride, relu;
-    int obs_rows;               // rows of obs: an index outside [0, obs_rows) reads row 0 instead of faulting
-};
-
-__device__ __forceinline__ u32x2 bytes_to_bf16x4(unsigned v) {     // four packed bytes -> four bf16, exact
-    const float4 f = bytes_to_f4(v);
-    return u32x2{hi_pair(f.x, f.y), hi_pair(f.z, f.w)};
-}
-
-constexpr int C1_NW = 16, C1_NT = C1_NW * 64, C1_MAX_IMG = 40960;
-
 __global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    constexpr int N = 32, KH = 8, MAXLD = (C1_MAX_IMG / 16 + C1_NT - 1) / C1_NT;
+    constexpr int MAXLD = (C1_MAX_IMG / 16 + C1_NT - 1) / C1_NT;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
+    const int half = lane >> 5;
     const int C = a.C, H = a.H, W = a.W, npix = C * H * W, K = C * 64, nsteps = K / 16;
     char* const sW = lds;                                   // [nsteps][3 planes][64 lanes] 16-byte fragments
     char* const sI = lds + nsteps * 3072;                   // two u8 images [C][H][W]
@@ -64,66 +47,17 @@ __global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) 
             if (tid + C1_NT * i < n16) *reinterpret_cast<u32x4*>(d + (tid + C1_NT * i) * 16) = ireg[i];
     };
     img_issue(blockIdx.x);
-    // weights: fragment (step s, lane) = filter l31, reduction indices 16 s + 8 half + 0..7 (index (c * 8 + ty) * 8 + tx)
-    for (int f = tid; f < nsteps * 64; f += C1_NT) {
-        const int s = f >> 6, fl = f & 63;
-        const float* src = a.w + (size_t)(fl & 31) * K + s * 16 + (fl >> 5) * 8;
-        const float4 v0 = *reinterpret_cast<const float4*>(src), v1 = *reinterpret_cast<const float4*>(src + 4);
-        unsigned h[4], m[4], l[4];
-        split_pair(v0.x, v0.y, h[0], m[0], l[0]);
-        split_pair(v0.z, v0.w, h[1], m[1], l[1]);
-        split_pair(v1.x, v1.y, h[2], m[2], l[2]);
-        split_pair(v1.z, v1.w, h[3], m[3], l[3]);
-        char* d = sW + s * 3072 + fl * 16;
-        *reinterpret_cast<u32x4*>(d) = u32x4{h[0], h[1], h[2], h[3]};
-        *reinterpret_cast<u32x4*>(d + 1024) = u32x4{m[0], m[1], m[2], m[3]};
-        *reinterpret_cast<u32x4*>(d + 2048) = u32x4{l[0], l[1], l[2], l[3]};
-    }
+    for (int f = tid; f < nsteps * 64; f += C1_NT) conv1_w_store(sW, f, conv1_w_load(a.w, K, f));
     const int rows = a.OH * a.OW, tiles = (rows + 31) / 32;
     float4 bq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.bias) bq[q] = *reinterpret_cast<const float4*>(a.bias + 8 * q + 4 * half);
-    }
+    conv1_bias_quads(a.bias, half, bq);
     img_store(0);
     if (blockIdx.x + gridDim.x < (unsigned)a.n_img) img_issue(blockIdx.x + gridDim.x);
     __syncthreads();
     int buf = 0;
     for (int img = blockIdx.x; img < a.n_img; img += gridDim.x, buf ^= 1) {
         const char* im = sI + buf * npix;
-        for (int tp = wave; tp < tiles; tp += C1_NW) {
-            const int m = tp * 32 + l31;
-            const int mm = m < rows ? m : 0;
-            const int oy = mm / a.OW, ox = mm - oy * a.OW;
-            const unsigned off = (unsigned)((oy * a.stride + half) * W + ox * a.stride);     // filter row `half` of a step
-            f32x16 acc;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-            const char* wl = sW + lane * 16;
-#pragma unroll 2
-            for (int s = 0; s < nsteps; ++s) {              // step s = plane s / 4, filter rows 2 (s % 4) + half
-                const unsigned po = (unsigned)(((s / (KH / 2)) * H + 2 * (s % (KH / 2))) * W);
-                u32x4 fb[3];
-#pragma unroll
-                for (int pl = 0; pl < 3; ++pl) fb[pl] = *reinterpret_cast<const u32x4*>(wl + s * 3072 + pl * 1024);
-                const unsigned* q = reinterpret_cast<const unsigned*>(im + po + off);
-                const u32x2 lo = bytes_to_bf16x4(q[0]), hi = bytes_to_bf16x4(q[1]);
-                const u32x4 fa = u32x4{lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-                for (int pl = 2; pl >= 0; --pl) acc = mfma_bf16(fb[pl], fa, acc);   // (split_products<.., 1, 3, true>: l, m, h)
-            }
-            if (m < rows) {                                 // lane = pixel m, channels 8 q + 4 half + 0..3
-                float* dst = a.y + ((size_t)img * rows + m) * N + 4 * half;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float4 v = make_float4(acc[4 * q] * a.scale + bq[q].x, acc[4 * q + 1] * a.scale + bq[q].y,
-                                           acc[4 * q + 2] * a.scale + bq[q].z, acc[4 * q + 3] * a.scale + bq[q].w);
-                    if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    *reinterpret_cast<float4*>(dst + 8 * q) = v;
-                }
-            }
-        }
+        for (int tp = wave; tp < tiles; tp += C1_NW) conv1_tile(a, im, sW, img, tp, lane, bq);
         // the next image's bytes (in flight while this one was computed) -> the other buffer, which every wave left at
         // the last barrier; the image after that starts its way from memory
         if (img + (int)gridDim.x < a.n_img) {

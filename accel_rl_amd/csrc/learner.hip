@@ -17,6 +17,7 @@
 // All fp32 (the reference's floatX); compiled with -ffp-contract=off.
 
 #include "arl_common.h"
+#include "head_dev.h"
 
 namespace {
 
@@ -134,14 +135,6 @@ __global__ __launch_bounds__(1024) void fold_partials_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------- heads
-__device__ __forceinline__ float readlane_f(float x, int uniform_lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), uniform_lane));
-}
-__device__ __forceinline__ float wave_sum_f(float x) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
-    return x;
-}
 
 struct HeadLossArgs {
     const float* h;          // [B][hid] post-relu hidden activations

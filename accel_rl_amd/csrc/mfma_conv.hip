@@ -154,8 +154,9 @@ extern "C" int arl_corun_job_run(const arl_corun_job* job, void* stream) {
 }
 
 namespace {
+// parts: leave a split reduction unfolded and describe it (arl_conv2d_fwd_parts); null = fold here
 int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y, const arl_conv_geom* geom, int32_t relu,
-             void* workspace, void* stream) {
+             void* workspace, void* stream, arl_fold_item* parts = nullptr) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
@@ -237,10 +238,27 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
         else if (small) rc = launch_rowgather<2, 2, 1, 1, 16, true>(a, splits, s);
         else rc = launch_rowgather<2, 2, 2, 2, 16, true>(a, splits, s);
     }
+    if (parts) {
+        parts->part = splits == 1 ? y : (const float*)workspace; parts->out = y; parts->total = (int64_t)a.M * a.N;
+        parts->splits = splits == 1 ? 0 : splits; parts->valid = 0;
+        return rc;
+    }
     if (rc || splits == 1) return rc;
     return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, bias_or_null, a.N, relu, y, s);
 }
 }  // namespace
+
+namespace arlc {
+int fold_wide_from() { return g_fold_wide; }
+}
+
+extern "C" int arl_conv2d_fwd_parts(const float* x, const float* w, const float* bias_or_null, float* y,
+                                    const arl_conv_geom* geom, int32_t relu, void* workspace, arl_fold_item* item,
+                                    void* stream) {
+    ARL_REQUIRE(item, ARL_E_ARG, "null pointer");
+    ARL_ROUTE_SCOPE(geom, nullptr);
+    return fwd_impl(x, w, bias_or_null, y, geom, relu, workspace, stream, item);
+}
 
 extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, float* y,
                               const arl_conv_geom* geom, int32_t relu, void* workspace, void* stream) {

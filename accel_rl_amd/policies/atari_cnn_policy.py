@@ -28,6 +28,7 @@ conv_i.b, hidden_i.W, hidden_i.b, output_pi.W, .b, output_v.W, .b
 (pg_cnn.py:47-86,118-119), conv W (out,in,kh,kw) for a flipped (true) convolution,
 dense W (in,out) with (c,h,w) input order.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -340,6 +341,59 @@ class AtariCnnPolicy(object):
             value = torch.empty(b, dtype=torch.float32, device=self.device)
             _lib.pg_head_infer(hids[-1], self.params[-2], self.params[-1], prob, value)
             return prob, value
+
+    # ------------------------------------------------- serving inside the env step's launch
+    def serve_supported(self):
+        """Can GpuVecSampler hand this policy's output layers to arl_env_step_served?  Only the plain feed-forward
+        network (subclasses with their own prob_value -- recurrent, Q-networks -- keep the separate launches)."""
+        return (type(self).prob_value is AtariCnnPolicy.prob_value and self._n_hid >= 1 and
+                self._hid_geom[-1][0] <= 1024 and self.n_act <= _lib.MAX_ACTIONS)
+
+    def serve_forward(self, game, observations, rows, y1=None, want_next=True):
+        """prob_value's trunk for arl_env_step_served: everything up to the last hidden layer, whose split partial sums
+        stay unfolded (the step launch folds them, applies bias + rectifier, evaluates the heads and samples).
+        y1: conv 1's output for these rows if the previous step's launch has already computed it (None: computed here).
+        Returns (head, conv1, y1_next): _lib.ArlServeHead; _lib.ArlServeConv1 or None (want_next False, or a first layer
+        the step launch does not take); the tensor that launch will leave the next rows' conv 1 output in (or None).
+        Same kernels, same arithmetic as prob_value (atari_cnn_policy.py:63-67 of the reference)."""
+        with torch.no_grad():
+            b = rows.shape[0]
+            conv_g, dense_g = self._layer_geoms(b)
+            w = self._w
+            nf, ci, sz, st, pad, ho, wo = self._conv_geom[0]
+            if y1 is None:
+                x = self._scaled(observations, rows)
+                y1 = self._buffer(("act", 0, b), (b, ho, wo, nf))
+                if isinstance(x, ObsRows):
+                    _lib.conv2d_u8_fwd(x.obs, x.idx, self._scale, w[0], w[1], y1, conv_g[0], True)
+                else:
+                    _lib.conv2d_fwd(x, w[0], w[1], y1, conv_g[0], True, self._conv_ws)
+            a = y1
+            for i in range(1, self._n_conv):
+                nf_i, _, _, _, _, ho_i, wo_i = self._conv_geom[i]
+                z = self._buffer(("act", i, b), (b, ho_i, wo_i, nf_i))
+                _lib.conv2d_fwd(a, w[2 * i], w[2 * i + 1], z, conv_g[i], True, self._conv_ws)
+                a = z
+            k = 2 * self._n_conv
+            for j, (hs, fan_in) in enumerate(self._hid_geom):
+                hcur = self._buffer(("hid", j, b), (b, hs))
+                if j + 1 < self._n_hid:
+                    _lib.conv2d_fwd(a, w[k], w[k + 1], hcur, dense_g[j], True, self._conv_ws)
+                else:
+                    item = _lib.conv2d_fwd_parts(a, w[k], w[k + 1], hcur, dense_g[j], True, self._conv_ws)
+                a = hcur
+                k += 2
+            head = _lib.ArlServeHead()
+            head.hidden = item
+            head.hidden_bias, head.hidden_relu, head.hid = w[k - 1].data_ptr(), 1, self._hid_geom[-1][0]
+            head.w_head, head.b_head = w[self._k_head].data_ptr(), w[self._k_head + 1].data_ptr()
+            conv1 = None
+            if want_next and self._u8 and _lib.serve_conv1_supported(game, conv_g[0]):
+                conv1 = _lib.ArlServeConv1()
+                conv1.geom = C.pointer(conv_g[0])
+                conv1.w, conv1.bias, conv1.y = w[0].data_ptr(), w[1].data_ptr(), y1.data_ptr()
+                conv1.scale, conv1.relu = self._scale, 1
+            return head, conv1, (y1 if conv1 is not None else None)
 
     # ------------------------------------------------------------- training
     def loss_and_grads(self, mb, kind, clip_param, v_loss_coeff, ent_loss_coeff, lr_mult,

@@ -21,6 +21,7 @@ into a device ring that env.hip consumes in the reference's order.
 env index e = (group * n_parallel + rank) * envs_per + i (sampler.py:160-185).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -99,6 +100,9 @@ class _LazyTrajInfos(list):
 class GpuVecSampler(BaseMbSampler):
 
     _alias_extra_obs = True     # (A/B switch of policy_init's aliasing of extra_observations onto step_obs)
+    # one launch per step for everything per-env (arl_env_step_served): the policy's last fold + output layers, the action
+    # draw, the env step and the next observation's first convolution (A/B switch; bit-identical either way)
+    _serve_in_step = os.environ.get("ARL_SERVE_IN_STEP", "1") != "0"
 
     def __init__(self, n_parallel=1, envs_per=1, device=None, use_graph=True, **kwargs):
         super().__init__(n_parallel=n_parallel, envs_per=envs_per, **kwargs)
@@ -257,6 +261,8 @@ class GpuVecSampler(BaseMbSampler):
         # rollout buffer's extra_observations is then the same memory, and the copy at the end of every batch (5.7 us of a
         # 515 us rollout at 256 envs) is not made.  Without mid-batch resets frozen envs are reset AFTER the reference has
         # copied (worker.py:108-113), so the copy stays.
+        self._serve_fused = bool(self._single_write and type(self)._serve_in_step and self._game.n_stack <= 4 and
+                                 hasattr(policy, "serve_forward") and policy.serve_supported())
         self._extra_is_step_obs = bool(self.need_extra_obs and self.mid_batch_reset and type(self)._alias_extra_obs)
         if self._extra_is_step_obs:
             self.samples_buf.extra_observations = self.envs_buf.extra_observations = self.step_obs
@@ -323,9 +329,16 @@ class GpuVecSampler(BaseMbSampler):
         buf, ro, env = self.samples_buf, self._rollout, self.env
         _lib.copy_bytes(self._uniforms, self._uniforms_host)   # (a kernel node reading the pinned buffer: no memcpy node)
         _lib.rollout_begin(self._game, self._state, ro)        # observations[:, 0] = step_obs (worker.py:30-32), done_count = 0
+        y1 = None                                              # conv 1 of the step's observations, once a step launch has left it
         for s in range(t):
             if hasattr(self.policy, "set_step"):
                 self.policy.set_step(s)
+            if self._serve_fused:
+                head, conv1, y1 = self.policy.serve_forward(self._game, buf.observations, self._step_rows[s], y1,
+                                                            want_next=s + 1 < t)
+                _lib.env_step_served(self._game, self._state, ro, head, conv1, self._uniforms[s], s,
+                                     self._kernel_max_path_length(), self.discount, env.max_start_noops)
+                continue
             if self._recurrent:
                 prob, value, *prev = self.policy.act_step(self.step_obs)
                 for key, state in zip(self.policy.state_info_keys, prev):      # stored at (env, step)

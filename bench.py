@@ -234,9 +234,12 @@ def env_step_sweep(device, n_env=ENV_SWEEP_ENVS):
         with open(os.path.join(ROOT, "profiles", "env_step_pmc.json")) as f:
             rec = json.load(f)
         import hashlib
-        with open(os.path.join(ROOT, "accel_rl_amd", "csrc", "env.hip"), "rb") as f:
-            if rec.get("env_hip_sha1") == hashlib.sha1(f.read()).hexdigest():
-                traffic = int(rec["hbm_bytes_per_env_step"] * n_env)
+        h = hashlib.sha1()
+        for name in ("env.hip", "env_dev.h"):                      # (tools/env_step_pmc.py: env_sources_sha1)
+            with open(os.path.join(ROOT, "accel_rl_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        if rec.get("env_hip_sha1") == h.hexdigest():
+            traffic = int(rec["hbm_bytes_per_env_step"] * n_env)
     except (OSError, ValueError, KeyError):
         pass
     smp.shutdown()

@@ -456,6 +456,59 @@ int arl_conv2d_bwd_weight_parts(const float* dy, const float* x, float* dw, cons
                                 float* dbias_or_null, arl_fold_item* bias_item_or_null, void* stream);
 int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream);
 
+/* Forward with the split reduction left unfolded: as arl_conv2d_fwd, but when the launch split its reduction the partial
+ * sums stay in `workspace` and *item describes them (part f32[splits][rows * out_c], total = rows * out_c; bias and
+ * rectifier NOT applied: they belong to whoever folds -- arl_env_step_served below does, per env, inside its launch);
+ * item->splits == 0: the launch did not split, y is final (bias and rectifier applied).  The workspace stays live until
+ * the consumer has run.  Replaces the same Lasagne DenseLayer forward as arl_conv2d_fwd (pg_cnn.py:57-68).          */
+int arl_conv2d_fwd_parts(const float* x, const float* w, const float* bias_or_null, float* y,
+                         const arl_conv_geom* geom, int32_t relu, void* workspace, arl_fold_item* item, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * One agent step of action serving in ONE launch
+ * ------------------------------------------------------------------------- */
+
+/* The policy's output layers as arl_env_step_served evaluates them for every env (row e of each array = env e). */
+typedef struct arl_serve_head {
+    arl_fold_item hidden;       /* the last hidden layer as arl_conv2d_fwd_parts left it: total = n_env * hid;
+                                 * splits > 0: part f32[splits][n_env][hid] partial sums (folded in arl_fold_many's order);
+                                 * splits == 0: part f32[n_env][hid] finished activations.  `out` is not used.          */
+    const float* hidden_bias;   /* f32[hid] or NULL: added after the fold (splits > 0 only)                             */
+    int32_t hidden_relu;        /* != 0: max(., 0) after the bias (splits > 0 only)                                     */
+    int32_t hid;                /* multiple of 4, <= 1024                                                               */
+    const float* w_head;        /* f32[n_actions + 1][hid], rows 0..A-1 pi, row A value (arl_pg_head_infer's layout)    */
+    const float* b_head;        /* f32[n_actions + 1]                                                                   */
+} arl_serve_head;
+
+/* The first convolution of the NEXT observation, evaluated from LDS right after the env step has built it
+ * (arl_conv2d_u8_fwd's arithmetic; geometries: arl_serve_conv1_supported).                                            */
+typedef struct arl_serve_conv1 {
+    const arl_conv_geom* geom;  /* batch = n_env, in_c = n_stack, 104 x 80 input, 32 filters of 8 x 8, no padding      */
+    const float* w;             /* f32[32][n_stack][8][8]                                                              */
+    const float* bias;          /* f32[32] or NULL                                                                     */
+    float* y;                   /* f32[n_env][out_h][out_w][32]                                                        */
+    float scale;                /* pixel scale (1 / 255), applied to the finished sums                                 */
+    int32_t relu;
+} arl_serve_conv1;
+
+/* 1 if arl_env_step_served can take this first layer (else: conv1_or_null = NULL and arl_conv2d_u8_fwd afterwards). */
+int arl_serve_conv1_supported(const arl_game* game, const arl_conv_geom* geom);
+
+/* One (step, all envs) turn of serve_actions with everything per-env in one launch (one workgroup per env): fold, bias
+ * and rectifier of the last hidden layer's split partials, the policy and value heads + softmax (arl_pg_head_infer),
+ * weighted_sample_n, the env step (arl_env_step with mid_batch_reset != 0, single_write != 0, every env stepping) and,
+ * with conv1, the first convolution of the observation the step has just produced (row e of conv1->y = env e; it
+ * belongs to step + 1, or to the bootstrap observation after the batch's last step).  prob and value are written
+ * straight to ro->prob / ro->value rows env * horizon + step.  Results are bit for bit those of the separate calls.
+ * Replaces accel_rl/sampler/act_server/alternating/overlap/sampler.py:120-151 (serve_actions), the output layers of
+ * _f_prob_value (policies/pg/atari_cnn_policy.py:63-67, pg/networks/pg_cnn.py:57-86), rllab/misc/special.py:22-27,
+ * overlap/worker.py:37-59, envs/atari_env.py:65-78,93-100,151-191 and pg_cnn.py:47-52 for the next observation.
+ * Needs st->next_reset, max_path_length >= 1, n_stack <= 4, 16-byte aligned observations / step_obs.               */
+int arl_env_step_served(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                        const arl_serve_head* head, const arl_serve_conv1* conv1_or_null,
+                        const double* uniforms, int32_t step, double max_path_length, double discount,
+                        int32_t max_start_noops, void* stream);
+
 /* A layer's data gradient and weight gradient (deferred fold) as ONE launch: the two are independent
  * and both read dy, so their workgroups share a grid -- one ramp-up and one tail instead of two, and
  * the second problem's workgroups fill the CUs the first one's last wave leaves idle.  Same results as

@@ -61,6 +61,9 @@ def test_abi_version_and_arg_errors(lib):
     assert lib.arl_standardize(None, None, 1, 1e-6, None, None) == -1
     assert lib.arl_preprocess_frames(None, None, 1, 0, None, None) == -1
     assert lib.arl_standardize_workspace_bytes() >= 3 * 8
+    assert lib.arl_env_step_served(None, None, None, None, None, None, 0, 1.0, 0.99, 0, None) == -1
+    assert lib.arl_serve_conv1_supported(None, None) == 0
+    assert lib.arl_conv2d_fwd_parts(None, None, None, None, None, 1, None, None, None) == -1
 
 
 def test_struct_layouts_match_header(lib):
@@ -69,9 +72,10 @@ def test_struct_layouts_match_header(lib):
     import tempfile
     from accel_rl_amd import _lib
     src = ('#include <stdio.h>\n#include "accel_rl_hip.h"\n#include "accel_rl_hip_dev.h"\n'
-           'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+           'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
            'sizeof(arl_game),sizeof(arl_env_state),sizeof(arl_rollout),sizeof(arl_opt_state),'
-           'sizeof(arl_conv_geom),sizeof(arl_replay),sizeof(arl_fold_item),sizeof(arl_corun_job));return 0;}')
+           'sizeof(arl_conv_geom),sizeof(arl_replay),sizeof(arl_fold_item),sizeof(arl_corun_job),'
+           'sizeof(arl_serve_head),sizeof(arl_serve_conv1));return 0;}')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -81,7 +85,7 @@ def test_struct_layouts_match_header(lib):
     assert sizes == [ctypes.sizeof(_lib.ArlGame), ctypes.sizeof(_lib.ArlEnvState),
                      ctypes.sizeof(_lib.ArlRollout), ctypes.sizeof(_lib.ArlOptState),
                      ctypes.sizeof(_lib.ArlConvGeom), ctypes.sizeof(_lib.ArlReplay), ctypes.sizeof(_lib.ArlFoldItem),
-                     ctypes.sizeof(_lib.ArlCorunJob)]
+                     ctypes.sizeof(_lib.ArlCorunJob), ctypes.sizeof(_lib.ArlServeHead), ctypes.sizeof(_lib.ArlServeConv1)]
 
 
 def test_struct_field_offsets_match_header(lib):
@@ -92,7 +96,8 @@ def test_struct_field_offsets_match_header(lib):
     from accel_rl_amd import _lib
     pairs = [("arl_game", _lib.ArlGame), ("arl_env_state", _lib.ArlEnvState), ("arl_rollout", _lib.ArlRollout),
              ("arl_opt_state", _lib.ArlOptState), ("arl_conv_geom", _lib.ArlConvGeom), ("arl_replay", _lib.ArlReplay),
-             ("arl_fold_item", _lib.ArlFoldItem)]
+             ("arl_fold_item", _lib.ArlFoldItem), ("arl_serve_head", _lib.ArlServeHead),
+             ("arl_serve_conv1", _lib.ArlServeConv1)]
     lines = ['printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (c, f[0], c, f[0]) for c, cls in pairs for f in cls._fields_]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "accel_rl_hip.h"\nint main(){%s return 0;}' % "\n".join(lines)
     with tempfile.TemporaryDirectory() as d:

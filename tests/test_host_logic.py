@@ -267,12 +267,15 @@ def test_committed_pmc_records_belong_to_the_current_kernels():
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for rec, key, src in (("gae_pmc_traffic.json", "scan_hip_sha1", "scan.hip"),
-                          ("env_step_pmc.json", "env_hip_sha1", "env.hip")):
+    for rec, key, src in (("gae_pmc_traffic.json", "scan_hip_sha1", ("scan.hip",)),
+                          ("env_step_pmc.json", "env_hip_sha1", ("env.hip", "env_dev.h"))):
         with open(os.path.join(root, "profiles", rec)) as f:
             have = json.load(f)[key]
-        with open(os.path.join(root, "accel_rl_amd", "csrc", src), "rb") as f:
-            want = hashlib.sha1(f.read()).hexdigest()
+        h = hashlib.sha1()
+        for name in src:
+            with open(os.path.join(root, "accel_rl_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        want = h.hexdigest()
         assert have == want, "profiles/%s was measured on another %s: re-run the PMC passes and commit the record" % (rec, src)
 
 

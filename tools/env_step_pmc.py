@@ -6,7 +6,15 @@ frames (67 200 B per env-step out of a 2 MB frame bank that lives in L2 / the In
 usage: env_step_pmc.py fetch.csv write.csv n_envs"""
 import csv, hashlib, json, os, sys
 
-SRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "accel_rl_amd", "csrc", "env.hip")
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "accel_rl_amd", "csrc")
+
+
+def env_sources_sha1():
+    """sha1 over the env step kernel's sources (env.hip + the device pieces it shares with serve_step.hip)"""
+    h = hashlib.sha1()
+    for name in ("env.hip", "env_dev.h"):
+        h.update(open(os.path.join(CSRC, name), "rb").read())
+    return h.hexdigest()
 
 
 def med(path, counter):
@@ -29,7 +37,7 @@ print(json.dumps(dict(
     kernel_writes_per_env_step=dict(stacked_row_incl_the_new_frame=33280, scalars_and_prob=15 + 4 * 4),
     hbm_bytes_per_env_step=round(2 * fetch_raw + write, 1),
     traffic_over_algorithmic=round((2 * fetch_raw + write) / algo, 3),
-    env_hip_sha1=hashlib.sha1(open(SRC, "rb").read()).hexdigest(),
+    env_hip_sha1=env_sources_sha1(),
     note="hbm_bytes_per_env_step = 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 correction for 16-byte-per-lane "
          "coalesced reads, which is what the kernel's frame and stack loads are); algorithmic bytes = preprocess + "
          "stack 75 520 + rollout store 33 295 + 4 A (SURVEY 8d).  Traffic BELOW the algorithmic figure: the raw frames come "
