@@ -133,6 +133,8 @@ _SIGNATURES = {
     "arl_fold_many": (_i32, [C.POINTER(ArlFoldItem), _i32, _vp]),
     "arl_conv2d_fwd_parts": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, C.POINTER(ArlFoldItem), _vp]),
     "arl_serve_conv1_supported": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlConvGeom)]),
+    "arl_rollout_begin_conv1": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
+                                       C.POINTER(ArlServeConv1), _vp]),
     "arl_env_step_served": (_i32, [C.POINTER(ArlGame), C.POINTER(ArlEnvState), C.POINTER(ArlRollout),
                                    C.POINTER(ArlServeHead), C.POINTER(ArlServeConv1), _vp, _i32, _f64, _f64, _i32, _vp]),
     "arl_conv2d_u8_fwd": (_i32, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp]),
@@ -392,6 +394,12 @@ def env_step(game, state, rollout, prob, value, uniforms, step, mid_batch_reset,
 def serve_conv1_supported(game, geom):
     """Can arl_env_step_served evaluate this first convolution inside its launch?"""
     return bool(load().arl_serve_conv1_supported(C.byref(game), C.byref(geom)))
+
+
+def rollout_begin_conv1(game, state, rollout, conv1, stream=None):
+    """rollout_begin + the first convolution of the rows it copies (conv1: ArlServeConv1), one launch."""
+    _check(load().arl_rollout_begin_conv1(C.byref(game), C.byref(state), C.byref(rollout), C.byref(conv1),
+                                          stream_ptr(stream)), "arl_rollout_begin_conv1")
 
 
 def env_step_served(game, state, rollout, head, conv1, uniforms, step, max_path_length, discount, max_start_noops,

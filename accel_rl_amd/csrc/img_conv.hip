@@ -40,18 +40,25 @@ __global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) 
         for (int i = 0; i < MAXLD; ++i)
             if (tid + C1_NT * i < n16) ireg[i] = src[tid + C1_NT * i];
     };
-    auto img_store = [&](int buf) {
+    auto img_store = [&](int buf, int img) {
         char* d = sI + buf * npix;
 #pragma unroll
         for (int i = 0; i < MAXLD; ++i)
             if (tid + C1_NT * i < n16) *reinterpret_cast<u32x4*>(d + (tid + C1_NT * i) * 16) = ireg[i];
+        if (a.copy_out) {
+            u32x4* o = reinterpret_cast<u32x4*>(a.copy_out + (long long)img * a.copy_stride);
+#pragma unroll
+            for (int i = 0; i < MAXLD; ++i)
+                if (tid + C1_NT * i < n16) o[tid + C1_NT * i] = ireg[i];
+        }
     };
+    if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0;
     img_issue(blockIdx.x);
     for (int f = tid; f < nsteps * 64; f += C1_NT) conv1_w_store(sW, f, conv1_w_load(a.w, K, f));
     const int rows = a.OH * a.OW, tiles = (rows + 31) / 32;
     float4 bq[4];
     conv1_bias_quads(a.bias, half, bq);
-    img_store(0);
+    img_store(0, blockIdx.x);
     if (blockIdx.x + gridDim.x < (unsigned)a.n_img) img_issue(blockIdx.x + gridDim.x);
     __syncthreads();
     int buf = 0;
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) 
         // the next image's bytes (in flight while this one was computed) -> the other buffer, which every wave left at
         // the last barrier; the image after that starts its way from memory
         if (img + (int)gridDim.x < a.n_img) {
-            img_store(buf ^ 1);
+            img_store(buf ^ 1, img + (int)gridDim.x);
             if (img + 2 * (int)gridDim.x < a.n_img) img_issue(img + 2 * gridDim.x);
         }
         __syncthreads();
@@ -73,14 +80,14 @@ bool g_no_img_kernels = false;          // arl_dev_conv_variant(1): the tap-gath
 // arl_conv2d_u8_fwd's geometries that take the image-stationary kernel; < 0: not one of them (nothing launched)
 int launch_conv1_img(const unsigned char* obs, int64_t obs_rows, const int32_t* idx, float scale, const float* w, const float* bias, float* y,
                      int64_t batch, int C, int H, int W, int K, int kh, int kw, int stride, int Ho, int Wo, int relu,
-                     hipStream_t s) {
+                     hipStream_t s, unsigned char* copy_out, long long copy_stride, int* zero_word) {
     const int npix = C * H * W;
     const size_t lds = (size_t)(C * 64 / 16) * 3072 + 2 * (size_t)npix;
     if (g_no_img_kernels || !t_ctx.split || K != 32 || kh != 8 || kw != 8 || npix % 16 != 0 || npix > C1_MAX_IMG ||
         lds > 160 * 1024 || ((uintptr_t)obs & 15) || (W & 3) || (stride & 3) || batch > 0x7fffffff)
         return -1;
     Conv1ImgArgs a = {obs, idx, w, bias, y, scale, (int)batch, C, H, W, Ho, Wo, stride, relu,
-                      (int)(obs_rows < 0x7fffffff ? obs_rows : 0x7fffffff)};
+                      (int)(obs_rows < 0x7fffffff ? obs_rows : 0x7fffffff), copy_out, copy_stride, zero_word};
     {   // per launch: the attribute belongs to the CURRENT device's copy of the kernel (no process-wide flag)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_img_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -89,6 +96,17 @@ int launch_conv1_img(const unsigned char* obs, int64_t obs_rows, const int32_t* 
     const int cus = 256;
     hipLaunchKernelGGL(conv1_img_kernel, dim3((unsigned)(batch < cus ? batch : cus)), dim3(C1_NT), lds, s, a);
     return arl::check_launch("conv1_img_kernel");
+}
+
+// arl_rollout_begin_conv1 (serve_step.hip): the same launch under the call's route, with the copy-out
+int launch_conv1_img_begin(const arl_conv_geom* geom, const unsigned char* obs, int64_t n_img, float scale, const float* w,
+                           const float* bias, float* y, int C, int relu, hipStream_t s, unsigned char* copy_out,
+                           long long copy_stride, int* zero_word) {
+    ARL_ROUTE_SCOPE(geom, nullptr);
+    const int st = geom->stride;
+    return launch_conv1_img(obs, n_img, nullptr, scale, w, bias, y, n_img, C, geom->in_h, geom->in_w, geom->out_c, geom->kh,
+                            geom->kw, st, (geom->in_h - geom->kh) / st + 1, (geom->in_w - geom->kw) / st + 1, relu, s, copy_out,
+                            copy_stride, zero_word);
 }
 
 }  // namespace arlc

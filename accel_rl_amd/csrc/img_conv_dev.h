@@ -15,6 +15,11 @@ struct Conv1ImgArgs {
     float scale;
     int n_img, C, H, W, OH, OW, stride, relu;
     int obs_rows;               // rows of obs: an index outside [0, obs_rows) reads row 0 instead of faulting
+    // arl_rollout_begin_conv1: image b is also copied, as it passes through the registers, to copy_out + b * copy_stride
+    // (the rollout buffer's row (env b, step 0)) and *zero_word = 0 (the completed-trajectory counter); null: neither
+    unsigned char* copy_out;
+    long long copy_stride;
+    int* zero_word;
 };
 
 __device__ __forceinline__ u32x2 bytes_to_bf16x4(unsigned v) {     // four packed bytes -> four bf16, exact

@@ -322,7 +322,7 @@ int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_
 // img_conv.hip: the image-stationary kernels (>= 0: launched / error code; -1: not their geometry)
 int launch_conv1_img(const unsigned char* obs, int64_t obs_rows, const int32_t* idx, float scale, const float* w, const float* bias, float* y,
                      int64_t batch, int C, int H, int W, int K, int kh, int kw, int stride, int Ho, int Wo, int relu,
-                     hipStream_t s);
+                     hipStream_t s, unsigned char* copy_out = nullptr, long long copy_stride = 0, int* zero_word = nullptr);
 
 // ---- the launcher instantiations, dealt out to translation units (mfma_conv_p<k>.hip define ARL_CONV_PART = k and hold the
 // definitions of part k; every other unit sees them as extern templates) so that hipcc builds them side by side

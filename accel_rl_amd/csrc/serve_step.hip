@@ -26,6 +26,10 @@
 #include "head_dev.h"
 
 namespace arlc {
+// img_conv.hip: conv1_img_kernel with the copy-out (>= 0: launched / error code; -1: not its geometry or route)
+int launch_conv1_img_begin(const arl_conv_geom* geom, const unsigned char* obs, int64_t n_img, float scale, const float* w,
+                           const float* bias, float* y, int C, int relu, hipStream_t s, unsigned char* copy_out,
+                           long long copy_stride, int* zero_word);
 int fold_wide_from();           // mfma_conv.hip: the split count from which a fold sums 64-way (arl_dev_fold_wide_from)
 extern bool g_no_img_kernels;   // img_conv.hip (arl_dev_conv_variant)
 }
@@ -90,6 +94,9 @@ __global__ __launch_bounds__(SV_NT) void serve_step_kernel(
 
     StepOut o = {};
     double u = 0.0;
+    int64_t* lead_cursor = nullptr;
+    int64_t lead_value = 0;
+    bool mismatch = false;
     float4* sF = reinterpret_cast<float4*>(sI);
     if (wave == 0) {
         // ---- the frame plan (env_step_kernel, steps (1) and (2)) on one wave
@@ -117,14 +124,10 @@ __global__ __launch_bounds__(SV_NT) void serve_step_kernel(
             if (max_start_noops > 0) noops = st.noop_ring[w * st.noop_ring_len + (cursor + rank) % st.noop_ring_len];
             reset_regs(g, o.s, noops, o.fa, o.fb, o.mode);
         }
-        if (lane == 0) {
-            s_plan[0] = o.fa; s_plan[1] = o.fb; s_plan[2] = o.mode;
-            // the step's stores that do not depend on the action (env_step_kernel: stream leader's cursor, the forecast
-            // for the next launch and its check)
-            if (e == g0) st.noop_cursor[(parity ^ 1) * n_streams + w] = cursor + total;
-            st.next_reset[(int64_t)(fpar ^ 1) * st.n_env + e] = (uint8_t)will_reset(g, o.s, max_path_length);
-            if ((o.reset_flag != 0) != (carried != 0)) atomicAdd(st.epoch + 2, 1);
-        }
+        if (lane == 0) { s_plan[0] = o.fa; s_plan[1] = o.fb; s_plan[2] = o.mode; }
+        lead_cursor = e == g0 ? st.noop_cursor + (parity ^ 1) * n_streams + w : nullptr;
+        lead_value = cursor + total;
+        mismatch = (o.reset_flag != 0) != (carried != 0);
     } else if (hd.splits > 0) {
         // ---- the hidden layer, first level of fold_splits_kernel's sum for this env's row: zgn threads share an output
         // float4, thread zg sums splits zg, zg + zgn, ...
@@ -148,6 +151,13 @@ __global__ __launch_bounds__(SV_NT) void serve_step_kernel(
     FramePush<true, SV_NT> fp;
     fp.template load<0>(g, fa, fb, mode, prev, tid);       // every load of the pixel work is in flight from here
     if (has_w) arlc::conv1_w_store(sW, tid, wf);          // (the weights have arrived long since: split, into LDS)
+    if (tid == 0) {
+        // the step's stores that do not depend on the action (env_step_kernel: the stream leader's next cursor, the reset
+        // forecast for the next launch and the check of this launch's)
+        if (lead_cursor) *lead_cursor = lead_value;
+        st.next_reset[(int64_t)(fpar ^ 1) * st.n_env + e] = (uint8_t)will_reset(g, o.s, max_path_length);
+        if (mismatch) atomicAdd(st.epoch + 2, 1);
+    }
     if (tid == SV_NT - 1) {
         // Arrival ticket (env_step_kernel, step (4)): every thread of this workgroup has read both counters.  Two levels:
         // env e arrives on shard e % 16, a shard's last arriver on the top word, the last of those bumps the counters.
@@ -312,4 +322,22 @@ extern "C" int arl_env_step_served(const arl_game* game, const arl_env_state* st
     if (conv1_or_null) ARL_SERVE(true); else ARL_SERVE(false);
 #undef ARL_SERVE
     return arl::check_launch("serve_step_kernel");
+}
+
+extern "C" int arl_rollout_begin_conv1(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                                       const arl_serve_conv1* conv1, void* stream) {
+    int rc = check_env_args(game, st, ro);
+    if (rc) return rc;
+    ARL_REQUIRE(ro->observations && conv1 && conv1->w && conv1->y && conv1->geom, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(arl_serve_conv1_supported(game, conv1->geom), ARL_E_RANGE,
+                "conv1 geometry / route not served (arl_serve_conv1_supported): arl_rollout_begin + arl_conv2d_u8_fwd");
+    ARL_REQUIRE(conv1->geom->batch == st->n_env, ARL_E_ARG, "conv1 geometry must be built for n_env images");
+    ARL_REQUIRE(arl::aligned16(ro->step_obs) && arl::aligned16(ro->observations) && arl::aligned16(conv1->w) &&
+                    arl::aligned16(conv1->y) && (!conv1->bias || arl::aligned16(conv1->bias)), ARL_E_ALIGN, "16-byte alignment");
+    const int64_t row = (int64_t)game->n_stack * OBS_FRAME;
+    rc = arlc::launch_conv1_img_begin(conv1->geom, ro->step_obs, st->n_env, conv1->scale, conv1->w, conv1->bias, conv1->y,
+                                      game->n_stack, conv1->relu, (hipStream_t)stream, ro->observations,
+                                      (long long)ro->horizon * row, st->done_count);
+    if (rc < 0) { arl::set_error("arl_rollout_begin_conv1: the image kernel refused this geometry"); return ARL_E_RANGE; }
+    return rc;
 }

@@ -349,6 +349,20 @@ class AtariCnnPolicy(object):
         return (type(self).prob_value is AtariCnnPolicy.prob_value and self._n_hid >= 1 and
                 self._hid_geom[-1][0] <= 1024 and self.n_act <= _lib.MAX_ACTIONS)
 
+    def serve_conv1(self, game, b):
+        """(_lib.ArlServeConv1, y1) for a launch that computes conv 1 of b observations itself (arl_env_step_served,
+        arl_rollout_begin_conv1), or (None, None) when this first layer / route is not one it takes."""
+        conv_g, _ = self._layer_geoms(b)
+        if not (self._u8 and _lib.serve_conv1_supported(game, conv_g[0])):
+            return None, None
+        nf, ci, sz, st, pad, ho, wo = self._conv_geom[0]
+        y1 = self._buffer(("act", 0, b), (b, ho, wo, nf))
+        conv1 = _lib.ArlServeConv1()
+        conv1.geom = C.pointer(conv_g[0])
+        conv1.w, conv1.bias, conv1.y = self._w[0].data_ptr(), self._w[1].data_ptr(), y1.data_ptr()
+        conv1.scale, conv1.relu = self._scale, 1
+        return conv1, y1
+
     def serve_forward(self, game, observations, rows, y1=None, want_next=True):
         """prob_value's trunk for arl_env_step_served: everything up to the last hidden layer, whose split partial sums
         stay unfolded (the step launch folds them, applies bias + rectifier, evaluates the heads and samples).
@@ -389,7 +403,7 @@ class AtariCnnPolicy(object):
             head.w_head, head.b_head = w[self._k_head].data_ptr(), w[self._k_head + 1].data_ptr()
             conv1 = None
             if want_next and self._u8 and _lib.serve_conv1_supported(game, conv_g[0]):
-                conv1 = _lib.ArlServeConv1()
+                conv1 = _lib.ArlServeConv1()            # (into the buffer this step's conv 2 has just read: stream order)
                 conv1.geom = C.pointer(conv_g[0])
                 conv1.w, conv1.bias, conv1.y = w[0].data_ptr(), w[1].data_ptr(), y1.data_ptr()
                 conv1.scale, conv1.relu = self._scale, 1

@@ -103,6 +103,10 @@ class GpuVecSampler(BaseMbSampler):
     # one launch per step for everything per-env (arl_env_step_served): the policy's last fold + output layers, the action
     # draw, the env step and the next observation's first convolution (A/B switch; bit-identical either way)
     _serve_in_step = os.environ.get("ARL_SERVE_IN_STEP", "1") != "0"
+    # ... while one 16-wave workgroup per env (one per CU at a time) beats the separate launches: measured up to 1024 envs
+    # when conv 1 rides along (spec 1: -15 % at 256, -4 % at 1024), up to 512 when it does not (spec 0: -13 % at 256, -4 % at
+    # 512, +1 % at 1024; tools/serve_step_probe.py, profiles/r06/serve_step_probe*.txt)
+    _serve_in_step_max_envs = (512, 1024)       # (without, with conv 1 in the launch)
 
     def __init__(self, n_parallel=1, envs_per=1, device=None, use_graph=True, **kwargs):
         super().__init__(n_parallel=n_parallel, envs_per=envs_per, **kwargs)
@@ -263,6 +267,9 @@ class GpuVecSampler(BaseMbSampler):
         # copied (worker.py:108-113), so the copy stays.
         self._serve_fused = bool(self._single_write and type(self)._serve_in_step and self._game.n_stack <= 4 and
                                  hasattr(policy, "serve_forward") and policy.serve_supported())
+        if self._serve_fused:
+            with_conv1 = policy.serve_conv1(self._game, n)[0] is not None
+            self._serve_fused = n <= type(self)._serve_in_step_max_envs[int(with_conv1)]
         self._extra_is_step_obs = bool(self.need_extra_obs and self.mid_batch_reset and type(self)._alias_extra_obs)
         if self._extra_is_step_obs:
             self.samples_buf.extra_observations = self.envs_buf.extra_observations = self.step_obs
@@ -328,8 +335,14 @@ class GpuVecSampler(BaseMbSampler):
         n, t = self._total_n_envs, self.horizon
         buf, ro, env = self.samples_buf, self._rollout, self.env
         _lib.copy_bytes(self._uniforms, self._uniforms_host)   # (a kernel node reading the pinned buffer: no memcpy node)
-        _lib.rollout_begin(self._game, self._state, ro)        # observations[:, 0] = step_obs (worker.py:30-32), done_count = 0
-        y1 = None                                              # conv 1 of the step's observations, once a step launch has left it
+        # observations[:, 0] = step_obs (worker.py:30-32), done_count = 0 -- and, when the steps are served in one launch
+        # each, conv 1 of those rows from the same pass over them (y1: conv 1 of the step's observations, once a launch
+        # has left it)
+        conv1, y1 = self.policy.serve_conv1(self._game, n) if self._serve_fused else (None, None)
+        if conv1 is not None:
+            _lib.rollout_begin_conv1(self._game, self._state, ro, conv1)
+        else:
+            _lib.rollout_begin(self._game, self._state, ro)
         for s in range(t):
             if hasattr(self.policy, "set_step"):
                 self.policy.set_step(s)

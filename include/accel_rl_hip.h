@@ -494,6 +494,12 @@ typedef struct arl_serve_conv1 {
 /* 1 if arl_env_step_served can take this first layer (else: conv1_or_null = NULL and arl_conv2d_u8_fwd afterwards). */
 int arl_serve_conv1_supported(const arl_game* game, const arl_conv_geom* geom);
 
+/* arl_rollout_begin and arl_conv2d_u8_fwd of the rows it copies as ONE launch: observations[env * horizon + 0] =
+ * step_obs[env] (overlap/worker.py:30-32), st->done_count[0] = 0, and conv1->y = the first convolution of those rows
+ * (pg_cnn.py:47-52) -- the image passes through the kernel's registers once.  Geometries: arl_serve_conv1_supported.  */
+int arl_rollout_begin_conv1(const arl_game* game, const arl_env_state* st, const arl_rollout* ro,
+                            const arl_serve_conv1* conv1, void* stream);
+
 /* One (step, all envs) turn of serve_actions with everything per-env in one launch (one workgroup per env): fold, bias
  * and rectifier of the last hidden layer's split partials, the policy and value heads + softmax (arl_pg_head_infer),
  * weighted_sample_n, the env step (arl_env_step with mid_batch_reset != 0, single_write != 0, every env stepping) and,

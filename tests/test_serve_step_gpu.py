@@ -201,6 +201,38 @@ def test_forward_parts_describe_the_fold():
     torch.testing.assert_close(ys, ys2, rtol=0, atol=0)
 
 
+def test_rollout_begin_with_conv1_is_the_two_launches():
+    """arl_rollout_begin_conv1 = arl_rollout_begin + arl_conv2d_u8_fwd of the copied rows, bit for bit."""
+    from accel_rl_amd import _lib
+    from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+    from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+    policy = AtariCnnPolicy(**cnn_specs[1])
+    smp = make_sampler("breakout", 3, 7, 5, 5, 9, dict(max_start_noops=30), policy, False, served=True)
+    n = 42
+    smp.obtain_samples(0)                                   # step_obs: real frames
+    torch.cuda.synchronize()
+    buf, st = smp.samples_buf, smp._st
+    conv1, y1 = policy.serve_conv1(smp._game, n)
+    assert conv1 is not None
+    buf.observations.fill_(7)
+    st.done_count.fill_(5)
+    _lib.rollout_begin(smp._game, smp._state, smp._rollout)
+    conv_g, _ = policy._layer_geoms(n)
+    want_y = torch.empty_like(y1)
+    _lib.conv2d_u8_fwd(buf.observations, smp._step_rows[0], policy._scale, policy._w[0], policy._w[1], want_y, conv_g[0], True)
+    want_obs = buf.observations.clone()
+    buf.observations.fill_(9)
+    st.done_count.fill_(5)
+    y1.fill_(-1.0)
+    _lib.rollout_begin_conv1(smp._game, smp._state, smp._rollout, conv1)
+    torch.cuda.synchronize()
+    rows = smp._step_rows[0].long()
+    assert torch.equal(buf.observations[rows], want_obs[rows]) and torch.equal(buf.observations[rows], smp.step_obs)
+    assert int(st.done_count.item()) == 0
+    assert torch.equal(y1, want_y) and float(y1.abs().sum()) > 0
+    smp.shutdown()
+
+
 def test_served_step_argument_errors():
     from accel_rl_amd import _lib
     from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
