@@ -12,7 +12,7 @@ import torch
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libaccel_rl_hip.so")
 
-ARL_ABI_VERSION = 3
+ARL_ABI_VERSION = 4
 PROMO_NEP50, PROMO_LEGACY, PROMO_ASSOC = 0, 1, 2
 PPO_TIE_THEANO, PPO_TIE_MATH, PPO_TIE_BOTH = 0, 1, 2      # ARL_PPO_TIE_*: whose gradient min() / clip() hand on (accel_rl_hip.h)
 OPT_ADAM, OPT_RMSPROP = 0, 1
@@ -72,6 +72,13 @@ class ArlFoldItem(C.Structure):
 FOLD_MAX_ITEMS = 24
 
 
+class ArlDgradWt(C.Structure):
+    _fields_ = [("w", _vp), ("wt", _vp), ("geom", C.POINTER(ArlConvGeom))]
+
+
+DGRAD_WT_MAX = 4
+
+
 class ArlServeHead(C.Structure):
     _fields_ = [("hidden", ArlFoldItem), ("hidden_bias", _vp), ("hidden_relu", _i32), ("hid", _i32),
                 ("w_head", _vp), ("b_head", _vp)]
@@ -126,7 +133,8 @@ _SIGNATURES = {
     "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
-    "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), C.POINTER(ArlCorunJob), C.POINTER(_i32), _vp]),
+    "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), C.POINTER(ArlCorunJob), C.POINTER(_i32), _vp]),
+    "arl_conv2d_dgrad_weights": (_i32, [C.POINTER(ArlDgradWt), _i32, _vp]),
     "arl_conv2d_bwd_weight": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _vp]),
     "arl_conv2d_bwd_weight_parts": (_i32, [_vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64, C.POINTER(ArlFoldItem),
                                            _vp, C.POINTER(ArlFoldItem), _vp]),
@@ -140,7 +148,7 @@ _SIGNATURES = {
     "arl_conv2d_u8_fwd": (_i32, [_vp, _i64, _vp, _f32, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp]),
     "arl_conv2d_u8_bwd_weight_parts": (_i32, [_vp, _vp, _i64, _vp, _f32, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
                                               C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), _vp]),
-    "arl_conv2d_bwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
+    "arl_conv2d_bwd_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _vp, _i64,
                                    C.POINTER(ArlFoldItem), _vp, C.POINTER(ArlFoldItem), C.POINTER(ArlCorunJob),
                                    C.POINTER(_i32), _vp]),
     "arl_relu_bwd_bias_parts": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, C.POINTER(ArlFoldItem), _vp]),
@@ -179,6 +187,7 @@ _DEV_SIGNATURES = {
     "arl_dev_conv_force_generic": (None, [_i32]),
     "arl_dev_conv_variant": (None, [_i32]),
     "arl_dev_fwd_tile": (None, [_i32]),
+    "arl_dev_dgrad_wt": (None, [_i32]),
     "arl_dev_fold_wide_from": (None, [_i32]),
     "arl_dev_scan_force_wave": (None, [_i32]),
     "arl_dev_scan_wave_groups": (None, [_i32]),
@@ -616,14 +625,27 @@ def conv2d_u8_fwd(obs, idx, scale, w, bias, y, geom, relu, stream=None):
            "arl_conv2d_u8_fwd")
 
 
-def conv2d_bwd_data(dy, w, mask, dx, geom, stream=None, corun=None):
-    """corun: an ArlCorunJob the launch may carry; returns True if it did (else the caller runs it: corun_job_run)."""
+def conv2d_dgrad_weights(layers, stream=None):
+    """layers: [(w, wt, geom)] -- wt <- the data gradient's k-contiguous copy of w (arl_conv2d_dgrad_weights), one launch."""
+    assert 0 < len(layers) <= DGRAD_WT_MAX
+    items = (ArlDgradWt * len(layers))()
+    for it, (w, wt, geom) in zip(items, layers):
+        _want(w, torch.float32, "w")
+        _want(wt, torch.float32, "wt")
+        assert w.numel() == wt.numel() == geom.out_c * geom.kh * geom.kw * geom.in_c, "w / wt size"
+        it.w, it.wt, it.geom = ptr(w), ptr(wt), C.pointer(geom)
+    _check(load().arl_conv2d_dgrad_weights(items, len(layers), stream_ptr(stream)), "arl_conv2d_dgrad_weights")
+
+
+def conv2d_bwd_data(dy, w, mask, dx, geom, stream=None, corun=None, wt=None):
+    """corun: an ArlCorunJob the launch may carry; returns True if it did (else the caller runs it: corun_job_run).
+    wt: conv2d_dgrad_weights' copy of w (same results; the split kernels read it instead of w)."""
     ho, wo = conv_out_hw(geom)
     assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
     assert dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "dx size"
     assert mask is None or mask.numel() == dx.numel()
     taken = _i32(0)
-    _check(load().arl_conv2d_bwd_data(dy.data_ptr(), w.data_ptr(), None if mask is None else mask.data_ptr(),
+    _check(load().arl_conv2d_bwd_data(dy.data_ptr(), w.data_ptr(), ptr(wt), None if mask is None else mask.data_ptr(),
                                       dx.data_ptr(), C.byref(geom), None if corun is None else C.byref(corun),
                                       C.byref(taken), stream_ptr(stream)), "arl_conv2d_bwd_data")
     return bool(taken.value)
@@ -696,9 +718,10 @@ class FoldList(object):
                                                      stream_ptr(stream)), "arl_conv2d_u8_bwd_weight_parts")
         return self._bias_done(dbias)
 
-    def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, dbias=None, stream=None, corun=None):
+    def conv2d_bwd_pair(self, dy, w, mask, dx, x, dw, geom, workspace, dbias=None, stream=None, corun=None, wt=None):
         """dx (times mask > 0 if given) and (deferred) dw [+ dbias] of one layer in a single launch.
-        corun: an ArlCorunJob the data-gradient launch may carry; `self.corun_taken` says whether it did."""
+        corun: an ArlCorunJob the data-gradient launch may carry; `self.corun_taken` says whether it did.
+        wt: conv2d_dgrad_weights' copy of w for the data gradient."""
         ho, wo = conv_out_hw(geom)
         assert dy.numel() == geom.batch * ho * wo * geom.out_c, "dy size"
         assert x.numel() == dx.numel() == geom.batch * geom.in_h * geom.in_w * geom.in_c, "x / dx size"
@@ -707,7 +730,7 @@ class FoldList(object):
         slot = self._n - 1
         pb, ib = self._bias_slot(dbias)
         taken = _i32(0)
-        _check(load().arl_conv2d_bwd_pair(dy.data_ptr(), w.data_ptr(), ptr(mask), dx.data_ptr(), x.data_ptr(),
+        _check(load().arl_conv2d_bwd_pair(dy.data_ptr(), w.data_ptr(), ptr(wt), ptr(mask), dx.data_ptr(), x.data_ptr(),
                                           dw.data_ptr(), C.byref(geom), ptr(workspace),
                                           workspace.numel() * workspace.element_size(), item, pb, ib,
                                           None if corun is None else C.byref(corun), C.byref(taken),

@@ -73,6 +73,8 @@ struct WeightDesc {
     const float* w;
     unsigned w_bytes;
     int ld, kc, taps_x, i0, j0, si, kw, c;
+    int cls;        // k-contiguous weights of a data gradient (arl_conv2d_dgrad_weights): elements between the parity
+                    // classes' matrices (class z's rows start at w + z * cls); 0 otherwise
 };
 
 struct OutDesc {
@@ -126,7 +128,7 @@ __device__ __forceinline__ void pin_gemm_args(const GemmArgs& a) {
                  "s"(a.g.mul), "s"(a.g.add_y), "s"(a.g.add_x), "s"(a.g.taps_x), "s"(a.g.step), "s"(a.g.taps_y), "s"(a.g.rmin),
                  "s"(a.g.dmin), "s"(a.g.origin), "s"(a.g.mg_w), "s"(a.g.mg_h));
     asm volatile("" :: "s"(a.b.w), "s"(a.b.w_bytes), "s"(a.b.ld), "s"(a.b.kc), "s"(a.b.taps_x), "s"(a.b.i0), "s"(a.b.j0),
-                 "s"(a.b.si), "s"(a.b.kw), "s"(a.b.c));
+                 "s"(a.b.si), "s"(a.b.kw), "s"(a.b.c), "s"(a.b.cls));
     asm volatile("" :: "s"(a.o.out), "s"(a.o.bias), "s"(a.o.mask), "s"(a.o.out_bytes), "s"(a.o.relu), "s"(a.o.dense), "s"(a.o.OH),
                  "s"(a.o.OW), "s"(a.o.omul), "s"(a.o.oadd_y), "s"(a.o.oadd_x), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.k_per_split),
                  "s"(a.split_stride), "s"(a.trace), "s"(a.n_par), "s"(a.xcd));

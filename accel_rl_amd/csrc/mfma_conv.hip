@@ -21,6 +21,7 @@ namespace {
 // item below FOLD_WIDE splits is exactly what the 256-thread kernel of rounds 1-5 did.
 constexpr int FOLD_WIDE = 128, FOLD_THREADS = 1024;
 int g_fold_wide = FOLD_WIDE;            // arl_dev_fold_wide_from (A/B of the threshold)
+bool g_dgrad_wt = true;                 // arl_dev_dgrad_wt: 0 = data gradients ignore the k-contiguous weights (A/B, parity tests)
 
 struct FoldSlot { int64_t i; int zg, zgn, row0, o; };
 __device__ __forceinline__ FoldSlot fold_slot(int splits, int local_block, int wide_from) {
@@ -133,6 +134,8 @@ extern "C" void arl_dev_conv_force_generic(int32_t on) { g_force_generic = on !=
 extern "C" void arl_dev_fold_wide_from(int32_t splits) { g_fold_wide = splits > 0 ? splits : FOLD_WIDE; }
 
 extern "C" void arl_dev_fwd_tile(int32_t v) { g_fwd_tile = (v >= 0 && v <= 2) ? v : -1; }
+
+extern "C" void arl_dev_dgrad_wt(int32_t on) { g_dgrad_wt = on != 0; }
 
 extern "C" int arl_corun_job_init(arl_corun_job* job, const arl_opt_state* opt, int32_t method, float learning_rate,
                                   float avg_factor, float beta1_or_rho, float beta2, float epsilon, int32_t k,
@@ -269,8 +272,13 @@ extern "C" int arl_conv2d_fwd(const float* x, const float* w, const float* bias_
 namespace {
 // plan_only: describe the fast launch instead of issuing it (fast == false: nothing was done)
 // workspace (optional): lets a dense layer whose output tiles cannot fill the chip split its reduction
+// wt (optional): the same weights as arl_conv2d_dgrad_weights lays them out -- per input-pixel parity class a matrix
+// [in_c][taps * out_c] with the reduction index contiguous.  The one-wave-per-row-tile split kernels then read them like a
+// forward pass reads its weights (one ds_read_b128 per fragment instead of four ds_read_b32, half the loader's packing
+// work): same piece products in the same k order, bit-identical results.
 int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float* dx, const arl_conv_geom* geom,
-               DgradPlan* plan_only, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0) {
+               DgradPlan* plan_only, void* stream, void* workspace = nullptr, int64_t workspace_bytes = 0,
+               const float* wt = nullptr) {
     Geom g;
     int rc = check_geom(geom, &g);
     if (rc) return rc;
@@ -278,7 +286,8 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
     ARL_REQUIRE(g.kh % g.stride == 0 && g.kw % g.stride == 0, ARL_E_RANGE,
                 "data gradient needs kernel size divisible by stride");
     ARL_REQUIRE(arl::aligned16(dy) && arl::aligned16(w) && arl::aligned16(dx) &&
-                    (!mask_or_null || arl::aligned16(mask_or_null)), ARL_E_ALIGN, "16-byte alignment");
+                    (!mask_or_null || arl::aligned16(mask_or_null)) && (!wt || arl::aligned16(wt)), ARL_E_ALIGN,
+                "16-byte alignment");
     hipStream_t s = (hipStream_t)stream;
     const int st = g.stride;
     constexpr int FBK = 32;
@@ -353,6 +362,15 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             else rc = launch_igemm<2, 2, 1, 1, FBK, false>(a, splits, false, has_pad, s);
             if (rc || splits == 1) return rc;
             return launch_fold((const float*)workspace, splits, (int64_t)a.M * a.N, nullptr, 4, 0, dx, s, mask_or_null);
+        }
+        if (wt && g_split && a.N > 16 && a.N <= 64 && g_dgrad_wt) {
+            // k-contiguous weights: the forward pass's kernels on the data gradient's gather (B_KC = true)
+            a.b.w = wt; a.b.ld = a.K; a.b.cls = a.N * a.K;
+            const int tiles = ((a.M + 127) / 128) * (a.n_par ? a.n_par : 1);
+            const int v = a.N <= 32 || (g_fwd_tile >= 0 ? (g_fwd_tile == 1) : (2 * tiles <= TARGET_WGS));
+            if (v) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, false, has_pad, s);
+            else rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, false, has_pad, s);
+            return rc;
         }
         if (a.N <= 16) rc = launch_igemm<4, 1, 2, 1, 16, false, true>(a, 1, false, has_pad, s);      // 16-wide MFMA tiles
         else if (g_split && a.N <= 32) rc = launch_igemm_split<4, 1, 1, 1, FBK, false, false, 2>(a, false, has_pad, s);
@@ -470,11 +488,11 @@ int wgrad_impl(const float* dy, const float* x, float* dw, const arl_conv_geom* 
 }
 }  // namespace
 
-extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
-                                   const arl_conv_geom* geom, const arl_corun_job* job_or_null, int32_t* job_taken_or_null,
-                                   void* stream) {
+extern "C" int arl_conv2d_bwd_data(const float* dy, const float* w, const float* wt_or_null, const float* mask_or_null,
+                                   float* dx, const arl_conv_geom* geom, const arl_corun_job* job_or_null,
+                                   int32_t* job_taken_or_null, void* stream) {
     ARL_ROUTE_SCOPE(geom, job_or_null);
-    const int rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream);
+    const int rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, nullptr, 0, wt_or_null);
     if (job_taken_or_null) *job_taken_or_null = t_ctx.corun_taken ? 1 : 0;
     return rc;
 }
@@ -657,8 +675,8 @@ extern "C" int arl_conv2d_u8_bwd_weight_parts(const float* dy, const uint8_t* ob
 }
 
 
-extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
-                                   const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
+extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* wt_or_null, const float* mask_or_null,
+                                   float* dx, const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
                                    int64_t workspace_bytes, arl_fold_item* item, float* dbias_or_null,
                                    arl_fold_item* bias_item_or_null, const arl_corun_job* job_or_null,
                                    int32_t* job_taken_or_null, void* stream) {
@@ -686,7 +704,8 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
         // the data gradient may split its reduction: it gets the upper half of the workspace (and is folded at
         // once), the weight gradient's deferred partials the lower half
         const int64_t half = (workspace_bytes / 2) & ~(int64_t)15;
-        rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, (char*)workspace + half, workspace_bytes - half);
+        rc = dgrad_impl(dy, w, mask_or_null, dx, geom, nullptr, stream, (char*)workspace + half, workspace_bytes - half,
+                        wt_or_null);
         if (job_taken_or_null) *job_taken_or_null = t_ctx.corun_taken ? 1 : 0;
         if (rc) return rc;
         return wgrad_parts_impl(dy, x, dw, geom, workspace, half, item, dbias_or_null, bias_item_or_null, stream);
@@ -702,6 +721,57 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
     item->valid = 0;
     if (dbias_or_null) bias_item(bias_item_or_null, bias_part, dbias_or_null, wp.splits, geom->out_c);
     return rc;
+}
+
+namespace {
+// Weights (out_c, kh, kw, in_c) -> per input-pixel parity class (ph, pw) of a stride-s data gradient a matrix
+// wt[z][c][(ty * taps_x + tx) * out_c + k] = w[k][i0 + s ty][j0 + s tx][c], (i0, j0) = ((ph + pad_h) % s, (pw + pad_w) % s),
+// z = ph * s + pw: exactly the element the data gradient's reduction index (tap, k) meets in column c (dgrad_impl).
+struct DgradWtItem { const float* w; float* wt; int K, kh, kw, C, st, taps_x, kred, total, i0[4], j0[4]; };
+struct DgradWtArgs { DgradWtItem it[ARL_DGRAD_WT_MAX]; int block_start[ARL_DGRAD_WT_MAX + 1]; int n; };
+
+__global__ __launch_bounds__(256) void dgrad_weights_kernel(const DgradWtArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.block_start[i + 1]) ++i;            // uniform
+    const DgradWtItem& q = a.it[i];
+    const int idx = ((int)blockIdx.x - a.block_start[i]) * 256 + (int)threadIdx.x;
+    if (idx >= q.total) return;
+    const int per = q.C * q.kred;
+    const int z = idx / per, rem = idx - z * per;
+    const int c = rem / q.kred, r = rem - c * q.kred;
+    const int tap = r / q.K, k = r - tap * q.K;
+    const int ty = tap / q.taps_x, tx = tap - ty * q.taps_x;
+    q.wt[idx] = q.w[((k * q.kh + q.i0[z] + q.st * ty) * q.kw + q.j0[z] + q.st * tx) * q.C + c];
+}
+}  // namespace
+
+extern "C" int arl_conv2d_dgrad_weights(const arl_dgrad_wt* items, int32_t n, void* stream) {
+    ARL_REQUIRE(items && n > 0 && n <= ARL_DGRAD_WT_MAX, ARL_E_ARG, "1 .. ARL_DGRAD_WT_MAX items");
+    DgradWtArgs a = {};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        Geom g;
+        int rc = check_geom(items[i].geom, &g);
+        if (rc) return rc;
+        ARL_REQUIRE(items[i].w && items[i].wt && items[i].w != items[i].wt, ARL_E_ARG, "null / aliased pointer");
+        ARL_REQUIRE(arl::aligned16(items[i].w) && arl::aligned16(items[i].wt), ARL_E_ALIGN, "16-byte alignment");
+        const int st = g.stride;
+        ARL_REQUIRE(g.kh % st == 0 && g.kw % st == 0 && st * st <= 4 && g.H >= st && g.W >= st, ARL_E_RANGE,
+                    "kernel size divisible by the stride, stride <= 2");
+        DgradWtItem& q = a.it[i];
+        q.w = items[i].w; q.wt = items[i].wt; q.K = g.K; q.kh = g.kh; q.kw = g.kw; q.C = g.C; q.st = st;
+        q.taps_x = g.kw / st; q.kred = (g.kh / st) * (g.kw / st) * g.K; q.total = g.K * g.kh * g.kw * g.C;
+        for (int ph = 0; ph < st; ++ph)
+            for (int pw = 0; pw < st; ++pw) {
+                q.i0[ph * st + pw] = (ph + g.pad_h) % st;
+                q.j0[ph * st + pw] = (pw + g.pad_w) % st;
+            }
+        a.block_start[i] = blocks;
+        blocks += (q.total + 255) / 256;
+    }
+    a.block_start[n] = blocks; a.n = n;
+    hipLaunchKernelGGL(dgrad_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return arl::check_launch("dgrad_weights_kernel");
 }
 
 extern "C" int arl_fold_many(const arl_fold_item* items, int32_t n, void* stream) {

@@ -154,7 +154,8 @@ int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStrea
     if constexpr (U8) {
         ARL_SPLIT_MODE(false, false, false);
     } else {
-        if constexpr (!B_KC) {
+        // (data gradients: k-major weights, or k-contiguous ones on the one-wave-per-row-tile shapes)
+        if constexpr (!B_KC || (WGM == 4 && WGN == 1 && TM == 1)) {
             if (!multi_tap && corun_take(&c, &grid)) {
                 if (has_pad) ARL_SPLIT_MODE(false, true, true); else ARL_SPLIT_MODE(false, false, true);
                 return rc ? rc : arl::check_launch("igemm_split_kernel (co-run)");

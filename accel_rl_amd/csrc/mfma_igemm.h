@@ -71,7 +71,9 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     // descriptor origins: the smallest element offset a valid (row, tap) pair can produce
     const __amdgpu_buffer_rsrc_t rsA = U8 ? make_rsrc(reinterpret_cast<const float*>(g.src8), g.src_bytes)
                                           : make_rsrc(g.src + g.origin, g.src_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w, a.b.w_bytes);
+    // (a data gradient on k-contiguous weights: this parity class's matrix)
+    const unsigned w_cls = (B_KC && a.n_par) ? (unsigned)bz * (unsigned)a.b.cls : 0u;
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(a.b.w + w_cls, a.b.w_bytes - 4u * w_cls);
 
     // ---- per-thread constants -------------------------------------------------------------
     const int a_chunk = tid % CH, a_row0 = tid / CH;

@@ -165,6 +165,11 @@ class AtariCnnPolicy(object):
         self._w = [self.flat_params[o:o + n] for o, n in zip(self._offsets, sizes)]
         self._g = [self.flat_grads[o:o + n] for o, n in zip(self._offsets, sizes)]
         self._conv_ws = _lib.conv_workspace(self.device)
+        # the data gradients' own copy of the conv weights (reduction index contiguous: _lib.conv2d_dgrad_weights), for
+        # the layers whose data gradient runs on the split kernels of 17 .. 64 columns; refreshed once per backward pass
+        self._wt = {i: torch.empty_like(self._w[2 * i]) for i, (nf, ci, sz, st, pad, ho, wo) in enumerate(self._conv_geom)
+                    if i > 0 and 16 < ci <= 64 and st <= 2 and sz % st == 0 and
+                    os.environ.get("ARL_DGRAD_WT", "1") != "0"}                     # (A/B switch)
         self._geoms = dict()
         for p, g in zip(self.params, self.grads):
             p.grad = g
@@ -536,11 +541,14 @@ class AtariCnnPolicy(object):
         that can carry it."""
         b = x.shape[0]
         conv_g, _ = self._layer_geoms(b)
+        if self._wt and _lib.default_route != _lib.ROUTE_FP32:
+            _lib.conv2d_dgrad_weights([(self._w[2 * i], wt, conv_g[i]) for i, wt in sorted(self._wt.items())])
         for i in range(self._n_conv - 1, -1, -1):
             nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
             d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape)) if i > 0 else None
             self._layer_grads(d_act, masked, acts[i], b * ho * wo, nf, 2 * i, conv_g[i], acts[i - 1] if i > 0 else x, d_in,
-                              corun=corun if i > 0 else None)
+                              corun=corun if i > 0 else None,
+                              wt=self._wt.get(i) if _lib.default_route != _lib.ROUTE_FP32 else None)
             if corun is not None and i > 0 and self._folds.corun_taken:
                 corun = None
             d_act, masked = d_in, True
@@ -548,7 +556,7 @@ class AtariCnnPolicy(object):
             _lib.corun_job_run(corun)           # no launch could carry it: on its own, ahead of the step's update
         self._folds.run()
 
-    def _layer_grads(self, d, masked, y, rows, channels, k, geom, inp, d_in, corun=None):
+    def _layer_grads(self, d, masked, y, rows, channels, k, geom, inp, d_in, corun=None, wt=None):
         """One layer's backward: bias and weight gradient (deferred folds) and, with d_in, the data gradient
         already multiplied by the rectifier mask of `inp` (the layer below's output), so that the layer below
         gets its pre-activation gradient without another pass.  Not `masked`: d still needs this layer's own
@@ -562,7 +570,7 @@ class AtariCnnPolicy(object):
                                               self._fold_ws(("dw", k)), dbias=dbias)
         elif d_in is not None:      # data + weight gradient share one launch where that pays (dense layers)
             done = folds.conv2d_bwd_pair(d, self._w[k], inp, d_in, inp, self._g[k], geom, self._fold_ws(("dw", k)),
-                                         dbias=dbias, corun=corun)
+                                         dbias=dbias, corun=corun, wt=wt)
         else:
             done = folds.conv2d_bwd_weight(d, inp, self._g[k], geom, self._fold_ws(("dw", k)), dbias=dbias)
         if not done:                # generic kernels leave the bias sums to the streaming kernel (its mask is idempotent)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ARL_ABI_VERSION 3
+#define ARL_ABI_VERSION 4
 
 #define ARL_E_ARG      (-1)   /* null pointer / non-positive size                 */
 #define ARL_E_RANGE    (-2)   /* size outside what the kernels support             */
@@ -436,9 +436,25 @@ int arl_conv2d_fwd(const float* x, const float* w, const float* bias_or_null, fl
  * *job_taken = 1 if it did (only the scalar-addressed data-gradient launches of layers with > 16 input channels
  * can), else 0 and the caller runs the job itself (arl_corun_job_run). */
 struct arl_corun_job;
-int arl_conv2d_bwd_data(const float* dy, const float* w, const float* mask_or_null, float* dx,
+int arl_conv2d_bwd_data(const float* dy, const float* w, const float* wt_or_null, const float* mask_or_null, float* dx,
                         const arl_conv_geom* geom, const struct arl_corun_job* job_or_null,
                         int32_t* job_taken_or_null, void* stream);
+
+/* The data gradient's own copy of a layer's weights (ABI 4): per input-pixel parity class (ph, pw) of the stride a matrix
+ * wt[ph * stride + pw][in_c][(ty * kw / stride + tx) * out_c + k] = w[k][i0 + stride ty][j0 + stride tx][c], (i0, j0) =
+ * ((ph + pad_h) % stride, (pw + pad_w) % stride) -- the reduction index of dx = conv^T(dy, w) contiguous, as a forward pass
+ * finds its weights.  Same size as w; one launch converts up to ARL_DGRAD_WT_MAX layers (after every parameter update,
+ * before the backward pass that reads them).  Given as wt_or_null to arl_conv2d_bwd_data / arl_conv2d_bwd_pair, the
+ * bf16-split kernels of 17 .. 64 input channels read it instead of w: the same piece products in the same order
+ * (bit-identical results), a third less LDS and loader work per k-tile.  The reference has no counterpart: Theano's
+ * conv gradient picks its own layout inside cuDNN (T.grad of pg_cnn.py:47-68, optimizers/single/ppo_optimizer.py:38-40). */
+typedef struct arl_dgrad_wt {
+    const float* w;             /* f32[out_c][kh][kw][in_c]                                                */
+    float* wt;                  /* f32[out_c * kh * kw * in_c], 16-byte aligned, not aliasing w            */
+    const arl_conv_geom* geom;  /* kh, kw divisible by stride, stride <= 2                                 */
+} arl_dgrad_wt;
+#define ARL_DGRAD_WT_MAX 4
+int arl_conv2d_dgrad_weights(const arl_dgrad_wt* items, int32_t n, void* stream);
 
 /* dw f32[out_c][kh][kw][in_c] = gradient of the layer weights given dy and the layer
  * input x; the reduction over batch x out_h x out_w is split across workgroups and
@@ -519,8 +535,8 @@ int arl_env_step_served(const arl_game* game, const arl_env_state* st, const arl
  * and both read dy, so their workgroups share a grid -- one ramp-up and one tail instead of two, and
  * the second problem's workgroups fill the CUs the first one's last wave leaves idle.  Same results as
  * arl_conv2d_bwd_data + arl_conv2d_bwd_weight_parts (which it falls back to when either side is not
- * on the scalar-addressed fast path). */
-int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* mask_or_null, float* dx,
+ * on the scalar-addressed fast path).  wt_or_null: arl_conv2d_dgrad_weights' copy of w for the data gradient. */
+int arl_conv2d_bwd_pair(const float* dy, const float* w, const float* wt_or_null, const float* mask_or_null, float* dx,
                         const float* x, float* dw, const arl_conv_geom* geom, void* workspace,
                         int64_t workspace_bytes, arl_fold_item* item, float* dbias_or_null,
                         arl_fold_item* bias_item_or_null, const struct arl_corun_job* job_or_null,

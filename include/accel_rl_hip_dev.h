@@ -25,6 +25,10 @@ void arl_dev_conv_force_generic(int32_t on);
  * -1 (default) = chosen by the launch's size: the column split while every half tile gets a CU of its own.           */
 void arl_dev_fwd_tile(int32_t v);
 
+/* Tests / A-B measurements: 0 = data gradients ignore the k-contiguous weights they are handed (wt_or_null of
+ * arl_conv2d_bwd_data / arl_conv2d_bwd_pair) and gather from w as before ABI 4; same results bit for bit.  Default 1. */
+void arl_dev_dgrad_wt(int32_t on);
+
 /* A-B measurements: split count from which a fold (arl_fold_many, the dense forward's fold) sums an output with 64
  * threads instead of 16 (csrc/mfma_conv.hip, FOLD_WIDE).  0 = the default (128).  Changes the association of the sums of
  * the items it moves across the threshold (still a fixed order), nothing else.                                       */

@@ -52,7 +52,7 @@ def test_the_boundary_header_keeps_no_state():
 
 
 def test_abi_version_and_arg_errors(lib):
-    assert lib.arl_abi_version() == 3
+    assert lib.arl_abi_version() == 4
     # null pointers / bad sizes are rejected before any HIP call is made
     assert lib.arl_gae_scan(None, None, None, None, 0.99, 0.95, 4, 5, 0, None, None, None) == -1
     assert b"null" in lib.arl_last_error()
@@ -97,7 +97,7 @@ def test_struct_field_offsets_match_header(lib):
     pairs = [("arl_game", _lib.ArlGame), ("arl_env_state", _lib.ArlEnvState), ("arl_rollout", _lib.ArlRollout),
              ("arl_opt_state", _lib.ArlOptState), ("arl_conv_geom", _lib.ArlConvGeom), ("arl_replay", _lib.ArlReplay),
              ("arl_fold_item", _lib.ArlFoldItem), ("arl_serve_head", _lib.ArlServeHead),
-             ("arl_serve_conv1", _lib.ArlServeConv1)]
+             ("arl_serve_conv1", _lib.ArlServeConv1), ("arl_dgrad_wt", _lib.ArlDgradWt)]
     lines = ['printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (c, f[0], c, f[0]) for c, cls in pairs for f in cls._fields_]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "accel_rl_hip.h"\nint main(){%s return 0;}' % "\n".join(lines)
     with tempfile.TemporaryDirectory() as d:

@@ -223,7 +223,7 @@ def test_argument_errors():
         _lib.load().arl_conv2d_fwd(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), _lib.C.byref(bad), 0,
                                    ws.data_ptr(), None) and (_ for _ in ()).throw(RuntimeError("rc"))
     odd = _lib.conv_geom(2, 13, 9, 64, 64, 3, 3, 2, 1, 1)       # kernel 3, stride 2: unsupported data gradient
-    rc = _lib.load().arl_conv2d_bwd_data(y.data_ptr(), wt.data_ptr(), None, x.data_ptr(), _lib.C.byref(odd), None, None, None)
+    rc = _lib.load().arl_conv2d_bwd_data(y.data_ptr(), wt.data_ptr(), None, None, x.data_ptr(), _lib.C.byref(odd), None, None, None)
     assert rc == -2 and b"stride" in _lib.load().arl_last_error()
     with pytest.raises(RuntimeError):
         _lib.conv2d_fwd(x.cpu(), wt, None, y, geom, False, ws) if False else _lib.ptr(x.cpu())
@@ -596,3 +596,54 @@ def test_tile_shapes_of_the_64_column_kernels_are_bit_identical(layer, batch):
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][1]).all()
     for y, dx in outs[1:]:
         assert torch.equal(y, outs[0][0]) and torch.equal(dx, outs[0][1])
+
+
+@pytest.mark.parametrize("case", [(512, 25, 19, 32, 64, 4, 2, 1),     # conv 2 of spec 1: stride 2, four parity classes
+                                  (512, 12, 9, 64, 64, 3, 1, 1),      # conv 3 of spec 1 (128 x 64 tiles)
+                                  (64, 12, 9, 64, 64, 3, 1, 1),       # ... at the column-split size
+                                  (37, 25, 19, 32, 64, 4, 2, 1),      # ragged rows
+                                  (96, 34, 26, 64, 64, 3, 1, 1),      # spec 2 / 3 style layers
+                                  (48, 16, 12, 48, 128, 2, 2, 0),     # 2 x 2 stride 2: one tap per class, no padding
+                                  (40, 12, 9, 20, 64, 3, 1, 1)])      # 20 columns
+@pytest.mark.parametrize("precision", [9, 6])
+def test_data_gradient_on_k_contiguous_weights_is_bit_identical(case, precision):
+    """arl_conv2d_dgrad_weights + wt_or_null (ABI 4): the data gradient reads its own k-contiguous copy of the weights
+    through the forward pass's loader -- same piece products, same order: dx bit for bit the one gathered from w, with
+    and without the rectifier mask; the copy itself is the documented permutation of w."""
+    from accel_rl_amd import _lib
+    b, h, w, c, k, ks, st, p = case
+    _lib.set_conv_precision(precision)
+    try:
+        x, wt, bias, geom, ws = _mk(case, seed=11)
+        ho, wo = _lib.conv_out_hw(geom)
+        dy = torch.randn(b, ho, wo, k, device=DEV, generator=torch.Generator(device=DEV).manual_seed(13))
+        wk = torch.full_like(wt, float("nan")).reshape(-1)
+        _lib.conv2d_dgrad_weights([(wt, wk, geom)])
+        # the layout: class z = ph * st + pw, [c][(ty * taps + tx) * K + k] = w[k][i0 + st ty][j0 + st tx][c]
+        taps = ks // st
+        want = []
+        for ph in range(st):
+            for pw in range(st):
+                i0, j0 = (ph + p) % st, (pw + p) % st
+                sub = wt[:, i0::st, j0::st, :]                        # [K][taps][taps][C]
+                want.append(sub.permute(3, 1, 2, 0).reshape(c, taps * taps * k))
+        assert torch.equal(wk, torch.stack(want).reshape(-1))
+        for mask in (None, x):
+            _lib.load().arl_dev_dgrad_wt(0)
+            dx0 = torch.full((b, h, w, c), float("nan"), device=DEV)
+            _lib.conv2d_bwd_data(dy, wt, mask, dx0, geom, wt=wk)      # handed over, ignored: gathers from w
+            dx1 = torch.full((b, h, w, c), float("nan"), device=DEV)
+            _lib.conv2d_bwd_data(dy, wt, mask, dx1, geom)
+            _lib.load().arl_dev_dgrad_wt(1)
+            dx2 = torch.full((b, h, w, c), float("nan"), device=DEV)
+            _lib.conv2d_bwd_data(dy, wt, mask, dx2, geom, wt=wk)
+            assert torch.isfinite(dx2).all() and torch.equal(dx0, dx1) and torch.equal(dx2, dx1)
+        # through the pair entry (separate launches for these shapes) with the deferred weight-gradient fold
+        folds, ws2 = _lib.FoldList(), _lib.conv_workspace(DEV)
+        dxp, dw = torch.empty_like(dx1), torch.empty_like(wt)
+        folds.conv2d_bwd_pair(dy, wt, x, dxp, x, dw, geom, ws2, wt=wk)
+        folds.run()
+        assert torch.equal(dxp, dx2)
+    finally:
+        _lib.load().arl_dev_dgrad_wt(1)
+        _lib.set_conv_precision(9)
