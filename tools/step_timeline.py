@@ -1,12 +1,12 @@
 """One steady-state step of bench.py as the device ran it: every launch between two consecutive rollout starts
-(the N-th and N+1-th batch_begin_kernel launch), with its start offset, duration and the idle gap in
+(the N-th and N+1-th launch of the marker kernel: the return scan, once per step), with its start offset, duration and the idle gap in
 front of it.  usage: step_timeline.py kernel_trace.csv [which_step [marker_substring]]"""
 import csv
 import sys
 
 path = sys.argv[1]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-marker = sys.argv[3] if len(sys.argv) > 3 else "batch_begin_kernel"
+marker = sys.argv[3] if len(sys.argv) > 3 else "scan_lds_kernel"
 rows = []
 with open(path) as f:
     for r in csv.DictReader(f):
