@@ -158,6 +158,8 @@ _SIGNATURES = {
     "arl_sumtree_add": (_i32, [_vp, _i32, _vp, _vp, _i64, _vp]),
     "arl_sumtree_gather": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_sumtree_sample": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "arl_sumtree_sample_batch": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f64, _vp, _vp, _i32, _vp]),
+    "arl_sumtree_update_pow": (_i32, [_vp, _i32, _vp, _vp, _vp, _f64, _i64, _vp]),
     "arl_is_weights": (_i32, [_vp, _i64, _f64, _vp, _vp]),
     "arl_priority_diffs": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -809,6 +811,33 @@ def sumtree_sample(tree, levels, uniforms, n, part_size, tree_idxs, env_idxs, st
     _check(load().arl_sumtree_sample(ptr(tree), levels, ptr(uniforms), uniforms.numel(), n, part_size,
                                      ptr(tree_idxs), ptr(env_idxs), ptr(step_idxs), ptr(probs), ptr(n_unique),
                                      stream_ptr(stream)), "arl_sumtree_sample")
+
+
+def sumtree_sample_batch(tree, levels, uniforms, n, part_size, tree_idxs, env_idxs, step_idxs, probs, n_unique,
+                         beta=0.0, is_weights=None, notify=None, ticket=0, stream=None):
+    """sumtree_sample + the batch's importance weights in one launch; uniforms: device or PINNED host f64; notify: a pinned
+    int64[1] that receives (ticket << 32) | n_unique when the launch is through (the host polls it)."""
+    _want(tree, torch.float64, "tree"), _want(uniforms, torch.float64, "uniforms")
+    _want(tree_idxs, torch.int32, "tree_idxs"), _want(probs, torch.float64, "probs")
+    if is_weights is not None:
+        _want(is_weights, torch.float32, "is_weights")
+        assert is_weights.numel() == n
+    if notify is not None:
+        _want(notify, torch.int64, "notify")
+        assert notify.is_pinned()
+    _check(load().arl_sumtree_sample_batch(ptr(tree), levels, staged_ptr(uniforms), uniforms.numel(), n, part_size,
+                                           ptr(tree_idxs), ptr(env_idxs), ptr(step_idxs), ptr(probs), ptr(n_unique),
+                                           float(beta), ptr(is_weights), None if notify is None else notify.data_ptr(),
+                                           int(ticket), stream_ptr(stream)), "arl_sumtree_sample_batch")
+
+
+def sumtree_update_pow(tree, levels, idxs, priorities, last_probs, alpha, stream=None):
+    """tree[path of idxs] += f32(priorities ** alpha) - last_probs, one launch (priority_diffs + sumtree_add)."""
+    _want(tree, torch.float64, "tree"), _want(idxs, torch.int32, "idxs")
+    _want(priorities, torch.float32, "priorities"), _want(last_probs, torch.float64, "last_probs")
+    assert priorities.numel() == idxs.numel() == last_probs.numel()
+    _check(load().arl_sumtree_update_pow(ptr(tree), levels, ptr(idxs), ptr(priorities), ptr(last_probs), float(alpha),
+                                         idxs.numel(), stream_ptr(stream)), "arl_sumtree_update_pow")
 
 
 def is_weights(probs, beta, out, stream=None):

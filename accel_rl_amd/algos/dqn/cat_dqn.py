@@ -44,6 +44,6 @@ class CategoricalDQN(DQN):
             term_u8 = term.view(torch.uint8) if term.dtype == torch.bool else term
             loss_rows, kl = policy.cat_loss_and_grads(obs, next_obs, act, ret, term_u8, isw, self.V_min, self.V_max,
                                                       gamma_n, double_dqn=self.double_dqn)
-            return kl, loss_rows.sum()
+            return kl, loss_rows                    # (the loss is their sum: DqnOptimizer)
 
         return inputs, loss

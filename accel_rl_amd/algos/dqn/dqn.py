@@ -90,7 +90,7 @@ class DQN(RLAlgorithm):
             term_u8 = term.view(torch.uint8) if term.dtype == torch.bool else term
             loss_rows, td_abs = policy.q_loss_and_grads(obs, next_obs, act, ret, term_u8, isw, gamma_n,
                                                         self.delta_clip, double_dqn=self.double_dqn)
-            return td_abs, loss_rows.sum()
+            return td_abs, loss_rows                # (the loss is their sum: DqnOptimizer)
 
         return inputs, loss
 
@@ -99,7 +99,7 @@ class DQN(RLAlgorithm):
         self.replay_buffer.append_data(samples_data)
         if itr < self._min_itr_learn:
             return None, dict()
-        priorities, losses = [], []
+        priorities, losses, slots = [], [], []
         for _ in range(self._updates_per_optimize):
             if self.prioritized_replay:
                 opt_minibatch = self.replay_buffer.sample_batch(self.batch_size, device_weights=True)
@@ -108,8 +108,16 @@ class DQN(RLAlgorithm):
             priority, loss = self.optimizer.optimize(opt_minibatch)
             if self.prioritized_replay:
                 self.replay_buffer.update_batch_priorities(priority)
-            priorities.append(priority[::8].clone())  # (downsample for stats)
-            losses.append(loss)
+            if loss.dim() == 1:                       # a slot of the optimizer's statistics ring: [loss rows | priorities]
+                slots.append(loss)
+            else:
+                priorities.append(priority[::8].clone())  # (downsample for stats)
+                losses.append(loss)
+        if slots:                                     # the update loop enqueued nothing for the statistics: one pass here
+            stats = torch.stack(slots)
+            b = stats.shape[1] // 2
+            losses += list(stats[:, :b].sum(dim=1))
+            priorities += list(stats[:, b::8])
         if itr % self._target_update_itr == 0:
             self.policy.update_target()
         self.update_epsilon(itr)

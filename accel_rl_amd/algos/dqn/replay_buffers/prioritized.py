@@ -36,12 +36,11 @@ class PrioritizedReplayBuffer(FrameReplayBuffer):
         """-> extract_batch(...) + (importance weights,): host f64 numpy as the reference returns them, or
         (device_weights=True, what the DQN algorithms ask for) a device f32 tensor -- then leaf selection,
         probabilities, batch extraction and weights never visit the host, which waits for one integer."""
-        dev = self.priority_tree.sample_n_device(batch_size) if device_weights else None
+        is_weights = self._weights_out(batch_size) if device_weights else None
+        dev = self.priority_tree.sample_n_device(batch_size, self.beta, is_weights) if device_weights else None
         if dev is not None:
-            env_idxs, step_idxs, probs = dev
+            env_idxs, step_idxs, probs = dev          # (the importance weights came with the same launch)
             batch_data = self.extract_batch(env_idxs, step_idxs)
-            is_weights = self._weights_out(batch_size)
-            _lib.is_weights(probs, self.beta, is_weights)
             if self.priority_tree.confirm_unique():
                 return batch_data + (is_weights,)
             env_idxs, step_idxs, probs = self.priority_tree.top_up()      # the reference would have drawn more

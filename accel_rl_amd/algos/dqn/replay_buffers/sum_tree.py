@@ -75,10 +75,14 @@ class PartedSumTree(object):
     # ---- sample_n without the host in the data path ------------------------------------------
     _SAMPLE_MAX = 4096
 
-    def sample_n_device(self, n):
+    def sample_n_device(self, n, beta=None, weights_out=None):
         """Enqueue :77-86 for the common case (enough distinct leaves in the first 1.05 n draws); returns
         device (env_idxs i32[n], step_idxs i32[n], probs f64[n]) -- valid only if `confirm_unique()` says so.
-        None when n is too large for the kernel (use sample_n)."""
+        None when n is too large for the kernel (use sample_n).
+        weights_out (f32[n], with beta): the same launch leaves the batch's importance-sampling weights there
+        (prioritized.py:33-35).  The host hands over its uniforms in page-locked memory (the kernel reads them where they
+        lie) and gets the one integer it needs -- how many distinct leaves -- by a store into page-locked memory that
+        confirm_unique() polls: no memcpy node, no event, in either direction."""
         m = int(1.05 * n)
         if m > self._SAMPLE_MAX or m < n:
             return None
@@ -89,28 +93,46 @@ class PartedSumTree(object):
                 n=n, u_host=torch.empty(m, dtype=torch.float64).pin_memory(),
                 u=torch.empty(m, dtype=torch.float64, device=self.device), idx=i32(n), env=i32(n), step=i32(n),
                 probs=torch.empty(n, dtype=torch.float64, device=self.device), count=i32(1),
-                count_host=torch.zeros(1, dtype=torch.int32).pin_memory(), event=torch.cuda.Event())
-        st["u_host"].copy_(torch.from_numpy(np.random.rand(m)))        # the reference's first draw (:79)
-        st["u"].copy_(st["u_host"], non_blocking=True)
-        _lib.sumtree_sample(self.tree, self.tree_level, st["u"], n, self.part_size, st["idx"], st["env"],
-                            st["step"], st["probs"], st["count"])
-        st["count_host"].copy_(st["count"], non_blocking=True)
+                notify=torch.zeros(1, dtype=torch.int64).pin_memory(), ticket=0, event=torch.cuda.Event())
+            st["u_np"], st["notify_np"] = st["u_host"].numpy(), st["notify"].numpy()
+        # the previous call's kernel must have read its uniforms before they are overwritten: its notification, which
+        # confirm_unique waits for, is the last thing it does (a caller that skipped confirm_unique waits here)
+        if not st.get("confirmed", True):
+            st["event"].synchronize()
+        st["u_np"][:] = np.random.rand(m)                               # the reference's first draw (:79)
+        st["ticket"] = (st["ticket"] + 1) & 0x7fffffff
+        _lib.sumtree_sample_batch(self.tree, self.tree_level, st["u_host"], n, self.part_size, st["idx"], st["env"],
+                                  st["step"], st["probs"], st["count"], beta=0.0 if beta is None else beta,
+                                  is_weights=weights_out, notify=st["notify"], ticket=st["ticket"])
         st["event"].record(torch.cuda.current_stream(self.device))
+        st["confirmed"] = False
         self.last_tree_idxs, self.last_probs = st["idx"], st["probs"]
         return st["env"], st["step"], st["probs"]
+
+    _POLL_SPINS = 200000        # ~0.1 s of polling before falling back to the stream event
 
     def confirm_unique(self):
         """Wait for the one integer of the last sample_n_device: were there n distinct leaves?"""
         st = self._dev_sample
-        st["event"].synchronize()
-        return int(st["count_host"][0]) >= st["n"]
+        word, want = st["notify_np"], st["ticket"]
+        for _ in range(self._POLL_SPINS):
+            v = int(word[0])
+            if (v >> 32) == want:
+                break
+        else:
+            st["event"].synchronize()
+            v = int(word[0])
+            assert (v >> 32) == want, "sumtree_sample_batch did not report"
+        st["confirmed"] = True
+        st["count_host"] = v & 0xffffffff
+        return st["count_host"] >= st["n"]
 
     def top_up(self):
         """The reference's while-loop (:80-86), continuing from the distinct leaves of the last
         sample_n_device; returns what sample_n returns."""
         st = self._dev_sample
         n = st["n"]
-        tree_idxs = st["idx"][:int(st["count_host"][0])].cpu().numpy().astype(np.int64)
+        tree_idxs = st["idx"][:int(st["count_host"])].cpu().numpy().astype(np.int64)
         return self._finish_sample(tree_idxs, n)
 
     def _finish_sample(self, tree_idxs, n):
@@ -136,6 +158,4 @@ class PartedSumTree(object):
 
     def update_last_samples_pow(self, priorities, alpha):
         """update_last_samples(priorities ** alpha) for device f32 priorities, without leaving the device."""
-        diffs = torch.empty(priorities.numel(), dtype=torch.float64, device=self.device)
-        _lib.priority_diffs(priorities, self.last_probs, alpha, diffs)
-        _lib.sumtree_add(self.tree, self.tree_level, self.last_tree_idxs, diffs)
+        _lib.sumtree_update_pow(self.tree, self.tree_level, self.last_tree_idxs, priorities, self.last_probs, alpha)

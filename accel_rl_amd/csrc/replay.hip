@@ -151,15 +151,19 @@ __global__ __launch_bounds__(256) void sumtree_gather_kernel(const double* __res
 // scanning the later items in order.  O(n^2 / 1024) LDS compares per thread, no sort, no atomics.
 constexpr int ADD_MAX = 4096;
 
+// priorities != null (arl_sumtree_update_pow): diffs[i] = priority_diffs_kernel's value, computed here
 __global__ __launch_bounds__(1024) void sumtree_add_kernel(double* __restrict__ tree,
                                                            const int32_t* __restrict__ idxs,
-                                                           const double* __restrict__ diffs, int n) {
+                                                           const double* __restrict__ diffs, int n,
+                                                           const float* __restrict__ priorities = nullptr,
+                                                           const double* __restrict__ last_probs = nullptr,
+                                                           double alpha = 0.0) {
     __shared__ __attribute__((aligned(16))) unsigned s_node[ADD_MAX];
     __shared__ double s_diff[ADD_MAX];
     const int tid = threadIdx.x, l = blockIdx.x;                 // one workgroup per tree level
     for (int i = tid; i < n; i += 1024) {
         s_node[i] = (unsigned)((idxs[i] + 1) >> l) - 1u;         // parent = (i - 1) / 2, l times
-        s_diff[i] = diffs[i];
+        s_diff[i] = priorities ? (double)(float)pow((double)priorities[i], (double)(float)alpha) - last_probs[i] : diffs[i];
     }
     __syncthreads();
     const uint4* node4 = reinterpret_cast<const uint4*>(s_node);
@@ -203,14 +207,17 @@ __global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __re
                                                               int32_t* __restrict__ env_idxs,
                                                               int32_t* __restrict__ step_idxs,
                                                               double* __restrict__ probs,
-                                                              int32_t* __restrict__ n_unique) {
+                                                              int32_t* __restrict__ n_unique, double beta,
+                                                              float* __restrict__ is_weights,
+                                                              volatile long long* notify, long long ticket) {
     __shared__ int s_key[SAMPLE_MAX];
     __shared__ int s_pos[SAMPLE_MAX];
-    const int tid = threadIdx.x;
+    __shared__ double s_max[1024];
+    const int tid = threadIdx.x, NT = blockDim.x;         // NT: a power of two, P / NT <= 4
     int P = 1;
     while (P < m) P <<= 1;
     const double root = tree[0];
-    for (int i = tid; i < P; i += 1024) {
+    for (int i = tid; i < P; i += NT) {
         int idx = 0x7fffffff;                                    // padding sorts behind every leaf
         if (i < m) {
             double v = uniforms[i] * root;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __re
     __syncthreads();
     for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += 1024) {
+            for (int i = tid; i < P; i += NT) {
                 const int partner = i ^ j;
                 if (partner > i) {
                     const int a = s_key[i], b = s_key[partner];
@@ -237,40 +244,68 @@ __global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __re
             __syncthreads();
         }
     // distinct leaves: flag the first of every run, inclusive scan of the flags (Hillis-Steele in LDS)
-    for (int i = tid; i < P; i += 1024)
+    for (int i = tid; i < P; i += NT)
         s_pos[i] = (s_key[i] != 0x7fffffff && (i == 0 || s_key[i] != s_key[i - 1])) ? 1 : 0;
     __syncthreads();
     for (int off = 1; off < P; off <<= 1) {
         int add[SAMPLE_MAX / 1024];
-        for (int i = tid, q = 0; i < P; i += 1024, ++q) add[q] = i >= off ? s_pos[i - off] : 0;
+        for (int i = tid, q = 0; i < P; i += NT, ++q) add[q] = i >= off ? s_pos[i - off] : 0;
         __syncthreads();
-        for (int i = tid, q = 0; i < P; i += 1024, ++q) s_pos[i] += add[q];
+        for (int i = tid, q = 0; i < P; i += NT, ++q) s_pos[i] += add[q];
         __syncthreads();
     }
     const int shift = (1 << (levels - 1)) - 1;                   // tree index of leaf 0
-    for (int i = tid; i < P; i += 1024) {
+    // importance-sampling weights of the batch (is_weights_kernel's arithmetic: w = (1 / p) ** beta in f64, divided by
+    // their maximum, rounded to f32), from the probabilities while they are in registers: wq[q] = this thread's q-th slot
+    double wq[SAMPLE_MAX / 1024], wmax = 0.0;
+    int wpos[SAMPLE_MAX / 1024];
+    for (int i = tid, q = 0; i < P; i += NT, ++q) {
         const int key = s_key[i];
         const bool first = key != 0x7fffffff && (i == 0 || key != s_key[i - 1]);
         const int pos = s_pos[i] - 1;
+        wpos[q] = -1;
         if (first && pos < n) {
+            const double pr = tree[key];
             tree_idxs[pos] = key;
-            probs[pos] = tree[key];
+            probs[pos] = pr;
             const int leaf = key - shift;
             env_idxs[pos] = leaf / part_size;
             step_idxs[pos] = leaf - (leaf / part_size) * part_size;
+            if (is_weights) { wq[q] = pow(1.0 / pr, beta); wpos[q] = pos; wmax = fmax(wmax, wq[q]); }
         }
     }
     // too few distinct leaves: the slots past them repeat the first one, so that work already queued behind this
     // kernel (batch extraction) stays in bounds while the host learns from n_unique that it has to top up
     const int total = s_pos[P - 1];
-    for (int pos = total + tid; pos < n; pos += 1024) {
+    for (int pos = total + tid; pos < n; pos += NT) {
         const int key = s_key[0], leaf = key - shift;
         tree_idxs[pos] = key;
         probs[pos] = tree[key];
         env_idxs[pos] = leaf / part_size;
         step_idxs[pos] = leaf - (leaf / part_size) * part_size;
     }
-    if (tid == 0) n_unique[0] = total;
+    if (is_weights) {                                            // (meaningful only with n distinct leaves: the caller checks)
+        s_max[tid] = wmax;
+        __syncthreads();
+        for (int off = NT >> 1; off > 0; off >>= 1) {
+            if (tid < off) s_max[tid] = fmax(s_max[tid], s_max[tid + off]);
+            __syncthreads();
+        }
+        const double mx = s_max[0];
+        for (int i = tid, q = 0; i < P; i += NT, ++q)
+            if (wpos[q] >= 0) is_weights[wpos[q]] = (float)(wq[q] / mx);
+        for (int pos = total + tid; pos < n; pos += NT) is_weights[pos] = 0.f;
+    }
+    if (tid == 0) {
+        n_unique[0] = total;
+        if (notify) {
+            // the host waits on this word in page-locked memory instead of a copy + event: every output above is
+            // queued work's business (stream order); the host only needs the count
+            __threadfence_system();
+            *notify = (ticket << 32) | (long long)(unsigned)total;
+            __threadfence_system();
+        }
+    }
 }
 
 // importance-sampling weights (prioritized.py:33-35): w = (1 / p) ** beta in f64, divided by their maximum,
@@ -363,15 +398,52 @@ extern "C" int arl_sumtree_find(const double* tree, int32_t levels, const double
     return arl::check_launch("sumtree_find_kernel");
 }
 
+// threads of sumtree_sample_kernel: one per padded candidate, 64 .. 1024 (a 33-candidate batch is ONE wave: its ~40
+// barriers cost a wave nothing and sixteen waves ~8 us)
+static int sample_threads(int m) {
+    int p = 64;
+    while (p < m && p < 1024) p <<= 1;
+    return p;
+}
+
 extern "C" int arl_sumtree_sample(const double* tree, int32_t levels, const double* uniforms, int32_t m, int32_t n,
                                   int32_t part_size, int32_t* tree_idxs, int32_t* env_idxs, int32_t* step_idxs,
                                   double* probs, int32_t* n_unique, void* stream) {
     ARL_REQUIRE(tree && uniforms && tree_idxs && env_idxs && step_idxs && probs && n_unique, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(levels >= 1 && levels <= 31 && m >= 1 && m <= SAMPLE_MAX && n >= 1 && n <= m && part_size >= 1,
                 ARL_E_RANGE, "need 1 <= n <= m <= 4096 candidates");
-    hipLaunchKernelGGL(sumtree_sample_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tree, levels, uniforms,
-                       m, n, part_size, tree_idxs, env_idxs, step_idxs, probs, n_unique);
+    hipLaunchKernelGGL(sumtree_sample_kernel, dim3(1), dim3(sample_threads(m)), 0, (hipStream_t)stream, tree, levels, uniforms,
+                       m, n, part_size, tree_idxs, env_idxs, step_idxs, probs, n_unique, 0.0, (float*)nullptr,
+                       (volatile long long*)nullptr, 0ll);
     return arl::check_launch("sumtree_sample_kernel");
+}
+
+extern "C" int arl_sumtree_sample_batch(const double* tree, int32_t levels, const double* uniforms, int32_t m, int32_t n,
+                                        int32_t part_size, int32_t* tree_idxs, int32_t* env_idxs, int32_t* step_idxs,
+                                        double* probs, int32_t* n_unique, double beta, float* is_weights_or_null,
+                                        int64_t* notify_or_null, int32_t ticket, void* stream) {
+    ARL_REQUIRE(tree && uniforms && tree_idxs && env_idxs && step_idxs && probs && n_unique, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(levels >= 1 && levels <= 31 && m >= 1 && m <= SAMPLE_MAX && n >= 1 && n <= m && part_size >= 1,
+                ARL_E_RANGE, "need 1 <= n <= m <= 4096 candidates");
+    ARL_REQUIRE(!notify_or_null || (reinterpret_cast<uintptr_t>(notify_or_null) & 7u) == 0, ARL_E_ALIGN, "notify: 8-byte aligned");
+    hipLaunchKernelGGL(sumtree_sample_kernel, dim3(1), dim3(sample_threads(m)), 0, (hipStream_t)stream, tree, levels, uniforms,
+                       m, n, part_size, tree_idxs, env_idxs, step_idxs, probs, n_unique, beta, is_weights_or_null,
+                       (volatile long long*)notify_or_null, (long long)ticket);
+    return arl::check_launch("sumtree_sample_kernel");
+}
+
+extern "C" int arl_sumtree_update_pow(double* tree, int32_t levels, const int32_t* tree_idxs, const float* priorities,
+                                      const double* last_probs, double alpha, int64_t n, void* stream) {
+    ARL_REQUIRE(tree && tree_idxs && priorities && last_probs, ARL_E_ARG, "null pointer");
+    ARL_REQUIRE(levels >= 1 && levels <= 31 && n >= 0, ARL_E_RANGE, "bad levels / n");
+    for (int64_t lo = 0; lo < n; lo += ADD_MAX) {            // (consecutive chunks are exact: arl_sumtree_add)
+        const int m = (int)((n - lo < ADD_MAX) ? n - lo : ADD_MAX);
+        hipLaunchKernelGGL(sumtree_add_kernel, dim3((unsigned)levels), dim3(1024), 0, (hipStream_t)stream, tree,
+                           tree_idxs + lo, (const double*)nullptr, m, priorities + lo, last_probs + lo, alpha);
+        int rc = arl::check_launch("sumtree_add_kernel");
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int arl_is_weights(const double* probs, int64_t n, double beta, float* out, void* stream) {

@@ -23,6 +23,7 @@ class DqnOptimizer(BaseOptimizer):
         self._grad_norm_clip = grad_norm_clip
         self._use_graph = use_graph
         self._static = self._graph = self._graph_out = None
+        self._ring, self._pack_rows = None, 0
         self._calls = 0
 
     def initialize(self, inputs, loss, target, priority_expr=None, givens=None, lr_mult=1):
@@ -39,6 +40,11 @@ class DqnOptimizer(BaseOptimizer):
         if self._graph is None:
             if self._calls <= 2:                                  # warm-up: buffers, kernel attributes
                 return self._step(static)
+            if self._pack_rows:                                   # (allocated here: not from the capture's private pool)
+                dev = self._target.device
+                self._ring = torch.zeros((self.STATS_RING, 2 * self._pack_rows), dtype=torch.float32, device=dev)
+                self._ring_count = torch.zeros(1, dtype=torch.int32, device=dev)
+                self._ring_replays = 0
             torch.cuda.synchronize(self._target.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
@@ -46,10 +52,29 @@ class DqnOptimizer(BaseOptimizer):
             self._graph = graph
         self._graph.replay()
         priority, loss = self._graph_out          # graph-owned: valid until the next replay
+        if self._ring is not None and loss.dim() == 1:     # the graph left [loss rows | priorities] in a ring slot: no launch here
+            slot = self._ring_replays % self._ring.shape[0]
+            self._ring_replays += 1
+            return priority, self._ring[slot]
         return priority, loss.clone()
+
+    STATS_RING = 1024           # updates whose statistics stay readable (one optimize_policy call enqueues at most this many)
 
     def _step(self, inputs):
         priority, loss = self._loss_fn(inputs)
+        if loss.dim() == 1:                            # per-row losses (the loss is their sum)
+            b = loss.numel()
+            capturing = loss.is_cuda and torch.cuda.is_current_stream_capturing()
+            packed = (priority.dim() == 1 and priority.numel() == b and loss.is_contiguous() and priority.is_contiguous()
+                      and priority.data_ptr() == loss.data_ptr() + 4 * b)
+            self._pack_rows = b if packed else 0           # (the warm-up calls tell optimize() how wide the ring is)
+            if capturing and packed and self._ring is not None and self._ring.shape[1] == 2 * b:
+                # inside the graph the statistics of an update are ONE ring append of both rows (the loss's sum and the
+                # downsampled priorities are taken from the ring after the update loop: algos/dqn/dqn.py)
+                from accel_rl_amd import _lib
+                _lib.ring_append(torch.as_strided(loss, (2 * b,), (1,)), self._ring, self._ring_count)
+            else:
+                loss = loss.sum()
         if self._scale_conv_grads:                     # the conv tensors lead the bucket (optimizers/util.py:122-126)
             self._target.flat_grads[:self._target.grad_split_offset].mul_(float(np.float32(2 ** -0.5)))
         self._apply_update(1.0)

@@ -110,8 +110,8 @@ class AtariCatDqnPolicy(QPolicyBase):
             b = obs.shape[0]
             x, logits, acts, hids, tgt_logits, pol_next = self._forward_for_loss(obs, next_obs, double_dqn)
             dlogits = self._buffer(("dlogits", b), tuple(logits.shape))
-            loss_rows = self._buffer(("loss_rows", b), (b,))
-            kl = self._buffer(("kl", b), (b,))
+            pack = self._buffer(("loss_kl", b), (2, b))         # one buffer: DqnOptimizer's statistics ring takes both rows at once
+            loss_rows, kl = pack[0], pack[1]
             _lib.catdqn_loss(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
                              self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl,
                              dueling=self._dueling)

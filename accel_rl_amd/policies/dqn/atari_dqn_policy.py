@@ -107,8 +107,8 @@ class AtariDqnPolicy(QPolicyBase):
             b = obs.shape[0]
             x, q, acts, hids, tgt_q, pol_next = self._forward_for_loss(obs, next_obs, double_dqn)
             dq = self._buffer(("dlogits", b), tuple(q.shape))
-            loss_rows = self._buffer(("loss_rows", b), (b,))
-            td_abs = self._buffer(("td_abs", b), (b,))
+            pack = self._buffer(("loss_td", b), (2, b))         # one buffer: DqnOptimizer's statistics ring takes both rows at once
+            loss_rows, td_abs = pack[0], pack[1]
             _lib.dqn_loss(q, tgt_q, pol_next, actions, returns, terminals, is_weights, self.n_act, gamma_n,
                           delta_clip, dq, loss_rows, td_abs, dueling=self._dueling)
             self._head_backward(dq, x, acts, hids)

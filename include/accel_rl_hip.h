@@ -627,6 +627,22 @@ int arl_sumtree_sample(const double* tree, int32_t levels, const double* uniform
                        int32_t part_size, int32_t* tree_idxs, int32_t* env_idxs, int32_t* step_idxs,
                        double* probs, int32_t* n_unique, void* stream);
 
+/* The same launch with the batch's importance-sampling weights (arl_is_weights on the n probabilities: prioritized.py:33-35)
+ * and a host hand-off without a copy: uniforms may live in page-locked host memory (read once each), and
+ * notify_or_null (page-locked, 8-byte aligned) receives (ticket << 32) | n_unique when everything above is written --
+ * the one integer sample_n's caller waits for (sum_tree.py:80: `while len(tree_idxs) < n`) arrives by a store the host
+ * polls instead of a memcpy node and an event.  is_weights_or_null f32[n] (slots past the distinct leaves: 0).       */
+int arl_sumtree_sample_batch(const double* tree, int32_t levels, const double* uniforms, int32_t m, int32_t n,
+                             int32_t part_size, int32_t* tree_idxs, int32_t* env_idxs, int32_t* step_idxs,
+                             double* probs, int32_t* n_unique, double beta, float* is_weights_or_null,
+                             int64_t* notify_or_null, int32_t ticket, void* stream);
+
+/* update_batch_priorities on the device in ONE launch: arl_priority_diffs (f32 priorities ** alpha - the probabilities
+ * sampled before) feeding arl_sumtree_add (np.add.at per level in input order); prioritized.py:37-38,
+ * sum_tree.py:50-57,74-75.                                                                                          */
+int arl_sumtree_update_pow(double* tree, int32_t levels, const int32_t* tree_idxs, const float* priorities,
+                           const double* last_probs, double alpha, int64_t n, void* stream);
+
 /* Importance-sampling weights of PrioritizedReplayBuffer.sample_batch (prioritized.py:33-35):
  * out[i] = f32( (1 / probs[i]) ** beta / max_j (1 / probs[j]) ** beta ), arithmetic in f64.        */
 int arl_is_weights(const double* probs, int64_t n, double beta, float* out, void* stream);

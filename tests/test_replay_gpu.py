@@ -231,7 +231,7 @@ def test_prioritized_device_path_tracks_the_reference_path():
                 got = dev.sample_batch(batch, device_weights=True)
                 assert np.random.randint(0, 2 ** 31 - 1) == after           # same host RNG consumption
                 st = dev.priority_tree._dev_sample
-                if int(st["count_host"][0]) >= batch:
+                if int(st["count_host"]) >= batch:
                     fast += 1
                 else:
                     slow += 1
