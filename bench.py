@@ -348,7 +348,12 @@ def mfma_table(device, policy, batch=512, reps=20):
             calls = [("fwd", lambda: _lib.conv2d_u8_fwd(obs8, idx8, 1. / 255, w, b, y, g, True)),
                      ("wgrad+fold", wgrad_u8)]
         if k > 0:                                   # the first layer's input needs no gradient
-            calls.append(("dgrad", lambda: _lib.conv2d_bwd_data(dy, w, None, dx, g)))
+            # as the learner runs it: on the layer's k-contiguous weight copy where the policy keeps one (round 6; the
+            # copy itself is one 5 us launch per backward pass for all layers, not counted in this row)
+            wt = getattr(policy, "_wt", {}).get(k // 2) if name.startswith("conv") else None
+            if wt is not None:
+                _lib.conv2d_dgrad_weights([(w, wt, g)])
+            calls.append(("dgrad", lambda: _lib.conv2d_bwd_data(dy, w, None, dx, g, wt=wt)))
         for tag, fn in calls:
             iso_ms, _ = event_time_ms(fn, reps)
             mean_ms = graph_time_ms(fn)
