@@ -109,6 +109,44 @@ def test_served_step_is_bit_identical_to_the_separate_launches(game, spec, n_par
     b.shutdown()
 
 
+def test_served_step_through_the_noop_ring_refills():
+    """350 batches of 2-step episodes: every worker stream consumes more start no-op draws than its device ring holds
+    (4096), so the ring is topped up from the streams' RandomStates several times and the cursors wrap -- the served
+    launch's forecast / rank / cursor logic against the separate launches, every array bit for bit (compared on the
+    device), no forecast mismatch."""
+    from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+    from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+    from accel_rl_amd.sampler import gpu_sampler
+    policy = AtariCnnPolicy(**cnn_specs[1])
+    kw = dict(max_start_noops=30)
+    a = make_sampler("breakout", 1, 8, 5, 41, 1, kw, policy, True, served=False)
+    b = make_sampler("breakout", 1, 8, 5, 41, 1, kw, policy, True, served=True)
+    with torch.no_grad():
+        policy.flat_params[policy._offsets[policy._k_head]:].mul_(40.0)
+    state = np.random.get_state()
+    n_traj = 0
+    for k in range(350):
+        np.random.set_state(state)
+        buf_a, infos_a = a.obtain_samples(k)
+        ta = traj_tuples(infos_a)
+        np.random.set_state(state)
+        buf_b, infos_b = b.obtain_samples(k)
+        tb = traj_tuples(infos_b)
+        state = np.random.get_state()
+        assert ta == tb, k
+        n_traj += len(ta)
+        for x, y in ((buf_a.observations, buf_b.observations), (buf_a.actions, buf_b.actions), (buf_a.rewards, buf_b.rewards),
+                     (buf_a.dones, buf_b.dones), (buf_a.agent_infos["prob"], buf_b.agent_infos["prob"]),
+                     (buf_a.agent_infos["value"], buf_b.agent_infos["value"]),
+                     (buf_a.extra_observations, buf_b.extra_observations), (a._st.noop_cursor, b._st.noop_cursor),
+                     (a._st.tick, b._st.tick), (a._st.next_reset, b._st.next_reset)):
+            assert torch.equal(x, y), k
+    assert int(a._st.noop_cursor.max().item()) > gpu_sampler.NOOP_RING          # the ring went round
+    assert n_traj > 16 * 500 and int(b._st.epoch[2].item()) == 0
+    a.shutdown()
+    b.shutdown()
+
+
 class EchoPolicy(object):
     """Host policy for the oracle's sampler port: serves a group's observations with the DEVICE network through the
     separate kernels (policy.prob_value on a full-size batch with the group's rows at their env positions, so that
