@@ -53,6 +53,10 @@ def rollout_ms(n_env, served, replays=60):
 if __name__ == "__main__":
     logger.set_quiet(True)
     argv = sys.argv[1:]
+    if argv[:1] == ["--pmc"]:          # a few replays of both forms, for counter passes (tools/serve_pmc.sh)
+        for served in (False, True):
+            rollout_ms(int(argv[1]), served, replays=4)
+        sys.exit(0)
     if argv[:1] == ["--spec"]:
         SPEC, argv = int(argv[1]), argv[2:]
     sizes = [int(a) for a in argv] or [128, 256, 384, 512, 768, 1024]
