@@ -61,16 +61,19 @@ class _LazyTrajInfos(list):
     enqueuing the rollout; a caller that first enqueues the learner (as the runners do) and only then
     looks at the trajectory statistics waits for the ROLLOUT's event while the learner already runs."""
 
-    def __init__(self, sampler):
+    def __init__(self, sampler, host_set=None, older=None):
         super().__init__()
-        self._sampler = sampler
+        self._sampler, self._set, self._older = sampler, host_set, older
 
     def resolve(self):
         smp, self._sampler = self._sampler, None
         if smp is not None:
-            if smp._pending is self:
-                smp._pending = None
-            super().extend(smp._drain_traj_infos())
+            older, self._older = self._older, None
+            if older is not None:                    # batches are read out in order (the no-op ring's top-up counts on it)
+                older.resolve()
+            if self._set is not None and self._set.pending is self:
+                self._set.pending = None
+            super().extend(smp._drain_traj_infos(self._set))
         return self
 
     def __len__(self):
@@ -107,13 +110,24 @@ class GpuVecSampler(BaseMbSampler):
     # when conv 1 rides along (spec 1: -15 % at 256, -4 % at 1024), up to 512 when it does not (spec 0: -13 % at 256, -4 % at
     # 512, +1 % at 1024; tools/serve_step_probe.py, profiles/r06/serve_step_probe*.txt)
     _serve_in_step_max_envs = (512, 1024)       # (without, with conv 1 in the launch)
+    _two_host_sets = os.environ.get("ARL_TWO_HOST_SETS", "1") != "0"     # (A/B switch, see _sets)
 
     def __init__(self, n_parallel=1, envs_per=1, device=None, use_graph=True, **kwargs):
         super().__init__(n_parallel=n_parallel, envs_per=envs_per, **kwargs)
         self._total_n_envs = 2 * n_parallel * envs_per
         self.device = device
         self.use_graph = use_graph
-        self._graph = None
+        self._sets, self._batch_no = [], 0
+
+    # Host-side per-batch buffers (pinned uniforms in, pinned results out, event, captured graph, lazily read trajectory
+    # records) come in TWO sets when batches are graph replays: batch i + 1 can be enqueued while batch i still runs, its
+    # results unread -- a caller that only samples (evaluation, data collection) then keeps the device busy back to back
+    # instead of paying a host round trip per batch.  samples_buf itself is one buffer, as the reference's: consume it
+    # before the next call.
+    _graph = property(lambda self: self._sets[0].graph if self._sets else None,
+                      lambda self, v: [setattr(h, "graph", v) for h in self._sets])
+    _pending = property(lambda self: next((h.pending for h in self._sets if h.pending is not None), None),
+                        lambda self, v: [setattr(h, "pending", v) for h in self._sets])
 
     # ------------------------------------------------------------------ API
     def initialize(self, seed, affinities=None, discount=1, need_extra_obs=False):
@@ -275,15 +289,19 @@ class GpuVecSampler(BaseMbSampler):
             self.samples_buf.extra_observations = self.envs_buf.extra_observations = self.step_obs
         self._step_rows = (torch.arange(n, dtype=torch.int32, device=dev)[None, :] * t +
                            torch.arange(t, dtype=torch.int32, device=dev)[:, None]).contiguous()
-        self._uniforms_host = torch.empty(t * n, dtype=torch.float64).pin_memory()
         self._uniforms = torch.empty((t, n), dtype=torch.float64, device=dev)
         # pinned mirrors of the batch's small results (completed-episode records, no-op ring cursors):
         # copied at the end of the batch ON the stream (inside the hipGraph), read by the host after
         # waiting for the batch event only -- not for whatever was enqueued behind it (the learner)
-        self._host_block, views = _packed_block(self._results_spec, "cpu", pinned=True)
-        self._host = struct(**views)
-        self._batch_event = torch.cuda.Event()
-        self._pending = None
+        self._sets, self._batch_no, self._last_pending = [], 0, None
+        # (two sets only where the HOST prepares nothing else per batch: a policy with its own per-batch draws -- the DQN
+        #  family's epsilon-greedy override table, staged through one pinned buffer -- or recurrent state keeps the strict
+        #  hand-over, in which a batch's host-side preparation starts when the previous batch has finished)
+        overlap = (self.use_graph and type(self)._two_host_sets and not hasattr(policy, "host_draws") and not self._recurrent)
+        for _ in range(2 if overlap else 1):
+            block, views = _packed_block(self._results_spec, "cpu", pinned=True)
+            self._sets.append(struct(uniforms_host=torch.empty(t * n, dtype=torch.float64).pin_memory(), host_block=block,
+                                     host=struct(**views), event=torch.cuda.Event(), pending=None, graph=None))
         logger.log("GpuVecSampler -- total_n_envs: {}".format(self.total_n_envs))
         logger.log("GpuVecSampler -- batch buffer size: {:,.1f} {}".format(
             *nbytes_unit(count_buffer_size(self.samples_buf))))
@@ -291,25 +309,29 @@ class GpuVecSampler(BaseMbSampler):
     def obtain_samples(self, itr):
         """reference: sampler.py:97-104 (+ serve_actions :120-151)"""
         n, t = self._total_n_envs, self.horizon
-        if self._pending is not None:                    # the previous batch's records must be read out
-            self._pending.resolve()                      # before this batch overwrites the pinned mirrors
+        cur = self._sets[self._batch_no % len(self._sets)]
+        self._batch_no += 1
+        if cur.pending is not None:                      # the records of the batch that used these pinned mirrors last must
+            cur.pending.resolve()                        # be read out before this batch overwrites them
         # one np.random.rand(B) per (step, group) in the reference == one flat draw here; a policy
         # with its own action randomness (epsilon-greedy) makes the reference's draws itself
         draws = self.policy.host_draws(t, n) if hasattr(self.policy, "host_draws") else np.random.rand(t * n)
-        self._uniforms_host.copy_(torch.from_numpy(draws))
+        cur.uniforms_host.copy_(torch.from_numpy(draws))
         with torch.cuda.device(self.device):
             if self.use_graph:
-                if self._graph is None:
-                    self._capture()
-                self._graph.replay()
+                if cur.graph is None:
+                    self._capture(cur)
+                cur.graph.replay()
             else:
-                self._enqueue_batch()
-            self._batch_event.record()
-        self._pending = _LazyTrajInfos(self)
-        return self.samples_buf, self._pending
+                self._enqueue_batch(cur)
+            cur.event.record()
+        older = self._last_pending if (self._last_pending is not None and self._last_pending._sampler is not None) else None
+        cur.pending = self._last_pending = _LazyTrajInfos(self, cur, older)
+        return self.samples_buf, cur.pending
 
     def shutdown(self):
-        self._graph = None
+        for h in self._sets:
+            h.graph = None
 
     @property
     def alternating(self):
@@ -330,11 +352,11 @@ class GpuVecSampler(BaseMbSampler):
             ro.prob, ro.value = buf.agent_infos["prob"].data_ptr(), buf.agent_infos["value"].data_ptr()
         return ro
 
-    def _enqueue_batch(self):
-        """All device work of one batch, on the current stream (graph-capturable)."""
+    def _enqueue_batch(self, cur):
+        """All device work of one batch, on the current stream (graph-capturable); cur: the host-side buffer set."""
         n, t = self._total_n_envs, self.horizon
         buf, ro, env = self.samples_buf, self._rollout, self.env
-        _lib.copy_bytes(self._uniforms, self._uniforms_host)   # (a kernel node reading the pinned buffer: no memcpy node)
+        _lib.copy_bytes(self._uniforms, cur.uniforms_host)     # (a kernel node reading the pinned buffer: no memcpy node)
         # observations[:, 0] = step_obs (worker.py:30-32), done_count = 0 -- and, when the steps are served in one launch
         # each, conv 1 of those rows from the same pass over them (y1: conv 1 of the step's observations, once a launch
         # has left it)
@@ -373,7 +395,7 @@ class GpuVecSampler(BaseMbSampler):
             _lib.copy_bytes(buf.extra_observations, self.step_obs)     # sampler.py:147-151 (a kernel node, 16-byte copies)
         if not self.mid_batch_reset:                           # worker.py:108-113
             _lib.env_reset(self._game, self._state, ro, self._st.frozen, env.max_start_noops)
-        _lib.copy_bytes(self._host_block, self._results_block)
+        _lib.copy_bytes(cur.host_block, self._results_block)
 
     def _kernel_max_path_length(self):
         """The kernels end an episode when Length > limit (worker.py:42)."""
@@ -394,20 +416,20 @@ class GpuVecSampler(BaseMbSampler):
                               self.discount, active=active)
             _lib.env_frame_step(self._game, state, ro, step, self.env.max_start_noops)
 
-    def _capture(self):
-        """Warm up on a side stream, then capture one batch into a hipGraph."""
+    def _capture(self, cur):
+        """Warm up on a side stream, then capture one batch into a hipGraph (one graph per host-side buffer set)."""
         snap = {k: v.clone() for k, v in self._st.items()}
         obs_snap = self.step_obs.clone()
         hidden_snap = [h.clone() for h in self.policy.get_prev_hiddens()] if self._recurrent else []
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._enqueue_batch()
+            self._enqueue_batch(cur)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, capture_error_mode=graph_capture_mode()):
-            self._enqueue_batch()
+            self._enqueue_batch(cur)
         # warm-up and capture-time work must not count: restore the state
         for k, v in snap.items():
             self._st[k].copy_(v)
@@ -415,13 +437,13 @@ class GpuVecSampler(BaseMbSampler):
         for h, v in zip(self.policy.get_prev_hiddens() if self._recurrent else [], hidden_snap):
             h.copy_(v)
         torch.cuda.synchronize(self.device)
-        self._graph = graph
+        cur.graph = graph
 
-    def _drain_traj_infos(self):
+    def _drain_traj_infos(self, cur):
         """Completed episodes of the batch whose event has passed (the reference's traj_infos_queue),
-        read from the pinned mirrors; tops the no-op ring up from the same snapshot."""
-        self._batch_event.synchronize()
-        h = self._host
+        read from the pinned mirrors of its buffer set; tops the no-op ring up from the same snapshot."""
+        cur.event.synchronize()
+        h = cur.host
         if int(h.epoch[2]):
             raise RuntimeError("arl_env_step: %d mid-batch resets were not announced by the previous launch's forecast "
                                "(st.next_reset): the start no-op draws of their RNG streams are misordered.  The length "

@@ -30,6 +30,7 @@ Round 6: what the reference's sampler serves on ANY environment is served here t
   * the evaluation variant (`HostEnvEvalSampler`, sampler_with_eval.py:6-54 / worker_with_eval.py:20-239): separate
     evaluation envs in every worker, `evaluate_policy(itr)`, and that family's `Length >= max_path_length` rule."""
 import multiprocessing as mp
+import gc
 import os
 import queue as pyqueue
 import time
@@ -107,7 +108,7 @@ def _worker(w, cfg, ctrl, gate, step, eval_step, batch, done_queue):
                 os.sched_setaffinity(0, [int(w.cpu)])
             except OSError:
                 pass
-        set_seed(w.seed)
+        set_seed(w.seed, device_generators=False)           # (a forked child: see set_seed)
         T, per, horizon_limit, discount = cfg.horizon, cfg.envs_per, cfg.max_path_length, cfg.discount
         envs = [cfg.EnvCls(**cfg.env_args) for _ in range(per)]
         eval_envs = [cfg.EnvCls(**cfg.env_args) for _ in range(cfg.eval_envs_per)]       # worker_with_eval.py:200
@@ -286,16 +287,27 @@ class HostEnvSampler(BaseMbSampler):
                      eval_envs_per=self.eval_envs_per, eval_horizon=self.eval_horizon)
         cpus = affinities.get("sim_cpus") if hasattr(affinities, "get") else None
         i = 0
-        for group in range(2):
-            for rank in range(self.n_parallel):
-                w = struct(group=group, rank=rank, index=i, seed=seed + i, first_env=(group * self.n_parallel + rank) * self.envs_per,
-                           cpu=cpus[i] if cpus is not None and i < len(cpus) else None)
-                p = ctx.Process(target=_worker, args=(w, cfg, self._ctrl, self._gates[group][rank], self._steps[group],
-                                                      self._eval_steps[group] if self._eval_steps else None,
-                                                      self._batch, self._done_queue), daemon=True)
-                p.start()
-                self.workers.append(p)
-                i += 1
+        # The workers are FORKED from a process whose HIP runtime may be up.  A child must never finalise an object of the
+        # parent's that owns device state (a captured graph, an event, page-locked memory left in an unreachable cycle):
+        # its destructor would call into a runtime the child does not have -- a segfault inside the child's first garbage
+        # collection, one worker start in a few hundred (tests/test_host_sampler_gpu.py after 200 other GPU tests).  So the
+        # parent collects its garbage HERE, and everything alive at the fork is frozen out of the children's collector.
+        gc.collect()
+        gc.freeze()
+        try:
+            for group in range(2):
+                for rank in range(self.n_parallel):
+                    w = struct(group=group, rank=rank, index=i, seed=seed + i,
+                               first_env=(group * self.n_parallel + rank) * self.envs_per,
+                               cpu=cpus[i] if cpus is not None and i < len(cpus) else None)
+                    p = ctx.Process(target=_worker, args=(w, cfg, self._ctrl, self._gates[group][rank], self._steps[group],
+                                                          self._eval_steps[group] if self._eval_steps else None,
+                                                          self._batch, self._done_queue), daemon=True)
+                    p.start()
+                    self.workers.append(p)
+                    i += 1
+        finally:
+            gc.unfreeze()
 
         # -- device side: the SAME buffers GpuVecSampler fills
         _lib.load()

@@ -153,13 +153,21 @@ class CpuSamplerMP(object):
         self._sem_obs = [self._ctx.Semaphore(0) for _ in range(n_workers)]     # sync.step_blockers
         self._sem_act = [self._ctx.Semaphore(0) for _ in range(n_workers)]     # sync.act_waiters
         cpus = sorted(os.sched_getaffinity(0))
-        for w in range(n_workers):
-            aff = cpus[(w + 1) % len(cpus)] if self._pin else None
-            p = self._ctx.Process(target=_worker, args=(w, self._cfg, self._raws, self._sem_obs[w],
-                                                        self._sem_act[w], self._bar_in, self._bar_out,
-                                                        self._quit, aff), daemon=True)
-            p.start()
-            self._procs.append(p)
+        # (forked from a process that may hold device objects -- bench.py's cpu_baseline leg --: none of them may be
+        #  finalised by a child's garbage collector; see accel_rl_amd/sampler/host_sampler.py)
+        import gc
+        gc.collect()
+        gc.freeze()
+        try:
+            for w in range(n_workers):
+                aff = cpus[(w + 1) % len(cpus)] if self._pin else None
+                p = self._ctx.Process(target=_worker, args=(w, self._cfg, self._raws, self._sem_obs[w],
+                                                            self._sem_act[w], self._bar_in, self._bar_out,
+                                                            self._quit, aff), daemon=True)
+                p.start()
+                self._procs.append(p)
+        finally:
+            gc.unfreeze()
         self._bar_out.wait(timeout=120)                            # envs are started
         self._completed_seen = 0
         return self.n_actions, n * t

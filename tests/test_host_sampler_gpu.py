@@ -126,8 +126,8 @@ def test_a_dead_worker_is_reported_not_waited_for():
                          max_decorrelation_steps=0, device=DEV)
     np.random.seed(1)
     smp.initialize(seed=2, discount=0.99, need_extra_obs=True)
-    smp.policy_init(DeviceTablePolicy(g["prob_table"], g["value_table"]))
     try:
+        smp.policy_init(DeviceTablePolicy(g["prob_table"], g["value_table"]))
         with pytest.raises(RuntimeError, match="simulation worker"):
             smp.obtain_samples(0)
     finally:
