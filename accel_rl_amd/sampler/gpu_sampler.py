@@ -124,10 +124,27 @@ class GpuVecSampler(BaseMbSampler):
     # results unread -- a caller that only samples (evaluation, data collection) then keeps the device busy back to back
     # instead of paying a host round trip per batch.  samples_buf itself is one buffer, as the reference's: consume it
     # before the next call.
-    _graph = property(lambda self: self._sets[0].graph if self._sets else None,
-                      lambda self, v: [setattr(h, "graph", v) for h in self._sets])
-    _pending = property(lambda self: next((h.pending for h in self._sets if h.pending is not None), None),
-                        lambda self, v: [setattr(h, "pending", v) for h in self._sets])
+    @property
+    def _graph(self):
+        """The captured rollout (of the first buffer set); assigning None drops every set's graph."""
+        return self._sets[0].graph if self._sets else None
+
+    @_graph.setter
+    def _graph(self, value):
+        for h in self._sets:
+            h.graph = value
+
+    @property
+    def _pending(self):
+        """A batch whose trajectory records have not been read yet, if any; assigning None forgets them all."""
+        return next((h.pending for h in self._sets if h.pending is not None), None)
+
+    @_pending.setter
+    def _pending(self, value):
+        for h in self._sets:
+            h.pending = value
+        if value is None:
+            self._last_pending = None
 
     # ------------------------------------------------------------------ API
     def initialize(self, seed, affinities=None, discount=1, need_extra_obs=False):
