@@ -130,7 +130,8 @@ _SIGNATURES = {
     "arl_pg_head_workspace_bytes": (_i64, []),
     "arl_pg_head_infer": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "arl_pg_head_loss": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 7),
-    "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 8),
+    "arl_pg_head_loss_parts": (_i32, [_vp] * 11 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32] + [_vp] * 7 +
+                               [_vp, _i32, _vp]),
     "arl_conv_workspace_bytes": (_i64, []),
     "arl_conv2d_fwd": (_i32, [_vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), _i32, _vp, _vp]),
     "arl_conv2d_bwd_data": (_i32, [_vp, _vp, _vp, _vp, _vp, C.POINTER(ArlConvGeom), C.POINTER(ArlCorunJob), C.POINTER(_i32), _vp]),
@@ -749,17 +750,27 @@ class FoldList(object):
     def pg_head_loss(self, h, w_head, b_head, actions, advantages, returns, old_prob, valids, idx, lr_mult,
                      inv_count, n_actions, kind, clip_param, v_loss_coeff, ent_loss_coeff,
                      dout, dh, dw_head, db_head, loss4, workspace, stream=None, relu_mask_dh=False,
-                 tie_rule=PPO_TIE_THEANO):
-        """pg_head_loss with its three small folds (dw_head, db_head, loss4) left to run()."""
+                 tie_rule=PPO_TIE_THEANO, dgrad_weights=None):
+        """pg_head_loss with its three small folds (dw_head, db_head, loss4) left to run().
+        dgrad_weights: [(w, wt, geom)] -- the launch also writes these layers' k-contiguous weight copies
+        (conv2d_dgrad_weights' work in extra workgroups: one launch less per backward pass)."""
         batch, hid = h.shape
         assert self._n + 3 <= FOLD_MAX_ITEMS, "too many pending folds"
         first = C.byref(self._items[self._n])
         self._n += 3
+        wt_items, n_wt = None, 0
+        if dgrad_weights:
+            n_wt = len(dgrad_weights)
+            assert n_wt <= DGRAD_WT_MAX
+            wt_items = (ArlDgradWt * n_wt)()
+            for it, (w, wt, geom) in zip(wt_items, dgrad_weights):
+                it.w, it.wt, it.geom = ptr(w), ptr(wt), C.pointer(geom)
         _check(load().arl_pg_head_loss_parts(
             ptr(h), w_head.data_ptr(), b_head.data_ptr(), ptr(actions), ptr(advantages), ptr(returns),
             ptr(old_prob), ptr(valids), ptr(idx), ptr(lr_mult), ptr(inv_count), batch, hid, n_actions,
             kind, int(tie_rule), float(clip_param), float(v_loss_coeff), float(ent_loss_coeff), int(bool(relu_mask_dh)), ptr(dout),
-            ptr(dh), dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), first, stream_ptr(stream)),
+            ptr(dh), dw_head.data_ptr(), db_head.data_ptr(), ptr(loss4), ptr(workspace), first,
+            None if wt_items is None else C.cast(wt_items, _vp), n_wt, stream_ptr(stream)),
             "arl_pg_head_loss_parts")
 
     def run(self, stream=None):

@@ -18,6 +18,7 @@
 
 #include "arl_common.h"
 #include "head_dev.h"
+#include "dgrad_wt_dev.h"
 
 namespace {
 
@@ -156,6 +157,7 @@ struct HeadLossArgs {
     int batch, hid, n_act, kind, tie_rule;
     float clip_param, v_coeff, ent_coeff;
     int mask_dh;             // dh *= (h > 0): h is a rectifier's output and the caller wants the gradient before it
+    int head_blocks;         // workgroups of the head itself (the launch may carry more: see head_kernel)
 };
 
 // one wave per row (looping); lanes split the hidden dimension.  Every per-action
@@ -163,9 +165,16 @@ struct HeadLossArgs {
 // `k < n_act` guards) so that it lives in VGPRs, not scratch.
 // HVT = hid / 64 when the hidden width is a multiple of 64 (no per-lane guards: a guarded element costs an
 // exec-mask save / branch / restore, and the generic kernel is mostly those), 0 = any width.
+// wt (TRAIN): the workgroups behind the head's own grid (blockIdx.x >= a.head_blocks) write the data gradients' k-contiguous
+// weight copies (dgrad_wt_dev.h) -- the backward pass that follows reads them, and this launch is where a minibatch's
+// parameters are final and nothing else needs the CUs (one launch less per minibatch).
 template <bool TRAIN, int HVT = 0>
 __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __restrict__ prob_out,
-                                                   float* __restrict__ value_out) {
+                                                   float* __restrict__ value_out, const arlw::DgradWtArgs wt) {
+    if (TRAIN && (int)blockIdx.x >= a.head_blocks) {
+        arlw::dgrad_wt_block(wt, (int)blockIdx.x - a.head_blocks, (int)threadIdx.x);
+        return;
+    }
     constexpr int HV = HVT ? HVT : HID_MAX / 64;
     extern __shared__ __attribute__((aligned(16))) float s_w[];     // [K][hid] (+ [4][K][hid] head-gradient slices)
     __shared__ float s_loss[4][4];
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256) void head_kernel(HeadLossArgs a, float* __rest
         }
         return m;
     };
-    const int waves_total = (gridDim.x * blockDim.x) >> 6;
+    const int waves_total = ((TRAIN ? a.head_blocks : (int)gridDim.x) * blockDim.x) >> 6;
     RowMeta meta = load_meta(blockIdx.x * (blockDim.x >> 6) + wave);
     if (((K * hid) & 3) || (reinterpret_cast<uintptr_t>(a.w_head) & 15)) {
         for (int i = threadIdx.x; i < K * hid; i += blockDim.x) s_w[i] = a.w_head[i];
@@ -486,7 +495,7 @@ extern "C" int arl_pg_head_infer(const float* h, const float* w_head, const floa
     a.h = h; a.w_head = w_head; a.b_head = b_head; a.batch = (int)batch; a.hid = hid; a.n_act = n_actions;
     const int grid = (int)((batch + 3) / 4 < 1024 ? (batch + 3) / 4 : 1024);
     const size_t lds = (size_t)(n_actions + 1) * hid * 4;
-#define ARL_HEAD_INFER(HVT_) hipLaunchKernelGGL((head_kernel<false, HVT_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, prob, value)
+#define ARL_HEAD_INFER(HVT_) hipLaunchKernelGGL((head_kernel<false, HVT_>), dim3(grid), dim3(256), lds, (hipStream_t)stream, a, prob, value, arlw::DgradWtArgs{})
     if (hid == 512) ARL_HEAD_INFER(8);
     else if (hid == 256) ARL_HEAD_INFER(4);
     else if (hid == 1024) ARL_HEAD_INFER(16);
@@ -504,7 +513,7 @@ extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const
                                 int32_t n_actions, int32_t kind, int32_t tie_rule, float clip_param, float v_loss_coeff,
                                 float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
                                 float* dw_head, float* db_head, float* loss4, void* workspace, arl_fold_item* items3,
-                                      void* stream) {
+                                      const arl_dgrad_wt* wt_items_or_null, int32_t n_wt, void* stream) {
     ARL_REQUIRE(h && w_head && b_head && actions && advantages && returns && lr_mult && dout && dh &&
                     dw_head && db_head && loss4 && workspace && items3, ARL_E_ARG, "null pointer");
     ARL_REQUIRE(kind == 0 || (kind == 1 && old_prob), ARL_E_ARG, "kind must be 0 (A2C) or 1 (PPO, needs old_prob)");
@@ -529,7 +538,14 @@ extern "C" int arl_pg_head_loss_parts(const float* h, const float* w_head, const
     float* part_b = part + (fused ? (int64_t)grid : (int64_t)WG_SPLITS) * K * hid;
     if (fused) { a.wpart = part; a.bpart = part_b; }
     const size_t head_lds = (size_t)(fused ? 5 : 1) * K * hid * 4;
-#define ARL_HEAD_TRAIN(HVT_) hipLaunchKernelGGL((head_kernel<true, HVT_>), dim3(grid), dim3(256), head_lds, s, a, (float*)nullptr, (float*)nullptr)
+    arlw::DgradWtArgs wt = {};
+    int wt_blocks = 0;
+    if (wt_items_or_null && n_wt > 0) {
+        rc = arlw::dgrad_wt_plan(wt_items_or_null, n_wt, &wt, &wt_blocks);
+        if (rc) return rc;
+    }
+    a.head_blocks = grid;
+#define ARL_HEAD_TRAIN(HVT_) hipLaunchKernelGGL((head_kernel<true, HVT_>), dim3(grid + wt_blocks), dim3(256), head_lds, s, a, (float*)nullptr, (float*)nullptr, wt)
     if (hid == 512) ARL_HEAD_TRAIN(8);
     else if (hid == 256) ARL_HEAD_TRAIN(4);
     else if (hid == 1024) ARL_HEAD_TRAIN(16);
@@ -568,7 +584,7 @@ extern "C" int arl_pg_head_loss(const float* h, const float* w_head, const float
     int rc = arl_pg_head_loss_parts(h, w_head, b_head, actions, advantages, returns, old_prob, valids_or_null,
                                     idx_or_null, lr_mult, inv_count_or_null, batch, hid, n_actions, kind, tie_rule, clip_param,
                                     v_loss_coeff, ent_loss_coeff, relu_mask_dh, dout, dh, dw_head, db_head, loss4,
-                                    workspace, items, stream);
+                                    workspace, items, nullptr, 0, stream);
     if (rc) return rc;
     return arl_fold_many(items, 3, stream);
 }

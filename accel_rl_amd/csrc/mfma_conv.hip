@@ -1,6 +1,7 @@
 // Entry points of the MFMA contraction kernels (kernels and launchers: mfma_conv_impl.h; their instantiations are
 // built in mfma_conv_p1 .. p7.hip so that the translation units compile side by side).
 #include "mfma_conv_impl.h"
+#include "dgrad_wt_dev.h"
 
 using namespace arlc;
 
@@ -724,34 +725,20 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
 }
 
 namespace {
-// Weights (out_c, kh, kw, in_c) -> per input-pixel parity class (ph, pw) of a stride-s data gradient a matrix
-// wt[z][c][(ty * taps_x + tx) * out_c + k] = w[k][i0 + s ty][j0 + s tx][c], (i0, j0) = ((ph + pad_h) % s, (pw + pad_w) % s),
-// z = ph * s + pw: exactly the element the data gradient's reduction index (tap, k) meets in column c (dgrad_impl).
-struct DgradWtItem { const float* w; float* wt; int K, kh, kw, C, st, taps_x, kred, total, i0[4], j0[4]; };
-struct DgradWtArgs { DgradWtItem it[ARL_DGRAD_WT_MAX]; int block_start[ARL_DGRAD_WT_MAX + 1]; int n; };
-
-__global__ __launch_bounds__(256) void dgrad_weights_kernel(const DgradWtArgs a) {
-    int i = 0;
-    while (i + 1 < a.n && (int)blockIdx.x >= a.block_start[i + 1]) ++i;            // uniform
-    const DgradWtItem& q = a.it[i];
-    const int idx = ((int)blockIdx.x - a.block_start[i]) * 256 + (int)threadIdx.x;
-    if (idx >= q.total) return;
-    const int per = q.C * q.kred;
-    const int z = idx / per, rem = idx - z * per;
-    const int c = rem / q.kred, r = rem - c * q.kred;
-    const int tap = r / q.K, k = r - tap * q.K;
-    const int ty = tap / q.taps_x, tx = tap - ty * q.taps_x;
-    q.wt[idx] = q.w[((k * q.kh + q.i0[z] + q.st * ty) * q.kw + q.j0[z] + q.st * tx) * q.C + c];
+__global__ __launch_bounds__(256) void dgrad_weights_kernel(const arlw::DgradWtArgs a) {
+    arlw::dgrad_wt_block(a, (int)blockIdx.x, (int)threadIdx.x);
 }
 }  // namespace
 
-extern "C" int arl_conv2d_dgrad_weights(const arl_dgrad_wt* items, int32_t n, void* stream) {
+namespace arlw {
+int dgrad_wt_plan(const arl_dgrad_wt* items, int32_t n, DgradWtArgs* out, int* blocks_out) {
     ARL_REQUIRE(items && n > 0 && n <= ARL_DGRAD_WT_MAX, ARL_E_ARG, "1 .. ARL_DGRAD_WT_MAX items");
-    DgradWtArgs a = {};
+    DgradWtArgs& a = *out;
+    a = DgradWtArgs{};
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
-        Geom g;
-        int rc = check_geom(items[i].geom, &g);
+        arlc::Geom g;
+        int rc = arlc::check_geom(items[i].geom, &g);
         if (rc) return rc;
         ARL_REQUIRE(items[i].w && items[i].wt && items[i].w != items[i].wt, ARL_E_ARG, "null / aliased pointer");
         ARL_REQUIRE(arl::aligned16(items[i].w) && arl::aligned16(items[i].wt), ARL_E_ALIGN, "16-byte alignment");
@@ -770,6 +757,16 @@ extern "C" int arl_conv2d_dgrad_weights(const arl_dgrad_wt* items, int32_t n, vo
         blocks += (q.total + 255) / 256;
     }
     a.block_start[n] = blocks; a.n = n;
+    *blocks_out = blocks;
+    return 0;
+}
+}  // namespace arlw
+
+extern "C" int arl_conv2d_dgrad_weights(const arl_dgrad_wt* items, int32_t n, void* stream) {
+    arlw::DgradWtArgs a;
+    int blocks = 0;
+    int rc = arlw::dgrad_wt_plan(items, n, &a, &blocks);
+    if (rc) return rc;
     hipLaunchKernelGGL(dgrad_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return arl::check_launch("dgrad_weights_kernel");
 }

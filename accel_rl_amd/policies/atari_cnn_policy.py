@@ -439,13 +439,19 @@ class AtariCnnPolicy(object):
             dout = self._buffer(("dout", b), (b, self.n_act + 1))
             dh = self._buffer(("dh", b), (b, hid))
             loss4 = self._buffer(("loss", b), (4,))
+            # (the head's launch also writes the data gradients' weight copies: _backward_convs then skips its own launch)
+            wts = self._dgrad_weight_items(b) if os.environ.get("ARL_WT_IN_HEAD", "1") != "0" else []      # (A/B switch)
             self._folds.pg_head_loss(hids[-1], self.params[k_head], self.params[k_head + 1], mb["actions"],
                               mb["advantages"], mb["returns"], mb.get("old_prob"), mb.get("valids"),
                               idx, lr_mult, inv_count, self.n_act, kind, clip_param, v_loss_coeff,
                               ent_loss_coeff, dout, dh, g[k_head], g[k_head + 1], loss4, self._loss_ws,
-                              relu_mask_dh=True, tie_rule=tie_rule)
-            self._backward_trunk(x, acts, hids, dh, masked=True, split_hook=mb.get("split_hook"),
-                                 dense_w_hook=mb.get("dense_w_hook"))
+                              relu_mask_dh=True, tie_rule=tie_rule, dgrad_weights=wts)
+            self._wt_fresh = bool(wts)
+            try:
+                self._backward_trunk(x, acts, hids, dh, masked=True, split_hook=mb.get("split_hook"),
+                                     dense_w_hook=mb.get("dense_w_hook"))
+            finally:
+                self._wt_fresh = False
             return loss4
 
     # Rows of a minibatch per forward + backward pass.  The activations of a pass and their gradients (fp32, every conv
@@ -535,14 +541,23 @@ class AtariCnnPolicy(object):
             split_hook()
         self._backward_convs(x, acts, d_cur, masked, corun=job)
 
+    def _dgrad_weight_items(self, b):
+        """[(w, wt, geom)] of the layers whose data gradient reads a k-contiguous copy of its weights (split routes)."""
+        if not self._wt or _lib.default_route == _lib.ROUTE_FP32:
+            return []
+        conv_g, _ = self._layer_geoms(b)
+        return [(self._w[2 * i], wt, conv_g[i]) for i, wt in sorted(self._wt.items())]
+
     def _backward_convs(self, x, acts, d_act, masked=False, corun=None):
         """Conv layers, last to first; d_act = NHWC gradient of the last conv output (masked: already
         multiplied by its rectifier mask); corun: an optimiser job (_lib.corun_job) for the first data-gradient launch
         that can carry it."""
         b = x.shape[0]
         conv_g, _ = self._layer_geoms(b)
-        if self._wt and _lib.default_route != _lib.ROUTE_FP32:
-            _lib.conv2d_dgrad_weights([(self._w[2 * i], wt, conv_g[i]) for i, wt in sorted(self._wt.items())])
+        if not getattr(self, "_wt_fresh", False):          # (else: written by the head's launch of this pass)
+            items = self._dgrad_weight_items(b)
+            if items:
+                _lib.conv2d_dgrad_weights(items)
         for i in range(self._n_conv - 1, -1, -1):
             nf, ci, sz, st, pad, ho, wo = self._conv_geom[i]
             d_in = self._buffer(("dx_conv", i, b), tuple(acts[i - 1].shape)) if i > 0 else None

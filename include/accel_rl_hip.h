@@ -377,7 +377,10 @@ int arl_pg_head_loss(const float* h, const float* w_head, const float* b_head,
 /* Same, stopping before the three small folds (dw_head, db_head, loss4): they are described in items3[0..2] for
  * arl_fold_many, so that a backward pass ends in ONE fold launch.  The bias partials are n_actions + 1 rounded
  * up to a multiple of 4 floats in the partials only (items3[1].valid = n_actions + 1); workspace stays live until the
- * fold has run.                                                                                                  */
+ * fold has run.
+ * wt_items_or_null / n_wt (ABI 4): the same launch also writes these layers' k-contiguous weight copies
+ * (arl_conv2d_dgrad_weights below) in extra workgroups -- the backward pass that follows reads them, and this launch is
+ * where a minibatch's parameters are final and the CUs are idle: one launch less per minibatch.                     */
 int arl_pg_head_loss_parts(const float* h, const float* w_head, const float* b_head,
                            const uint8_t* actions, const float* advantages, const float* returns,
                            const float* old_prob, const int8_t* valids_or_null,
@@ -386,7 +389,8 @@ int arl_pg_head_loss_parts(const float* h, const float* w_head, const float* b_h
                            int32_t n_actions, int32_t kind, int32_t tie_rule, float clip_param,
                            float v_loss_coeff, float ent_loss_coeff, int32_t relu_mask_dh, float* dout, float* dh,
                            float* dw_head, float* db_head, float* loss4, void* workspace,
-                           struct arl_fold_item* items3, void* stream);
+                           struct arl_fold_item* items3, const struct arl_dgrad_wt* wt_items_or_null, int32_t n_wt,
+                           void* stream);
 
 /* ------------------------------------------------------------------------- *
  * The policy network's dense contractions on the matrix cores (fp32 MFMA)
