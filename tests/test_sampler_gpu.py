@@ -481,3 +481,47 @@ def test_gpu_sampler_recurrent_plumbing_matches_reference(use_graph):
         np.testing.assert_array_equal(crc_rows(buf.extra_observations), g["extra_crc"][b], err_msg=msg)
         np.testing.assert_array_equal(policy._h.cpu().numpy(), g["state_after"][b], err_msg=msg)
     smp.shutdown()
+
+
+def test_batches_enqueued_ahead_of_their_records():
+    """Two host-side buffer sets (round 6): a caller may enqueue batch i + 1 before it has read batch i's trajectory
+    records.  Whatever the order in which the lazily read records are looked at, every batch reports exactly what a run
+    that reads each batch at once reports (served step, hipGraph), and the no-op ring's top-ups stay in step."""
+    from accel_rl_amd.envs.synthetic_atari import SynthAtariEnv
+    from accel_rl_amd.policies.atari_cnn_policy import AtariCnnPolicy
+    from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
+    from accel_rl_amd.sampler.gpu_sampler import GpuVecSampler
+    from accel_rl_amd.util import logger
+    logger.set_quiet(True)
+
+    def run(lazy):
+        smp = GpuVecSampler(EnvCls=SynthAtariEnv, env_args=dict(game="breakout", max_start_noops=30), horizon=5, n_parallel=2,
+                            envs_per=4, mid_batch_reset=True, max_path_length=3, max_decorrelation_steps=0, device=DEV,
+                            use_graph=True)
+        np.random.seed(5)
+        env_spec, *_ = smp.initialize(seed=6, affinities=dict(), discount=0.99, need_extra_obs=True)
+        np.random.seed(7)
+        policy = AtariCnnPolicy(**cnn_specs[1])
+        policy.initialize(env_spec, device=DEV)
+        smp.policy_init(policy)
+        assert len(smp._sets) == 2
+        out, held = [], []
+        for b in range(40):
+            buf, infos = smp.obtain_samples(b)
+            crc = zlib.crc32(buf.actions.cpu().numpy().tobytes())        # (reads the device: the batch itself is complete)
+            if lazy:
+                held.append((b, crc, infos))
+                if len(held) == 2:                  # the newer batch first: it reads the older one's records before its own
+                    for bb, cc, inf in reversed(held):
+                        out.append((bb, cc, sorted((ti._env, ti.Length, ti.Return) for ti in inf)))
+                    held = []
+            else:
+                out.append((b, crc, sorted((ti._env, ti.Length, ti.Return) for ti in infos)))
+        cursors = smp._st.noop_cursor.cpu().numpy().copy()
+        smp.shutdown()
+        return sorted(out), cursors
+
+    eager, c0 = run(False)
+    lazy, c1 = run(True)
+    assert eager == lazy and sum(len(t) for _, _, t in eager) > 100
+    np.testing.assert_array_equal(c0, c1)
