@@ -500,9 +500,12 @@ def test_batches_enqueued_ahead_of_their_records():
                             use_graph=True)
         np.random.seed(5)
         env_spec, *_ = smp.initialize(seed=6, affinities=dict(), discount=0.99, need_extra_obs=True)
-        np.random.seed(7)
+        from accel_rl_amd.util.seed import set_seed
+        set_seed(7)                                 # (numpy's stream AND the conv initialiser's private one)
         policy = AtariCnnPolicy(**cnn_specs[1])
         policy.initialize(env_spec, device=DEV)
+        with torch.no_grad():                       # a sharp head: the actions depend on the network, not just on the draws
+            policy.flat_params[policy._offsets[policy._k_head]:].mul_(40.0)
         smp.policy_init(policy)
         assert len(smp._sets) == 2
         out, held = [], []
