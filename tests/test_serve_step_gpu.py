@@ -64,6 +64,7 @@ def traj_tuples(infos):
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("game,spec,n_parallel,envs_per,max_len", [
     ("breakout", 1, 16, 8, 9),        # BASELINE config 2's sampler: 256 envs, spec-1 CNN (conv 1 inside the step launch)
+    ("breakout", 1, 64, 8, 9),        # 1024 envs: the upper end of the size rule (four workgroups per CU in turn)
     ("seaquest", 1, 3, 5, 7),         # 18 actions, odd stream sizes, episodes end every other batch
     ("pong", 0, 4, 2, 11),            # spec 0: 16 filters of 8 x 8 -- conv 1 stays a launch of its own; hid 256
     ("qbert", 1, 2, 2, 66),           # long episodes: life losses before any over-length reset
