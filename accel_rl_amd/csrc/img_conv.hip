@@ -54,10 +54,10 @@ __global__ __launch_bounds__(C1_NT) void conv1_img_kernel(const Conv1ImgArgs a) 
     };
     if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0;
     img_issue(blockIdx.x);
-    for (int f = tid; f < nsteps * 64; f += C1_NT) conv1_w_store(sW, f, conv1_w_load(a.w, K, f));
+    for (int f = tid; f < nsteps * 64; f += C1_NT) conv1_w_store(sW, f, conv1_w_load(a.w, K, f, a.NF));
     const int rows = a.OH * a.OW, tiles = (rows + 31) / 32;
     float4 bq[4];
-    conv1_bias_quads(a.bias, half, bq);
+    conv1_bias_quads(a.bias, half, bq, a.NF);
     img_store(0, blockIdx.x);
     if (blockIdx.x + gridDim.x < (unsigned)a.n_img) img_issue(blockIdx.x + gridDim.x);
     __syncthreads();
@@ -83,10 +83,10 @@ int launch_conv1_img(const unsigned char* obs, int64_t obs_rows, const int32_t* 
                      hipStream_t s, unsigned char* copy_out, long long copy_stride, int* zero_word) {
     const int npix = C * H * W;
     const size_t lds = (size_t)(C * 64 / 16) * 3072 + 2 * (size_t)npix;
-    if (g_no_img_kernels || !t_ctx.split || K != 32 || kh != 8 || kw != 8 || npix % 16 != 0 || npix > C1_MAX_IMG ||
+    if (g_no_img_kernels || !t_ctx.split || (K != 32 && K != 16) || kh != 8 || kw != 8 || npix % 16 != 0 || npix > C1_MAX_IMG ||
         lds > 160 * 1024 || ((uintptr_t)obs & 15) || (W & 3) || (stride & 3) || batch > 0x7fffffff)
         return -1;
-    Conv1ImgArgs a = {obs, idx, w, bias, y, scale, (int)batch, C, H, W, Ho, Wo, stride, relu,
+    Conv1ImgArgs a = {obs, idx, w, bias, y, scale, (int)batch, C, H, W, Ho, Wo, stride, relu, K,
                       (int)(obs_rows < 0x7fffffff ? obs_rows : 0x7fffffff), copy_out, copy_stride, zero_word};
     {   // per launch: the attribute belongs to the CURRENT device's copy of the kernel (no process-wide flag)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_img_kernel),

@@ -14,6 +14,8 @@ struct Conv1ImgArgs {
     float* y;                   // f32 [B][OH][OW][32]
     float scale;
     int n_img, C, H, W, OH, OW, stride, relu;
+    int NF;                     // filters: 32, or 16 (the upper half of the 32-row MFMA tile then multiplies zeros: at three
+                                // piece products per multiply on the bf16 pipe still 2.7 x the fp32 chain's rate)
     int obs_rows;               // rows of obs: an index outside [0, obs_rows) reads row 0 instead of faulting
     // arl_rollout_begin_conv1: image b is also copied, as it passes through the registers, to copy_out + b * copy_stride
     // (the rollout buffer's row (env b, step 0)) and *zero_word = 0 (the completed-trajectory counter); null: neither
@@ -31,8 +33,9 @@ __device__ __forceinline__ u32x2 bytes_to_bf16x4(unsigned v) {     // four packe
 // filter fl & 31, reduction indices 16 s + 8 (fl >> 5) + 0..7 (index (c * 8 + ty) * 8 + tx), split exactly into three
 // bf16 planes.  Load and split + store are separate so that a caller can put other work under the load's latency.
 struct Conv1WFrag { float4 v0, v1; };
-__device__ __forceinline__ Conv1WFrag conv1_w_load(const float* __restrict__ w, const int K, const int f) {
+__device__ __forceinline__ Conv1WFrag conv1_w_load(const float* __restrict__ w, const int K, const int f, const int NF = 32) {
     const int s = f >> 6, fl = f & 63;
+    if ((fl & 31) >= NF) return Conv1WFrag{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
     const float* src = w + (size_t)(fl & 31) * K + s * 16 + (fl >> 5) * 8;
     return Conv1WFrag{*reinterpret_cast<const float4*>(src), *reinterpret_cast<const float4*>(src + 4)};
 }
@@ -50,11 +53,12 @@ __device__ __forceinline__ void conv1_w_store(char* sW, const int f, const Conv1
 }
 
 // the lane's bias quads (channels 8 q + 4 half + 0..3)
-__device__ __forceinline__ void conv1_bias_quads(const float* __restrict__ bias, const int half, float4 (&bq)[4]) {
+__device__ __forceinline__ void conv1_bias_quads(const float* __restrict__ bias, const int half, float4 (&bq)[4],
+                                                 const int NF = 32) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (bias) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q + 4 * half);
+        if (bias && 8 * q + 4 * half < NF) bq[q] = *reinterpret_cast<const float4*>(bias + 8 * q + 4 * half);
     }
 }
 
@@ -62,7 +66,8 @@ __device__ __forceinline__ void conv1_bias_quads(const float* __restrict__ bias,
 // row) order, weight planes l, m, h per step (split_products<.., 1, 3, true>), scale + bias + rectifier, 16-byte stores.
 __device__ __forceinline__ void conv1_tile(const Conv1ImgArgs& a, const char* im, const char* sW, const int img,
                                            const int tp, const int lane, const float4 (&bq)[4]) {
-    constexpr int N = 32, KH = 8;
+    constexpr int KH = 8;
+    const int N = a.NF;
     const int l31 = lane & 31, half = lane >> 5;
     const int H = a.H, W = a.W, nsteps = a.C * 64 / 16;
     const int rows = a.OH * a.OW;
@@ -90,6 +95,7 @@ __device__ __forceinline__ void conv1_tile(const Conv1ImgArgs& a, const char* im
         float* dst = a.y + ((size_t)img * rows + m) * N + 4 * half;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            if (8 * q + 4 * half >= N) continue;            // (16 filters: the tile's upper rows are padding)
             float4 v = make_float4(acc[4 * q] * a.scale + bq[q].x, acc[4 * q + 1] * a.scale + bq[q].y,
                                    acc[4 * q + 2] * a.scale + bq[q].z, acc[4 * q + 3] * a.scale + bq[q].w);
             if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }

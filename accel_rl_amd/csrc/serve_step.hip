@@ -79,7 +79,7 @@ __global__ __launch_bounds__(SV_NT) void serve_step_kernel(
     // ---- top: loads that depend on nothing
     arlc::Conv1WFrag wf = {};
     const bool has_w = CONV1 && tid < nsteps * 64;
-    if (has_w) wf = arlc::conv1_w_load(c1.w, c1.C * 64, tid);
+    if (has_w) wf = arlc::conv1_w_load(c1.w, c1.C * 64, tid, c1.NF);
     // head row k goes to wave (k + 1) % 16: wave 0, which walks the step's serial part, gets one only from 16 rows on
     const int k_first = (wave + SV_NW - 1) % SV_NW;
     float wrow[SV_HID_MAX / 64];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(SV_NT) void serve_step_kernel(
         // ---- conv 1 of the observation just written, from LDS: the 32-pixel row tiles go to waves 1 .. 15 first (wave 0
         // is busy above); bit for bit conv1_img_kernel's tiles
         float4 bq[4];
-        arlc::conv1_bias_quads(c1.bias, lane >> 5, bq);
+        arlc::conv1_bias_quads(c1.bias, lane >> 5, bq, c1.NF);
         const int tiles = (c1.OH * c1.OW + 31) / 32;
         for (int tp = (wave + SV_NW - 1) % SV_NW; tp < tiles; tp += SV_NW) arlc::conv1_tile(c1, sI, sW, (int)e, tp, lane, bq);
     }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(SV_NT) void serve_step_kernel(
 extern "C" int arl_serve_conv1_supported(const arl_game* game, const arl_conv_geom* geom) {
     if (!game || !geom) return 0;
     const int64_t npix = (int64_t)game->n_stack * OBS_FRAME;
-    return geom->in_c == game->n_stack && geom->in_h == ARL_OBS_H && geom->in_w == ARL_OBS_W && geom->out_c == 32 &&
+    return geom->in_c == game->n_stack && geom->in_h == ARL_OBS_H && geom->in_w == ARL_OBS_W && (geom->out_c == 32 || geom->out_c == 16) &&
            geom->kh == 8 && geom->kw == 8 && geom->pad_h == 0 && geom->pad_w == 0 && geom->stride > 0 &&
            (geom->stride & 3) == 0 && geom->stride <= 8 && game->n_stack * 64 <= SV_NT && npix <= arlc::C1_MAX_IMG &&
            (geom->route == ARL_CONV_ROUTE_SPLIT9 || geom->route == ARL_CONV_ROUTE_SPLIT6) && !arlc::g_no_img_kernels;
@@ -305,7 +305,7 @@ extern "C" int arl_env_step_served(const arl_game* game, const arl_env_state* st
                     "16-byte alignment");
         const int npix = game->n_stack * OBS_FRAME;
         c1.w = c.w; c1.bias = c.bias; c1.y = c.y; c1.scale = c.scale; c1.n_img = (int)st->n_env; c1.C = game->n_stack;
-        c1.H = ARL_OBS_H; c1.W = ARL_OBS_W; c1.stride = c.geom->stride; c1.relu = c.relu;
+        c1.H = ARL_OBS_H; c1.W = ARL_OBS_W; c1.stride = c.geom->stride; c1.relu = c.relu; c1.NF = c.geom->out_c;
         c1.OH = (ARL_OBS_H - 8) / c.geom->stride + 1; c1.OW = (ARL_OBS_W - 8) / c.geom->stride + 1;
         lds = (size_t)game->n_stack * 4 * 3072 + (fold_lds > (size_t)npix ? fold_lds : (size_t)npix);
     }

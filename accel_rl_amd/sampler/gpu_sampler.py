@@ -107,8 +107,9 @@ class GpuVecSampler(BaseMbSampler):
     # draw, the env step and the next observation's first convolution (A/B switch; bit-identical either way)
     _serve_in_step = os.environ.get("ARL_SERVE_IN_STEP", "1") != "0"
     # ... while one 16-wave workgroup per env (one per CU at a time) beats the separate launches: measured up to 1024 envs
-    # when conv 1 rides along (spec 1: -15 % at 256, -4 % at 1024), up to 512 when it does not (spec 0: -13 % at 256, -4 % at
-    # 512, +1 % at 1024; tools/serve_step_probe.py, profiles/r06/serve_step_probe*.txt)
+    # when conv 1 rides along (spec 1: -15 % at 256, -4 % at 1024; spec 0: -23 % / -5 %), up to 512 when it does not (a first
+    # layer the launch does not take: -13 % at 256, -4 % at 512, +1 % at 1024; tools/serve_step_probe.py,
+    # profiles/r06/serve_step_probe*.txt)
     _serve_in_step_max_envs = (512, 1024)       # (without, with conv 1 in the launch)
     _two_host_sets = os.environ.get("ARL_TWO_HOST_SETS", "1") != "0"     # (A/B switch, see _sets)
 

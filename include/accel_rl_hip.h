@@ -416,7 +416,8 @@ typedef struct arl_conv_geom {
  *   ARL_CONV_ROUTE_FP32   v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain (157 TF/s peak on gfx950);
  *   ARL_CONV_ROUTE_SPLIT6 as SPLIT9 without the three smallest piece products (each below 2^-24 of |x y|).
  * u8 observations are exact in one bf16 piece (three products on both split routes).  Layers with <= 16 output
- * columns and the generic (any channel count) kernels always take the fp32 chain.  Deterministic on every route;
+ * columns and the generic (any channel count) kernels always take the fp32 chain -- except the first convolution from u8
+ * rows with 16 filters of 8 x 8 (spec 0), which runs on the image-stationary bf16-split kernel with half its tile idle.  Deterministic on every route;
  * any other value: ARL_E_ARG.  The route is an argument of the call: the library keeps no mode.                     */
 #define ARL_CONV_ROUTE_SPLIT9 0
 #define ARL_CONV_ROUTE_FP32   1
@@ -503,10 +504,10 @@ typedef struct arl_serve_head {
 /* The first convolution of the NEXT observation, evaluated from LDS right after the env step has built it
  * (arl_conv2d_u8_fwd's arithmetic; geometries: arl_serve_conv1_supported).                                            */
 typedef struct arl_serve_conv1 {
-    const arl_conv_geom* geom;  /* batch = n_env, in_c = n_stack, 104 x 80 input, 32 filters of 8 x 8, no padding      */
-    const float* w;             /* f32[32][n_stack][8][8]                                                              */
-    const float* bias;          /* f32[32] or NULL                                                                     */
-    float* y;                   /* f32[n_env][out_h][out_w][32]                                                        */
+    const arl_conv_geom* geom;  /* batch = n_env, in_c = n_stack, 104 x 80 input, 32 or 16 filters of 8 x 8, no padding*/
+    const float* w;             /* f32[out_c][n_stack][8][8]                                                           */
+    const float* bias;          /* f32[out_c] or NULL                                                                  */
+    float* y;                   /* f32[n_env][out_h][out_w][out_c]                                                     */
     float scale;                /* pixel scale (1 / 255), applied to the finished sums                                 */
     int32_t relu;
 } arl_serve_conv1;

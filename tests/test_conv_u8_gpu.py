@@ -16,7 +16,7 @@ SCALE = float(np.float32(1. / 255.))
 #        rows  batch(idx)  C   H    W    K   kh  kw  stride
 CASES = [(700, 512, 4, 104, 80, 32, 8, 8, 4),      # spec-1 conv 1 at the PPO minibatch, gathered rows
          (37, None, 4, 104, 80, 32, 8, 8, 4),      # ragged batch, rows in place
-         (64, None, 4, 104, 80, 16, 8, 8, 4),      # spec-0 conv 1 (16-wide MFMA tiles)
+         (64, None, 4, 104, 80, 16, 8, 8, 4),      # spec-0 conv 1 (forward: the image kernel with half its tile idle; weight gradient: 16-wide tiles)
          (90, 33, 1, 104, 80, 16, 8, 8, 4),        # one frame per observation (the A2C example), ragged
          (21, 21, 3, 40, 36, 24, 4, 4, 4),         # 4-wide filter rows: four rows per k-tile
          (19, 7, 2, 48, 64, 8, 3, 16, 8),          # 16-wide filter rows: one row per k-tile, stride 8
@@ -26,7 +26,7 @@ CASES = [(700, 512, 4, 104, 80, 32, 8, 8, 4),      # spec-1 conv 1 at the PPO mi
 @pytest.fixture(autouse=True, params=[9, 6, 0], ids=["split9", "split6", "fp32chain"])
 def precision(request):
     """Every test under the three routes of arl_conv_geom.route (u8 pixels are exact in ONE bf16 piece: three piece
-    products per k in both split routes; layers of <= 16 filters take the fp32 chain in every mode)."""
+    products per k in both split routes; layers of <= 16 filters take the fp32 chain in every mode, except the 8 x 8 first layer's forward)."""
     from accel_rl_amd import _lib
     _lib.set_conv_precision(request.param)          # (the geometries built below take this module default)
     yield request.param

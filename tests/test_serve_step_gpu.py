@@ -66,7 +66,7 @@ def traj_tuples(infos):
     ("breakout", 1, 16, 8, 9),        # BASELINE config 2's sampler: 256 envs, spec-1 CNN (conv 1 inside the step launch)
     ("breakout", 1, 64, 8, 9),        # 1024 envs: the upper end of the size rule (four workgroups per CU in turn)
     ("seaquest", 1, 3, 5, 7),         # 18 actions, odd stream sizes, episodes end every other batch
-    ("pong", 0, 4, 2, 11),            # spec 0: 16 filters of 8 x 8 -- conv 1 stays a launch of its own; hid 256
+    ("pong", 0, 4, 2, 11),            # spec 0: 16 filters of 8 x 8 (half of conv 1's MFMA tile idle), hid 256
     ("qbert", 1, 2, 2, 66),           # long episodes: life losses before any over-length reset
 ])
 def test_served_step_is_bit_identical_to_the_separate_launches(game, spec, n_parallel, envs_per, max_len, use_graph):
@@ -292,7 +292,8 @@ def test_served_step_argument_errors():
         _lib.env_step_served(smp._game, smp._state, smp._rollout, bad, None, u, 0, 9, 0.99, 30)
     with pytest.raises(RuntimeError, match="horizon"):
         _lib.env_step_served(smp._game, smp._state, smp._rollout, head, None, u, 5, 9, 0.99, 30)
-    g = _lib.conv_geom(n, 104, 80, 4, 16, 8, 8, 4, 0, 0)              # 16 filters: not served
+    g = _lib.conv_geom(n, 104, 80, 4, 24, 8, 8, 4, 0, 0)              # 24 filters: not served (32 and 16 are)
+    assert _lib.serve_conv1_supported(smp._game, _lib.conv_geom(n, 104, 80, 4, 16, 8, 8, 4, 0, 0))
     assert not _lib.serve_conv1_supported(smp._game, g)
     c = _lib.ArlServeConv1.from_buffer_copy(conv1)
     import ctypes
