@@ -202,17 +202,18 @@ DEV_SYMBOLS = tuple(_DEV_SIGNATURES)
 
 # arl_conv_geom.route (ARL_CONV_ROUTE_*): how the fp32 contractions are computed.  The library keeps no mode; this
 # module's default is what conv_geom() / dense_geom() stamp into the geometries they build (host-side policy).
-ROUTE_SPLIT9, ROUTE_FP32, ROUTE_SPLIT6 = 0, 1, 6
-_PRECISION_TO_ROUTE = {9: ROUTE_SPLIT9, 0: ROUTE_FP32, 6: ROUTE_SPLIT6}
+ROUTE_SPLIT9, ROUTE_FP32, ROUTE_SPLIT6, ROUTE_BF16 = 0, 1, 6, 2
+_PRECISION_TO_ROUTE = {9: ROUTE_SPLIT9, 0: ROUTE_FP32, 6: ROUTE_SPLIT6, 1: ROUTE_BF16}
 default_route = _PRECISION_TO_ROUTE[int(os.environ.get("ARL_CONV_PRECISION", "9"))]    # measurement switch (tools/, bench A/B)
 
 
 def set_conv_precision(mode):
     """Route of the geometries built from now on: 9 = nine exact bf16-split products (the default), 6 = six,
-    0 = the fp32 MFMA chain.  Geometries already built keep theirs (ArlConvGeom.route)."""
+    0 = the fp32 MFMA chain, 1 = plain bf16 operands (ARL_CONV_ROUTE_BF16: the labelled reduced-precision option, not an
+    fp32 contraction).  Geometries already built keep theirs (ArlConvGeom.route)."""
     global default_route
     if mode not in _PRECISION_TO_ROUTE:
-        raise ValueError("conv precision: 0 (fp32 MFMA), 6 or 9 (bf16-split products)")
+        raise ValueError("conv precision: 0 (fp32 MFMA), 6 or 9 (bf16-split products) or 1 (bf16 operands)")
     default_route = _PRECISION_TO_ROUTE[mode]
 
 

@@ -83,7 +83,7 @@ int launch_conv1_img(const unsigned char* obs, int64_t obs_rows, const int32_t* 
                      hipStream_t s, unsigned char* copy_out, long long copy_stride, int* zero_word) {
     const int npix = C * H * W;
     const size_t lds = (size_t)(C * 64 / 16) * 3072 + 2 * (size_t)npix;
-    if (g_no_img_kernels || !t_ctx.split || (K != 32 && K != 16) || kh != 8 || kw != 8 || npix % 16 != 0 || npix > C1_MAX_IMG ||
+    if (g_no_img_kernels || !t_ctx.split || t_ctx.split == 1 || (K != 32 && K != 16) || kh != 8 || kw != 8 || npix % 16 != 0 || npix > C1_MAX_IMG ||
         lds > 160 * 1024 || ((uintptr_t)obs & 15) || (W & 3) || (stride & 3) || batch > 0x7fffffff)
         return -1;
     Conv1ImgArgs a = {obs, idx, w, bias, y, scale, (int)batch, C, H, W, Ho, Wo, stride, relu, K,

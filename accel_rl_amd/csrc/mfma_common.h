@@ -193,6 +193,20 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& h, unsi
     l = hi_pair(lo_part(r0), lo_part(r1));
 }
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// SPLIT = 1 (the labelled bf16 route, arl_conv_geom.route = ARL_CONV_ROUTE_BF16): ONE plane per operand, rounded to
+// nearest even (v_cvt_pk_bf16_f32) -- a truncated piece is only right as the first term of an exact sum
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rne_pair(float x0, float x1) {
+    const f32x2_t v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// planes of an fp32 operand under a split mode, and its pieces (NP == 1: h alone, rounded; m and l untouched)
+constexpr int planes_of(int split) { return split == 1 ? 1 : 3; }
+template <int NP> __device__ __forceinline__ void split_pair_n(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+    if constexpr (NP == 1) h = rne_pair(x0, x1);
+    else split_pair(x0, x1, h, m, l);
+}
 
 // Epilogue of the operand-swapped kernels (acc = W-tile x X-tile^T): D'[row][col] with col = lane & 31
 // the GEMM row m and row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5) the output channel n, so a lane holds
@@ -340,7 +354,8 @@ __device__ __forceinline__ unsigned tap_mask(int ry, int rx, int Hs, int Ws, int
 //     x * y = sum over the nine (or the six largest) products of their pieces,
 // each product exact in the fp32 accumulator (8 x 8 significand bits).  SPLIT = 9: all nine -- every product term of
 // the fp32 contraction enters the sum exactly, only the accumulation rounds (as it does in the fp32 MFMA chain);
-// SPLIT = 6: the terms below 2^-24 |x y| (m l, l m, l l) are dropped.  The split happens between the global load
+// SPLIT = 6: the terms below 2^-24 |x y| (m l, l m, l l) are dropped; SPLIT = 1: plain bf16 operands (rounded, one
+// product: NOT an fp32 contraction -- a labelled option, never a default).  The split happens between the global load
 // and the LDS store (11 vector instructions per pair of elements, hidden under the MFMAs of the co-resident waves);
 // LDS holds three bf16 planes per operand tile.  u8 observations are exact in ONE bf16 plane (255 < 2^8): conv 1
 // needs three products, not nine.

@@ -77,10 +77,11 @@ struct CallScope {
 // arl_conv_geom::route -> split mode (-1: not a route)
 inline int split_of(const arl_conv_geom* g) {
     if (!g) return 9;
-    return g->route == ARL_CONV_ROUTE_SPLIT9 ? 9 : g->route == ARL_CONV_ROUTE_FP32 ? 0 : g->route == ARL_CONV_ROUTE_SPLIT6 ? 6 : -1;
+    return g->route == ARL_CONV_ROUTE_SPLIT9 ? 9 : g->route == ARL_CONV_ROUTE_FP32 ? 0 : g->route == ARL_CONV_ROUTE_SPLIT6 ? 6
+         : g->route == ARL_CONV_ROUTE_BF16 ? 1 : -1;
 }
 #define ARL_ROUTE_SCOPE(geom, job)                                                                         \
-    ARL_REQUIRE(split_of(geom) >= 0, ARL_E_ARG, "conv route: ARL_CONV_ROUTE_SPLIT9, _FP32 or _SPLIT6");    \
+    ARL_REQUIRE(split_of(geom) >= 0, ARL_E_ARG, "conv route: ARL_CONV_ROUTE_SPLIT9, _FP32, _SPLIT6 or _BF16");    \
     const CallScope call_scope_(split_of(geom), job)
 // a pending optimiser job for a data-gradient launch to host?  (taken at most once per call)
 inline bool corun_take(arl::OptSeg* c, dim3* grid) {
@@ -118,9 +119,9 @@ int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_
 }
 
 #ifdef ARL_NO_SPLIT6        // development builds: half the split kernels (mode 6 then runs the nine-product kernels)
-#define ARL_BY_MODE(X6, X9) do { X9; } while (0)
+#define ARL_BY_MODE(X1, X6, X9) do { X9; } while (0)
 #else
-#define ARL_BY_MODE(X6, X9) do { if (g_split == 6) { X6; } else { X9; } } while (0)
+#define ARL_BY_MODE(X1, X6, X9) do { if (g_split == 1) { X1; } else if (g_split == 6) { X6; } else { X9; } } while (0)
 #endif
 
 // the launch of igemm_split_kernel: two LDS stages of (1 or 3) + 3 bf16 planes; a data gradient hosts the pending
@@ -128,8 +129,9 @@ int launch_igemm_occ(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_
 template <int WGM, int WGN, int TM, int TN, int BK, bool B_KC, bool U8, int MINW>
 int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStream_t s, int splits = 1) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    const size_t lds = (size_t)2 * ((U8 ? 1 : 3) * BM + 3 * BN) * BK * 2;
-    const size_t lds_dir = (size_t)2 * 3 * BN * BK * 2;         // direct gathered operand: only the weights live in LDS
+    const int npl = planes_of(g_split);
+    const size_t lds = (size_t)2 * ((U8 ? 1 : npl) * BM + npl * BN) * BK * 2;
+    const size_t lds_dir = (size_t)2 * npl * BN * BK * 2;       // direct gathered operand: only the weights live in LDS
     (void)lds_dir;
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.n_par ? a.n_par : splits);
     arl::OptSeg c = {};
@@ -149,7 +151,7 @@ int launch_igemm_split(const GemmArgs& a, bool multi_tap, bool has_pad, hipStrea
     } while (0)
 #define ARL_SPLIT_MODE(MT, HP, CO)                                                                         \
     do {                                                                                                   \
-        ARL_BY_MODE(ARL_SPLIT_PIN(MT, HP, 6, CO), ARL_SPLIT_PIN(MT, HP, 9, CO));                           \
+        ARL_BY_MODE(ARL_SPLIT_PIN(MT, HP, 1, CO), ARL_SPLIT_PIN(MT, HP, 6, CO), ARL_SPLIT_PIN(MT, HP, 9, CO));                           \
     } while (0)
     if constexpr (U8) {
         ARL_SPLIT_MODE(false, false, false);
@@ -193,7 +195,8 @@ int launch_wgrad_fast(const WgradArgs& a, int splits, bool has_pad, hipStream_t 
 template <int WGM, int WGN, int TM, int TN, int BK, bool U8, int MINW>
 int launch_wgrad_split(const WgradArgs& a, int splits, bool has_pad, hipStream_t s) {
     constexpr int BM = WGM * TM * 32, BN = WGN * TN * 32;
-    const size_t lds = (size_t)2 * (3 * BM + (U8 ? 1 : 3) * BN) * BK * 2;
+    const int npl = planes_of(g_split);
+    const size_t lds = (size_t)2 * (npl * BM + (U8 ? 1 : npl) * BN) * BK * 2;
     dim3 grid((a.N + BN - 1) / BN, (a.K_out + BM - 1) / BM, splits);
     int rc = 0;
 #define ARL_WSPLIT(HP, SPL)                                                                                \
@@ -203,11 +206,11 @@ int launch_wgrad_split(const WgradArgs& a, int splits, bool has_pad, hipStream_t
         if (!rc) hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);                                        \
     } while (0)
     if constexpr (U8) {
-        ARL_BY_MODE(ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
+        ARL_BY_MODE(ARL_WSPLIT(false, 1), ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
     } else if (has_pad) {
-        ARL_BY_MODE(ARL_WSPLIT(true, 6), ARL_WSPLIT(true, 9));
+        ARL_BY_MODE(ARL_WSPLIT(true, 1), ARL_WSPLIT(true, 6), ARL_WSPLIT(true, 9));
     } else {
-        ARL_BY_MODE(ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
+        ARL_BY_MODE(ARL_WSPLIT(false, 1), ARL_WSPLIT(false, 6), ARL_WSPLIT(false, 9));
     }
 #undef ARL_WSPLIT
     return rc ? rc : arl::check_launch("wgrad_split_kernel");
@@ -297,15 +300,15 @@ int launch_pair(const DgradPlan& d, const WgradPlan& w, bool has_pad, hipStream_
     const int n_ig = dgx * dgy * dgz, n_wg = wgx * wgy * wgz;
     int rc;
     if (g_split) {
-        const size_t lds_s = (size_t)2 * 3 * ((DBM + DBN) > (WBM + WBN) ? (DBM + DBN) : (WBM + WBN)) * BK * 2;
+        const size_t lds_s = (size_t)2 * planes_of(g_split) * ((DBM + DBN) > (WBM + WBN) ? (DBM + DBN) : (WBM + WBN)) * BK * 2;
 #define ARL_PSPLIT(HP, SPL)                                                                                \
     do {                                                                                                   \
         auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, HP, SPL>;                 \
         rc = allow_big_lds(k, lds_s + 4096);                                                               \
         if (!rc) hipLaunchKernelGGL(k, dim3(n_ig + n_wg), dim3(256), lds_s, s, d.a, w.a, dgx, dgy, n_ig, wgx, wgy); \
     } while (0)
-        if (has_pad) ARL_BY_MODE(ARL_PSPLIT(true, 6), ARL_PSPLIT(true, 9));
-        else ARL_BY_MODE(ARL_PSPLIT(false, 6), ARL_PSPLIT(false, 9));
+        if (has_pad) ARL_BY_MODE(ARL_PSPLIT(true, 1), ARL_PSPLIT(true, 6), ARL_PSPLIT(true, 9));
+        else ARL_BY_MODE(ARL_PSPLIT(false, 1), ARL_PSPLIT(false, 6), ARL_PSPLIT(false, 9));
 #undef ARL_PSPLIT
     } else if (has_pad) {
         auto k = bwd_pair_kernel<DWGM, DWGN, DTM, DTN, WWGM, WWGN, WTM, WTN, BK, true>;

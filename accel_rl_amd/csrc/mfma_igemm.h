@@ -41,9 +41,9 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
     float* sA = smem;
     float* sB = smem + NST * A_SZ;
     // split images (bytes): PA planes of BM x BK bf16 + 3 planes of BK x BN bf16 per stage
-    constexpr int PA = U8 ? 1 : 3, ROWB = BK * 2, NS = BK / 8;
+    constexpr int PA = U8 ? 1 : planes_of(SPLIT), PB = planes_of(SPLIT), ROWB = BK * 2, NS = BK / 8;
     constexpr int LPA = ADIR ? 0 : PA;              // planes of the gathered operand that live in LDS
-    constexpr int SPA = BM * ROWB, SPB = BN * ROWB, STAGE = LPA * SPA + 3 * SPB;
+    constexpr int SPA = BM * ROWB, SPB = BN * ROWB, STAGE = LPA * SPA + PB * SPB;
     char* const sS = reinterpret_cast<char*>(smem);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -232,13 +232,15 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                 for (int ks = 0; ks < DST; ++ks) {
                     const float4 q0 = rd_[i][ks][0], q1 = rd_[i][ks][1];
                     unsigned h[4], m[4], l[4];
-                    split_pair(q0.x, q0.y, h[0], m[0], l[0]);
-                    split_pair(q0.z, q0.w, h[1], m[1], l[1]);
-                    split_pair(q1.x, q1.y, h[2], m[2], l[2]);
-                    split_pair(q1.z, q1.w, h[3], m[3], l[3]);
+                    split_pair_n<PA>(q0.x, q0.y, h[0], m[0], l[0]);
+                    split_pair_n<PA>(q0.z, q0.w, h[1], m[1], l[1]);
+                    split_pair_n<PA>(q1.x, q1.y, h[2], m[2], l[2]);
+                    split_pair_n<PA>(q1.z, q1.w, h[3], m[3], l[3]);
                     fd_[rs][i][ks][0] = u32x4{h[0], h[1], h[2], h[3]};
-                    fd_[rs][i][ks][1] = u32x4{m[0], m[1], m[2], m[3]};
-                    fd_[rs][i][ks][2] = u32x4{l[0], l[1], l[2], l[3]};
+                    if constexpr (PA == 3) {
+                        fd_[rs][i][ks][1] = u32x4{m[0], m[1], m[2], m[3]};
+                        fd_[rs][i][ks][2] = u32x4{l[0], l[1], l[2], l[3]};
+                    }
                 }
         }
     };
@@ -295,11 +297,13 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                     *reinterpret_cast<uint2*>(d) = make_uint2(hi_pair(f.x, f.y), hi_pair(f.z, f.w));
                 } else {
                     uint2 h, m, l;
-                    split_pair(va[p].x, va[p].y, h.x, m.x, l.x);
-                    split_pair(va[p].z, va[p].w, h.y, m.y, l.y);
+                    split_pair_n<PA>(va[p].x, va[p].y, h.x, m.x, l.x);
+                    split_pair_n<PA>(va[p].z, va[p].w, h.y, m.y, l.y);
                     *reinterpret_cast<uint2*>(d) = h;
-                    *reinterpret_cast<uint2*>(d + SPA) = m;
-                    *reinterpret_cast<uint2*>(d + 2 * SPA) = l;
+                    if constexpr (PA == 3) {
+                        *reinterpret_cast<uint2*>(d + SPA) = m;
+                        *reinterpret_cast<uint2*>(d + 2 * SPA) = l;
+                    }
                 }
             }
             char* dB = dS + LPA * SPA;
@@ -311,11 +315,13 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                     const int nl = idx / CH, chunk = idx - nl * CH;
                     char* d = dB + kc_write_off(nl, chunk);
                     uint2 h, m, l;
-                    split_pair(vb[p].x, vb[p].y, h.x, m.x, l.x);
-                    split_pair(vb[p].z, vb[p].w, h.y, m.y, l.y);
+                    split_pair_n<PB>(vb[p].x, vb[p].y, h.x, m.x, l.x);
+                    split_pair_n<PB>(vb[p].z, vb[p].w, h.y, m.y, l.y);
                     *reinterpret_cast<uint2*>(d) = h;
-                    *reinterpret_cast<uint2*>(d + SPB) = m;
-                    *reinterpret_cast<uint2*>(d + 2 * SPB) = l;
+                    if constexpr (PB == 3) {
+                        *reinterpret_cast<uint2*>(d + SPB) = m;
+                        *reinterpret_cast<uint2*>(d + 2 * SPB) = l;
+                    }
                 }
             } else {
 #pragma unroll
@@ -327,13 +333,15 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                     char* d = dB + (kl2 * BN + nch * 4) * 4;
                     const float4 v0 = vb[2 * q], v1 = vb[2 * q + 1];
                     uint4 h, m, l;
-                    split_pair(v0.x, v1.x, h.x, m.x, l.x);
-                    split_pair(v0.y, v1.y, h.y, m.y, l.y);
-                    split_pair(v0.z, v1.z, h.z, m.z, l.z);
-                    split_pair(v0.w, v1.w, h.w, m.w, l.w);
+                    split_pair_n<PB>(v0.x, v1.x, h.x, m.x, l.x);
+                    split_pair_n<PB>(v0.y, v1.y, h.y, m.y, l.y);
+                    split_pair_n<PB>(v0.z, v1.z, h.z, m.z, l.z);
+                    split_pair_n<PB>(v0.w, v1.w, h.w, m.w, l.w);
                     *reinterpret_cast<uint4*>(d) = h;
-                    *reinterpret_cast<uint4*>(d + SPB) = m;
-                    *reinterpret_cast<uint4*>(d + 2 * SPB) = l;
+                    if constexpr (PB == 3) {
+                        *reinterpret_cast<uint4*>(d + SPB) = m;
+                        *reinterpret_cast<uint4*>(d + 2 * SPB) = l;
+                    }
                 }
             }
             return;
@@ -446,7 +454,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < PB; ++pl) {
                         if constexpr (B_KC) {
                             fb[j][pl] = *reinterpret_cast<const u32x4*>(cB + pl * SPB + j * 32 * ROWB + slot);
                         } else {
@@ -454,7 +462,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
                             fb[j][pl] = u32x4{q[0], q[BN], q[2 * BN], q[3 * BN]};
                         }
                     }
-                split_products<SPLIT, PA, 3, true, TM, TN>(fa, fb, acc);
+                split_products<SPLIT, PA, PB, true, TM, TN>(fa, fb, acc);
             }
         } else if constexpr (N16) {
             const float* cA = sA + buf * A_SZ + (wm * TM * 16 + l15) * LDA + quad * 4;
@@ -548,10 +556,11 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
         // tile kt + 1 (register set and stage buf ^ 1) -- left to itself the scheduler issues the MFMAs in one clump
         // and the ~130 vector instructions of the split after them; the group barriers below deal the vector work and
         // the LDS stores out between the MFMAs, where they cost nothing (tools/mfma_bf16_mix.hip: 4-6 per MFMA are free).
-        constexpr int NPROD = PA == 1 ? 3 : SPLIT;
+        constexpr int NPROD = SPLIT == 1 ? 1 : PA == 1 ? 3 : SPLIT;
         constexpr int NM = TM * TN * NPROD * STEPS;                                     // MFMAs per k-tile and wave
-        constexpr int NV = RA * (U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44);   // the split's vector instructions
-        constexpr int NW = RA * PA + (B_KC ? RB * 3 : (RB / 2) * 3);                    // its LDS stores
+        constexpr int NV = SPLIT == 1 ? RA * (U8 ? 6 : 2) + (B_KC ? RB * 2 : (RB / 2) * 4)
+                                      : RA * (U8 ? 6 : 22) + (B_KC ? RB * 22 : (RB / 2) * 44);   // the split's vector instructions
+        constexpr int NW = RA * PA + (B_KC ? RB * PB : (RB / 2) * PB);                  // its LDS stores
         constexpr int VPM = (NV + NM - 1) / NM < 6 ? (NV + NM - 1) / NM : 6;
         constexpr int WEV = NM / NW > 0 ? NM / NW : 1;
         auto mid_tile = [&](auto buf_c, int kt) {       // tiles 0 .. nk - 2
@@ -575,7 +584,7 @@ __device__ __forceinline__ void igemm_body(const GemmArgs& a, const int bx, cons
             store_tiles(buf ^ 1, buf ^ 1);
             // (every fragment read first: the LDS stores of the other stage cannot be proven not to alias them and would
             //  otherwise queue up behind the last read, at the end of the tile)
-            __builtin_amdgcn_sched_group_barrier(0x100, STEPS * (TM * PA + TN * 3 * (B_KC ? 1 : 4)), 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, STEPS * (TM * PA + TN * PB * (B_KC ? 1 : 4)), 0);
 #pragma unroll
             for (int m = 0; m < NM; ++m) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -35,8 +35,8 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
     constexpr int CW = W8 ? 8 : 4;                           // columns per gather task
     constexpr int NC4 = BN / CW, KROWS = 256 / NC4, RB = BK / KROWS;
     static_assert(!SP || RB % 2 == 0, "split products: an even number of gather passes (row pairs)");
-    constexpr int PB = U8 ? 1 : 3;
-    constexpr int SPA = BK * BM * 2, SPB = BK * BN * 2, STAGE = 3 * SPA + PB * SPB;   // bytes per plane / stage
+    constexpr int PA = planes_of(SPLIT), PB = U8 ? 1 : planes_of(SPLIT);
+    constexpr int SPA = BK * BM * 2, SPB = BK * BN * 2, STAGE = PA * SPA + PB * SPB;  // bytes per plane / stage
     char* const sS = reinterpret_cast<char*>(smem);
     constexpr int TILES_PER_GROUP = WG_ROWS / BK;
     static_assert(WGM * WGN == 4 && 256 % NC4 == 0 && BK % KROWS == 0 && BK % 8 == 0 && WG_ROWS % BK == 0, "tile shape");
@@ -146,15 +146,17 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
             else vb[p] = buf_ld4s(rsB, HAS_PAD ? mask_off(e.y, tap, off) : off, 0);
         }
     };
-    auto pack4 = [&](const float4& v0, const float4& v1, char* d, int plane_bytes) {     // rows k, k + 1 -> three planes
+    auto pack4 = [&](const float4& v0, const float4& v1, char* d, int plane_bytes) {     // rows k, k + 1 -> PA planes
         uint4 h, m, l;
-        split_pair(v0.x, v1.x, h.x, m.x, l.x);
-        split_pair(v0.y, v1.y, h.y, m.y, l.y);
-        split_pair(v0.z, v1.z, h.z, m.z, l.z);
-        split_pair(v0.w, v1.w, h.w, m.w, l.w);
+        split_pair_n<PA>(v0.x, v1.x, h.x, m.x, l.x);
+        split_pair_n<PA>(v0.y, v1.y, h.y, m.y, l.y);
+        split_pair_n<PA>(v0.z, v1.z, h.z, m.z, l.z);
+        split_pair_n<PA>(v0.w, v1.w, h.w, m.w, l.w);
         *reinterpret_cast<uint4*>(d) = h;
-        *reinterpret_cast<uint4*>(d + plane_bytes) = m;
-        *reinterpret_cast<uint4*>(d + 2 * plane_bytes) = l;
+        if constexpr (PA == 3) {
+            *reinterpret_cast<uint4*>(d + plane_bytes) = m;
+            *reinterpret_cast<uint4*>(d + 2 * plane_bytes) = l;
+        }
     };
     auto store_tiles = [&](int buf, bool fresh) {   // fresh: va holds a tile not stored before
         if constexpr (SP) {
@@ -172,7 +174,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
                     }
                 }
             }
-            char* dB = dS + 3 * SPA;
+            char* dB = dS + PA * SPA;
 #pragma unroll
             for (int q = 0; q < RB / 2; ++q) {
                 char* d = dB + ((b_k0 + q * KROWS) * BN + b_c4 * CW) * 4;
@@ -249,7 +251,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         // slot is rewritten (group + 2) one iteration later, after this iteration's barrier.
         if (kt % TILES_PER_GROUP == 0 && kt >= TILES_PER_GROUP) produce_rows(((kt / TILES_PER_GROUP) + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (WIL && !LAST && !U8) {
+        if constexpr (WIL && !LAST && !U8 && SPLIT != 1) {
             // Hand-made interleave (hipcc sinks the split behind the last MFMA under every scheduling hint tried:
             // profiles/r05/ring_conv_evidence.md): the MFMAs as volatile asm in the production order, and after MFMA n
             // the next few SLICES of the split of tile kt + 1 -- a task = one pack4 = 4 pairs x 4 stages of 3 / 3 / 3 / 2
@@ -353,14 +355,14 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         if constexpr (SP) {
             // fragment = column l31 (of its 32-wide tile), k octet 2 ks + half = pair rows 8 ks + 4 half .. + 3
             const unsigned* cA = reinterpret_cast<const unsigned*>(sS + buf * STAGE) + (half * 4) * BM + wm * TM * 32 + l31;
-            const unsigned* cB = reinterpret_cast<const unsigned*>(sS + buf * STAGE + 3 * SPA) + (half * 4) * BN + wn * TN * 32 + l31;
+            const unsigned* cB = reinterpret_cast<const unsigned*>(sS + buf * STAGE + PA * SPA) + (half * 4) * BN + wn * TN * 32 + l31;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 u32x4 fa[TM][3], fb[TN][3];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl) {
+                    for (int pl = 0; pl < PA; ++pl) {
                         const unsigned* q = cA + pl * (SPA / 4) + ks * 8 * BM + i * 32;
                         fa[i][pl] = u32x4{q[0], q[BM], q[2 * BM], q[3 * BM]};
                     }
@@ -371,7 +373,7 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
                         const unsigned* q = cB + pl * (SPB / 4) + ks * 8 * BN + j * 32;
                         fb[j][pl] = u32x4{q[0], q[BN], q[2 * BN], q[3 * BN]};
                     }
-                split_products<SPLIT, 3, PB, false, TM, TN>(fa, fb, acc);
+                split_products<SPLIT, PA, PB, false, TM, TN>(fa, fb, acc);
             }
         } else if constexpr (M16) {
             const float* cA = sA + buf * A_SZ + (quad * 4) * BM + l15;
@@ -416,12 +418,12 @@ __device__ __forceinline__ void wgrad_fast_body(const WgradArgs& a, const int bx
         if constexpr (WIL) {
             if constexpr (!LAST) {
                 store_tiles(buf ^ 1, true);
-                constexpr int NMW = TM * TN * (PB == 1 ? 3 : SPLIT) * (BK / 16);        // MFMAs per k-tile and wave
-                constexpr int NVW = (RA / 2) * 44 + (RB / 2) * (U8 ? 12 : 44);           // the split's vector instructions
-                constexpr int NWW = (RA / 2) * 3 + (RB / 2) * PB;                        // its LDS stores
+                constexpr int NMW = TM * TN * (SPLIT == 1 ? 1 : PB == 1 ? 3 : SPLIT) * (BK / 16);   // MFMAs per k-tile and wave
+                constexpr int NVW = (RA / 2) * (PA == 1 ? 4 : 44) + (RB / 2) * (U8 ? 12 : PB == 1 ? 4 : 44);   // the split's vector instructions
+                constexpr int NWW = (RA / 2) * PA + (RB / 2) * PB;                       // its LDS stores
                 constexpr int VPMW = (NVW + NMW - 1) / NMW < 6 ? (NVW + NMW - 1) / NMW : 6;
                 constexpr int WEVW = NMW / NWW > 0 ? NMW / NWW : 1;
-                __builtin_amdgcn_sched_group_barrier(0x100, (BK / 16) * 4 * (TM * 3 + TN * PB), 0);   // every fragment read first
+                __builtin_amdgcn_sched_group_barrier(0x100, (BK / 16) * 4 * (TM * PA + TN * PB), 0);   // every fragment read first
 #pragma unroll
                 for (int m = 0; m < NMW; ++m) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

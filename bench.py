@@ -362,7 +362,7 @@ def mfma_table(device, policy, batch=512, reps=20):
             # and for the <= 16-column layers, the bf16 pipe for the split routes -- where one fp32 multiply is
             # `products` bf16 MFMA products, i.e. a ceiling of 2 500 / products TF/s of fp32 flops (278 at nine, 833
             # for u8 pixels).  `frac` is against THAT ceiling; the fp32-MFMA fraction stays as a secondary key.
-            products = (3 if "u8" in name else mode) if (mode and g.out_c > 16) else 0
+            products = (1 if mode == 1 else 3 if "u8" in name else mode) if (mode and g.out_c > 16) else 0
             route_peak = MFMA_BF16_PEAK_TFS / products if products else MFMA_F32_PEAK_TFS
             row = dict(kernel="%s %s" % (name, tag), avg_launch_us=round(mean_ms * 1e3, 2),
                        isolated_launch_us=round(iso_ms * 1e3, 2),
@@ -424,14 +424,15 @@ def mfma_table(device, policy, batch=512, reps=20):
     return out
 
 
-ROUTE_NAMES = {9: "split9", 6: "split6", 0: "fp32_mfma"}
+ROUTE_NAMES = {9: "split9", 6: "split6", 0: "fp32_mfma", 1: "bf16_operands"}
 SPEC1_LAYERS = [("conv1", 104, 80, 4, 32, 8, 4, 0), ("conv2", 25, 19, 32, 64, 4, 2, 1),
                 ("conv3", 12, 9, 64, 64, 3, 1, 1), ("dense1", 1, 1, 6912, 512, 1, 1, 0)]
 
 
-def route_accuracy(device, batch=48, modes=(9, 6, 0), seed=3):
+def route_accuracy(device, batch=48, modes=(9, 6, 0, 1), seed=3):
     """Error of every contraction kernel of the spec-1 network (config 2's layer shapes) on each arithmetic route
-    (arl_conv_geom.route: nine / six exact bf16-split products, fp32 MFMA chain) against a FLOAT64 contraction of the
+    (arl_conv_geom.route: nine / six exact bf16-split products, fp32 MFMA chain, and the labelled reduced-precision
+    option -- operands rounded to bf16, one product) against a FLOAT64 contraction of the
     same inputs: {layer: {pass: {"rms_err_vs_f64": {route: rms(err) / rms(ref)}, "max_err_vs_f64": {route: max|err| /
     max|ref|}}}}.  The float64 reference is torch's (ATen) convolution -- a checker, not the product path.  The batch
     is small because the float64 reference is slow; the errors do not depend on it (every output is its own dot
@@ -503,7 +504,7 @@ def route_accuracy(device, batch=48, modes=(9, 6, 0), seed=3):
     return table
 
 
-def alt_routes(device, steps, warmup, priming, modes=(6, 0)):
+def alt_routes(device, steps, warmup, priming, modes=(6, 0, 1)):
     """The SAME workload, steps and timed region as the headline on the other arithmetic routes of the fp32
     contractions (arl_conv_geom.route): a second and a third runner built from scratch with the route stamped into
     every layer geometry, primed, warmed up and timed exactly like `value`.  The default route is not changed."""
@@ -525,7 +526,8 @@ def alt_routes(device, steps, warmup, priming, modes=(6, 0)):
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             out[ROUTE_NAMES[mode]] = dict(value=round(steps * N_ENVS * HORIZON / dt, 1), ms_per_step=round(dt / steps * 1e3, 4),
-                                          steps=steps, products_per_multiply=mode if mode else 1)
+                                          steps=steps, products_per_multiply=mode if mode else 1,
+                                          fp32_contraction=mode != 1)
             runner.shutdown()
             algo._graph = algo._graph_out = None
             sampler._graph = None
@@ -537,7 +539,9 @@ def alt_routes(device, steps, warmup, priming, modes=(6, 0)):
         _lib.set_conv_precision(was)
     out["note"] = ("same workload, steps, warm-up and timed region as `value`, which runs on split9 (the default, unchanged): "
                    "split6 drops the three piece products below 2^-24 of a product (m*l, l*m, l*l), fp32_mfma is the "
-                   "v_mfma_f32_32x32x2_f32 chain; per-layer errors of all three against float64 are in `accuracy`")
+                   "v_mfma_f32_32x32x2_f32 chain; bf16_operands (ARL_CONV_ROUTE_BF16) is the labelled reduced-precision option "
+                   "(SURVEY 8d: fp32 default, bf16 optional): operands rounded to bf16, one product, fp32 accumulation -- NOT an "
+                   "fp32 contraction, never `value`; per-layer errors of all four against float64 are in `accuracy`")
     return out
 
 

@@ -414,14 +414,19 @@ typedef struct arl_conv_geom {
  *      in fp32 by v_mfma_f32_32x32x16_bf16: every product term of the fp32 contraction enters the sum exactly, only
  *      the accumulation rounds;
  *   ARL_CONV_ROUTE_FP32   v_mfma_f32_32x32x2_f32: bit for bit a k-ordered fmaf chain (157 TF/s peak on gfx950);
- *   ARL_CONV_ROUTE_SPLIT6 as SPLIT9 without the three smallest piece products (each below 2^-24 of |x y|).
- * u8 observations are exact in one bf16 piece (three products on both split routes).  Layers with <= 16 output
+ *   ARL_CONV_ROUTE_SPLIT6 as SPLIT9 without the three smallest piece products (each below 2^-24 of |x y|);
+ *   ARL_CONV_ROUTE_BF16   NOT an fp32 contraction -- the labelled reduced-precision option: each fp32 operand is ROUNDED
+ *      (to nearest even) to one bf16 value on its way into the matrix cores, one product per multiply, fp32
+ *      accumulation; tensors in memory stay fp32.  8 significand bits per operand: results differ from the other
+ *      routes by ~2^-9 relative per product; never a default, never selected by the library.
+ * u8 observations are exact in one bf16 piece (three products on both split routes, one on BF16).  Layers with <= 16 output
  * columns and the generic (any channel count) kernels always take the fp32 chain -- except the first convolution from u8
  * rows with 16 filters of 8 x 8 (spec 0), which runs on the image-stationary bf16-split kernel with half its tile idle.  Deterministic on every route;
  * any other value: ARL_E_ARG.  The route is an argument of the call: the library keeps no mode.                     */
 #define ARL_CONV_ROUTE_SPLIT9 0
 #define ARL_CONV_ROUTE_FP32   1
 #define ARL_CONV_ROUTE_SPLIT6 6
+#define ARL_CONV_ROUTE_BF16   2
 
 /* Scratch for the split reductions below (fixed; the caller allocates once). */
 int64_t arl_conv_workspace_bytes(void);
