@@ -699,7 +699,12 @@ extern "C" int arl_conv2d_bwd_pair(const float* dy, const float* w, const float*
     // Only the widest tile configuration pairs up: a shared launch runs every workgroup at the larger of the
     // two LDS / register footprints, which costs the smaller-tile weight-gradient kernels their occupancy
     // (measured: conv 2 / conv 3 pairs 9-18 us slower than apart, the dense pair 11 us faster).
-    const bool paired = dp.fast && wp.fast && dp.cfg == 2 && wp.cfg == 2 &&
+    // ... and only while the data gradient has at most two 128 x 128 tiles per CU: beyond that the shared launch falls
+    // behind the two separate ones, and badly (spec-0 dense at the A2C-1024 batch, 5 120 x 3 456 x 256: 380.6 us paired,
+    // 213.5 apart, weight-gradient fold included; 6 912 x 512 at 4 096 rows: 1 393 against 569; the PPO minibatch's 216
+    // tiles: 63.3 against 79.3 -- profiles/r06/pair_size_probe.txt)
+    const int64_t dgrad_tiles = (int64_t)((dp.a.M + 127) / 128) * ((dp.a.N + 127) / 128) * (dp.a.n_par ? dp.a.n_par : 1);
+    const bool paired = dp.fast && wp.fast && dp.cfg == 2 && wp.cfg == 2 && dgrad_tiles <= 2 * TARGET_WGS &&
                         (!has_pad || geom->kh * geom->kw <= 32) && !g_trace;
     if (!paired) {
         // the data gradient may split its reduction: it gets the upper half of the workspace (and is folded at
