@@ -454,21 +454,21 @@ class AtariCnnPolicy(object):
                 self._wt_fresh = False
             return loss4
 
-    # Rows of a minibatch per forward + backward pass.  The activations of a pass and their gradients (fp32, every conv
-    # layer's output twice) plus the u8 rows it reads want to stay in the 256 MiB Infinity Cache between the launch
-    # that writes them and the launches that read them: measured (tools/batch_sweep.py, profiles/r03/batch_sweep.txt)
-    # the cost per row is lowest at 1024 rows for spec 1 (232 KB + 33 KB per row; the formula below gives 1024) and around
-    # 2048 for spec 0 (88 + 33 KB; the formula gives 2304 = (2218 + 128) // 256 * 256, i.e. passes start at 6912 rows)
-    # and, for spec 1, 15-25 % higher at 4096-5120 rows in one pass (spec 0: 2 %).  A minibatch of three or more such
-    # passes (the strong-scaling bench's 4096 rows of spec 1 on one GPU) is therefore walked in passes of that size
-    # whose gradients are added in a fixed order -- the same mean-loss gradient, other summation order
-    # (accel_rl/optimizers/single/a2c_optimizer.py:37-43 takes one step on the whole batch; so does this); the
-    # accumulation costs ~3 % of a pass, so smaller multiples stay in one pass.  None = one pass whatever the size.
-    max_rows_per_pass = "auto"
+    # Rows of a minibatch per forward + backward pass: None (the default) = one pass whatever the size; a number, or
+    # "auto" (as many rows as keep a pass's activations, their gradients and the u8 rows it reads inside the 256 MiB
+    # Infinity Cache: 1024 for spec 1, 2304 for spec 0), walks a minibatch of three or more such passes in passes whose
+    # gradients are added in a fixed order -- the same mean-loss gradient, other summation order
+    # (accel_rl/optimizers/single/a2c_optimizer.py:37-43 takes one step on the whole batch; so does this).  "auto" was the
+    # default from round 3 (cost per row of spec 1 15-25 % higher at 4096-5120 rows in one pass,
+    # profiles/r03/batch_sweep.txt) until round 6 found that rise in ONE launch -- the dense layer's data + weight
+    # gradient sharing a launch, now bounded by size (arl_conv2d_bwd_pair) -- and not in the cache: with it gone one pass
+    # is the cheaper walk at every size (spec 1 at 4096 rows: 2 782 us in one pass, 3 144 in passes of 1024;
+    # profiles/r06/batch_sweep_passes.txt), so the option stays for memory-bound callers only.
+    max_rows_per_pass = None
     CACHE_BYTES = 256 << 20
 
     def rows_per_pass(self):
-        if self.max_rows_per_pass != "auto":
+        if not isinstance(self.max_rows_per_pass, str):
             return self.max_rows_per_pass
         per_row = int(np.prod(self._obs_shape)) + 8 * sum(nf * ho * wo for nf, ci, sz, st, pad, ho, wo in self._conv_geom)
         return max(256, (self.CACHE_BYTES // per_row + 128) // 256 * 256)
