@@ -221,17 +221,48 @@ __global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __re
     int P = 1;
     while (P < m) P <<= 1;
     const int top_levels = levels < TOP_LEVELS ? levels : TOP_LEVELS;
-    for (int i = tid; i < (1 << top_levels) - 1; i += NT) s_top[i] = tree[i];
+    // the uniforms may lie in page-locked HOST memory (arl_sumtree_sample_batch: ~2 us away): on their way while the top
+    // of the tree is fetched (P / NT <= 4 candidates per thread)
+    double u_pre[SAMPLE_MAX / 1024];
+    for (int i = tid, q = 0; i < P; i += NT, ++q) u_pre[q] = i < m ? uniforms[i] : 0.0;
+    {   // eight loads in flight per thread and round (a lone wave -- the 33-candidate batch -- would otherwise walk the
+        // 2 047 nodes as 32 dependent round trips: the compiler does not hoist the loads over the LDS stores)
+        const int nodes = (1 << top_levels) - 1;
+        for (int base = 0; base < nodes; base += 8 * NT) {
+            double t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int i = base + j * NT + tid; t[j] = i < nodes ? tree[i] : 0.0; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int i = base + j * NT + tid; if (i < nodes) s_top[i] = t[j]; }
+        }
+    }
     __syncthreads();
     const double root = s_top[0];
-    for (int i = tid; i < P; i += NT) {
+    for (int i = tid, q = 0; i < P; i += NT, ++q) {
         int idx = 0x7fffffff;                                    // padding sorts behind every leaf
         if (i < m) {
-            double v = uniforms[i] * root;
+            double v = u_pre[q] * root;
             idx = 0;
-            for (int l = 0; l < levels - 1; ++l) {
+            int l = 0;
+            for (; l < levels - 1 && l + 1 < top_levels; ++l) {  // node idx is on level l + 1: in LDS
                 idx = 2 * idx + 1;
-                const double left = l + 1 < top_levels ? s_top[idx] : tree[idx];     // (node idx is on level l + 1)
+                const double left = s_top[idx];
+                if (v > left) { v -= left; idx += 1; }
+            }
+            // below the cached levels a level is a dependent load from L2 / HBM: TWO levels per round trip -- the left
+            // child and both candidates for the level under it are fetched together (same comparisons and
+            // subtractions in the same order: the same leaf)
+            for (; l + 1 < levels - 1; l += 2) {
+                const int c = 2 * idx + 1;
+                const double left = tree[c], left_l = tree[2 * c + 1], left_r = tree[2 * c + 3];
+                double left2;
+                if (v > left) { v -= left; idx = c + 1; left2 = left_r; } else { idx = c; left2 = left_l; }
+                idx = 2 * idx + 1;
+                if (v > left2) { v -= left2; idx += 1; }
+            }
+            if (l < levels - 1) {
+                idx = 2 * idx + 1;
+                const double left = tree[idx];
                 if (v > left) { v -= left; idx += 1; }
             }
         }
@@ -261,6 +292,18 @@ __global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __re
         for (int i = tid, q = 0; i < P; i += NT, ++q) s_pos[i] += add[q];
         __syncthreads();
     }
+    const int total = s_pos[P - 1];
+    if (tid == 0) {
+        n_unique[0] = total;
+        if (notify) {
+            // the host waits on this word in page-locked memory instead of a copy + event; all it needs is the count, known
+            // here -- the uniforms were consumed before the sort -- so it is told now and reacts (launches the update's
+            // graph) while the probabilities and weights below are still being written: every output is queued work's
+            // business (stream order).  No system-scope fence: the word carries everything the host reads directly (a
+            // fence here writes the XCD's dirty L2 back first -- microseconds the update's critical path waits for)
+            *notify = (ticket << 32) | (long long)(unsigned)total;
+        }
+    }
     const int shift = (1 << (levels - 1)) - 1;                   // tree index of leaf 0
     // importance-sampling weights of the batch (is_weights_kernel's arithmetic: w = (1 / p) ** beta in f64, divided by
     // their maximum, rounded to f32), from the probabilities while they are in registers: wq[q] = this thread's q-th slot
@@ -283,7 +326,6 @@ __global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __re
     }
     // too few distinct leaves: the slots past them repeat the first one, so that work already queued behind this
     // kernel (batch extraction) stays in bounds while the host learns from n_unique that it has to top up
-    const int total = s_pos[P - 1];
     for (int pos = total + tid; pos < n; pos += NT) {
         const int key = s_key[0], leaf = key - shift;
         tree_idxs[pos] = key;
@@ -302,16 +344,6 @@ __global__ __launch_bounds__(1024) void sumtree_sample_kernel(const double* __re
         for (int i = tid, q = 0; i < P; i += NT, ++q)
             if (wpos[q] >= 0) is_weights[wpos[q]] = (float)(wq[q] / mx);
         for (int pos = total + tid; pos < n; pos += NT) is_weights[pos] = 0.f;
-    }
-    if (tid == 0) {
-        n_unique[0] = total;
-        if (notify) {
-            // the host waits on this word in page-locked memory instead of a copy + event: every output above is
-            // queued work's business (stream order); the host only needs the count
-            __threadfence_system();
-            *notify = (ticket << 32) | (long long)(unsigned)total;
-            __threadfence_system();
-        }
     }
 }
 
