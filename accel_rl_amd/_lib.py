@@ -72,6 +72,10 @@ class ArlFoldItem(C.Structure):
 FOLD_MAX_ITEMS = 24
 
 
+class ArlLogitSrc(C.Structure):
+    _fields_ = [("part", _vp), ("bias_or_null", _vp), ("split_stride", _i64), ("splits", _i32), ("reserved", _i32)]
+
+
 class ArlDgradWt(C.Structure):
     _fields_ = [("w", _vp), ("wt", _vp), ("geom", C.POINTER(ArlConvGeom))]
 
@@ -165,6 +169,7 @@ _SIGNATURES = {
     "arl_priority_diffs": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "arl_catdqn_loss_parts": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_dqn_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "arl_dqn_loss": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_lstm_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
@@ -891,6 +896,28 @@ def catdqn_loss(pred_logits, tgt_next_logits, pol_next_logits, z, actions, retur
                                   ptr(actions), ptr(returns), ptr(terminals), ptr(is_weights), batch, n_actions,
                                   n_atoms, stride, int(dueling), float(v_min), float(v_max), float(gamma_n),
                                   ptr(dlogits), ptr(loss_rows), ptr(kl), stream_ptr(stream)), "arl_catdqn_loss")
+
+
+def logit_src(item, bias, row0=0, row_floats=0):
+    """ArlLogitSrc for arl_catdqn_loss_parts from what conv2d_fwd_parts returned for the output layer: rows from `row0`
+    on (row_floats floats per row); an unsplit launch (item.splits == 0: `out` is final) reads as one split, no bias."""
+    src = ArlLogitSrc()
+    split = item.splits > 0
+    src.part = (item.part if split else item.out) + 4 * row0 * row_floats
+    src.bias_or_null = bias.data_ptr() if (split and bias is not None) else None
+    src.split_stride = item.total
+    src.splits = item.splits if split else 1
+    return src
+
+
+def catdqn_loss_parts(pred, tgt_next, pol_next, z, actions, returns, terminals, is_weights, n_actions, n_atoms,
+                      atom_stride, v_min, v_max, gamma_n, dlogits, loss_rows, kl, dueling=False, stream=None):
+    """arl_catdqn_loss on logit blocks still in split partial sums (ArlLogitSrc each; pol_next None: not double DQN)."""
+    _check(load().arl_catdqn_loss_parts(C.byref(pred), C.byref(tgt_next), None if pol_next is None else C.byref(pol_next),
+                                        ptr(z), ptr(actions), ptr(returns), ptr(terminals), ptr(is_weights),
+                                        actions.numel(), n_actions, n_atoms, atom_stride, int(dueling), float(v_min),
+                                        float(v_max), float(gamma_n), ptr(dlogits), ptr(loss_rows), ptr(kl),
+                                        stream_ptr(stream)), "arl_catdqn_loss_parts")
 
 
 def dqn_act(q, override, n_actions, onehot, greedy=None, dueling=False, stream=None):

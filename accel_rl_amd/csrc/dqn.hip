@@ -20,6 +20,7 @@
 // kernel) / one workgroup per sample (loss kernel); n_atoms <= 64.  fp32, compiled with -ffp-contract=off.
 
 #include "arl_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -42,31 +43,70 @@ __device__ __forceinline__ float atom_softmax(float x, int lane, int n_atoms) {
     return e / wave_sum(e);
 }
 
+// Where a sample's logit block [A (+ 1)][stride] is read from: the finished logits, or (Parts) the output layer's split
+// partial sums as arl_conv2d_fwd_parts left them -- logit = fold_splits_kernel's sum of the partials + bias, operation for
+// operation (its 16 lanes-of-a-group partial sums s_g = 0 + p_g + p_{g+16} + ..., then s_0 + s_1 + ... + s_15, then the bias),
+// so that the loss kernel can take the place of the fold launch without moving a bit.
+struct Plain {
+    const float* p;
+    __device__ __forceinline__ float operator()(int off) const { return p[off]; }
+};
+template <int NS>                  // NS: compile-time number of splits (1, 2, 4, 8, 16), 0 = run-time (<= 127)
+struct Parts {
+    const float* p;             // this sample's block inside split 0
+    const float* bias;          // [A (+ 1)][stride] (the output layer's bias), or null
+    long long ss;               // floats between consecutive splits
+    int splits;                 // 1 .. 127
+    __device__ __forceinline__ float operator()(int off) const {
+        if constexpr (NS > 0) {         // every partial requested before the first is used: ONE round trip
+            float v[NS];
+#pragma unroll
+            for (int g = 0; g < NS; ++g) v[g] = p[(long long)g * ss + off];
+            const float b = bias ? bias[off] : 0.f;
+            float tot = 0.f + v[0];
+#pragma unroll
+            for (int g = 1; g < NS; ++g) tot += 0.f + v[g];
+            return bias ? tot + b : tot;
+        } else {
+            float tot = 0.f;
+            for (int g = 0; g < 16 && g < splits; ++g) {
+                float sg = 0.f;
+                for (int z = g; z < splits; z += 16) sg += p[(long long)z * ss + off];
+                tot = g == 0 ? sg : tot + sg;
+            }
+            return bias ? tot + bias[off] : tot;
+        }
+    }
+};
+
 // Dueling heads (policies/dqn/layers/dueling_merge_layer.py:32-35): the block holds n_actions advantage rows
 // followed by ONE value row; logit(a, i) = val_i + (adv_ai - mean_a adv_ai).  Per lane (= atom): the mean and
 // the value, read once per sample.
 struct Duel { float mean, val; bool on; };
-__device__ __forceinline__ Duel duel_terms(const float* logits, int lane, int n_actions, int n_atoms, int stride,
+template <class L>
+__device__ __forceinline__ Duel duel_terms(const L& logits, int lane, int n_actions, int n_atoms, int stride,
                                            bool dueling) {
     Duel d = {0.f, 0.f, dueling};
     if (dueling && lane < n_atoms) {
         float sum = 0.f;
-        for (int a = 0; a < n_actions; ++a) sum += logits[a * stride + lane];
+        for (int a = 0; a < n_actions; ++a) sum += logits(a * stride + lane);
         d.mean = sum / (float)n_actions;
-        d.val = logits[n_actions * stride + lane];
+        d.val = logits(n_actions * stride + lane);
     }
     return d;
 }
-__device__ __forceinline__ float atom_logit(const float* logits, int a, int lane, int n_atoms, int stride,
+template <class L>
+__device__ __forceinline__ float atom_logit(const L& logits, int a, int lane, int n_atoms, int stride,
                                             const Duel& d) {
     if (lane >= n_atoms) return 0.f;
-    const float x = logits[a * stride + lane];
+    const float x = logits(a * stride + lane);
     return d.on ? d.val + (x - d.mean) : x;
 }
 
 // greedy action of one sample under `logits`: argmax_a sum_i softmax(logit(a, .))_i z_i, first maximum
-__device__ __forceinline__ int greedy_action(const float* logits, int lane, int n_actions, int n_atoms,
+__device__ __forceinline__ int greedy_action(const float* logits_p, int lane, int n_actions, int n_atoms,
                                              int stride, float z_lane, bool dueling) {
+    const Plain logits = {logits_p};
     const Duel d = duel_terms(logits, lane, n_actions, n_atoms, stride, dueling);
     int best = 0;
     float best_q = -3.0e38f;
@@ -95,10 +135,12 @@ __global__ __launch_bounds__(256) void catdqn_act_kernel(const float* __restrict
     if (lane == 0 && greedy) greedy[b] = (uint8_t)g;
 }
 
+struct LogitSrc { const float* p; const float* bias; long long ss; int splits; };     // splits == 0: finished logits
 struct CatLossArgs {
     const float* pred_logits;       // policy net on obs              [B][A][S]
     const float* tgt_next_logits;   // target net on next_obs         [B][A][S]
     const float* pol_next_logits;   // policy net on next_obs (double DQN) or null
+    LogitSrc src[3];                // PARTS: the same three (pred, tgt_next, pol_next), as split partial sums
     const float* z;                 // [n_atoms] support
     const uint8_t* actions;         // [B]
     const float* returns;           // [B] n-step discounted return
@@ -116,7 +158,9 @@ struct CatLossArgs {
 // One workgroup per sample.  The greedy next action needs a softmax expectation per action -- a serial chain
 // of wave reductions -- so the actions are dealt to the four waves; wave 0 then carries the sample through
 // projection, loss and gradient (lane i = atom i).
+template <int NS>                  // -1: finished logits; >= 0: split partial sums (Parts<NS>)
 __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
+    constexpr bool PARTS = NS >= 0;
     __shared__ float s_next[64], s_znext[64], s_q[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = blockIdx.x;
@@ -124,16 +168,40 @@ __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
     const bool duel = a.dueling != 0;
     const int64_t R = (int64_t)(A + a.dueling) * S;      // floats per sample
     const float z_lane = lane < n ? a.z[lane] : 0.f;
-    const float* tgt = a.tgt_next_logits + b * R;
+    using L = typename std::conditional<PARTS, Parts<(NS > 0 ? NS : 0)>, Plain>::type;
+    auto block_of = [&](int which, const float* plain) -> L {
+        if constexpr (PARTS) {
+            const LogitSrc& q = a.src[which];
+            return L{q.p + b * R, q.bias, q.ss, q.splits};
+        } else {
+            return Plain{plain + b * R};
+        }
+    };
+    const L tgt = block_of(1, a.tgt_next_logits);
     // greedy next action: under the policy net (double DQN) or the target net (cat_dqn.py:77-81), first maximum
     {
-        const float* sel = a.pol_next_logits ? a.pol_next_logits + b * R : tgt;
+        const bool dbl = PARTS ? a.src[2].p != nullptr : a.pol_next_logits != nullptr;
+        const L sel = dbl ? block_of(2, a.pol_next_logits) : tgt;
         const Duel d = duel_terms(sel, lane, A, n, S, duel);
-        for (int k = wave; k < A; k += 4) {
-            const float q = wave_sum(atom_softmax(atom_logit(sel, k, lane, n, S, d), lane, n) * z_lane);
-            if (lane == 0) s_q[k] = q;
+        // this wave's actions (k = wave, wave + 4, ...; at most 16 of the <= 64): every logit requested before the first
+        // softmax -- a lone global round trip instead of one per action
+        float xs[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xs[j] = wave + 4 * j < A ? atom_logit(sel, wave + 4 * j, lane, n, S, d) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int k = wave + 4 * j;
+            if (k < A) {
+                const float q = wave_sum(atom_softmax(xs[j], lane, n) * z_lane);
+                if (lane == 0) s_q[k] = q;
+            }
         }
     }
+    // (wave 0's prediction logits do not depend on anything above: on their way across the barrier)
+    const int act = a.actions[b];
+    const L prd = block_of(0, a.pred_logits);
+    float pred_x = 0.f;
+    if (wave == 0) pred_x = atom_logit(prd, act, lane, n, S, duel_terms(prd, lane, A, n, S, duel));
     __syncthreads();
     if (wave != 0) return;
     int a_next = 0;
@@ -159,9 +227,7 @@ __global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
             proj += s_next[j] * fminf(fmaxf(c, 0.f), 1.f);
         }
     // prediction, cross-entropy with NaN guard (:92-94)
-    const int act = a.actions[b];
-    const float* prd = a.pred_logits + b * R;
-    const float pred = atom_softmax(atom_logit(prd, act, lane, n, S, duel_terms(prd, lane, A, n, S, duel)), lane, n);
+    const float pred = atom_softmax(pred_x, lane, n);
     const float pc = fminf(fmaxf(pred, 1e-6f), 1.f);
     const float w = (a.is_weights ? a.is_weights[b] : 1.f) / (float)a.batch;
     const float ce = lane < n ? -(proj * logf(pc)) : 0.f;
@@ -352,6 +418,47 @@ extern "C" int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_l
     a.dlogits = dlogits; a.loss_rows = loss_rows; a.kl = kl; a.batch = batch;
     a.n_actions = n_actions; a.n_atoms = n_atoms; a.stride = atom_stride; a.dueling = dueling != 0;
     a.v_min = v_min; a.v_max = v_max; a.gamma_n = gamma_n;
-    hipLaunchKernelGGL(catdqn_loss_kernel, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(catdqn_loss_kernel<-1>, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
     return arl::check_launch("catdqn_loss_kernel");
+}
+
+extern "C" int arl_catdqn_loss_parts(const arl_logit_src* pred, const arl_logit_src* tgt_next,
+                                     const arl_logit_src* pol_next_or_null, const float* z, const uint8_t* actions,
+                                     const float* returns, const uint8_t* terminals, const float* is_weights_or_null,
+                                     int64_t batch, int32_t n_actions, int32_t n_atoms, int32_t atom_stride,
+                                     int32_t dueling, float v_min, float v_max, float gamma_n, float* dlogits,
+                                     float* loss_rows, float* kl, void* stream) {
+    ARL_REQUIRE(pred && tgt_next && pred->part && tgt_next->part && z && actions && returns && terminals && dlogits &&
+                    loss_rows && kl && (!pol_next_or_null || pol_next_or_null->part), ARL_E_ARG, "null pointer");
+    int rc = check_cat(batch, n_actions, n_atoms, atom_stride);
+    if (rc) return rc;
+    ARL_REQUIRE(v_max > v_min, ARL_E_ARG, "v_max must exceed v_min");
+    const arl_logit_src* in[3] = {pred, tgt_next, pol_next_or_null};
+    CatLossArgs a = {};
+    for (int i = 0; i < 3; ++i) {
+        if (!in[i]) continue;
+        ARL_REQUIRE(in[i]->splits >= 1 && in[i]->splits < 128 && in[i]->split_stride > 0, ARL_E_RANGE,
+                    "logit source: 1 <= splits < 128 partial sums, split_stride > 0 (finished logits: one split, no bias)");
+        a.src[i].p = in[i]->part; a.src[i].bias = in[i]->bias_or_null; a.src[i].ss = in[i]->split_stride;
+        a.src[i].splits = in[i]->splits;
+    }
+    a.z = z; a.actions = actions; a.returns = returns; a.terminals = terminals; a.is_weights = is_weights_or_null;
+    a.dlogits = dlogits; a.loss_rows = loss_rows; a.kl = kl; a.batch = batch;
+    a.n_actions = n_actions; a.n_atoms = n_atoms; a.stride = atom_stride; a.dueling = dueling != 0;
+    a.v_min = v_min; a.v_max = v_max; a.gamma_n = gamma_n;
+    // all sources on the same power-of-two split count (the usual case: the same layer at two batch sizes): unrolled loads
+    int ns = a.src[0].splits;
+    for (int i = 1; i < 3; ++i)
+        if (in[i] && a.src[i].splits != ns) ns = 0;
+    const dim3 grid((unsigned)batch);
+    hipStream_t st = (hipStream_t)stream;
+    switch (ns) {
+    case 1: hipLaunchKernelGGL(catdqn_loss_kernel<1>, grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(catdqn_loss_kernel<2>, grid, dim3(256), 0, st, a); break;
+    case 4: hipLaunchKernelGGL(catdqn_loss_kernel<4>, grid, dim3(256), 0, st, a); break;
+    case 8: hipLaunchKernelGGL(catdqn_loss_kernel<8>, grid, dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(catdqn_loss_kernel<16>, grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(catdqn_loss_kernel<0>, grid, dim3(256), 0, st, a);
+    }
+    return arl::check_launch("catdqn_loss_kernel (parts)");
 }

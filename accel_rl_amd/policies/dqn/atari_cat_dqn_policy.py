@@ -14,6 +14,8 @@ made for a whole rollout at once (`host_draws`) and shipped as an override table
 action needs no host round trip.  Dueling (`dueling=True`): see QPolicyBase -- the stored block is
 n_actions advantage rows followed by one value row of atoms.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -23,6 +25,10 @@ from accel_rl_amd.policies.dqn.q_policy_base import QPolicyBase
 
 
 class AtariCatDqnPolicy(QPolicyBase):
+
+    # the loss launch reads the two output layers' split partial sums and folds them itself (arl_catdqn_loss_parts): two
+    # launches fewer per update, same bits (tests/test_catdqn_gpu.py); False: the separate fold launches
+    loss_folds_heads = os.environ.get("ARL_LOSS_FOLDS_HEADS", "1") != "0"       # (the env switch: same-box A/B)
 
     def __init__(self, conv_filters, conv_filter_sizes, conv_strides, conv_pads, hidden_sizes=(),
                  pixel_scale=255., epsilon=1, n_atoms=51, dueling=False, initial_param_values=None):
@@ -108,12 +114,18 @@ class AtariCatDqnPolicy(QPolicyBase):
         full backward pass into flat_grads.  Returns (loss_rows f32[B] whose sum is the loss, kl f32[B])."""
         with torch.no_grad():
             b = obs.shape[0]
-            x, logits, acts, hids, tgt_logits, pol_next = self._forward_for_loss(obs, next_obs, double_dqn)
-            dlogits = self._buffer(("dlogits", b), tuple(logits.shape))
+            x, logits, acts, hids, tgt_logits, pol_next = self._forward_for_loss(obs, next_obs, double_dqn,
+                                                                                 head_parts=self.loss_folds_heads)
+            dlogits = self._buffer(("dlogits", b), (b, self._head_width))
             pack = self._buffer(("loss_kl", b), (2, b))         # one buffer: DqnOptimizer's statistics ring takes both rows at once
             loss_rows, kl = pack[0], pack[1]
-            _lib.catdqn_loss(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
-                             self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl,
-                             dueling=self._dueling)
+            if isinstance(logits, _lib.ArlLogitSrc):            # the output layers' partial sums, folded as they are read
+                _lib.catdqn_loss_parts(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
+                                       self.n_act, self.n_atoms, self._atom_stride, v_min, v_max, gamma_n, dlogits,
+                                       loss_rows, kl, dueling=self._dueling)
+            else:
+                _lib.catdqn_loss(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
+                                 self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl,
+                                 dueling=self._dueling)
             self._head_backward(dlogits, x, acts, hids)
             return loss_rows, kl

@@ -103,16 +103,27 @@ class QPolicyBase(AtariCnnPolicy):
 
 
     # ---- forward -----------------------------------------------------------
-    def _logits(self, x, w=None, tag=""):
-        """[B, head width] output-layer pre-activations (+ the trunk's activations)."""
+    def _logits(self, x, w=None, tag="", parts_ws=None):
+        """[B, head width] output-layer pre-activations (+ the trunk's activations).
+        parts_ws (a conv workspace of its own): the output layer's split reduction stays unfolded there and the first
+        return value is the ArlFoldItem describing it (for a loss kernel that folds while it reads: _lib.logit_src)."""
         w = self._w if w is None else w
         b = x.shape[0]
         acts, hids = self._trunk(x, w=w, tag=tag)
         k = self._k_head
         out = self._buffer(("logits" + tag, b), (b, self._head_width))
         geom = self._head_geom(b)
+        if parts_ws is not None:
+            return _lib.conv2d_fwd_parts(hids[-1], w[k], w[k + 1], out, geom, False, parts_ws), acts, hids
         _lib.conv2d_fwd(hids[-1], w[k], w[k + 1], out, geom, False, self._conv_ws)
         return out, acts, hids
+
+    def _head_parts_ws(self):
+        """Two workspaces for the output layers' unfolded partial sums (online pass, target pass): they must outlive the
+        other launches of the forward passes, which split into the policy's common workspace."""
+        if getattr(self, "_head_ws", None) is None:
+            self._head_ws = (_lib.conv_workspace(self.device), _lib.conv_workspace(self.device))
+        return self._head_ws
 
     def _pair_rows(self, obs, next_obs):
         """u8 [2B,C,H,W] = obs followed by next_obs: in place when the replay memory handed them out adjacent
@@ -132,16 +143,26 @@ class QPolicyBase(AtariCnnPolicy):
         both[b:].copy_(next_obs)
         return both
 
-    def _forward_for_loss(self, obs, next_obs, double_dqn):
+    def _forward_for_loss(self, obs, next_obs, double_dqn, head_parts=False):
         """The three forward passes of a DQN-family loss: online net on obs (activations kept for the backward
         pass), target net on next_obs and -- double DQN -- online net on next_obs.  The two online passes run as
         ONE pass over 2B rows (at the DQN batch of 32 every layer is latency-bound, so the second half is nearly
         free), whose first-half slices feed the backward pass; the target pass reads the same scaled next_obs.
+        head_parts (taken on the double-DQN path from u8 rows, the one the benchmarks run; ignored elsewhere): the three
+        logit entries come back as _lib.ArlLogitSrc -- the output layers' split partial sums, unfolded.
         Returns (x, out, acts, hids, target_out, online_next_out or None)."""
         b = obs.shape[0]
         c, h, w = self._obs_shape
         if double_dqn and self._u8:                     # conv 1 reads the u8 rows itself: no scaled copy at all
             both = self._pair_rows(obs, next_obs)
+            if head_parts:          # the two output layers' folds are left to the loss kernel (arl_catdqn_loss_parts)
+                ws2, wst = self._head_parts_ws()
+                k, r = self._k_head, self._head_width
+                it_t, _, _ = self._logits(ObsRows(both[b:], None), w=self._w_target, tag="t", parts_ws=wst)
+                it_2, acts2, hids2 = self._logits(ObsRows(both, None), tag="2", parts_ws=ws2)
+                return (ObsRows(both[:b], None), _lib.logit_src(it_2, self._w[k + 1], 0, r), [a[:b] for a in acts2],
+                        [hd[:b] for hd in hids2], _lib.logit_src(it_t, self._w_target[k + 1], 0, r),
+                        _lib.logit_src(it_2, self._w[k + 1], b, r))
             tgt, _, _ = self._logits(ObsRows(both[b:], None), w=self._w_target, tag="t")
             out2, acts2, hids2 = self._logits(ObsRows(both, None), tag="2")
             return (ObsRows(both[:b], None), out2[:b], [a[:b] for a in acts2], [hd[:b] for hd in hids2], tgt,

@@ -695,6 +695,30 @@ int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_logits, cons
                     int32_t atom_stride, int32_t dueling, float v_min, float v_max, float gamma_n,
                     float* dlogits, float* loss_rows, float* kl, void* stream);
 
+/* The same loss reading its three logit blocks as the output layer's SPLIT PARTIAL SUMS (arl_conv2d_fwd_parts on the
+ * "action_atoms" dense layer, catdqn_cnn.py:69-76): at the reference's minibatch of 32 (accel_rl/algos/dqn/dqn.py:18) an
+ * update is a chain of launch latencies, and the two launches that only fold the output layers' partials are taken
+ * over by the loss kernel -- logit = (the partials summed in arl_fold_many's order) + bias, operation for operation, so
+ * the results are arl_catdqn_loss's on the folded logits bit for bit.
+ *   part          f32: this block's row 0 inside split 0 (the online pass over [obs; next_obs] hands `pred` its first
+ *                 batch rows and `pol_next` the rows from batch on, same split_stride)
+ *   split_stride  floats between consecutive splits (arl_fold_item.total of the forward launch)
+ *   splits        1 .. 127 (arl_fold_item.splits; a launch that did not split: 1, with part = its finished output and
+ *                 bias_or_null = NULL)
+ *   bias_or_null  f32[(n_actions (+ 1)) * atom_stride]: the output layer's bias, added after the sum                  */
+typedef struct arl_logit_src {
+    const float* part;
+    const float* bias_or_null;
+    int64_t split_stride;
+    int32_t splits;
+    int32_t reserved;
+} arl_logit_src;
+int arl_catdqn_loss_parts(const arl_logit_src* pred, const arl_logit_src* tgt_next, const arl_logit_src* pol_next_or_null,
+                          const float* z, const uint8_t* actions, const float* returns, const uint8_t* terminals,
+                          const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t n_atoms,
+                          int32_t atom_stride, int32_t dueling, float v_min, float v_max, float gamma_n,
+                          float* dlogits, float* loss_rows, float* kl, void* stream);
+
 /* Plain DQN action serving: greedy action = first maximum of the Q row (T.argmax), override as
  * above, one-hot row out.  Replaces AtariDqnPolicy.get_actions / actions_sym,
  * accel_rl/policies/dqn/atari_dqn_policy.py:61-63,76-79,118-130.

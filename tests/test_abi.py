@@ -72,10 +72,10 @@ def test_struct_layouts_match_header(lib):
     import tempfile
     from accel_rl_amd import _lib
     src = ('#include <stdio.h>\n#include "accel_rl_hip.h"\n#include "accel_rl_hip_dev.h"\n'
-           'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+           'int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
            'sizeof(arl_game),sizeof(arl_env_state),sizeof(arl_rollout),sizeof(arl_opt_state),'
            'sizeof(arl_conv_geom),sizeof(arl_replay),sizeof(arl_fold_item),sizeof(arl_corun_job),'
-           'sizeof(arl_serve_head),sizeof(arl_serve_conv1));return 0;}')
+           'sizeof(arl_serve_head),sizeof(arl_serve_conv1),sizeof(arl_logit_src));return 0;}')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
@@ -85,7 +85,8 @@ def test_struct_layouts_match_header(lib):
     assert sizes == [ctypes.sizeof(_lib.ArlGame), ctypes.sizeof(_lib.ArlEnvState),
                      ctypes.sizeof(_lib.ArlRollout), ctypes.sizeof(_lib.ArlOptState),
                      ctypes.sizeof(_lib.ArlConvGeom), ctypes.sizeof(_lib.ArlReplay), ctypes.sizeof(_lib.ArlFoldItem),
-                     ctypes.sizeof(_lib.ArlCorunJob), ctypes.sizeof(_lib.ArlServeHead), ctypes.sizeof(_lib.ArlServeConv1)]
+                     ctypes.sizeof(_lib.ArlCorunJob), ctypes.sizeof(_lib.ArlServeHead), ctypes.sizeof(_lib.ArlServeConv1),
+                     ctypes.sizeof(_lib.ArlLogitSrc)]
 
 
 def test_struct_field_offsets_match_header(lib):
@@ -97,7 +98,8 @@ def test_struct_field_offsets_match_header(lib):
     pairs = [("arl_game", _lib.ArlGame), ("arl_env_state", _lib.ArlEnvState), ("arl_rollout", _lib.ArlRollout),
              ("arl_opt_state", _lib.ArlOptState), ("arl_conv_geom", _lib.ArlConvGeom), ("arl_replay", _lib.ArlReplay),
              ("arl_fold_item", _lib.ArlFoldItem), ("arl_serve_head", _lib.ArlServeHead),
-             ("arl_serve_conv1", _lib.ArlServeConv1), ("arl_dgrad_wt", _lib.ArlDgradWt)]
+             ("arl_serve_conv1", _lib.ArlServeConv1), ("arl_dgrad_wt", _lib.ArlDgradWt),
+             ("arl_logit_src", _lib.ArlLogitSrc)]
     lines = ['printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (c, f[0], c, f[0]) for c, cls in pairs for f in cls._fields_]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "accel_rl_hip.h"\nint main(){%s return 0;}' % "\n".join(lines)
     with tempfile.TemporaryDirectory() as d:

@@ -80,14 +80,14 @@ def test_action_kernel_greedy_and_override():
     assert torch.equal(onehot, F.one_hot(chosen, a).float())
 
 
-def _make_policy(n_act=6, eps=0.3):
+def _make_policy(n_act=6, eps=0.3, dueling=False):
     from accel_rl_amd.policies.atari_cnn_specs import cnn_specs
     from accel_rl_amd.policies.dqn.atari_cat_dqn_policy import AtariCatDqnPolicy
     from accel_rl_amd.spaces import Discrete, UintBox, EnvSpec
     from accel_rl_amd.util.seed import set_seed
     set_seed(5)
     spec = dict(cnn_specs[0])
-    policy = AtariCatDqnPolicy(epsilon=eps, **spec)
+    policy = AtariCatDqnPolicy(epsilon=eps, dueling=dueling, **spec)
     policy.initialize(EnvSpec(UintBox((4, 104, 80)), Discrete(n_act)), device=DEV)
     policy.incorporate_z(np.linspace(-10, 10, 51, dtype=np.float32))
     return policy, spec
@@ -182,6 +182,44 @@ def test_training_step_matches_autograd_through_plain_torch():
     assert abs(rows.sum().item() - loss.item()) <= 1e-4 * abs(loss.item())
     assert torch.allclose(kl, kl_ref, rtol=2e-3, atol=1e-5)
     assert np.allclose(got, want, rtol=2e-3, atol=2e-5 * max(np.abs(want).max(), 1e-3)), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("dueling", [False, True])
+@pytest.mark.parametrize("b", [32, 6])
+def test_loss_reading_split_partial_sums_is_the_folded_loss_bit_for_bit(dueling, b):
+    """arl_catdqn_loss_parts (the loss launch folds the two output layers' split partial sums while it reads them; two
+    launches fewer per update) against the separate folds + arl_catdqn_loss: loss rows, priorities and EVERY gradient
+    identical to the last bit, at the reference's minibatch (32: the output layer splits its reduction) and at one that
+    does not split the same way."""
+    from accel_rl_amd import _lib
+    policy, spec = _make_policy(dueling=dueling)
+    rs = np.random.RandomState(5 + b)
+    obs = torch.from_numpy(rs.randint(0, 256, size=(b, 4, 104, 80), dtype=np.uint8)).to(DEV)
+    nxt = torch.from_numpy(rs.randint(0, 256, size=(b, 4, 104, 80), dtype=np.uint8)).to(DEV)
+    act = torch.from_numpy(rs.randint(0, 6, size=b).astype(np.uint8)).to(DEV)
+    ret = torch.from_numpy(rs.randn(b).astype(np.float32)).to(DEV)
+    term = torch.from_numpy((rs.rand(b) < 0.2).astype(np.uint8)).to(DEV)
+    isw = torch.from_numpy((rs.rand(b) + 0.2).astype(np.float32)).to(DEV)
+    policy.flat_target.copy_(policy.flat_params * 0.9)
+    k = policy._k_head
+    policy._w[k + 1].normal_()                                  # (the reference initialises the biases to zero)
+    policy._w_target[k + 1].normal_()
+    outs = []
+    for parts in (False, True):
+        policy.loss_folds_heads = parts
+        policy.flat_grads.fill_(float("nan"))
+        rows, kl = policy.cat_loss_and_grads(obs, nxt, act, ret, term, isw, -10., 10., float(np.float32(0.99)),
+                                             double_dqn=True)
+        torch.cuda.synchronize()
+        outs.append((rows.clone(), kl.clone(), policy.flat_grads.clone()))
+    assert torch.isfinite(outs[1][2]).all()
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+    # the parts path really ran on split partial sums at the reference's minibatch
+    it = _lib.conv2d_fwd_parts(torch.zeros(2 * b, policy._hid_geom[-1][0], device=DEV), policy._w[k], policy._w[k + 1],
+                               torch.empty(2 * b, policy._head_width, device=DEV), policy._head_geom(2 * b), False,
+                               policy._head_parts_ws()[0])
+    assert b != 32 or it.splits > 1
 
 
 def test_cat_dqn_trains_with_prioritized_replay_and_eval():
