@@ -169,7 +169,8 @@ _SIGNATURES = {
     "arl_priority_diffs": (_i32, [_vp, _vp, _i64, _f64, _vp, _vp]),
     "arl_catdqn_act": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "arl_catdqn_loss": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
-    "arl_catdqn_loss_parts": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "arl_catdqn_loss_parts": (_i32, [_vp] * 8 + [_i64, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp, _vp, _i32,
+                               _vp]),
     "arl_dqn_act": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "arl_dqn_loss": (_i32, [_vp] * 7 + [_i64, _i32, _i32, _i32, _f32, _f32, _vp, _vp, _vp, _vp]),
     "arl_lstm_cell_fwd": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
@@ -911,12 +912,22 @@ def logit_src(item, bias, row0=0, row_floats=0):
 
 
 def catdqn_loss_parts(pred, tgt_next, pol_next, z, actions, returns, terminals, is_weights, n_actions, n_atoms,
-                      atom_stride, v_min, v_max, gamma_n, dlogits, loss_rows, kl, dueling=False, stream=None):
-    """arl_catdqn_loss on logit blocks still in split partial sums (ArlLogitSrc each; pol_next None: not double DQN)."""
+                      atom_stride, v_min, v_max, gamma_n, dlogits, loss_rows, kl, dueling=False, stream=None,
+                      dgrad_weights=None):
+    """arl_catdqn_loss on logit blocks still in split partial sums (ArlLogitSrc each; pol_next None: not double DQN).
+    dgrad_weights: [(w, wt, geom)] -- the launch also writes these layers' k-contiguous weight copies."""
+    wt_items, n_wt = None, 0
+    if dgrad_weights:
+        n_wt = len(dgrad_weights)
+        assert n_wt <= DGRAD_WT_MAX
+        wt_items = (ArlDgradWt * n_wt)()
+        for it, (w, wt, geom) in zip(wt_items, dgrad_weights):
+            it.w, it.wt, it.geom = ptr(w), ptr(wt), C.pointer(geom)
     _check(load().arl_catdqn_loss_parts(C.byref(pred), C.byref(tgt_next), None if pol_next is None else C.byref(pol_next),
                                         ptr(z), ptr(actions), ptr(returns), ptr(terminals), ptr(is_weights),
                                         actions.numel(), n_actions, n_atoms, atom_stride, int(dueling), float(v_min),
                                         float(v_max), float(gamma_n), ptr(dlogits), ptr(loss_rows), ptr(kl),
+                                        None if wt_items is None else C.cast(wt_items, _vp), n_wt,
                                         stream_ptr(stream)), "arl_catdqn_loss_parts")
 
 

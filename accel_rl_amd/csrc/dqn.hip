@@ -20,6 +20,7 @@
 // kernel) / one workgroup per sample (loss kernel); n_atoms <= 64.  fp32, compiled with -ffp-contract=off.
 
 #include "arl_common.h"
+#include "dgrad_wt_dev.h"
 #include <type_traits>
 
 namespace {
@@ -158,9 +159,15 @@ struct CatLossArgs {
 // One workgroup per sample.  The greedy next action needs a softmax expectation per action -- a serial chain
 // of wave reductions -- so the actions are dealt to the four waves; wave 0 then carries the sample through
 // projection, loss and gradient (lane i = atom i).
+// wt (PARTS): the workgroups behind the samples' own (blockIdx.x >= batch) write the data gradients' k-contiguous weight
+// copies (dgrad_wt_dev.h) for the backward pass that follows -- as the policy-gradient head's launch does (learner.hip)
 template <int NS>                  // -1: finished logits; >= 0: split partial sums (Parts<NS>)
-__global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a) {
+__global__ __launch_bounds__(256) void catdqn_loss_kernel(const CatLossArgs a, const arlw::DgradWtArgs wt) {
     constexpr bool PARTS = NS >= 0;
+    if (PARTS && (int64_t)blockIdx.x >= a.batch) {
+        arlw::dgrad_wt_block(wt, (int)(blockIdx.x - a.batch), (int)threadIdx.x);
+        return;
+    }
     __shared__ float s_next[64], s_znext[64], s_q[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = blockIdx.x;
@@ -418,7 +425,7 @@ extern "C" int arl_catdqn_loss(const float* pred_logits, const float* tgt_next_l
     a.dlogits = dlogits; a.loss_rows = loss_rows; a.kl = kl; a.batch = batch;
     a.n_actions = n_actions; a.n_atoms = n_atoms; a.stride = atom_stride; a.dueling = dueling != 0;
     a.v_min = v_min; a.v_max = v_max; a.gamma_n = gamma_n;
-    hipLaunchKernelGGL(catdqn_loss_kernel<-1>, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(catdqn_loss_kernel<-1>, dim3((unsigned)batch), dim3(256), 0, (hipStream_t)stream, a, arlw::DgradWtArgs{});
     return arl::check_launch("catdqn_loss_kernel");
 }
 
@@ -427,7 +434,8 @@ extern "C" int arl_catdqn_loss_parts(const arl_logit_src* pred, const arl_logit_
                                      const float* returns, const uint8_t* terminals, const float* is_weights_or_null,
                                      int64_t batch, int32_t n_actions, int32_t n_atoms, int32_t atom_stride,
                                      int32_t dueling, float v_min, float v_max, float gamma_n, float* dlogits,
-                                     float* loss_rows, float* kl, void* stream) {
+                                     float* loss_rows, float* kl, const arl_dgrad_wt* wt_items_or_null, int32_t n_wt,
+                                     void* stream) {
     ARL_REQUIRE(pred && tgt_next && pred->part && tgt_next->part && z && actions && returns && terminals && dlogits &&
                     loss_rows && kl && (!pol_next_or_null || pol_next_or_null->part), ARL_E_ARG, "null pointer");
     int rc = check_cat(batch, n_actions, n_atoms, atom_stride);
@@ -450,15 +458,21 @@ extern "C" int arl_catdqn_loss_parts(const arl_logit_src* pred, const arl_logit_
     int ns = a.src[0].splits;
     for (int i = 1; i < 3; ++i)
         if (in[i] && a.src[i].splits != ns) ns = 0;
-    const dim3 grid((unsigned)batch);
+    arlw::DgradWtArgs wt = {};
+    int wt_blocks = 0;
+    if (wt_items_or_null && n_wt > 0) {
+        rc = arlw::dgrad_wt_plan(wt_items_or_null, n_wt, &wt, &wt_blocks);
+        if (rc) return rc;
+    }
+    const dim3 grid((unsigned)(batch + wt_blocks));
     hipStream_t st = (hipStream_t)stream;
     switch (ns) {
-    case 1: hipLaunchKernelGGL(catdqn_loss_kernel<1>, grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL(catdqn_loss_kernel<2>, grid, dim3(256), 0, st, a); break;
-    case 4: hipLaunchKernelGGL(catdqn_loss_kernel<4>, grid, dim3(256), 0, st, a); break;
-    case 8: hipLaunchKernelGGL(catdqn_loss_kernel<8>, grid, dim3(256), 0, st, a); break;
-    case 16: hipLaunchKernelGGL(catdqn_loss_kernel<16>, grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL(catdqn_loss_kernel<0>, grid, dim3(256), 0, st, a);
+    case 1: hipLaunchKernelGGL(catdqn_loss_kernel<1>, grid, dim3(256), 0, st, a, wt); break;
+    case 2: hipLaunchKernelGGL(catdqn_loss_kernel<2>, grid, dim3(256), 0, st, a, wt); break;
+    case 4: hipLaunchKernelGGL(catdqn_loss_kernel<4>, grid, dim3(256), 0, st, a, wt); break;
+    case 8: hipLaunchKernelGGL(catdqn_loss_kernel<8>, grid, dim3(256), 0, st, a, wt); break;
+    case 16: hipLaunchKernelGGL(catdqn_loss_kernel<16>, grid, dim3(256), 0, st, a, wt); break;
+    default: hipLaunchKernelGGL(catdqn_loss_kernel<0>, grid, dim3(256), 0, st, a, wt);
     }
     return arl::check_launch("catdqn_loss_kernel (parts)");
 }

@@ -120,12 +120,18 @@ class AtariCatDqnPolicy(QPolicyBase):
             pack = self._buffer(("loss_kl", b), (2, b))         # one buffer: DqnOptimizer's statistics ring takes both rows at once
             loss_rows, kl = pack[0], pack[1]
             if isinstance(logits, _lib.ArlLogitSrc):            # the output layers' partial sums, folded as they are read
+                # (the launch also writes the data gradients' weight copies: the backward pass skips its own launch)
+                wts = self._dgrad_weight_items(b) if os.environ.get("ARL_WT_IN_LOSS", "1") != "0" else []     # (A/B switch)
                 _lib.catdqn_loss_parts(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
                                        self.n_act, self.n_atoms, self._atom_stride, v_min, v_max, gamma_n, dlogits,
-                                       loss_rows, kl, dueling=self._dueling)
+                                       loss_rows, kl, dueling=self._dueling, dgrad_weights=wts)
+                self._wt_fresh = bool(wts)
             else:
                 _lib.catdqn_loss(logits, tgt_logits, pol_next, self.z, actions, returns, terminals, is_weights,
                                  self.n_act, self.n_atoms, v_min, v_max, gamma_n, dlogits, loss_rows, kl,
                                  dueling=self._dueling)
-            self._head_backward(dlogits, x, acts, hids)
+            try:
+                self._head_backward(dlogits, x, acts, hids)
+            finally:
+                self._wt_fresh = False
             return loss_rows, kl

@@ -717,7 +717,10 @@ int arl_catdqn_loss_parts(const arl_logit_src* pred, const arl_logit_src* tgt_ne
                           const float* z, const uint8_t* actions, const float* returns, const uint8_t* terminals,
                           const float* is_weights_or_null, int64_t batch, int32_t n_actions, int32_t n_atoms,
                           int32_t atom_stride, int32_t dueling, float v_min, float v_max, float gamma_n,
-                          float* dlogits, float* loss_rows, float* kl, void* stream);
+                          float* dlogits, float* loss_rows, float* kl, const struct arl_dgrad_wt* wt_items_or_null,
+                          int32_t n_wt, void* stream);
+/* (wt_items_or_null / n_wt: as in arl_pg_head_loss_parts -- the launch also writes these layers' k-contiguous weight copies
+ *  for the backward pass that follows, in extra workgroups.) */
 
 /* Plain DQN action serving: greedy action = first maximum of the Q row (T.argmax), override as
  * above, one-hot row out.  Replaces AtariDqnPolicy.get_actions / actions_sym,
