@@ -184,6 +184,63 @@ def test_training_step_matches_autograd_through_plain_torch():
     assert np.allclose(got, want, rtol=2e-3, atol=2e-5 * max(np.abs(want).max(), 1e-3)), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize("splits", [(1, 1, 1), (4, 4, 4), (3, 3, 3), (8, 2, 16), (17, 17, 17), (40, 5, 126)])
+@pytest.mark.parametrize("dueling", [False, True])
+def test_parts_loss_kernel_folds_like_the_fold_launch(splits, dueling):
+    """arl_catdqn_loss_parts at the kernel level: partial sums of 1 .. 126 splits (the templated counts 1 / 2 / 4 / 8 /
+    16, the run-time loop for anything else and for sources that differ, more than 16 splits = more than one member per
+    fold group) against arl_catdqn_loss on what arl_fold_many leaves of the same partial sums, + bias: bit for bit."""
+    from accel_rl_amd import _lib
+    import ctypes as C
+    n_act, n_atoms, batch = 6, 51, 19
+    stride, rows = 52, n_act + int(dueling)
+    r = rows * stride
+    gen = torch.Generator(device=DEV).manual_seed(sum(splits) + int(dueling))
+    srcs, folded, keep = [], [], []
+    for sp in splits:
+        parts = torch.randn(sp, batch * r, device=DEV, generator=gen)
+        bias = torch.randn(r, device=DEV, generator=gen)
+        out = torch.empty(batch * r, device=DEV)
+        if sp > 1:
+            folds = _lib.FoldList()
+            folds._n = 1
+            it = folds._items[0]
+            it.part, it.out, it.total, it.splits, it.valid = parts.data_ptr(), out.data_ptr(), batch * r, sp, 0
+            folds.run()
+        else:
+            out.copy_(0. + parts[0])
+        folded.append((out.view(batch, r) + bias).contiguous())
+        src = _lib.ArlLogitSrc()
+        src.part, src.bias_or_null, src.split_stride, src.splits = parts.data_ptr(), bias.data_ptr(), batch * r, sp
+        srcs.append(src)
+        keep += [parts, bias]
+    z = torch.linspace(-10, 10, n_atoms, device=DEV)
+    act = torch.randint(0, n_act, (batch,), device=DEV, generator=gen).to(torch.uint8)
+    ret = torch.randn(batch, device=DEV, generator=gen) * 6
+    term = (torch.rand(batch, device=DEV, generator=gen) < 0.3).to(torch.uint8)
+    isw = torch.rand(batch, device=DEV, generator=gen) + 0.1
+    gamma_n = float(np.float32(0.99 ** 3))
+    outs = []
+    for parts_path in (False, True):
+        dl = torch.full((batch, r), float("nan"), device=DEV)
+        lr, kl = torch.empty(batch, device=DEV), torch.empty(batch, device=DEV)
+        if parts_path:
+            _lib.catdqn_loss_parts(srcs[0], srcs[1], srcs[2], z, act, ret, term, isw, n_act, n_atoms, stride, -10., 10.,
+                                   gamma_n, dl, lr, kl, dueling=dueling)
+        else:
+            _lib.catdqn_loss(folded[0], folded[1], folded[2], z, act, ret, term, isw, n_act, n_atoms, -10., 10., gamma_n,
+                             dl, lr, kl, dueling=dueling)
+        torch.cuda.synchronize()
+        outs.append((dl, lr, kl))
+    assert torch.isfinite(outs[0][0]).all()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), splits
+    with pytest.raises(RuntimeError, match="splits"):
+        srcs[0].splits = 128
+        _lib.catdqn_loss_parts(srcs[0], srcs[1], srcs[2], z, act, ret, term, isw, n_act, n_atoms, stride, -10., 10.,
+                               gamma_n, outs[1][0], outs[1][1], outs[1][2], dueling=dueling)
+
+
 @pytest.mark.parametrize("dueling", [False, True])
 @pytest.mark.parametrize("b", [32, 6])
 def test_loss_reading_split_partial_sums_is_the_folded_loss_bit_for_bit(dueling, b):
