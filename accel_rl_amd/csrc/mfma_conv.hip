@@ -134,7 +134,7 @@ extern "C" void arl_dev_conv_force_generic(int32_t on) { g_force_generic = on !=
 
 extern "C" void arl_dev_fold_wide_from(int32_t splits) { g_fold_wide = splits > 0 ? splits : FOLD_WIDE; }
 
-extern "C" void arl_dev_fwd_tile(int32_t v) { g_fwd_tile = (v >= 0 && v <= 2) ? v : -1; }
+extern "C" void arl_dev_fwd_tile(int32_t v) { g_fwd_tile = ((v >= 0 && v <= 2) || v == 6 || v == 7) ? v : -1; }
 
 extern "C" void arl_dev_dgrad_wt(int32_t on) { g_dgrad_wt = on != 0; }
 
@@ -184,6 +184,14 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
     // 80 tiles walking 88 k-tiles each, 231 us)
     const int tiles128 = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (!small && a.N >= 128 && tiles128 * 4 <= TARGET_WGS * 3) plan_split(tiles128, a.K, &splits, &per, TARGET_WGS);
+    // ... and unsplit ones whose 128x128 tiles fill the last round of CUs badly (160 tiles on 256 CUs: 62 %): 64x64 tiles,
+    // four times the workgroups, when their fill beats it by more than their lower per-tile efficiency (0.85) -- spec-1
+    // dense at 5 120 rows 378.7 -> 309.4 us, 10 240 x 3 456 -> 256: 194.2 -> 160.7, 20 000 x 256 -> 128: 21.1 -> 17.3; 256
+    // tiles stay (419 against 459); same k order, bit-identical (profiles/r06/dense_fwd_tile_probe.txt)
+    auto cu_fill = [](int t) { return (double)t / (double)(((t + TARGET_WGS - 1) / TARGET_WGS) * TARGET_WGS); };
+    const int tiles64 = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    const bool fill64 = !small && a.N >= 128 && splits == 1 && g_split && g_fwd_tile != 7 &&
+                        (g_fwd_tile == 6 || 0.85 * cu_fill(tiles64) > cu_fill(tiles128));
     a.k_per_split = per;
     if (splits > 1) {
         ARL_REQUIRE((int64_t)splits * a.M * a.N * 4 <= arl_conv_workspace_bytes(), ARL_E_RANGE, "workspace too small");
@@ -221,12 +229,12 @@ int fwd_impl(const float* x, const float* w, const float* bias_or_null, float* y
             // 128 row tiles: the DQN updates' 32 .. 64-row batches, evaluation groups) the column split is the faster
             // launch (108 row tiles: 19.1 -> 15.6 us); from 129 row tiles on two half workgroups per CU cost what one
             // whole one does, plus the second load and split of the gathered operand (216 row tiles: 19.8 -> 22.7 us).
-            const int v = g_fwd_tile >= 0 ? g_fwd_tile : (2 * ((a.M + 127) / 128) <= TARGET_WGS ? 1 : 0);
+            const int v = (g_fwd_tile >= 0 && g_fwd_tile <= 2) ? g_fwd_tile : (2 * ((a.M + 127) / 128) <= TARGET_WGS ? 1 : 0);
             if (v == 1) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
             else if (v == 2) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
             else rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, multi_tap, has_pad, s, splits);
         }
-        else if (g_split && small) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
+        else if (g_split && (small || fill64)) rc = launch_igemm_split<2, 2, 1, 1, FBK, true, false, 3>(a, multi_tap, has_pad, s, splits);
         else if (g_split) rc = launch_igemm_split<2, 2, 2, 2, FBK, true, false, 1>(a, multi_tap, has_pad, s, splits);
         else if (a.N <= 32 && a.K % 16 == 0 && per % 16 == 0 && (g.C % 16 == 0 || (16 % g.C == 0 && g.kw % (16 / g.C) == 0)))
             rc = launch_igemm<4, 1, 1, 1, 16, true>(a, splits, multi_tap, has_pad, s);
@@ -368,7 +376,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
             // k-contiguous weights: the forward pass's kernels on the data gradient's gather (B_KC = true)
             a.b.w = wt; a.b.ld = a.K; a.b.cls = a.N * a.K;
             const int tiles = ((a.M + 127) / 128) * (a.n_par ? a.n_par : 1);
-            const int v = a.N <= 32 || (g_fwd_tile >= 0 ? (g_fwd_tile == 1) : (2 * tiles <= TARGET_WGS));
+            const int v = a.N <= 32 || ((g_fwd_tile >= 0 && g_fwd_tile <= 2) ? (g_fwd_tile == 1) : (2 * tiles <= TARGET_WGS));
             if (v) rc = launch_igemm_split<4, 1, 1, 1, FBK, true, false, 2>(a, false, has_pad, s);
             else rc = launch_igemm_split<4, 1, 1, 2, FBK, true, false, 2>(a, false, has_pad, s);
             return rc;
@@ -378,7 +386,7 @@ int dgrad_impl(const float* dy, const float* w, const float* mask_or_null, float
         else if (g_split && a.N <= 64) {
             // (as in the forward: the column split while every half tile gets a CU of its own; same products, same order)
             const int tiles = ((a.M + 127) / 128) * (a.n_par ? a.n_par : 1);
-            const int v = g_fwd_tile >= 0 ? (g_fwd_tile == 1) : (2 * tiles <= TARGET_WGS);
+            const int v = (g_fwd_tile >= 0 && g_fwd_tile <= 2) ? (g_fwd_tile == 1) : (2 * tiles <= TARGET_WGS);
             if (v) rc = launch_igemm_split<4, 1, 1, 1, FBK, false, false, 2>(a, false, has_pad, s);
             else rc = launch_igemm_split<4, 1, 1, 2, FBK, false, false, 2>(a, false, has_pad, s);
         }

@@ -21,7 +21,8 @@ void arl_dev_conv_force_generic(int32_t on);
 
 /* Tests / A-B measurements: tile shape of the split-route forward (and, for 0 / 1, data-gradient) kernels of layers with
  * 33 .. 64 output columns -- 0: 128 x 64 (one wave per 32-row tile, both column halves), 1: 128 x 32 (two column tiles
- * per row tile), 2: 64 x 64 (forward only: both operands through LDS); every value gives the same results bit for bit.
+ * per row tile), 2: 64 x 64 (forward only: both operands through LDS); 6 / 7: the unsplit forward of >= 128-column layers
+ * on 64 x 64 tiles always / never (else by how the tiles fill the CUs); every value gives the same results bit for bit.
  * -1 (default) = chosen by the launch's size: the column split while every half tile gets a CU of its own.           */
 void arl_dev_fwd_tile(int32_t v);
 
