@@ -1,5 +1,5 @@
 # Regenerates the one-box part of profiles/r06 on one MI355X box: bash tools/refresh_profiles.sh  (from the repo root;
-# ~12 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r06 (and profiles/*.json: the PMC records bench.py reads)
+# ~14 GPU-minutes); output in gpurun_out/fin, to be copied into profiles/r06 (and profiles/*.json: the PMC records bench.py reads)
 set -x
 R=$(pwd); O=$R/gpurun_out/fin; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
@@ -48,4 +48,15 @@ bash tools/conv1_pmc.sh gpurun_out/fin/conv1_pmc.txt > /dev/null 2>&1
 python tools/replay_bench.py 2>&1 | grep -v amdgpu > $O/replay_bench.txt
 (for k in "conv2 fwd" "conv2 wgrad" "conv2 dgrad" "dense pair"; do echo "== $k"; bash tools/pmc_one.sh $k 2>&1 | grep -v amdgpu; done) > $O/pmc_one_split_kernels.txt
 python tools/wave_scan_probe.py 26 2>&1 | grep -v amdgpu > $O/wave_scan_probe.txt
+python tools/route_kernel_times.py 2>&1 | grep -v amdgpu > $O/route_kernel_times.txt
+python tools/dense_fwd_tile_probe.py 2>&1 | grep -v amdgpu > $O/dense_fwd_tile_probe.txt
+# configs 3 and 5 launch by launch (rocprofv3 kernel trace + tools/trace_sequence.py)
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pF -o a -- python $R/bench.py --workload a2c1024 --steps 60 --warmup 10 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+cp $(find /tmp/pF -name "*kernel_stats.csv" | head -n 1) $O/a2c1024_kernel_stats.csv
+python $R/tools/trace_sequence.py $(find /tmp/pF -name "*kernel_trace.csv" | head -n 1) scan_lds_kernel -3 > $O/a2c1024_step_sequence.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pG -o c -- python $R/bench.py --workload catdqn --steps 8 --warmup 3 --no-cpu-baseline --no-roofline --no-alt-routes > /dev/null 2>&1
+cp $(find /tmp/pG -name "*kernel_stats.csv" | head -n 1) $O/catdqn_kernel_stats.csv
+python $R/tools/trace_sequence.py $(find /tmp/pG -name "*kernel_trace.csv" | head -n 1) sumtree_sample_kernel -5 > $O/catdqn_update_sequence.txt
+cd $R
 ls -la $O
